@@ -1,0 +1,71 @@
+/*
+ * natinf_ncsnpp.h -- C ABI of the NCSN++ / DDPM++ denoiser engine inside libnatinf.so.
+ *
+ * Replaces the `model(x, labels)` call made by the reference's score function
+ * (deps/score_sde_pytorch/models/utils.py:144-160 -> models/utils.py:118-123), i.e.
+ * NCSNpp.forward (deps/score_sde_pytorch/models/ncsnpp.py:232-381) under the configuration the
+ * CIFAR10 script imports (configs/vp/cifar10_ddpmpp_continuous.py:41-64: nf 128, ch_mult (1,2,2,2),
+ * 4 BigGAN res-blocks per level, attention at 16 px, positional embedding, fir=False,
+ * skip_rescale=True, progressive none, centered data, scale_by_sigma=False, eval mode).
+ *
+ * Arithmetic: bf16 operands on the gfx950 matrix cores (v_mfma_f32_16x16x32_bf16), fp32
+ * accumulation, fp32 GroupNorm statistics / softmax, bf16 activations between layers.  The parity
+ * bar against the reference's fp32 forward is a floating-point tolerance (stated in the tests),
+ * not bit equality.
+ *
+ * Conventions are those of natinf.h: device pointers owned by the caller, explicit stream, int
+ * return codes, no device allocation (the caller supplies the packed-weight buffer and the
+ * activation workspace; sizes are queried below).
+ */
+#ifndef NATINF_NCSNPP_H
+#define NATINF_NCSNPP_H
+
+#include <stdint.h>
+#include "natinf.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct natinf_ncsnpp* natinf_ncsnpp_t;
+
+/* keep every module's output alive in the workspace (bump allocation, no reuse) so that
+ * natinf_ncsnpp_debug_tap can read any of them after a forward; tests only. */
+#define NATINF_NCSNPP_KEEP_ACTIVATIONS 1
+
+/* Number of fp32 parameters (61,804,419) in the flat order documented at natinf_ncsnpp_load. */
+int64_t natinf_ncsnpp_param_count(void);
+/* Bytes of device memory for the packed (bf16, GEMM-ready) weights + fp32 biases / affine terms. */
+int64_t natinf_ncsnpp_packed_bytes(void);
+/* Bytes of device workspace a forward at batch <= max_batch needs (depends on the handle's flags). */
+int64_t natinf_ncsnpp_workspace_bytes(natinf_ncsnpp_t h, int max_batch);
+
+/* Host-side object: the static execution plan (op list, arena offsets, weight offsets).  No GPU needed. */
+int natinf_ncsnpp_create(natinf_ncsnpp_t* out, int flags);
+int natinf_ncsnpp_destroy(natinf_ncsnpp_t h);
+
+/* One line per all_modules entry: "idx kind cin cout up down res param_offset"; returns the number of
+ * bytes written (excluding the NUL) or NATINF_EINVAL if `cap` is too small.  Host only. */
+int natinf_ncsnpp_describe(natinf_ncsnpp_t h, char* buf, int cap);
+
+/* Pack the weights.  `params_f32` = every parameter of NCSNpp, fp32, concatenated in
+ * `all_modules` order with the leaves of each module in registration order -- exactly the order of
+ * `model.parameters()` / of the EMA `shadow_params` list the reference restores
+ * (deps/score_sde_pytorch/models/ema.py:53-64); n_params must equal natinf_ncsnpp_param_count().
+ * `packed` must stay alive and untouched for the life of the handle's forwards. */
+int natinf_ncsnpp_load(natinf_ncsnpp_t h, const float* params_f32, int64_t n_params,
+                       void* packed, int64_t packed_bytes, natinf_stream_t stream);
+
+/* out = model(x, labels): x, out [B,3,32,32] fp32 NCHW; labels [B] fp32 (= t*999). */
+int natinf_ncsnpp_forward(natinf_ncsnpp_t h, const float* x, const float* labels, float* out, int B,
+                          void* workspace, int64_t workspace_bytes, natinf_stream_t stream);
+
+/* After a forward on a KEEP_ACTIVATIONS handle: copy the output of all_modules[module_idx]
+ * (module_idx >= 2) as fp32 NCHW into `out` (capacity in elements).  Same B / workspace as the forward. */
+int natinf_ncsnpp_debug_tap(natinf_ncsnpp_t h, int module_idx, float* out, int64_t capacity_elems,
+                            natinf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NATINF_NCSNPP_H */

@@ -1,0 +1,146 @@
+"""Drop-in for ``src/CIFAR10NaturalInference.py`` (the Natural Inference part, lines 202-317).
+
+Same public names, argument meaning and defaults as the reference script: ``to_pixel``, ``data_fn``,
+``weighted_sum``, ``natural_inference_tx``, ``calc_fid``.  The sampling loop runs on one MI355X:
+the NCSN++ forward in the HIP engine (include/natinf_ncsnpp.h) and one fused ``ni_step`` launch per
+step (include/natinf.h).  Constants the reference edits in-source are keyword arguments with the
+reference's values as defaults (batch 500, 50 000 samples, seed 888, step_5_weight_00.npz).
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr, stream_ptr
+from .coeff import load_coeff_npz, SparseRows
+from .sampler import CifarNI, vp_std_f32
+
+root_path = Path(__file__).resolve().parent.parent
+
+
+def _to_pixel(x: torch.Tensor, centered: int) -> torch.Tensor:
+    _lib.require_gpu()
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    out = torch.empty((B, H, W, C), dtype=torch.uint8, device=x.device)
+    check(lib.natinf_to_pixel_u8(ptr(x), ptr(out), B, C, H, W, centered, stream_ptr()), "natinf_to_pixel_u8")
+    return out.cpu()
+
+
+def to_pixel(batch: torch.Tensor) -> torch.Tensor:
+    """Reference :212-216: [B,C,H,W] fp32 in [0,1] -> uint8 [B,H,W,C] on the CPU."""
+    return _to_pixel(batch, 0)
+
+
+def to_pixel_from_centered(x: torch.Tensor) -> torch.Tensor:
+    """inverse_scaler (datasets.py:32-38) + to_pixel in one launch: x in [-1,1] -> uint8 NHWC (CPU)."""
+    return _to_pixel(x, 1)
+
+
+@torch.no_grad()
+def data_fn(score_fn: Callable, xt: torch.Tensor, t, x_coeff, eps_coeff, device) -> torch.Tensor:
+    """Reference :219-230.  ``score_fn(xt, vec_t)`` is the caller's score function; the fp64 conversion
+    ``(score*eps_coeff**2 + xt)/x_coeff`` runs in ``natinf_step_f64hist`` (std = -1 makes its internal
+    ``-out/std`` the identity on the score)."""
+    _lib.require_gpu()
+    vec_t = t * torch.ones(xt.shape[0], device=device)
+    score = score_fn(xt, vec_t).contiguous()
+    xt = xt.contiguous()
+    E = xt.numel()
+    hist = torch.empty((1, E), dtype=torch.float64, device=xt.device)
+    scratch = torch.empty(E, dtype=torch.float32, device=xt.device)
+    check(lib.natinf_step_f64hist(ptr(xt), ptr(score), ptr(xt), ptr(hist), ptr(scratch), None, None, 0, 0.0, 0,
+                                  float(x_coeff), float(eps_coeff), -1.0, 0.0, E, stream_ptr()), "natinf_step_f64hist")
+    return hist.view(xt.shape)
+
+
+def weighted_sum(past_x0_coeff: Sequence[float], seq_x0: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Reference :233-238: fp64 sum_i seq_x0[i]*coeff[i] (ascending i) -> fp32."""
+    _lib.require_gpu()
+    slab = torch.stack([s.contiguous().reshape(-1) for s in seq_x0]).to(torch.float64)
+    n, E = slab.shape
+    rows = SparseRows(np.asarray(past_x0_coeff, np.float64)[None, :n], lambda k: n, torch.float64, slab.device,
+                      dense=True, diag=False)
+    out = torch.empty(E, dtype=torch.float32, device=slab.device)
+    idx, val, nt = rows.ptrs(0)
+    check(lib.natinf_weighted_sum_f64(ptr(slab), ptr(out), idx, val, nt, E, stream_ptr()), "natinf_weighted_sum_f64")
+    return out.view(seq_x0[0].shape)
+
+
+@torch.no_grad()
+def natural_inference(model_fn: Callable, noise: torch.Tensor, weight_path, dense: bool = False,
+                      fast_f32: bool = False, return_all: bool = False):
+    """The loop body of ``natural_inference_tx`` (:292-304) for one batch of initial noise."""
+    C, B, node = load_coeff_npz(weight_path)
+    ni = CifarNI(C, B, node, noise.numel(), device=noise.device, dense=dense, fast_f32=fast_f32)
+    return ni.run(model_fn, noise, return_all=return_all)
+
+
+def calc_fid(imgs, ref_path, device):
+    """Reference :73-86 (InceptionV3 pool3 + Frechet distance).  Needs ``pytorch_fid`` and the
+    ``cifar10_mu_sigma.npz`` statistics, neither of which ships with the reference."""
+    try:
+        from pytorch_fid.inception import InceptionV3
+        from pytorch_fid.fid_score import calculate_frechet_distance
+    except ImportError as e:
+        raise ImportError("calc_fid needs the `pytorch_fid` package (InceptionV3 weights); it is not installed") from e
+    if not os.path.exists(ref_path):
+        raise FileNotFoundError(f"{ref_path} (CIFAR10 Inception statistics) is missing")
+    model = InceptionV3([InceptionV3.BLOCK_INDEX_BY_DIM[2048]]).to(device).eval()
+    acts = []
+    with torch.no_grad():
+        for i in range(0, len(imgs), 50):
+            b = imgs[i:i + 50].to(dtype=torch.float32, device=device) / 255
+            p = model(b.permute(0, 3, 1, 2))[0]
+            acts.append(p.squeeze(3).squeeze(2).cpu().numpy())
+    act = np.concatenate(acts).astype(np.float64)
+    ref = np.load(ref_path)
+    return calculate_frechet_distance(ref["mu"], ref["sigma"], np.mean(act, axis=0), np.cov(act, rowvar=False))
+
+
+@torch.no_grad()
+def natural_inference_tx(batch_size: int = 500,
+                         ckpt_filename: Optional[str] = None,
+                         weight_path: Optional[str] = None,
+                         sample_count: int = 50 * 1000, seed: int = 888, device: str = "cuda:0",
+                         compute_fid: bool = True, flat_params: Optional[torch.Tensor] = None):
+    """Reference :242-317: generate ``sample_count`` CIFAR10 images with the NI matrix at ``weight_path``
+    and score them.  ``flat_params`` lets a caller supply weights directly (engine order) instead of the
+    score_sde checkpoint."""
+    from .ncsnpp import NCSNppEngine, load_score_sde_checkpoint
+    ckpt_filename = ckpt_filename or str(root_path / "deps/score_sde_pytorch/checkpoint_8.pth")
+    weight_path = weight_path or str(root_path / "weights/step_5_weight_00.npz")
+    if flat_params is None:
+        assert os.path.exists(ckpt_filename)
+        flat_params = load_score_sde_checkpoint(ckpt_filename)
+    C, B, node = load_coeff_npz(weight_path)
+    print(C / np.diag(C)[:, None])
+    print(weight_path)
+    engine = NCSNppEngine(flat_params, max_batch=batch_size, device=device)
+    bz = batch_size
+    num = int(np.ceil(sample_count / bz))
+    ni = CifarNI(C, B, node, bz * 3 * 32 * 32, device=device)
+    torch.manual_seed(seed)
+    all_batch = []
+    for ii in range(num):
+        print("processing", ii)
+        noise = torch.randn(bz, 3, 32, 32, dtype=torch.float32, device=device)
+        out = ni.run(engine, noise)
+        all_batch.append(to_pixel_from_centered(out))
+    all_batch = torch.concatenate(all_batch)
+    if not compute_fid:
+        return all_batch
+    fid_value = calc_fid(all_batch, root_path / "weights/cifar10_mu_sigma.npz", device)
+    print(fid_value)
+    print(weight_path)
+    print(C / np.diag(C)[:, None])
+    return fid_value
+
+
+if __name__ == "__main__":
+    natural_inference_tx()

@@ -1,0 +1,158 @@
+"""Drop-in for ``src/SD3NaturalInference.py``: SD3-medium, 28 steps, CFG 7, fp16, seed 10, n = 4.
+
+Public names as in the reference: ``weighted_sum(seq_xstarts, weights=None)``, ``euler_weighted_sum``,
+``sd_natural_inference_tx()``, ``sd_euler_natural_inference_tx()``.  Per step the two MMDiT calls are
+followed by ONE fused launch (``natinf_step_f16chain``: x0 from velocity, CFG fuse, append, row-normalised
+fp16 weighted mean, next model input).  The MMDiT / text encoders / VAE are third-party (``diffusers``,
+un-vendored and unpinned in the reference); a ``pipe`` object with the same attributes can be passed in.
+The reference's 28x5x4 intermediate VAE decodes (:223-236, visualisation only) are off by default.
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr, stream_ptr
+from .coeff import load_sd3_csv, SparseRows
+from .sampler import SD3NI
+
+root_path = Path(__file__).resolve().parent.parent
+PROMPT = "A cat holding a sign that says hello world"
+
+
+def weighted_sum(seq_xstarts: Sequence[torch.Tensor], weights=None) -> torch.Tensor:
+    """Reference :157-168: fp16 chain, row ``len(seq)-1`` of ``weights`` (uniform mean if None)."""
+    _lib.require_gpu()
+    n = len(seq_xstarts)
+    slab = torch.stack([s.contiguous().reshape(-1) for s in seq_xstarts]).to(torch.float16)
+    E = slab.shape[1]
+    row = np.ones((1, n)) if weights is None else np.asarray(weights, np.float64)[n - 1:n, :n]
+    rows = SparseRows(row, lambda k: n, torch.float32, slab.device, dense=True, diag=False)
+    out = torch.empty(E, dtype=torch.float16, device=slab.device)
+    idx, val, nt = rows.ptrs(0)
+    check(lib.natinf_weighted_mean_f16(ptr(slab), ptr(out), idx, val, nt, rows.rows[0].total, E, stream_ptr()),
+          "natinf_weighted_mean_f16")
+    return out.view(seq_xstarts[0].shape)
+
+
+def euler_weighted_sum(seq_xstarts, cliplen=0):
+    """Reference :61-69: ``seq_xstarts`` = [(weight 0-d tensor, x0)], returns (acc, acc/sum_w) in fp16 ops."""
+    _lib.require_gpu()
+    seq = seq_xstarts[-cliplen:]
+    n = len(seq)
+    slab = torch.stack([x.contiguous().reshape(-1) for _, x in seq]).to(torch.float16)
+    E = slab.shape[1]
+    h = lambda t: float(torch.as_tensor(t, dtype=torch.float32).to(torch.float16))
+    tot = 0
+    for w, _ in seq:
+        tot = tot + torch.as_tensor(w, dtype=torch.float32).cpu()
+    row = np.array([[h(torch.as_tensor(w).cpu()) for w, _ in seq]])
+    rows = SparseRows(row, lambda k: n, torch.float32, slab.device, dense=True, diag=False)
+    idx, val, nt = rows.ptrs(0)
+    acc = torch.empty(E, dtype=torch.float16, device=slab.device)
+    mean = torch.empty(E, dtype=torch.float16, device=slab.device)
+    check(lib.natinf_weighted_mean_f16(ptr(slab), ptr(acc), idx, val, nt, 1.0, E, stream_ptr()), "natinf_weighted_mean_f16")
+    check(lib.natinf_weighted_mean_f16(ptr(slab), ptr(mean), idx, val, nt, h(tot), E, stream_ptr()), "natinf_weighted_mean_f16")
+    shape = seq[0][1].shape
+    return acc.view(shape), mean.view(shape)
+
+
+def _load_pipe(pipe, device, dtype):
+    if pipe is not None:
+        return pipe
+    try:
+        from diffusers import StableDiffusion3Pipeline
+    except ImportError as e:
+        raise ImportError("SD3 needs the `diffusers` package and the stabilityai/stable-diffusion-3-medium-diffusers "
+                          "weights (un-vendored in the reference); pass pipe=... to use another denoiser") from e
+    return StableDiffusion3Pipeline.from_pretrained("stabilityai/stable-diffusion-3-medium-diffusers",
+                                                    torch_dtype=dtype, local_files_only=True).to(device)
+
+
+def _prepare(pipe, device, dtype, n, seed, num_step, noises):
+    prompts = [PROMPT] * n
+    if noises is None:
+        generator = torch.Generator(device)
+        generator.manual_seed(seed)
+        noises = torch.randn(n, 16, 128, 128, device=device, dtype=dtype, generator=generator)
+    emb = pipe.encode_prompt(prompt=prompts, prompt_2=None, prompt_3=None, negative_prompt="")
+    pipe.scheduler.set_timesteps(num_step, device=device)
+    return noises, emb, pipe.scheduler.timesteps.to(device), pipe.scheduler.sigmas.to(device)
+
+
+def _decode(pipe, latents):
+    z = (latents / pipe.vae.config.scaling_factor) + pipe.vae.config.shift_factor
+    images = pipe.vae.decode(z, return_dict=False)[0]
+    return pipe.image_processor.postprocess(images, output_type="pil")
+
+
+def _velocities(pipe, x, ts, emb):
+    pe, ne, ppe, npe = emb
+    vt = pipe.transformer(hidden_states=x, timestep=ts, encoder_hidden_states=pe, pooled_projections=ppe, return_dict=False)[0]
+    vn = pipe.transformer(hidden_states=x, timestep=ts, encoder_hidden_states=ne, pooled_projections=npe, return_dict=False)[0]
+    return vt.contiguous(), vn.contiguous()
+
+
+@torch.no_grad()
+def sd_natural_inference_tx(pipe=None, device="cuda", noises: Optional[torch.Tensor] = None, n: int = 4, seed: int = 10,
+                            num_step: int = 28, weight_names=("sd3_step_28_weight.csv", "sd3_step_28_weight_sharp.csv"),
+                            decode: bool = True) -> List[torch.Tensor]:
+    """Reference :172-245.  Returns the final latents per weight file (and writes ``results/sd3/sgl_*.png``
+    when ``decode``)."""
+    dtype = torch.float16
+    pipe = _load_pipe(pipe, device, dtype)
+    noises, emb, timesteps, sigmas = _prepare(pipe, device, dtype, n, seed, num_step, noises)
+    shape, finals = noises.shape, []
+    for weight_name in weight_names:
+        weights = load_sd3_csv(os.path.join(root_path / "weights", weight_name))
+        ni = SD3NI(weights, sigmas, noises.numel(), device=noises.device, cfg=7.0)
+        flat_noise = noises.contiguous().reshape(-1)
+        x = ni.first_input(flat_noise)
+        for kk in range(num_step):
+            ts = timesteps[kk].expand(shape[0])
+            vt, vn = _velocities(pipe, x.view(shape), ts, emb)
+            mean, x = ni.step(kk, x, vt.reshape(-1), vn.reshape(-1), flat_noise, want_next=kk + 1 < num_step)
+        out = mean.view(shape).clone()
+        finals.append(out)
+        if decode:
+            import cv2
+            images = _decode(pipe, out)
+            img_all = np.hstack([np.array(image)[:, :, ::-1] for image in images])
+            path = root_path / ("results/sd3/sgl_%s.png" % (weight_name[:-4]))
+            os.makedirs(path.parent, exist_ok=True)
+            cv2.imwrite(str(path), img_all)
+    return finals
+
+
+@torch.no_grad()
+def sd_euler_natural_inference_tx(pipe=None, device="cuda", noises: Optional[torch.Tensor] = None, n: int = 4,
+                                  seed: int = 10, num_step: int = 28, decode: bool = True) -> torch.Tensor:
+    """Reference :81-154 with ``is_vanilla_update = False``: flow-Euler written as Natural Inference."""
+    dtype = torch.float16
+    pipe = _load_pipe(pipe, device, dtype)
+    noises, emb, timesteps, sigmas = _prepare(pipe, device, dtype, n, seed, num_step, noises)
+    shape = noises.shape
+    ni = SD3NI(None, sigmas, noises.numel(), device=noises.device, cfg=7.0, euler=True)
+    flat_noise = noises.contiguous().reshape(-1)
+    x = ni.first_input(flat_noise)
+    for i in range(num_step):
+        ts = timesteps[i].expand(shape[0])
+        vt, vn = _velocities(pipe, x.view(shape), ts, emb)
+        mean, x = ni.step(i, x, vt.reshape(-1), vn.reshape(-1), flat_noise, want_next=i + 1 < num_step)
+    out = mean.view(shape).clone()
+    if decode:
+        import cv2
+        images = _decode(pipe, out)
+        path = root_path / "results/sd3/euler_sgl_clip0.png"
+        os.makedirs(path.parent, exist_ok=True)
+        cv2.imwrite(str(path), np.hstack([np.array(image)[:, :, ::-1] for image in images]))
+    return out
+
+
+if __name__ == "__main__":
+    sd_natural_inference_tx()

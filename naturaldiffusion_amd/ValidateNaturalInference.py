@@ -1,0 +1,235 @@
+"""Drop-in for ``src/ValidateNaturalInference.py``: original DDPM / DDIM skip samplers vs their
+Natural Inference (coefficient-matrix) form, DiT-XL/2 + CFG 4.0, 24 steps, seed 0.
+
+Same public names as the reference (``space_timesteps``, ``create_ddpm_coeff``, ``skip_ddpm_coeff``,
+``create_ddim_coeff``, ``skip_ddim_coeff``, ``calc_x0_mean_z``, ``forward_cfg``, ``weighted_sum``,
+``ddpm_skip_sample``, ``ddim_skip_sample``, ``natural_inference``, ``compare_output_tx``; globals
+``vae_path``, ``model_path``).  ``natural_inference`` -- the path being accelerated -- runs one fused
+``natinf_step_f32prod`` launch per step.  The two *original* samplers are the baselines it is compared
+with and stay host-sequenced tensor algebra.  The DiT-XL/2 denoiser and the VAE come from un-vendored
+packages (``timm``/``diffusers``, reference requirements.txt:13-14); they are injected through
+``denoiser_factory`` / ``decoder_factory`` so the samplers can be exercised without them.
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr, stream_ptr
+from .coeff import load_coeff_npz, SparseRows
+from .sampler import ValidateNI
+
+root_path = Path(__file__).resolve().parent.parent
+vae_path = None
+model_path = None
+device = "cuda:0"
+
+# hooks: () -> object with .forward(z, t, y) returning [B, 8, H, W]; () -> callable(latents) -> images
+denoiser_factory: Optional[Callable] = None
+decoder_factory: Optional[Callable] = None
+last_latents: Optional[torch.Tensor] = None      # final latents of the most recent sampler call
+
+
+def make_path(path):
+    path = os.path.abspath(path)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    return path
+
+
+def space_timesteps(num_timesteps, section_counts):
+    """Timesteps kept when striding a ``num_timesteps`` process (reference :28-79; improved-DDPM recipe)."""
+    if isinstance(section_counts, str):
+        if section_counts.startswith("ddim"):
+            want = int(section_counts[4:])
+            for stride in range(1, num_timesteps):
+                if len(range(0, num_timesteps, stride)) == want:
+                    return set(range(0, num_timesteps, stride))
+            raise ValueError(f"cannot create exactly {num_timesteps} steps with an integer stride")
+        section_counts = [int(v) for v in section_counts.split(",")]
+    base, extra = divmod(num_timesteps, len(section_counts))
+    start, steps = 0, []
+    for i, count in enumerate(section_counts):
+        size = base + (1 if i < extra else 0)
+        if size < count:
+            raise ValueError(f"cannot divide section of {size} steps into {count}")
+        stride = 1 if count <= 1 else (size - 1) / (count - 1)
+        pos = 0.0
+        for _ in range(count):
+            steps.append(start + round(pos))
+            pos += stride
+        start += size
+    return set(steps)
+
+
+def _abar():
+    betas = np.linspace(0.0001, 0.02, 1000, dtype=np.float64)
+    alphas = 1 - betas
+    return betas, alphas, np.cumprod(alphas)
+
+
+def create_ddpm_coeff():
+    """[alphas, alphas_bar, log_var, coeff_xt2x0, coeff_eps2x0, coeff_xt, coeff_x0] (reference :82-99)."""
+    betas, alphas, abar = _abar()
+    prev = np.append(1.0, abar[:-1])
+    var = betas * (1.0 - prev) / (1.0 - abar)
+    return [alphas, abar, np.log(np.append(1E-5, var[1:])), np.sqrt(1.0 / abar), np.sqrt(1.0 / abar - 1),
+            np.sqrt(alphas) * (1 - prev) / (1 - abar), np.sqrt(prev) * betas / (1 - abar)]
+
+
+def _skip(abar, num_step):
+    idx = sorted(space_timesteps(1000, str(num_step)))
+    sab = abar[idx]
+    sa = np.zeros_like(sab)
+    sa[0] = sab[0]
+    sa[1:] = sab[1:] / sab[:-1]
+    return idx, sa, sab, np.append(1.0, sab[:-1])
+
+
+def skip_ddpm_coeff(coeff_all, num_step=50):
+    """Re-derive the DDPM tables on the strided schedule (reference :102-133)."""
+    idx, sa, sab, prev = _skip(coeff_all[1], num_step)
+    sb = 1 - sa
+    var = sb * (1.0 - prev) / (1.0 - sab)
+    out = [sa, sab, np.log(np.append(1E-5, var[1:])), np.sqrt(1.0 / sab), np.sqrt(1.0 / sab - 1),
+           np.sqrt(sa) * (1 - prev) / (1 - sab), np.sqrt(prev) * sb / (1 - sab)]
+    return out, idx
+
+
+def create_ddim_coeff():
+    """(alphas, alphas_bar, coeff_xt2x0, coeff_eps2x0, coeff_xt, coeff_x0) (reference :136-151)."""
+    _, alphas, abar = _abar()
+    prev = np.append(1.0, abar[:-1])
+    rect = np.sqrt((1 - prev) / (1 - abar))
+    return alphas, abar, np.sqrt(1.0 / abar), np.sqrt(1.0 / abar - 1), rect, np.sqrt(prev) - rect * np.sqrt(abar)
+
+
+def skip_ddim_coeff(coeff_all, num_step=50):
+    """Reference :154-174."""
+    idx, sa, sab, prev = _skip(coeff_all[1], num_step)
+    rect = np.sqrt((1 - prev) / (1 - sab))
+    return (sa, sab, np.sqrt(1.0 / sab), np.sqrt(1.0 / sab - 1), rect, np.sqrt(prev) - rect * np.sqrt(sab)), idx
+
+
+def calc_x0_mean_z(input_z, eps, coeff, ii):
+    """Reference :177-182."""
+    coeff_xt2x0, coeff_eps2x0, coeff_xt, coeff_x0 = coeff
+    x0 = coeff_xt2x0[ii] * input_z - coeff_eps2x0[ii] * eps
+    return x0, coeff_xt[ii] * input_z + coeff_x0[ii] * x0
+
+
+@torch.no_grad()
+def forward_cfg(model, zt, timesteps, classlabels, cfg_scale, cls):
+    """Reference :185-195: two denoiser calls, first 4 of 8 channels, CFG fuse."""
+    classnulls = torch.tensor([cls] * len(zt), device=zt.device)
+    cond_eps = model.forward(zt, timesteps, classlabels)[:, :4, :, :]
+    uncond_eps = model.forward(zt, timesteps, classnulls)[:, :4, :, :]
+    return cond_eps, uncond_eps, uncond_eps + cfg_scale * (cond_eps - uncond_eps)
+
+
+@torch.no_grad()
+def weighted_sum(weights, seq_elem):
+    """Reference :198-204: fp32 products accumulated in fp64 -> fp32 (``natinf_weighted_sum_f32prod``)."""
+    _lib.require_gpu()
+    slab = torch.stack([s.contiguous().reshape(-1) for s in seq_elem]).to(torch.float32)
+    n, E = slab.shape
+    rows = SparseRows(np.asarray(weights, np.float64)[None, :n], lambda k: n, torch.float32, slab.device, dense=True, diag=False)
+    out = torch.empty(E, dtype=torch.float32, device=slab.device)
+    idx, val, nt = rows.ptrs(0)
+    check(lib.natinf_weighted_sum_f32prod(ptr(slab), ptr(out), idx, val, nt, E, stream_ptr()), "natinf_weighted_sum_f32prod")
+    return out.view(seq_elem[0].shape)
+
+
+def _setup(seed):
+    torch.manual_seed(seed)
+    torch.set_grad_enabled(False)
+    if denoiser_factory is None:
+        raise RuntimeError("set ValidateNaturalInference.denoiser_factory (DiT-XL/2 needs the un-vendored `timm`; "
+                           "see INTEGRATION.md)")
+    model = denoiser_factory()
+    labels = torch.tensor([207, 360, 387, 974, 88, 979, 417, 279], device=device)
+    return model, labels, len(labels)
+
+
+def _finish(input_z, name):
+    global last_latents
+    last_latents = input_z
+    if decoder_factory is not None:
+        decoder_factory()(input_z / 0.18215, make_path(root_path / ("results/validation/" + name)))
+    return input_z
+
+
+def _original(num_step, stochastic, seed=0):
+    model, labels, n = _setup(seed)
+    tables, skip_idxs = (skip_ddpm_coeff(create_ddpm_coeff(), num_step) if stochastic
+                         else skip_ddim_coeff(create_ddim_coeff(), num_step))
+    tb = [torch.from_numpy(e).to(device=device, dtype=torch.float32) for e in tables]
+    log_var = tb[2] if stochastic else None
+    coeff = tuple(tb[3:7]) if stochastic else tuple(tb[2:6])
+    input_z = torch.randn(n, 4, 32, 32, device=device)
+    for ii in list(range(0, num_step))[::-1]:
+        timesteps = torch.ones(n, dtype=torch.int32, device=device) * skip_idxs[ii]
+        _, _, fuse_eps = forward_cfg(model, input_z, timesteps, labels, 4.0, 1000)
+        _, mean_z = calc_x0_mean_z(input_z, fuse_eps, coeff, ii)
+        if stochastic:
+            noise = torch.randn_like(input_z, dtype=torch.float32, device=device)
+            input_z = mean_z + torch.exp(0.5 * log_var[ii]) * noise
+        else:
+            input_z = mean_z
+    return input_z
+
+
+def ddpm_skip_sample(num_step=24):
+    """Reference :207-256 (the classical ancestral sampler NI is compared with)."""
+    return _finish(_original(num_step, True), "ddpm_%03d__seed_%d__original.png" % (num_step, 0))
+
+
+@torch.no_grad()
+def ddim_skip_sample(num_step=24):
+    """Reference :259-308."""
+    return _finish(_original(num_step, False), "ddim_%03d__seed_%d__original.png" % (num_step, 0))
+
+
+def natural_inference(alg_name="ddpm", num_step=24):
+    """Reference :311-372 on the fused kernel: per step two denoiser calls, one fresh ``randn_like`` written
+    straight into the noise-history slab, one ``natinf_step_f32prod`` launch."""
+    model, labels, n = _setup(0)
+    weight_path = root_path / ("results/%s/%s_%03d.npz" % (alg_name.replace("_sympy", ""), alg_name, num_step))
+    C, B, node = load_coeff_npz(weight_path)
+    num_step = B.shape[0]
+    tables, _ = skip_ddim_coeff(create_ddim_coeff(), num_step)
+    c1 = np.asarray(tables[2])[::-1]
+    c2 = np.asarray(tables[3])[::-1]
+    E = n * 4 * 32 * 32
+    ni = ValidateNI(C, B, node, c1.astype(np.float32), c2.astype(np.float32), E, device=device)
+    noise = torch.randn(n, 4, 32, 32, device=device)
+    ni.hist_eps[0].copy_(noise.reshape(-1))
+    input_z = noise.clone()
+    for kk in range(num_step):
+        timesteps = torch.ones(n, dtype=torch.int32, device=device) * int(node[kk, 0])
+        classnulls = torch.tensor([1000] * n, device=device)
+        cond = model.forward(input_z, timesteps, labels)          # [n, 8, 32, 32]; first 4 channels used
+        uncond = model.forward(input_z, timesteps, classnulls)
+        ni.hist_eps[kk + 1].copy_(torch.randn_like(input_z, dtype=torch.float32, device=device).reshape(-1))
+        per, stride = 4 * 32 * 32, cond.shape[1] * 32 * 32
+        z = ni.step(kk, input_z.reshape(-1), cond.contiguous(), uncond.contiguous(), 4.0, per, stride)
+        input_z = z.view(n, 4, 32, 32)
+    weight_name = os.path.basename(weight_path)[:-4]
+    return _finish(input_z.clone(), "%s__seed_%d__natural.png" % (weight_name, 0))
+
+
+def compare_output_tx():
+    ddpm_skip_sample(24)
+    ddim_skip_sample(24)
+    natural_inference("ddpm_sympy", 24)
+    natural_inference("ddim_sympy", 24)
+
+
+if __name__ == "__main__":
+    vae_path = "./sd-vae-ft-ema"
+    model_path = "./DiT-XL-2-256x256.pt"
+    compare_output_tx()

@@ -1,0 +1,83 @@
+"""ctypes binding of libnatinf.so (include/natinf.h, include/natinf_ncsnpp.h).
+
+The product path fails loudly: no library -> ImportError with the build command; a negative
+return code -> RuntimeError naming the entry point.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("NATINF_LIB", _HERE / "libnatinf.so"))
+
+if not LIB_PATH.exists():
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `make -C {_HERE / 'csrc'}` "
+        "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+        "naturaldiffusion_amd has no CPU or eager-PyTorch fallback.")
+
+lib = C.CDLL(str(LIB_PATH))
+
+_p, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+
+SIGNATURES = {
+    "natinf_abi_version": (C.c_int, []),
+    "natinf_strerror": (C.c_char_p, [_i32]),
+    "natinf_probe": (C.c_int, []),
+    "natinf_step_f64hist": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _f64, _i32, _f64, _f64, _f32, _f32, _i64, _p]),
+    "natinf_step_f32hist": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _f32, _i32, _f32, _f32, _f32, _f32, _i64, _p]),
+    "natinf_weighted_sum_f64": (C.c_int, [_p, _p, _p, _p, _i32, _i64, _p]),
+    "natinf_to_pixel_u8": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "natinf_step_f32prod": (C.c_int, [_p, _p, _p, _f32, _i64, _i64, _p, _p, _p, _p, _p, _i32, _f32, _p, _p, _i32,
+                                      _i32, _f32, _f32, _i64, _p]),
+    "natinf_weighted_sum_f32prod": (C.c_int, [_p, _p, _p, _p, _i32, _i64, _p]),
+    "natinf_step_f16chain": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _f32, _f32, _i32, _f32, _f32, _f32,
+                                       _f32, _i32, _i64, _p]),
+    "natinf_weighted_mean_f16": (C.c_int, [_p, _p, _p, _p, _i32, _f32, _i64, _p]),
+    "natinf_flow_input_f16": (C.c_int, [_p, _p, _p, _f32, _f32, _i64, _p]),
+    # include/natinf_ncsnpp.h
+    "natinf_ncsnpp_param_count": (C.c_int64, []),
+    "natinf_ncsnpp_workspace_bytes": (C.c_int64, [_p, _i32]),
+    "natinf_ncsnpp_packed_bytes": (C.c_int64, []),
+    "natinf_ncsnpp_create": (C.c_int, [C.POINTER(_p), _i32]),
+    "natinf_ncsnpp_describe": (C.c_int, [_p, C.c_char_p, _i32]),
+    "natinf_ncsnpp_destroy": (C.c_int, [_p]),
+    "natinf_ncsnpp_load": (C.c_int, [_p, _p, _i64, _p, _i64, _p]),
+    "natinf_ncsnpp_forward": (C.c_int, [_p, _p, _p, _p, _i32, _p, _i64, _p]),
+    "natinf_ncsnpp_debug_tap": (C.c_int, [_p, _i32, _p, _i64, _p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    try:
+        _fn = getattr(lib, _name)
+    except AttributeError as e:                       # header and library out of sync
+        raise ImportError(f"{LIB_PATH} does not export {_name}; rebuild it") from e
+    _fn.restype, _fn.argtypes = _res, _args
+
+SD3_CFG_ON_VELOCITY = 1
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {lib.natinf_strerror(rc).decode()} ({rc})")
+
+
+def stream_ptr(stream=None) -> int:
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return int(s.cuda_stream)
+
+
+def ptr(t) -> int:
+    return 0 if t is None else int(t.data_ptr())
+
+
+def require_gpu() -> None:
+    """Raise unless a gfx950 device is visible and the code object loads on it."""
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("naturaldiffusion_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False "
+                           "and there is no CPU fallback")
+    check(lib.natinf_probe(), "natinf_probe")

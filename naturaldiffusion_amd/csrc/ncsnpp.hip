@@ -1,0 +1,649 @@
+// ncsnpp.hip -- host side of the NCSN++ denoiser engine: static execution plan, weight packing,
+// forward; C ABI of include/natinf_ncsnpp.h.  Kernels: ncsnpp_kernels.h.
+//
+// Design (MI355X-first, not a translation of the reference's nn.Module tree):
+//   * the network is compiled once into a flat op list (~330 launches) over ONE caller-supplied
+//     workspace; every tensor offset is "bytes per image", so a plan built once serves any batch;
+//   * activations are NHWC bf16; U-Net skip tensors are written by their producer straight into the
+//     channel slice of the concat buffer their consumer will read (no torch.cat copies), and an up-path
+//     block writes its output into the first channel slice of the next block's concat buffer;
+//   * a res-block is 6 launches: GN-stats, GN-apply(+SiLU, +up/down of both branches), conv3x3 GEMM
+//     (+bias +time-embedding row), GN-stats, GN-apply, conv3x3 GEMM whose K range is extended by the
+//     1x1 shortcut conv (one GEMM computes Conv_1(h) + Conv_2(x)) with the residual add and the
+//     1/sqrt(2) rescale in its epilogue;
+//   * the 44 per-block time-embedding projections (Dense_0) are one GEMM at the top of the forward.
+//
+// Reference: deps/score_sde_pytorch/models/ncsnpp.py:232-381, layerspp.py:75-91,242-274,
+// layers.py:515-555, up_or_down_sampling.py:59-69.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "natinf_ncsnpp.h"
+#include "ncsnpp_kernels.h"
+
+using namespace ncsn;
+
+namespace {
+
+constexpr int NF = 128, NUM_RES = 4, IMG = 32, TEMB = 512, NLEVEL = 4;
+constexpr int CH_MULT[NLEVEL] = {1, 2, 2, 2};
+constexpr float GN_EPS = 1e-6f;
+constexpr float INV_SQRT2 = 0.70710678118654752440f;
+inline bool attn_at(int res) { return res == 16; }
+inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+enum Kind { K_LIN, K_CONV, K_RES, K_ATTN, K_GN };
+const char* kind_name(int k) { static const char* n[] = {"lin", "conv", "res", "attn", "gn"}; return n[k]; }
+
+struct Mod { int idx, kind, cin, cout, up, down, res; int64_t poff; };
+
+// tensor reference inside the workspace: `off` is BYTES PER IMAGE (actual = off * B)
+struct TRef { int64_t off = -1; int C = 0, ld = 0, res = 0, coff = 0; };   // coff: channel offset inside a wider buffer
+
+struct Ctx {                     // per-forward launch context
+    int B; unsigned char* ws; const unsigned char* wp; hipStream_t stream;
+    const float* x; const float* labels; float* out;
+    bf16* act(const TRef& t) const { return reinterpret_cast<bf16*>(ws + t.off * B) + t.coff; }
+    template <class T> T* at(int64_t off) const { return reinterpret_cast<T*>(ws + off * B); }
+    template <class T> const T* w(int64_t off) const { return reinterpret_cast<const T*>(wp + off); }
+};
+using OpFn = std::function<void(const Ctx&)>;
+
+struct PackCtx { const float* params; unsigned char* packed; hipStream_t stream; };
+using PackFn = std::function<void(const PackCtx&)>;
+
+// first-fit arena over "bytes per image"
+struct Arena {
+    bool keep = false; int64_t top = 0, peak = 0;
+    std::map<int64_t, int64_t> free_;      // off -> size
+    std::map<int64_t, int64_t> live_;
+    int64_t alloc(int64_t bytes) {
+        bytes = align_up(bytes, 256);
+        if (!keep)
+            for (auto it = free_.begin(); it != free_.end(); ++it)
+                if (it->second >= bytes) {
+                    const int64_t off = it->first, rest = it->second - bytes;
+                    free_.erase(it);
+                    if (rest) free_[off + bytes] = rest;
+                    live_[off] = bytes;
+                    return off;
+                }
+        const int64_t off = top; top += bytes; if (top > peak) peak = top;
+        live_[off] = bytes;
+        return off;
+    }
+    void release(int64_t off) {
+        if (keep || off < 0) return;
+        auto it = live_.find(off);
+        if (it == live_.end()) return;
+        int64_t o = off, s = it->second;
+        live_.erase(it);
+        auto nx = free_.lower_bound(o);
+        if (nx != free_.end() && o + s == nx->first) { s += nx->second; nx = free_.erase(nx); }
+        if (nx != free_.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == o) { o = pv->first; s += pv->second; free_.erase(pv); } }
+        if (o + s == top) top = o; else free_[o] = s;
+    }
+};
+
+}  // namespace
+
+struct natinf_ncsnpp {
+    int flags = 0;
+    std::vector<Mod> mods;
+    int64_t n_params = 0;
+    std::vector<OpFn> ops;
+    std::vector<PackFn> packs;
+    std::map<int, TRef> taps;            // module idx -> output tensor
+    int64_t ws_per_image = 0, packed_bytes = 0;
+    const unsigned char* packed = nullptr;
+    bool attr_set = false;
+    int last_B = 0; unsigned char* last_ws = nullptr;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+GemmArgs gemm_defaults() {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.taps = 1; g.batch = 1; g.scale = 1.0f; g.act = ACT_NONE; g.c_mode = OUT_BF16;
+    return g;
+}
+void launch_gemm(const GemmArgs& g, hipStream_t s) {
+    const int nM = (g.M + BM - 1) / BM, nN = (g.N + BN - 1) / BN;
+    hipLaunchKernelGGL(k_gemm_bf16, dim3(nM * nN, 1, g.batch), dim3(256), GEMM_LDS_BYTES, s, g);
+}
+inline int grid1d(int64_t n, int block = 256, int cap = 4096) {
+    int64_t g = (n + block - 1) / block; return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ------------------------------------------------------------------------------------------------
+// plan builder
+// ------------------------------------------------------------------------------------------------
+struct Builder {
+    natinf_ncsnpp& E;
+    Arena arena;
+    int64_t wtop = 0;                    // packed-weight bump pointer (bytes)
+    int64_t poff = 0;                    // running parameter offset (floats)
+    // time-embedding projection bank
+    int dense_total = 0; int64_t dense_w = 0, dense_b = 0, dense_out = 0;
+
+    explicit Builder(natinf_ncsnpp& e) : E(e) { arena.keep = (e.flags & NATINF_NCSNPP_KEEP_ACTIVATIONS) != 0; }
+
+    int64_t wres(int64_t bytes) { const int64_t o = wtop; wtop += align_up(bytes, 256); return o; }
+    int64_t take(int64_t n) { const int64_t o = poff; poff += n; return o; }
+
+    // ---- weight packing recipes -------------------------------------------------------------
+    void pack_conv(int64_t src, int64_t dst, int N, int Cin, int taps, int dst_ld, int koff, int tapstride) {
+        E.packs.push_back([=](const PackCtx& p) {
+            const int64_t n = (int64_t)N * Cin * taps;
+            hipLaunchKernelGGL(k_pack_conv, dim3(grid1d(n, 256, 1 << 30)), dim3(256), 0, p.stream, p.params + src,
+                               reinterpret_cast<bf16*>(p.packed + dst), N, Cin, taps, dst_ld, koff, tapstride);
+        });
+    }
+    void pack_transpose(int64_t src, int64_t dst, int K, int N, int dst_ld) {
+        E.packs.push_back([=](const PackCtx& p) {
+            hipLaunchKernelGGL(k_pack_transpose, dim3(grid1d((int64_t)K * N, 256, 1 << 30)), dim3(256), 0, p.stream,
+                               p.params + src, reinterpret_cast<bf16*>(p.packed + dst), K, N, dst_ld);
+        });
+    }
+    void pack_zero(int64_t dst, int64_t n) {
+        E.packs.push_back([=](const PackCtx& p) {
+            hipLaunchKernelGGL(k_fill_bf16_zero, dim3(grid1d(n, 256, 1 << 30)), dim3(256), 0, p.stream,
+                               reinterpret_cast<bf16*>(p.packed + dst), n);
+        });
+    }
+    int64_t pack_f32(int64_t src, int n, int64_t src2 = -1) {          // returns packed offset of an fp32 vector
+        const int64_t dst = wres((int64_t)n * 4);
+        pack_f32_at(src, n, dst, src2);
+        return dst;
+    }
+    void pack_f32_at(int64_t src, int n, int64_t dst, int64_t src2 = -1) {
+        E.packs.push_back([=](const PackCtx& p) {
+            hipLaunchKernelGGL(k_copy_add_f32, dim3(grid1d(n)), dim3(256), 0, p.stream, p.params + src,
+                               src2 >= 0 ? p.params + src2 : nullptr, reinterpret_cast<float*>(p.packed + dst), n);
+        });
+    }
+
+    // ---- op emitters ------------------------------------------------------------------------
+    struct GN { int64_t gamma, beta; };
+    GN take_gn(int C) { GN g; g.gamma = pack_f32(take(C), C); g.beta = pack_f32(take(C), C); return g; }
+
+    // GroupNorm statistics of x -> (scale, shift) per (image, channel); returns their arena offsets
+    void emit_gn_stats(const TRef& x, GN gn, int64_t sc, int64_t sh) {
+        const int HW = x.res * x.res;
+        E.ops.push_back([=](const Ctx& c) {
+            hipLaunchKernelGGL(k_gn_stats, dim3(c.B), dim3(256), 0, c.stream, c.act(x), x.ld, x.C, HW,
+                               c.w<float>(gn.gamma), c.w<float>(gn.beta), c.at<float>(sc), c.at<float>(sh), GN_EPS);
+        });
+    }
+    void emit_gn_apply(const TRef& x, int64_t sc, int64_t sh, const TRef& y, const TRef* xr, int act, int mode) {
+        const int HW = x.res * x.res;
+        const int64_t chunks_per_img = (int64_t)(mode == RS_DOWN ? HW / 4 : HW) * (x.C / 8);
+        const int logW = ilog2(x.res), logHW = 2 * logW;
+        const TRef xrr = xr ? *xr : TRef();
+        E.ops.push_back([=](const Ctx& c) {
+            const int64_t total = chunks_per_img * c.B;
+            hipLaunchKernelGGL(k_gn_apply, dim3(grid1d(total, 256, 8192)), dim3(256), 0, c.stream, c.act(x), x.ld, x.C,
+                               logW, logHW, c.at<float>(sc), c.at<float>(sh), c.act(y),
+                               xrr.off >= 0 ? c.act(xrr) : (bf16*)nullptr, act, mode, total);
+        });
+    }
+    TRef new_act(int res, int C) { TRef t; t.off = arena.alloc((int64_t)res * res * C * 2); t.C = C; t.ld = C; t.res = res; return t; }
+
+    void emit_res(const Mod& m, const TRef& x, const TRef& out) {
+        const int cin = m.cin, cout = m.cout;
+        const int ro = m.up ? m.res * 2 : (m.down ? m.res / 2 : m.res);
+        const bool shortcut = cin != cout || m.up || m.down;
+        // parameters in registration order (layerspp.py:204-228)
+        const GN gn0 = take_gn(cin);
+        const int64_t p_c0w = take((int64_t)cout * cin * 9), p_c0b = take(cout);
+        const int64_t p_dw = take((int64_t)cout * TEMB), p_db = take(cout);
+        const GN gn1 = take_gn(cout);
+        const int64_t p_c1w = take((int64_t)cout * cout * 9), p_c1b = take(cout);
+        const int64_t p_c2w = shortcut ? take((int64_t)cout * cin) : -1, p_c2b = shortcut ? take(cout) : -1;
+
+        const int K0a = 9 * cin, K1tot = 9 * cout + (shortcut ? cin : 0);
+        const int64_t w0 = wres((int64_t)cout * K0a * 2), w1 = wres((int64_t)cout * K1tot * 2);
+        pack_conv(p_c0w, w0, cout, cin, 9, K0a, 0, cin);
+        pack_conv(p_c1w, w1, cout, cout, 9, K1tot, 0, cout);
+        if (shortcut) pack_conv(p_c2w, w1, cout, cin, 1, K1tot, 9 * cout, cin);
+        const int64_t b0 = pack_f32(p_c0b, cout), b1 = pack_f32(p_c1b, cout, shortcut ? p_c2b : -1);
+        // time-embedding projection rows of this block inside the shared bank
+        const int drow = dense_rows_next;
+        pack_conv(p_dw, dense_w + (int64_t)drow * TEMB * 2, cout, TEMB, 1, TEMB, 0, TEMB);
+        pack_f32_at(p_db, cout, dense_b + (int64_t)drow * 4);
+        dense_rows_next += cout;
+
+        const int64_t sc = arena.alloc((int64_t)std::max(cin, cout) * 4), sh = arena.alloc((int64_t)std::max(cin, cout) * 4);
+        emit_gn_stats(x, gn0, sc, sh);
+        TRef h = new_act(ro, cin), xr;
+        if (m.up || m.down) xr = new_act(ro, cin);
+        emit_gn_apply(x, sc, sh, h, (m.up || m.down) ? &xr : nullptr, ACT_SILU, m.up ? RS_UP : (m.down ? RS_DOWN : RS_NONE));
+
+        TRef t = new_act(ro, cout);
+        const int logW = ilog2(ro), logHW = 2 * logW, HWo = ro * ro;
+        const int dtotal = dense_total; const int64_t dout = dense_out;
+        E.ops.push_back([=](const Ctx& c) {
+            GemmArgs g = gemm_defaults();
+            g.a0 = c.act(h); g.a0_ld = h.ld; g.a0_C = cin; g.taps = 9; g.logW = logW; g.logHW = logHW;
+            g.M = c.B * HWo; g.N = cout; g.b = c.w<bf16>(w0); g.b_ld = K0a;
+            g.bias_n = c.w<float>(b0);
+            g.rowvec = c.at<float>(dout) + drow; g.rowvec_ld = dtotal; g.log_rows_per_sample = logHW;
+            g.c = c.act(t); g.c_ld = t.ld;
+            launch_gemm(g, c.stream);
+        });
+        arena.release(h.off);
+        emit_gn_stats(t, gn1, sc, sh);
+        TRef u = new_act(ro, cout);
+        emit_gn_apply(t, sc, sh, u, nullptr, ACT_SILU, RS_NONE);
+        arena.release(t.off);
+        const TRef xs = (m.up || m.down) ? xr : x;           // shortcut source at the output resolution
+        E.ops.push_back([=](const Ctx& c) {
+            GemmArgs g = gemm_defaults();
+            g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_C = cout; g.taps = 9; g.logW = logW; g.logHW = logHW;
+            if (shortcut) { g.a1 = c.act(xs); g.a1_ld = xs.ld; g.a1_C = cin; }
+            else { g.resid = c.act(xs); g.resid_ld = xs.ld; }
+            g.M = c.B * HWo; g.N = cout; g.b = c.w<bf16>(w1); g.b_ld = K1tot;
+            g.bias_n = c.w<float>(b1); g.scale = INV_SQRT2;
+            g.c = c.act(out); g.c_ld = out.ld;
+            launch_gemm(g, c.stream);
+        });
+        arena.release(u.off);
+        if (m.up || m.down) arena.release(xr.off);
+        arena.release(sc); arena.release(sh);
+        E.taps[m.idx] = out;
+    }
+
+    void emit_attn(const Mod& m, const TRef& x, const TRef& out) {
+        const int C = m.cin, T = m.res * m.res;
+        const GN gn = take_gn(C);
+        int64_t pw[4], pb[4];
+        for (int i = 0; i < 4; ++i) { pw[i] = take((int64_t)C * C); pb[i] = take(C); }
+        const int64_t wqk = wres((int64_t)2 * C * C * 2), wv = wres((int64_t)C * C * 2), w3 = wres((int64_t)C * C * 2);
+        pack_transpose(pw[0], wqk, C, C, C);
+        pack_transpose(pw[1], wqk + (int64_t)C * C * 2, C, C, C);
+        pack_transpose(pw[2], wv, C, C, C);
+        pack_transpose(pw[3], w3, C, C, C);
+        const int64_t bqk = wres((int64_t)2 * C * 4);
+        pack_f32_at(pb[0], C, bqk); pack_f32_at(pb[1], C, bqk + (int64_t)C * 4);
+        const int64_t bv = pack_f32(pb[2], C), b3 = pack_f32(pb[3], C);
+
+        const int64_t sc = arena.alloc((int64_t)C * 4), sh = arena.alloc((int64_t)C * 4);
+        emit_gn_stats(x, gn, sc, sh);
+        TRef h = new_act(m.res, C);
+        emit_gn_apply(x, sc, sh, h, nullptr, ACT_NONE, RS_NONE);
+        const int64_t qk = arena.alloc((int64_t)T * 2 * C * 2), vT = arena.alloc((int64_t)C * T * 2);
+        E.ops.push_back([=](const Ctx& c) {             // q | k  = h Wq | h Wk
+            GemmArgs g = gemm_defaults();
+            g.a0 = c.act(h); g.a0_ld = C; g.a0_C = C; g.M = c.B * T; g.N = 2 * C;
+            g.b = c.w<bf16>(wqk); g.b_ld = C; g.bias_n = c.w<float>(bqk);
+            g.c = c.at<bf16>(qk); g.c_ld = 2 * C;
+            launch_gemm(g, c.stream);
+        });
+        E.ops.push_back([=](const Ctx& c) {             // V^T[b] = Wv^T h[b]^T  (so that P V is an "A B^T" product)
+            GemmArgs g = gemm_defaults();
+            g.a0 = c.w<bf16>(wv); g.a0_ld = C; g.a0_C = C; g.a_bs = 0; g.M = C; g.N = T;
+            g.b = c.act(h); g.b_ld = C; g.b_bs = (int64_t)T * C; g.bias_m = c.w<float>(bv);
+            g.c = c.at<bf16>(vT); g.c_ld = T; g.c_bs = (int64_t)C * T; g.batch = c.B;
+            launch_gemm(g, c.stream);
+        });
+        arena.release(h.off);
+        const int64_t S = arena.alloc((int64_t)T * T * 4);
+        E.ops.push_back([=](const Ctx& c) {             // S[b] = q[b] k[b]^T / sqrt(C)
+            GemmArgs g = gemm_defaults();
+            g.a0 = c.at<bf16>(qk); g.a0_ld = 2 * C; g.a0_C = C; g.a_bs = (int64_t)T * 2 * C; g.M = T; g.N = T;
+            g.b = c.at<bf16>(qk) + C; g.b_ld = 2 * C; g.b_bs = (int64_t)T * 2 * C;
+            g.scale = 1.0f / sqrtf((float)C);
+            g.c = c.at<float>(S); g.c_ld = T; g.c_bs = (int64_t)T * T; g.c_mode = OUT_F32; g.batch = c.B;
+            launch_gemm(g, c.stream);
+        });
+        const int64_t P = arena.alloc((int64_t)T * T * 2);
+        E.ops.push_back([=](const Ctx& c) {
+            const int64_t rows = (int64_t)c.B * T;
+            hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c.stream,
+                               c.at<float>(S), c.at<bf16>(P), T, rows);
+        });
+        arena.release(S);
+        TRef O = new_act(m.res, C);
+        E.ops.push_back([=](const Ctx& c) {             // O[b] = P[b] V[b]
+            GemmArgs g = gemm_defaults();
+            g.a0 = c.at<bf16>(P); g.a0_ld = T; g.a0_C = T; g.a_bs = (int64_t)T * T; g.M = T; g.N = C;
+            g.b = c.at<bf16>(vT); g.b_ld = T; g.b_bs = (int64_t)C * T;
+            g.c = c.act(O); g.c_ld = C; g.c_bs = (int64_t)T * C; g.batch = c.B;
+            launch_gemm(g, c.stream);
+        });
+        arena.release(P); arena.release(vT); arena.release(qk);
+        E.ops.push_back([=](const Ctx& c) {             // out = (x + O W3 + b3) / sqrt(2)
+            GemmArgs g = gemm_defaults();
+            g.a0 = c.act(O); g.a0_ld = C; g.a0_C = C; g.M = c.B * T; g.N = C;
+            g.b = c.w<bf16>(w3); g.b_ld = C; g.bias_n = c.w<float>(b3);
+            g.resid = c.act(x); g.resid_ld = x.ld; g.scale = INV_SQRT2;
+            g.c = c.act(out); g.c_ld = out.ld;
+            launch_gemm(g, c.stream);
+        });
+        arena.release(O.off); arena.release(sc); arena.release(sh);
+        E.taps[m.idx] = out;
+    }
+
+    int dense_rows_next = 0;
+
+    // ---- module list (ncsnpp.py:66-230) ----------------------------------------------------
+    void list_modules() {
+        auto add = [&](int kind, int cin, int cout, int up, int down, int res) {
+            Mod m; m.idx = (int)E.mods.size(); m.kind = kind; m.cin = cin; m.cout = cout; m.up = up; m.down = down; m.res = res; m.poff = 0;
+            E.mods.push_back(m);
+        };
+        add(K_LIN, NF, TEMB, 0, 0, 0); add(K_LIN, TEMB, TEMB, 0, 0, 0); add(K_CONV, 3, NF, 0, 0, IMG);
+        std::vector<int> skip = {NF};
+        int ch = NF, res = IMG;
+        for (int l = 0; l < NLEVEL; ++l) {
+            for (int b = 0; b < NUM_RES; ++b) {
+                add(K_RES, ch, NF * CH_MULT[l], 0, 0, res); ch = NF * CH_MULT[l];
+                if (attn_at(res)) add(K_ATTN, ch, ch, 0, 0, res);
+                skip.push_back(ch);
+            }
+            if (l != NLEVEL - 1) { add(K_RES, ch, ch, 0, 1, res); res /= 2; skip.push_back(ch); }
+        }
+        add(K_RES, ch, ch, 0, 0, res); add(K_ATTN, ch, ch, 0, 0, res); add(K_RES, ch, ch, 0, 0, res);
+        for (int l = NLEVEL - 1; l >= 0; --l) {
+            for (int b = 0; b < NUM_RES + 1; ++b) { add(K_RES, ch + skip.back(), NF * CH_MULT[l], 0, 0, res); skip.pop_back(); ch = NF * CH_MULT[l]; }
+            if (attn_at(res)) add(K_ATTN, ch, ch, 0, 0, res);
+            if (l != 0) { add(K_RES, ch, ch, 1, 0, res); res *= 2; }
+        }
+        add(K_GN, ch, ch, 0, 0, res); add(K_CONV, ch, 3, 0, 0, res);
+    }
+
+    void build() {
+        list_modules();
+        auto& M = E.mods;
+        // ---- the U-Net's concat buffers: up-path res-block j reads cat([h, skip]) --------------
+        struct Cat { TRef buf; int ch_h, ch_s; };
+        std::vector<Cat> cats;
+        std::vector<int> skip_ch, skip_res;
+        {   // dry walk to size them
+            int ch = NF, res = IMG; skip_ch.push_back(NF); skip_res.push_back(IMG);
+            for (int l = 0; l < NLEVEL; ++l) {
+                for (int b = 0; b < NUM_RES; ++b) { ch = NF * CH_MULT[l]; skip_ch.push_back(ch); skip_res.push_back(res); }
+                if (l != NLEVEL - 1) { res /= 2; skip_ch.push_back(ch); skip_res.push_back(res); }
+            }
+            int sp = (int)skip_ch.size();
+            for (int l = NLEVEL - 1; l >= 0; --l) {
+                for (int b = 0; b < NUM_RES + 1; ++b) {
+                    --sp;
+                    Cat c; c.ch_h = ch; c.ch_s = skip_ch[sp];
+                    c.buf = new_act(res, c.ch_h + c.ch_s);
+                    cats.push_back(c);
+                    ch = NF * CH_MULT[l];
+                }
+                if (l != 0) res *= 2;
+            }
+        }
+        const int P = (int)skip_ch.size();
+        auto skip_slot = [&](int i) { const Cat& c = cats[P - 1 - i]; TRef t = c.buf; t.C = c.ch_s; t.coff = c.ch_h; return t; };
+        auto h_slot = [&](int j) { const Cat& c = cats[j]; TRef t = c.buf; t.C = c.ch_h; t.coff = 0; return t; };
+
+        // ---- shared time-embedding bank -------------------------------------------------------
+        for (auto& m : M) if (m.kind == K_RES) dense_total += m.cout;
+        dense_w = wres((int64_t)dense_total * TEMB * 2); dense_b = wres((int64_t)dense_total * 4);
+        dense_out = arena.alloc((int64_t)dense_total * 4);
+        const int64_t emb = arena.alloc(128 * 2), t1 = arena.alloc(TEMB * 2), t2 = arena.alloc(TEMB * 2);
+
+        size_t mi = 0;
+        // modules 0, 1: Linear(128,512), Linear(512,512)
+        {
+            const Mod& m0 = M[mi++]; const Mod& m1 = M[mi++]; (void)m0; (void)m1;
+            const int64_t pw0 = take((int64_t)TEMB * NF), pb0 = take(TEMB), pw1 = take((int64_t)TEMB * TEMB), pb1 = take(TEMB);
+            const int64_t w0 = wres((int64_t)TEMB * NF * 2), w1 = wres((int64_t)TEMB * TEMB * 2);
+            pack_conv(pw0, w0, TEMB, NF, 1, NF, 0, NF); pack_conv(pw1, w1, TEMB, TEMB, 1, TEMB, 0, TEMB);
+            const int64_t b0 = pack_f32(pb0, TEMB), b1 = pack_f32(pb1, TEMB);
+            const int64_t dw = dense_w, db = dense_b, dout = dense_out; const int dtot = dense_total;
+            E.ops.push_back([=](const Ctx& c) {
+                hipLaunchKernelGGL(k_time_embed, dim3(grid1d((int64_t)c.B * 128)), dim3(256), 0, c.stream, c.labels, c.at<bf16>(emb), c.B);
+                GemmArgs g = gemm_defaults();                        // act(Linear_0(emb))
+                g.a0 = c.at<bf16>(emb); g.a0_ld = NF; g.a0_C = NF; g.M = c.B; g.N = TEMB;
+                g.b = c.w<bf16>(w0); g.b_ld = NF; g.bias_n = c.w<float>(b0); g.act = ACT_SILU;
+                g.c = c.at<bf16>(t1); g.c_ld = TEMB;
+                launch_gemm(g, c.stream);
+                g = gemm_defaults();                                 // act(temb) = act(Linear_1(.))
+                g.a0 = c.at<bf16>(t1); g.a0_ld = TEMB; g.a0_C = TEMB; g.M = c.B; g.N = TEMB;
+                g.b = c.w<bf16>(w1); g.b_ld = TEMB; g.bias_n = c.w<float>(b1); g.act = ACT_SILU;
+                g.c = c.at<bf16>(t2); g.c_ld = TEMB;
+                launch_gemm(g, c.stream);
+                g = gemm_defaults();                                 // every block's Dense_0(act(temb)) at once
+                g.a0 = c.at<bf16>(t2); g.a0_ld = TEMB; g.a0_C = TEMB; g.M = c.B; g.N = dtot;
+                g.b = c.w<bf16>(dw); g.b_ld = TEMB; g.bias_n = c.w<float>(db);
+                g.c = c.at<float>(dout); g.c_ld = dtot; g.c_mode = OUT_F32;
+                launch_gemm(g, c.stream);
+            });
+        }
+        // module 2: stem conv 3 -> 128 as im2col (K padded 27 -> 64) + GEMM
+        int si = 0;
+        TRef cur = skip_slot(si++);
+        {
+            const Mod& m = M[mi++];
+            const int64_t pw = take((int64_t)NF * 27), pb = take(NF);
+            const int64_t w = wres((int64_t)NF * 64 * 2);
+            pack_zero(w, (int64_t)NF * 64);
+            pack_conv(pw, w, NF, 3, 9, 64, 0, 3);
+            const int64_t b = pack_f32(pb, NF);
+            const int64_t a0 = arena.alloc((int64_t)IMG * IMG * 64 * 2);
+            const TRef dst = cur;
+            E.ops.push_back([=](const Ctx& c) {
+                const int64_t rows = (int64_t)c.B * IMG * IMG;
+                hipLaunchKernelGGL(k_stem_im2col, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, c.stream, c.x, c.at<bf16>(a0), rows);
+                GemmArgs g = gemm_defaults();
+                g.a0 = c.at<bf16>(a0); g.a0_ld = 64; g.a0_C = 64; g.M = (int)rows; g.N = NF;
+                g.b = c.w<bf16>(w); g.b_ld = 64; g.bias_n = c.w<float>(b);
+                g.c = c.act(dst); g.c_ld = dst.ld;
+                launch_gemm(g, c.stream);
+            });
+            arena.release(a0);
+            E.taps[m.idx] = dst;
+        }
+        // ---- down path ------------------------------------------------------------------------
+        int res = IMG;
+        for (int l = 0; l < NLEVEL; ++l) {
+            for (int b = 0; b < NUM_RES; ++b) {
+                const Mod& m = M[mi++];
+                const TRef dst = skip_slot(si++);
+                if (attn_at(res)) {
+                    TRef tmp = new_act(res, m.cout);
+                    emit_res(m, cur, tmp);
+                    emit_attn(M[mi++], tmp, dst);
+                    arena.release(tmp.off);
+                } else {
+                    emit_res(m, cur, dst);
+                }
+                cur = dst;
+            }
+            if (l != NLEVEL - 1) {
+                const Mod& m = M[mi++];
+                const TRef dst = skip_slot(si++);
+                emit_res(m, cur, dst);
+                cur = dst; res /= 2;
+            }
+        }
+        // ---- middle ---------------------------------------------------------------------------
+        {
+            TRef a = new_act(res, cur.C), b = new_act(res, cur.C);
+            emit_res(M[mi++], cur, a);
+            emit_attn(M[mi++], a, b);
+            arena.release(a.off);
+            emit_res(M[mi++], b, h_slot(0));
+            arena.release(b.off);
+        }
+        // ---- up path --------------------------------------------------------------------------
+        int j = 0;
+        TRef last;
+        for (int l = NLEVEL - 1; l >= 0; --l) {
+            for (int b = 0; b < NUM_RES + 1; ++b) {
+                const Mod& m = M[mi++];
+                const bool level_end = b == NUM_RES;
+                TRef in = cats[j].buf;                           // cat([h, skip]) along channels
+                TRef dst = level_end ? new_act(res, m.cout) : h_slot(j + 1);
+                emit_res(m, in, dst);
+                arena.release(cats[j].buf.off);
+                last = dst; ++j;
+            }
+            if (attn_at(res)) {
+                TRef dst = new_act(res, last.C);
+                emit_attn(M[mi++], last, dst);
+                arena.release(last.off);
+                last = dst;
+            }
+            if (l != 0) {
+                const Mod& m = M[mi++];
+                emit_res(m, last, h_slot(j));
+                arena.release(last.off);
+                res *= 2;
+            }
+        }
+        // ---- head: GroupNorm -> SiLU -> conv3x3 128 -> 3, written as fp32 NCHW -----------------
+        {
+            const Mod& mg = M[mi++]; const Mod& mc = M[mi++];
+            const GN gn = take_gn(mg.cin);
+            const int64_t pw = take((int64_t)3 * mc.cin * 9), pb = take(3);
+            const int Kf = 9 * mc.cin;
+            const int64_t w = wres((int64_t)3 * Kf * 2);
+            pack_conv(pw, w, 3, mc.cin, 9, Kf, 0, mc.cin);
+            const int64_t b = pack_f32(pb, 3);
+            const int64_t sc = arena.alloc((int64_t)mg.cin * 4), sh = arena.alloc((int64_t)mg.cin * 4);
+            emit_gn_stats(last, gn, sc, sh);
+            TRef u = new_act(res, mg.cin);
+            emit_gn_apply(last, sc, sh, u, nullptr, ACT_SILU, RS_NONE);
+            const int logW = ilog2(res), cinf = mc.cin;
+            E.ops.push_back([=](const Ctx& c) {
+                GemmArgs g = gemm_defaults();
+                g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_C = cinf; g.taps = 9; g.logW = logW; g.logHW = 2 * logW;
+                g.M = c.B * res * res; g.N = 3; g.b = c.w<bf16>(w); g.b_ld = Kf; g.bias_n = c.w<float>(b);
+                g.c = c.out; g.c_mode = OUT_F32_NCHW;
+                launch_gemm(g, c.stream);
+            });
+            E.taps[mg.idx] = last;          // (pre-norm tensor; the GN module's own output is internal)
+        }
+        E.n_params = poff;
+        E.ws_per_image = arena.peak;
+        E.packed_bytes = wtop;
+        // parameter offsets for describe(): recompute by module in order
+    }
+};
+
+int64_t module_param_count(const Mod& m) {
+    switch (m.kind) {
+        case K_LIN: return (int64_t)m.cout * m.cin + m.cout;
+        case K_CONV: return (int64_t)m.cout * m.cin * 9 + m.cout;
+        case K_GN: return 2 * (int64_t)m.cin;
+        case K_ATTN: return 2 * (int64_t)m.cin + 4 * ((int64_t)m.cin * m.cin + m.cin);
+        case K_RES: {
+            int64_t n = 2 * (int64_t)m.cin + (int64_t)m.cout * m.cin * 9 + m.cout + (int64_t)m.cout * TEMB + m.cout +
+                        2 * (int64_t)m.cout + (int64_t)m.cout * m.cout * 9 + m.cout;
+            if (m.cin != m.cout || m.up || m.down) n += (int64_t)m.cout * m.cin + m.cout;
+            return n;
+        }
+    }
+    return 0;
+}
+
+natinf_ncsnpp* make_engine(int flags) {
+    natinf_ncsnpp* e = new natinf_ncsnpp();
+    e->flags = flags;
+    Builder b(*e);
+    b.build();
+    int64_t off = 0;
+    for (auto& m : e->mods) { m.poff = off; off += module_param_count(m); }
+    if (off != e->n_params) { delete e; return nullptr; }      // plan and parameter walk disagree
+    return e;
+}
+
+const natinf_ncsnpp& reference_engine() { static natinf_ncsnpp* e = make_engine(0); return *e; }
+
+}  // namespace
+
+extern "C" {
+
+int64_t natinf_ncsnpp_param_count(void) { return reference_engine().n_params; }
+int64_t natinf_ncsnpp_packed_bytes(void) { return reference_engine().packed_bytes; }
+
+int64_t natinf_ncsnpp_workspace_bytes(natinf_ncsnpp_t h, int max_batch) {
+    if (!h || max_batch <= 0) return NATINF_EINVAL;
+    return h->ws_per_image * (int64_t)max_batch;
+}
+
+int natinf_ncsnpp_create(natinf_ncsnpp_t* out, int flags) {
+    if (!out || (flags & ~NATINF_NCSNPP_KEEP_ACTIVATIONS)) return NATINF_EINVAL;
+    natinf_ncsnpp* e = make_engine(flags);
+    if (!e) return NATINF_ESTATE;
+    *out = e;
+    return NATINF_OK;
+}
+
+int natinf_ncsnpp_destroy(natinf_ncsnpp_t h) {
+    if (!h) return NATINF_EINVAL;
+    delete h;
+    return NATINF_OK;
+}
+
+int natinf_ncsnpp_describe(natinf_ncsnpp_t h, char* buf, int cap) {
+    if (!h || !buf || cap <= 0) return NATINF_EINVAL;
+    std::string s;
+    char line[160];
+    for (const auto& m : h->mods) {
+        snprintf(line, sizeof(line), "%d %s %d %d %d %d %d %lld\n", m.idx, kind_name(m.kind), m.cin, m.cout, m.up, m.down, m.res,
+                 (long long)m.poff);
+        s += line;
+    }
+    if ((int)s.size() + 1 > cap) return NATINF_EINVAL;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
+int natinf_ncsnpp_load(natinf_ncsnpp_t h, const float* params_f32, int64_t n_params, void* packed, int64_t packed_bytes,
+                       natinf_stream_t stream) {
+    if (!h || !params_f32 || !packed || n_params != h->n_params || packed_bytes < h->packed_bytes) return NATINF_EINVAL;
+    PackCtx p{params_f32, reinterpret_cast<unsigned char*>(packed), (hipStream_t)stream};
+    for (const auto& f : h->packs) f(p);
+    h->packed = reinterpret_cast<const unsigned char*>(packed);
+    return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
+}
+
+int natinf_ncsnpp_forward(natinf_ncsnpp_t h, const float* x, const float* labels, float* out, int B, void* workspace,
+                          int64_t workspace_bytes, natinf_stream_t stream) {
+    if (!h || !x || !labels || !out || !workspace || B <= 0) return NATINF_EINVAL;
+    if (!h->packed) return NATINF_ESTATE;
+    if (workspace_bytes < h->ws_per_image * (int64_t)B || (int64_t)B * IMG * IMG >= (1LL << 31)) return NATINF_EINVAL;
+    if (!h->attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GEMM_LDS_BYTES) != hipSuccess) { (void)hipGetLastError(); return NATINF_ENODEV; }
+        h->attr_set = true;
+    }
+    Ctx c{B, reinterpret_cast<unsigned char*>(workspace), h->packed, (hipStream_t)stream, x, labels, out};
+    for (const auto& f : h->ops) f(c);
+    h->last_B = B; h->last_ws = c.ws;
+    return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
+}
+
+int natinf_ncsnpp_debug_tap(natinf_ncsnpp_t h, int module_idx, float* out, int64_t capacity_elems, natinf_stream_t stream) {
+    if (!h || !out) return NATINF_EINVAL;
+    if (!(h->flags & NATINF_NCSNPP_KEEP_ACTIVATIONS) || !h->last_ws) return NATINF_ESTATE;
+    auto it = h->taps.find(module_idx);
+    if (it == h->taps.end()) return NATINF_EINVAL;
+    const TRef& t = it->second;
+    const int HW = t.res * t.res;
+    const int64_t total = (int64_t)h->last_B * t.C * HW;
+    if (capacity_elems < total) return NATINF_EINVAL;
+    const bf16* src = reinterpret_cast<const bf16*>(h->last_ws + t.off * h->last_B) + t.coff;
+    hipLaunchKernelGGL(k_nhwc_to_nchw_f32, dim3(grid1d(total, 256, 1 << 30)), dim3(256), 0, (hipStream_t)stream, src, t.ld, t.C, HW, out, total);
+    return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
+}
+
+}  // extern "C"

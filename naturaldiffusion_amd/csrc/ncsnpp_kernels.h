@@ -1,0 +1,488 @@
+// ncsnpp_kernels.h -- gfx950 kernels of the NCSN++ denoiser engine.
+//
+// Layout: every activation is NHWC bf16 ("pixel rows" of C channels, pixel stride ld >= C so a
+// tensor can live inside a wider concat buffer).  With channels innermost, a 3x3 convolution is an
+// implicit GEMM  C[m, n] = sum_k A[m, k] * Wp[n, k]  with m = (b, y, x), k = (tap, c): each K-tile of
+// 64 channels of one tap is a contiguous 128-byte run per pixel row.  All matmul-shaped work of the
+// network (3x3 / 1x1 convolutions, NIN, linear layers, attention products) goes through ONE
+// MFMA kernel, `k_gemm_bf16`, with fused epilogues.
+//
+//   tile 128(M) x 128(N) x 64(K), 256 threads = 4 waves in 2x2, each wave 64x64 via 4x4
+//   v_mfma_f32_16x16x32_bf16; LDS double buffer, 128-byte rows with the 16-byte chunk index XOR-ed by
+//   (row>>1)&7 (conflict-free for ds_read_b128's 16-lane groups: worked out in DESIGN.md);
+//   global->register prefetch of tile k+1 while tile k is multiplied; one barrier per K-tile;
+//   epilogue staged through LDS as fp32 so bias / time-embedding / residual adds happen in fp32 and
+//   stores are 16-byte coalesced; XCD-aware tile order (neighbouring N-tiles of one M-tile share an L2).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ncsn {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDS_ROW = BK;                           // 64 bf16 = 128 B rows, chunk-swizzled
+constexpr int TILE_ELEMS = BM * LDS_ROW;              // per operand per buffer
+constexpr int C_ROW = BN + 4;                         // fp32 epilogue staging row stride
+constexpr int GEMM_LDS_BYTES = BM * C_ROW * 4;        // 67,584 B: max(tiles 65,536 B, epilogue staging)
+static_assert(4 * TILE_ELEMS * 2 <= GEMM_LDS_BYTES, "tile buffers must fit");
+
+enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_NCHW = 2 };
+enum { ACT_NONE = 0, ACT_SILU = 1 };
+
+struct GemmArgs {
+    // A operand: segment 0 = `taps` (1 or 9) shifted views of a0, segment 1 = a1 (1x1), concatenated along K
+    const bf16* a0; int a0_ld; int a0_C;
+    const bf16* a1; int a1_ld; int a1_C;
+    int taps; int logW; int logHW;                    // spatial decode of m for taps == 9 (power-of-two H, W)
+    int M, N;
+    const bf16* b; int b_ld;                          // [N][K0+K1], K contiguous
+    int64_t a_bs, b_bs, c_bs; int batch;              // per-batch element strides (blockIdx.z)
+    const float* bias_n; const float* bias_m;
+    const float* rowvec; int rowvec_ld; int log_rows_per_sample;   // + rowvec[(m >> log)*ld + n]
+    const bf16* resid; int resid_ld;                  // + resid[m*ld + n]
+    float scale; int act;
+    void* c; int c_ld; int c_mode;
+};
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+
+// XCD-aware bijective remap of a linear block id: consecutive ids land on different XCDs (round-robin
+// dispatch), so give every XCD a contiguous run of tiles.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7, x = bid & 7, l = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
+}
+
+// Branch-free masked 16-byte load: the address is always a readable one (the operand's base when
+// masked), the select zeroes the value.  Keeps the staging registers out of scratch.
+__device__ __forceinline__ uint4 ld_or_zero(const bf16* p, bool ok) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    return ok ? v : make_uint4(0u, 0u, 0u, 0u);
+}
+
+__global__ __launch_bounds__(256, 2) void k_gemm_bf16(const GemmArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16* sA = reinterpret_cast<bf16*>(smem);
+    bf16* sB = sA + 2 * TILE_ELEMS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nN = (g.N + BN - 1) / BN, nM = (g.M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, nM * nN);
+    const int m0 = (tile / nN) * BM, n0 = (tile % nN) * BN;
+    const int z = blockIdx.z;
+
+    const bf16* a0 = g.a0 + (int64_t)z * g.a_bs;
+    const bf16* a1 = g.a1 ? g.a1 + (int64_t)z * g.a_bs : nullptr;
+    const bf16* bp = g.b + (int64_t)z * g.b_bs;
+
+    const int K0 = g.taps * g.a0_C, K1 = g.a1 ? g.a1_C : 0;
+    const int nk0 = (K0 + BK - 1) / BK, nk1 = (K1 + BK - 1) / BK, nk = nk0 + nk1;
+
+    // ---- per-thread load slots: 4 rows x one 16-byte column chunk, for A and for B
+    const int colc = tid & 7;                      // chunk column (8 bf16)
+    const int row0 = tid >> 3;                     // rows row0 + 32*i
+    int a_y[4], a_x[4];
+    int64_t a_off0[4], a_off1[4], b_off[4];
+    bool a_ok[4], b_ok[4];
+    const int Wd = 1 << g.logW, Hd = 1 << (g.logHW - g.logW);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + row0 + 32 * i;
+        a_ok[i] = m < g.M;
+        const int p = m & ((1 << g.logHW) - 1);
+        a_y[i] = p >> g.logW; a_x[i] = p & (Wd - 1);
+        a_off0[i] = (int64_t)m * g.a0_ld;
+        a_off1[i] = (int64_t)m * g.a1_ld;
+        const int n = n0 + row0 + 32 * i;
+        b_ok[i] = n < g.N;
+        b_off[i] = (int64_t)n * g.b_ld;
+    }
+
+    uint4 ra[4], rb[4];
+    auto load_tile = [&](int kt) __attribute__((always_inline)) {
+        if (kt < nk0) {
+            const int kbase = kt * BK;
+            int tap = 0, c0 = kbase;
+            if (g.taps == 9) { tap = kbase / g.a0_C; c0 = kbase - tap * g.a0_C; }
+            const int dy = g.taps == 9 ? tap / 3 - 1 : 0, dx = g.taps == 9 ? tap % 3 - 1 : 0;
+            const int cc = c0 + colc * 8;
+            const bool kin = cc < (g.taps == 9 ? g.a0_C : K0);
+            const int64_t shift = (int64_t)(dy * Wd + dx) * g.a0_ld + cc;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = a_ok[i] && kin && (unsigned)(a_y[i] + dy) < (unsigned)Hd && (unsigned)(a_x[i] + dx) < (unsigned)Wd;
+                ra[i] = ld_or_zero(ok ? a0 + a_off0[i] + shift : a0, ok);
+            }
+        } else {
+            const int cc = (kt - nk0) * BK + colc * 8;
+            const bool kin = cc < K1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                ra[i] = ld_or_zero((a_ok[i] && kin) ? a1 + a_off1[i] + cc : a1, a_ok[i] && kin);
+        }
+        {
+            // B columns follow the same K order: segment 0 at [0, K0), segment 1 at [K0, K0+K1)
+            const int kk = (kt < nk0 ? kt * BK : K0 + (kt - nk0) * BK) + colc * 8;
+            const bool kin = kt < nk0 ? (kk < K0) : (kk < K0 + K1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                rb[i] = ld_or_zero((b_ok[i] && kin) ? bp + b_off[i] + kk : bp, b_ok[i] && kin);
+        }
+    };
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+        bf16* da = sA + buf * TILE_ELEMS;
+        bf16* db = sB + buf * TILE_ELEMS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = row0 + 32 * i;
+            const int o = r * LDS_ROW + ((colc ^ ((r >> 1) & 7)) << 3);
+            *reinterpret_cast<uint4*>(da + o) = ra[i];
+            *reinterpret_cast<uint4*>(db + o) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int frow = lane & 15, fq = lane >> 4, fswz = (frow >> 1) & 7;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const bf16* ta = sA + cur * TILE_ELEMS + (wm * 64 + frow) * LDS_ROW;
+        const bf16* tb = sB + cur * TILE_ELEMS + (wn * 64 + frow) * LDS_ROW;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+            const int ko = (((ks << 2) | fq) ^ fswz) << 3;       // swizzled chunk of this lane's 8 k-values
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = *reinterpret_cast<const bf16x8*>(ta + i * 16 * LDS_ROW + ko);
+                fb[i] = *reinterpret_cast<const bf16x8*>(tb + i * 16 * LDS_ROW + ko);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS (fp32) -> fused adds -> coalesced stores
+    float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                sC[(wm * 64 + i * 16 + (lane >> 4) * 4 + r) * C_ROW + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
+
+    if (g.c_mode == OUT_F32_NCHW) {
+        // out[b][n][p] fp32, N small (final 3-channel conv): consecutive threads -> consecutive pixels
+        float* out = reinterpret_cast<float*>(g.c);
+        const int nvalid = min(BN, g.N - n0);
+        for (int e = tid; e < BM * nvalid; e += 256) {
+            const int r = e & (BM - 1), n = e >> 7;
+            const int m = m0 + r;
+            if (m < g.M) {
+                float v = sC[r * C_ROW + n];
+                if (g.bias_n) v += g.bias_n[n0 + n];
+                v *= g.scale;
+                const int b = m >> g.logHW, p = m & ((1 << g.logHW) - 1);
+                out[((int64_t)b * g.N + n0 + n) * ((int64_t)1 << g.logHW) + p] = v;
+            }
+        }
+        return;
+    }
+
+    const int cchunk = tid & 15;                   // 8 consecutive columns
+    const int n = n0 + cchunk * 8;
+    const bool n_in = n < g.N;                     // N is a multiple of 8 whenever this path is used
+    float bn[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bn[q] = 0.f;
+    if (g.bias_n && n_in) {
+        const float4 u = *reinterpret_cast<const float4*>(g.bias_n + n), w = *reinterpret_cast<const float4*>(g.bias_n + n + 4);
+        bn[0] = u.x; bn[1] = u.y; bn[2] = u.z; bn[3] = u.w; bn[4] = w.x; bn[5] = w.y; bn[6] = w.z; bn[7] = w.w;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int r = pass * 16 + (tid >> 4);
+        const int m = m0 + r;
+        if (m >= g.M || !n_in) continue;
+        const float4 u = *reinterpret_cast<const float4*>(sC + r * C_ROW + cchunk * 8);
+        const float4 w = *reinterpret_cast<const float4*>(sC + r * C_ROW + cchunk * 8 + 4);
+        float v[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += bn[q];
+        if (g.bias_m) {
+            const float bm = g.bias_m[m];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += bm;
+        }
+        if (g.rowvec) {
+            const float* rv = g.rowvec + (int64_t)(m >> g.log_rows_per_sample) * g.rowvec_ld + n;
+            const float4 s = *reinterpret_cast<const float4*>(rv), t = *reinterpret_cast<const float4*>(rv + 4);
+            v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w; v[4] += t.x; v[5] += t.y; v[6] += t.z; v[7] += t.w;
+        }
+        if (g.resid) {
+            const bf16x8 rs = *reinterpret_cast<const bf16x8*>(g.resid + (int64_t)z * g.c_bs + (int64_t)m * g.resid_ld + n);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += (float)rs[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            v[q] *= g.scale;
+            if (g.act == ACT_SILU) v[q] = silu_f(v[q]);
+        }
+        if (g.c_mode == OUT_BF16) {
+            bf16x8 o;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = (bf16)v[q];
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(g.c) + (int64_t)z * g.c_bs + (int64_t)m * g.c_ld + n) = o;
+        } else {
+            float* o = reinterpret_cast<float*>(g.c) + (int64_t)z * g.c_bs + (int64_t)m * g.c_ld + n;
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm (32 groups, eps 1e-6): statistics pass -> per-(sample, channel) scale / shift
+// ------------------------------------------------------------------------------------------------
+// One 256-thread block per sample.  scale[b][c] = rstd*gamma[c], shift[b][c] = beta[c] - mean*scale.
+__global__ __launch_bounds__(256) void k_gn_stats(const bf16* __restrict__ x, int ld, int C, int HW,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  float* __restrict__ scale, float* __restrict__ shift, float eps)
+{
+    __shared__ float s_sum[512], s_sq[512], s_mean[32], s_rstd[32];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    for (int c = tid; c < C; c += 256) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
+    __syncthreads();
+    const int cpp = C >> 3;                        // 16-byte chunks per pixel
+    const int lanes = 256 / cpp;                   // pixel lanes
+    if (tid < cpp * lanes) {
+        const int chunk = tid % cpp, pl = tid / cpp;
+        float s[8], q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
+        const bf16* base = x + (int64_t)b * HW * ld + chunk * 8;
+        for (int p = pl; p < HW; p += lanes) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + (int64_t)p * ld);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float f = (float)v[i]; s[i] += f; q[i] += f * f; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { atomicAdd(&s_sum[chunk * 8 + i], s[i]); atomicAdd(&s_sq[chunk * 8 + i], q[i]); }
+    }
+    __syncthreads();
+    const int cg = C >> 5;
+    if (tid < 32) {
+        float s = 0.f, q = 0.f;
+        for (int i = 0; i < cg; ++i) { s += s_sum[tid * cg + i]; q += s_sq[tid * cg + i]; }
+        const float inv = 1.0f / (float)(cg * HW);
+        const float mean = s * inv;
+        float var = q * inv - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        s_mean[tid] = mean;
+        s_rstd[tid] = 1.0f / sqrtf(var + eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int gi = c / cg;
+        const float sc = s_rstd[gi] * gamma[c];
+        scale[(int64_t)b * C + c] = sc;
+        shift[(int64_t)b * C + c] = beta[c] - s_mean[gi] * sc;
+    }
+}
+
+// y = act(x*scale + shift) with optional 2x nearest up-sampling / 2x2 mean down-sampling of BOTH the
+// activated tensor (-> y) and the raw input (-> xr), as ResnetBlockBigGANpp does (layerspp.py:245-257).
+enum { RS_NONE = 0, RS_UP = 1, RS_DOWN = 2 };
+__global__ __launch_bounds__(256) void k_gn_apply(const bf16* __restrict__ x, int ld, int C, int logW, int logHW,
+                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                  bf16* __restrict__ y, bf16* __restrict__ xr, int act, int mode,
+                                                  int64_t total_chunks)
+{
+    const int cpp = C >> 3;
+    const int W = 1 << logW, HW = 1 << logHW;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total_chunks; idx += (int64_t)gridDim.x * 256) {
+        const int chunk = (int)(idx % cpp);
+        const int64_t pix = idx / cpp;             // pixel index in the SOURCE (none/up) or DEST (down) grid
+        float sc[8], sh[8];
+        if (mode != RS_DOWN) {
+            const int b = (int)(pix >> logHW);
+            const float* ps = scale + (int64_t)b * C + chunk * 8; const float* ph = shift + (int64_t)b * C + chunk * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sc[i] = ps[i]; sh[i] = ph[i]; }
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + pix * ld + chunk * 8);
+            bf16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float f = (float)v[i] * sc[i] + sh[i];
+                if (act == ACT_SILU) f = silu_f(f);
+                o[i] = (bf16)f;
+            }
+            if (mode == RS_NONE) {
+                *reinterpret_cast<bf16x8*>(y + pix * C + chunk * 8) = o;
+            } else {
+                const int p = (int)(pix & (HW - 1)), yy = p >> logW, xx = p & (W - 1);
+                const int64_t ob = (pix >> logHW) * 4 * HW;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int64_t op = ob + (int64_t)(2 * yy + (d >> 1)) * (2 * W) + 2 * xx + (d & 1);
+                    *reinterpret_cast<bf16x8*>(y + op * C + chunk * 8) = o;
+                    if (xr) *reinterpret_cast<bf16x8*>(xr + op * C + chunk * 8) = v;
+                }
+            }
+        } else {
+            // dest grid is (H/2, W/2): logHW/logW describe the SOURCE grid
+            const int HWd = HW >> 2, Wd = W >> 1;
+            const int b = (int)(pix / HWd), p = (int)(pix % HWd), yy = p / Wd, xx = p % Wd;
+            const float* ps = scale + (int64_t)b * C + chunk * 8; const float* ph = shift + (int64_t)b * C + chunk * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sc[i] = ps[i]; sh[i] = ph[i]; }
+            float ay[8], ax[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { ay[i] = 0.f; ax[i] = 0.f; }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int64_t sp = (int64_t)b * HW + (int64_t)(2 * yy + (d >> 1)) * W + 2 * xx + (d & 1);
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + sp * ld + chunk * 8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float raw = (float)v[i];
+                    float f = raw * sc[i] + sh[i];
+                    if (act == ACT_SILU) f = silu_f(f);
+                    ay[i] += f; ax[i] += raw;
+                }
+            }
+            bf16x8 oy, ox;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { oy[i] = (bf16)(ay[i] * 0.25f); ox[i] = (bf16)(ax[i] * 0.25f); }
+            *reinterpret_cast<bf16x8*>(y + pix * C + chunk * 8) = oy;
+            if (xr) *reinterpret_cast<bf16x8*>(xr + pix * C + chunk * 8) = ox;
+        }
+    }
+}
+
+// row softmax: S fp32 [rows][T] -> P bf16 [rows][T]; one wave per row, T <= 256, T % 4 == 0 or T == 16
+__global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ S, bf16* __restrict__ P, int T, int64_t rows)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* s = S + row * T;
+    float v[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < T ? s[c] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = (lane + 64 * i < T) ? __expf(v[i] - mx) : 0.f; sum += v[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < T) P[row * T + c] = (bf16)(v[i] * inv);
+    }
+}
+
+// sinusoidal embedding (layers.py:515-530): labels [B] -> emb bf16 [B][128]
+__global__ void k_time_embed(const float* __restrict__ labels, bf16* __restrict__ emb, int B)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 128) return;
+    const int b = i >> 7, j = i & 127, h = j & 63;
+    const float freq = expf((float)h * -(9.210340371976184f / 63.0f));        // ln(10000)/(half-1)
+    const float a = labels[b] * freq;
+    emb[i] = (bf16)(j < 64 ? sinf(a) : cosf(a));
+}
+
+// stem im2col: x fp32 NCHW [B][3][32][32] -> A bf16 [B*1024][64], k = tap*3 + c (27 used, rest zero)
+__global__ __launch_bounds__(256) void k_stem_im2col(const float* __restrict__ x, bf16* __restrict__ A, int64_t rows)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one thread per (row, 8-wide chunk)
+    if (idx >= rows * 8) return;
+    const int64_t m = idx >> 3; const int ch = (int)(idx & 7);
+    const int b = (int)(m >> 10), p = (int)(m & 1023), yy = p >> 5, xx = p & 31;
+    bf16x8 o;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = ch * 8 + q;
+        float v = 0.f;
+        if (k < 27) {
+            const int tap = k / 3, c = k - tap * 3, sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+            if ((unsigned)sy < 32u && (unsigned)sx < 32u) v = x[(((int64_t)b * 3 + c) << 10) + sy * 32 + sx];
+        }
+        o[q] = (bf16)v;
+    }
+    *reinterpret_cast<bf16x8*>(A + m * 64 + ch * 8) = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing (fp32 reference layouts -> bf16 GEMM layouts), run once per load
+// ------------------------------------------------------------------------------------------------
+// src [N][Cin][taps] (OIHW flattened) -> dst[n*dst_ld + koff + tap*Cin + c]
+__global__ void k_pack_conv(const float* __restrict__ src, bf16* __restrict__ dst, int N, int Cin, int taps,
+                            int dst_ld, int koff, int tap_stride_c)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * Cin * taps) return;
+    const int tap = (int)(i % taps); const int64_t r = i / taps; const int c = (int)(r % Cin); const int n = (int)(r / Cin);
+    dst[(int64_t)n * dst_ld + koff + tap * tap_stride_c + c] = (bf16)src[i];
+}
+// src [K][N] (NIN.W) -> dst[n*dst_ld + k]
+__global__ void k_pack_transpose(const float* __restrict__ src, bf16* __restrict__ dst, int K, int N, int dst_ld)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)K * N) return;
+    const int n = (int)(i % N), k = (int)(i / N);
+    dst[(int64_t)n * dst_ld + k] = (bf16)src[i];
+}
+__global__ void k_fill_bf16_zero(bf16* __restrict__ dst, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (bf16)0.0f;
+}
+// dst = a (+ b)
+__global__ void k_copy_add_f32(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ dst, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = a[i] + (b ? b[i] : 0.f);
+}
+// tap: NHWC bf16 (ld) -> NCHW fp32
+__global__ void k_nhwc_to_nchw_f32(const bf16* __restrict__ x, int ld, int C, int HW, float* __restrict__ out, int64_t total)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // over out index (b, c, p)
+    if (i >= total) return;
+    const int p = (int)(i % HW); const int64_t r = i / HW; const int c = (int)(r % C); const int64_t b = r / C;
+    out[i] = (float)x[(b * HW + p) * ld + c];
+}
+
+}  // namespace ncsn

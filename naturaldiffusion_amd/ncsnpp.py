@@ -1,0 +1,151 @@
+"""Host wrapper of the gfx950 NCSN++ denoiser engine (include/natinf_ncsnpp.h).
+
+``NCSNppEngine`` is what the reference's ``mutils.create_model(config)`` + ``restore_checkpoint`` +
+``ema.copy_to`` produce (src/CIFAR10NaturalInference.py:258-265), as one object whose ``__call__(x,
+labels)`` replaces ``model(x, labels)`` (deps/score_sde_pytorch/models/utils.py:118-123).  PyTorch only
+provides device memory and the stream; every FLOP runs in libnatinf.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr, stream_ptr
+
+KEEP_ACTIVATIONS = 1
+TEMB = 512
+
+
+def module_table(handle=None) -> List[Tuple[int, str, int, int, int, int, int, int]]:
+    """(idx, kind, cin, cout, up, down, res, param_offset) per ``all_modules`` entry, from the engine's plan."""
+    own = handle is None
+    if own:
+        h = C.c_void_p()
+        check(lib.natinf_ncsnpp_create(C.byref(h), 0), "natinf_ncsnpp_create")
+        handle = h
+    buf = C.create_string_buffer(1 << 14)
+    n = lib.natinf_ncsnpp_describe(handle, buf, len(buf))
+    if n < 0:
+        check(n, "natinf_ncsnpp_describe")
+    if own:
+        lib.natinf_ncsnpp_destroy(handle)
+    rows = []
+    for line in buf.value.decode().strip().split("\n"):
+        f = line.split()
+        rows.append((int(f[0]), f[1], *map(int, f[2:])))
+    return rows
+
+
+def param_layout() -> List[Tuple[str, Tuple[int, ...]]]:
+    """Flat parameter order the engine expects: ``all_modules`` order, leaves in registration order
+    (= ``model.parameters()`` order = EMA ``shadow_params`` order, ema.py:28-29)."""
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+    for idx, kind, cin, cout, up, down, res, _ in module_table():
+        p = f"all_modules.{idx}."
+        if kind == "lin":
+            out += [(p + "weight", (cout, cin)), (p + "bias", (cout,))]
+        elif kind == "conv":
+            out += [(p + "weight", (cout, cin, 3, 3)), (p + "bias", (cout,))]
+        elif kind == "gn":
+            out += [(p + "weight", (cin,)), (p + "bias", (cin,))]
+        elif kind == "attn":
+            out += [(p + "GroupNorm_0.weight", (cin,)), (p + "GroupNorm_0.bias", (cin,))]
+            for i in range(4):
+                out += [(p + f"NIN_{i}.W", (cin, cin)), (p + f"NIN_{i}.b", (cin,))]
+        elif kind == "res":
+            out += [(p + "GroupNorm_0.weight", (cin,)), (p + "GroupNorm_0.bias", (cin,)),
+                    (p + "Conv_0.weight", (cout, cin, 3, 3)), (p + "Conv_0.bias", (cout,)),
+                    (p + "Dense_0.weight", (cout, TEMB)), (p + "Dense_0.bias", (cout,)),
+                    (p + "GroupNorm_1.weight", (cout,)), (p + "GroupNorm_1.bias", (cout,)),
+                    (p + "Conv_1.weight", (cout, cout, 3, 3)), (p + "Conv_1.bias", (cout,))]
+            if cin != cout or up or down:
+                out += [(p + "Conv_2.weight", (cout, cin, 1, 1)), (p + "Conv_2.bias", (cout,))]
+        else:
+            raise RuntimeError(f"unknown module kind {kind}")
+    return out
+
+
+def flatten_state_dict(sd: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """name -> tensor dict (reference keys, with or without the DataParallel ``module.`` prefix,
+    models/utils.py:93) -> one fp32 CPU vector in engine order.  Shapes are checked."""
+    sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    parts = []
+    for name, shape in param_layout():
+        if name not in sd:
+            raise KeyError(f"checkpoint lacks {name}")
+        t = sd[name]
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name}: shape {tuple(t.shape)} != expected {shape}")
+        parts.append(t.detach().to("cpu", torch.float32).reshape(-1))
+    return torch.cat(parts)
+
+
+def flatten_ema(shadow_params: List[torch.Tensor]) -> torch.Tensor:
+    """EMA list of the score_sde checkpoint (``state['ema']['shadow_params']``, ema.py:91-97)."""
+    layout = param_layout()
+    if len(shadow_params) != len(layout):
+        raise ValueError(f"EMA list has {len(shadow_params)} tensors, the model has {len(layout)} parameters")
+    parts = []
+    for (name, shape), t in zip(layout, shadow_params):
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"EMA entry for {name}: shape {tuple(t.shape)} != expected {shape}")
+        parts.append(t.detach().to("cpu", torch.float32).reshape(-1))
+    return torch.cat(parts)
+
+
+def load_score_sde_checkpoint(path: str) -> torch.Tensor:
+    """``restore_checkpoint`` + ``ema.copy_to`` (deps/score_sde_pytorch/utils.py:7-19, ema.py:53-64):
+    the weights the reference samples with are the EMA shadow parameters."""
+    state = torch.load(path, map_location="cpu", weights_only=False)
+    return flatten_ema(list(state["ema"]["shadow_params"]))
+
+
+class NCSNppEngine:
+    def __init__(self, flat_params: torch.Tensor, max_batch: int, device="cuda:0", keep_activations: bool = False):
+        _lib.require_gpu()
+        self.device = torch.device(device)
+        self.max_batch = int(max_batch)
+        self._h = C.c_void_p()
+        check(lib.natinf_ncsnpp_create(C.byref(self._h), KEEP_ACTIVATIONS if keep_activations else 0), "natinf_ncsnpp_create")
+        n = lib.natinf_ncsnpp_param_count()
+        if flat_params.numel() != n:
+            raise ValueError(f"expected {n} parameters, got {flat_params.numel()}")
+        with torch.cuda.device(self.device):
+            params = flat_params.to(self.device, torch.float32).contiguous()
+            self._packed = torch.empty(lib.natinf_ncsnpp_packed_bytes(), dtype=torch.uint8, device=self.device)
+            check(lib.natinf_ncsnpp_load(self._h, ptr(params), n, ptr(self._packed), self._packed.numel(), stream_ptr()),
+                  "natinf_ncsnpp_load")
+            torch.cuda.current_stream().synchronize()      # params may be freed after this
+            ws = lib.natinf_ncsnpp_workspace_bytes(self._h, self.max_batch)
+            self._ws = torch.empty(ws, dtype=torch.uint8, device=self.device)
+        self.workspace_bytes = ws
+
+    def __call__(self, x: torch.Tensor, labels: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        if x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (3, 32, 32) or not x.is_cuda:
+            raise ValueError("x must be a CUDA fp32 tensor of shape [B,3,32,32]")
+        B = x.shape[0]
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} exceeds max_batch {self.max_batch}")
+        x = x.contiguous()
+        labels = labels.to(x.device, torch.float32).contiguous()
+        if labels.numel() != B:
+            raise ValueError("labels must have one entry per sample")
+        if out is None:
+            out = torch.empty_like(x)
+        check(lib.natinf_ncsnpp_forward(self._h, ptr(x), ptr(labels), ptr(out), B, ptr(self._ws), self._ws.numel(),
+                                        stream_ptr()), "natinf_ncsnpp_forward")
+        return out
+
+    def tap(self, module_idx: int, shape) -> torch.Tensor:
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        check(lib.natinf_ncsnpp_debug_tap(self._h, module_idx, ptr(out), out.numel(), stream_ptr()), "natinf_ncsnpp_debug_tap")
+        return out
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.natinf_ncsnpp_destroy(h)
+            self._h = None

@@ -1,0 +1,148 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol the headers declare, the engine's
+static plan agrees with the oracle's description of the network, and the host logic around the kernels
+(sparse coefficient rows, schedules) is right.  No compute call is made (there is no GPU here)."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ncsnpp_oracle as N
+from oracle import ni_oracle as O
+
+
+def _declared(header_text):
+    return set(re.findall(r"\b(natinf_[a-z0-9_]+)\s*\(", header_text))
+
+
+def test_library_exports_every_declared_symbol(repo_root):
+    from naturaldiffusion_amd import _lib
+    names = set()
+    for h in ("natinf.h", "natinf_ncsnpp.h"):
+        names |= _declared((repo_root / "include" / h).read_text())
+    names -= {"natinf_stream_t", "natinf_ncsnpp_t"}
+    assert len(names) >= 20
+    for n in sorted(names):
+        assert hasattr(_lib.lib, n), f"libnatinf.so does not export {n}"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert set(_lib.SIGNATURES) <= names
+    assert _lib.lib.natinf_abi_version() == 1
+    assert _lib.lib.natinf_strerror(-1) == b"invalid argument"
+
+
+def test_product_does_not_import_the_oracle(repo_root):
+    for p in (repo_root / "naturaldiffusion_amd").rglob("*.py"):
+        src = p.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f"{p} imports the oracle"
+    for p in (repo_root / "naturaldiffusion_amd" / "csrc").glob("*"):
+        if p.is_file():
+            assert "oracle" not in p.read_text(errors="ignore").lower() or p.name == "Makefile"
+
+
+def test_engine_plan_matches_oracle_plan():
+    from naturaldiffusion_amd import ncsnpp
+    from naturaldiffusion_amd._lib import lib
+    tab = ncsnpp.module_table()
+    ref = N.plan()
+    assert len(tab) == len(ref) == 55
+    for row, m in zip(tab, ref):
+        idx, kind, cin, cout, up, down, res, poff = row
+        assert (idx, kind, cin, cout, bool(up), bool(down), res) == (m.idx, m.kind, m.cin, m.cout, m.up, m.down, m.res)
+    shapes = N.param_shapes()
+    lay = ncsnpp.param_layout()
+    assert [n for n, _ in lay] == list(shapes.keys())
+    assert all(tuple(s) == tuple(shapes[n]) for n, s in lay)
+    total = sum(int(np.prod(s)) for _, s in lay)
+    assert total == lib.natinf_ncsnpp_param_count() == 61804419
+    # module parameter offsets are the running sum in that order
+    offs = {}
+    run = 0
+    for n, s in lay:
+        i = int(n.split(".")[1])
+        offs.setdefault(i, run)
+        run += int(np.prod(s))
+    assert all(offs[row[0]] == row[7] for row in tab)
+
+
+def test_workspace_queries():
+    from naturaldiffusion_amd._lib import lib
+    h = C.c_void_p()
+    assert lib.natinf_ncsnpp_create(C.byref(h), 0) == 0
+    w1, w512 = lib.natinf_ncsnpp_workspace_bytes(h, 1), lib.natinf_ncsnpp_workspace_bytes(h, 512)
+    assert w512 == 512 * w1 and 1e6 < w1 < 2e7
+    hk = C.c_void_p()
+    assert lib.natinf_ncsnpp_create(C.byref(hk), 1) == 0
+    assert lib.natinf_ncsnpp_workspace_bytes(hk, 1) > w1
+    assert lib.natinf_ncsnpp_create(C.byref(C.c_void_p()), 2) == -1
+    # forward before load -> ESTATE; bad args -> EINVAL (no launch happens)
+    assert lib.natinf_ncsnpp_forward(h, 1, 1, 1, 1, 1, 1 << 40, None) == -4
+    assert lib.natinf_ncsnpp_forward(h, None, None, None, 1, None, 0, None) == -1
+    assert lib.natinf_ncsnpp_destroy(h) == 0 and lib.natinf_ncsnpp_destroy(hk) == 0
+
+
+def test_flatten_state_dict_and_ema_order():
+    from naturaldiffusion_amd import ncsnpp
+    shapes = N.param_shapes()
+    sd = {"module." + k: torch.full(s, float(i)) for i, (k, s) in enumerate(shapes.items())}
+    flat = ncsnpp.flatten_state_dict(sd)
+    ema = ncsnpp.flatten_ema([torch.full(s, float(i)) for i, s in enumerate(shapes.values())])
+    assert flat.numel() == 61804419 and torch.equal(flat, ema)
+    with pytest.raises(ValueError):
+        ncsnpp.flatten_state_dict({**sd, "module.all_modules.2.weight": torch.zeros(128, 3, 1, 1)})
+    with pytest.raises(KeyError):
+        ncsnpp.flatten_state_dict({k: v for k, v in sd.items() if not k.endswith("all_modules.54.bias")})
+
+
+def test_sparse_rows(repo_root):
+    from naturaldiffusion_amd.coeff import SparseRows, load_coeff_npz, load_sd3_csv
+    C_, B_, node = load_coeff_npz(repo_root / "weights/step_15_weight_173.npz")
+    for dense in (False, True):
+        rows = SparseRows(C_, lambda k: k + 1, torch.float64, None, dense=dense)
+        for k, r in enumerate(rows.rows):
+            idx = rows.idx_host[r.start:r.start + r.n]
+            val = rows.val_host[r.start:r.start + r.n]
+            assert np.all(np.diff(idx) > 0) and (r.n == 0 or idx.max() < k)
+            assert r.diag == C_[k, k]
+            rebuilt = np.zeros(k + 1)
+            rebuilt[idx] = val
+            rebuilt[k] = r.diag
+            assert np.array_equal(rebuilt, C_[k, :k + 1])
+            assert r.n == (k if dense else np.count_nonzero(C_[k, :k]))
+    W = load_sd3_csv(repo_root / "weights/sd3_step_28_weight.csv")
+    rows = SparseRows(W, lambda k: k + 1, torch.float32, None)
+    assert rows.val_host.dtype == np.float32
+    tot = 0
+    for j in range(28):
+        tot = tot + W[27][j]
+    assert rows.rows[27].total == float(tot)
+    with pytest.raises(ValueError):
+        load_coeff_npz(repo_root / "tests/golden/cifar_form.npz")
+
+
+def test_host_schedule_matches_oracle(repo_root):
+    from naturaldiffusion_amd.sampler import vp_std_f32
+    from naturaldiffusion_amd.coeff import load_coeff_npz
+    _, _, node = load_coeff_npz(repo_root / "weights/step_10_weight_42.npz")
+    for t in node[:-1, 0]:
+        assert vp_std_f32(t) == float(O.vp_std_f32(t))
+
+
+def test_gpu_required_is_loud():
+    from naturaldiffusion_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.require_gpu()
+    from naturaldiffusion_amd.sampler import CifarNI
+    with pytest.raises(RuntimeError):
+        CifarNI(np.eye(2), np.ones((2, 2)), np.ones((3, 3)), 8)
+
+
+def test_synthetic_weights_match_the_oracle_recipe():
+    """bench.py feeds the GPU engine from naturaldiffusion_amd.synth and its CPU baseline from the oracle:
+    the two generators must produce the same tensors."""
+    from naturaldiffusion_amd.synth import synthetic_state_dict
+    a, b = synthetic_state_dict(0), N.make_params(0)
+    assert list(a) == list(b)
+    assert all(torch.equal(a[k], b[k]) for k in a)
