@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of N-step Natural Inference on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch: BASELINE config 2, i.e. 15-step Natural
+Inference with ``weights/step_15_weight_173.npz`` on a batch of 512 CIFAR10-shaped samples: 15 NCSN++
+forwards in the HIP engine (bf16 MFMA) + 15 fused ``ni_step`` launches (fp64 history, the reference's
+arithmetic).  Inputs (noise, weights, coefficient rows) are resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W        # N>1: launched by torch.distributed.run
+
+Multi-GPU: generation batches are independent, so rank r simply runs its own batches (weak scaling, no
+collective on the data path); timing is barrier + synchronize on both sides and the max over ranks.
+
+The JSON line also carries
+  roofline          the dominant kernel (k_gemm_bf16, MFMA-bound): algorithmic flops per launch / mean launch
+                    duration, measured with HIP events on the engine's stream over a timed region
+  roofline_ni_step  the named recurrence kernel (HBM-bound): algorithmic bytes per launch / mean duration
+  cpu_baseline      the CPU oracle (eager PyTorch restatement of the reference path) timed on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0                # HBM3E spec, same guide
+GFLOP_PER_IMAGE_FORWARD = 21.69307136  # 2*MAC of conv/linear/attention matmuls (oracle.flops_per_image)
+
+
+def ni_step_bytes_per_element(C, s_x=4, s_h=8):
+    """reads s_x*(2 + nnzB) + s_h*(nnzA-1), writes s_h + s_x, per element per step
+    (zero-skipped rows; B has one non-zero per row in weights/step_*)."""
+    import numpy as np
+    out = []
+    for k in range(C.shape[0]):
+        nnz_a = int(np.count_nonzero(C[k, :k + 1]))
+        out.append(s_x * (2 + 1) + s_h * (nnz_a - 1) + s_h + s_x)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--weights", default=str(ROOT / "weights" / "step_15_weight_173.npz"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the event-instrumented replica (for rocprof runs)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from naturaldiffusion_amd import _lib
+    from naturaldiffusion_amd.coeff import load_coeff_npz
+    from naturaldiffusion_amd.ncsnpp import NCSNppEngine
+    from naturaldiffusion_amd.sampler import CifarNI
+    from naturaldiffusion_amd.synth import synthetic_flat_params
+
+    _lib.require_gpu()
+    Bz = args.batch
+    C, Bm, node = load_coeff_npz(args.weights)
+    n_step = node.shape[0] - 1
+    E = Bz * 3 * 32 * 32
+    engine = NCSNppEngine(synthetic_flat_params(0), max_batch=Bz, device=dev)
+    ni = CifarNI(C, Bm, node, E, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(888 + rank)
+    noises = [torch.randn(Bz, 3, 32, 32, generator=gen, device=dev) for _ in range(2)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step(i):
+        return ni.run(engine, noises[i & 1])
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    assert torch.isfinite(out).all()
+    imgs = world * Bz * args.steps
+    value = imgs / dt
+
+    line = {
+        "metric": "images/sec at 15-step Natural Inference (CIFAR10 32x32, NCSN++)",
+        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "CIFAR10 Natural Inference 15-step (step_15_weight_173.npz), batch=512 per GPU, "
+                               "NCSN++ (cifar10_ddpmpp_continuous, 61.8M params, synthetic weights) bf16 MFMA / fp32 acc, "
+                               "ni_step fp64 history",
+                   "coeff_file": os.path.basename(args.weights), "nfe": n_step, "batch_per_gpu": Bz,
+                   "sharding": f"batch-sharded x{world}, no collective"},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # ---- instrumented replica of the timed region: HIP events around every engine launch group and
+        # ---- every ni_step launch (same stream)
+        engine.profile(True)
+        ev = []
+        orig_step = ni.step
+
+        def timed_step(k, *a, **kw):
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            r = orig_step(k, *a, **kw)
+            a1.record()
+            ev.append((k, a0, a1))
+            return r
+        ni.step = timed_step
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(i)
+        torch.cuda.synchronize()
+        dt_inst = time.perf_counter() - t1
+        prof = engine.profile_read()
+        engine.profile(False)
+        ni.step = orig_step
+        gemm_ms, gemm_n = prof["gemm"]
+        other_ms, other_n = prof["other"]
+        fwd = args.steps * n_step
+        flops_total = GFLOP_PER_IMAGE_FORWARD * 1e9 * Bz * fwd
+        flops_per_launch = flops_total / gemm_n
+        mean_ms = gemm_ms / gemm_n
+        ach = flops_per_launch / (mean_ms * 1e-3) / 1e12
+        line["roofline"] = {
+            "kernel": "k_gemm_bf16", "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+            "launches": int(gemm_n), "mean_launch_ms": round(mean_ms, 5),
+            "flops_per_launch": flops_per_launch, "device_ms_total": round(gemm_ms, 3),
+            "other_kernels_device_ms": round(other_ms, 3), "other_launches": int(other_n),
+            "ms_per_step_instrumented": round(dt_inst / args.steps * 1e3, 3),
+        }
+        bpe = ni_step_bytes_per_element(C)
+        tot_ms = sum(a0.elapsed_time(a1) for _, a0, a1 in ev)
+        tot_bytes = sum(bpe[k] * E for k, _, _ in ev)
+        ach_gbs = tot_bytes / (tot_ms * 1e-3) / 1e9
+        line["roofline_ni_step"] = {
+            "kernel": "k_step_f64hist", "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(ach_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "launches": len(ev), "mean_launch_ms": round(tot_ms / len(ev), 5),
+            "bytes_per_launch": tot_bytes / len(ev), "bytes_per_element_by_step": bpe,
+        }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # ---- CPU baseline: the oracle (eager-PyTorch restatement of the reference path, fp32 NCSN++ + fp64
+        # ---- recurrence) on this host's cores, bounded sample of the same workload
+        from oracle import ni_oracle as O, ncsnpp_oracle as N
+        from naturaldiffusion_amd.synth import synthetic_state_dict
+        threads = torch.get_num_threads()
+        P = synthetic_state_dict(0)
+        model = N.model_fn_from_params(P)
+        nb = 4
+        z = torch.randn(nb, 3, 32, 32, generator=torch.Generator().manual_seed(888))
+        model(z[:1], torch.zeros(1))                       # page in / warm the thread pool
+        tc = time.perf_counter()
+        O.cifar_ni_trajectory(model, z, C, Bm, node)
+        dc = time.perf_counter() - tc
+        line["cpu_baseline"] = {"value": round(nb / dc, 4), "unit": "images/s", "cores": threads, "kind": "port",
+                                "sample": f"{nb} images x {n_step} steps, same coefficient file and synthetic weights "
+                                          f"(fp32 NCSN++ oracle + fp64 recurrence), {dc:.1f} s; host has {os.cpu_count()} logical CPUs"}
+
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -60,6 +60,14 @@ int natinf_ncsnpp_load(natinf_ncsnpp_t h, const float* params_f32, int64_t n_par
 int natinf_ncsnpp_forward(natinf_ncsnpp_t h, const float* x, const float* labels, float* out, int B,
                           void* workspace, int64_t workspace_bytes, natinf_stream_t stream);
 
+/* Measurement hooks (bench.py): while enabled, every launch group of a forward is bracketed by a HIP event
+ * pair on `stream`.  natinf_ncsnpp_profile_read waits for the recorded events and returns, per class
+ * (0 = the MFMA GEMM kernel k_gemm_bf16: all convolutions / NIN / linear / attention products;
+ * 1 = everything else: GroupNorm statistics + apply, softmax, embedding, stem im2col), the summed
+ * device time in milliseconds and the number of launches since the previous read. */
+int natinf_ncsnpp_profile(natinf_ncsnpp_t h, int enable);
+int natinf_ncsnpp_profile_read(natinf_ncsnpp_t h, double* ms_by_class /*[2]*/, int64_t* launches_by_class /*[2]*/);
+
 /* After a forward on a KEEP_ACTIVATIONS handle: copy the output of all_modules[module_idx]
  * (module_idx >= 2) as fp32 NCHW into `out` (capacity in elements).  Same B / workspace as the forward. */
 int natinf_ncsnpp_debug_tap(natinf_ncsnpp_t h, int module_idx, float* out, int64_t capacity_elems,

@@ -55,6 +55,7 @@ struct Ctx {                     // per-forward launch context
     template <class T> const T* w(int64_t off) const { return reinterpret_cast<const T*>(wp + off); }
 };
 using OpFn = std::function<void(const Ctx&)>;
+enum { CLS_GEMM = 0, CLS_OTHER = 1, N_CLS = 2 };
 
 struct PackCtx { const float* params; unsigned char* packed; hipStream_t stream; };
 using PackFn = std::function<void(const PackCtx&)>;
@@ -99,7 +100,13 @@ struct natinf_ncsnpp {
     std::vector<Mod> mods;
     int64_t n_params = 0;
     std::vector<OpFn> ops;
+    std::vector<int> op_cls;             // CLS_* per op (profiling)
     std::vector<PackFn> packs;
+    // profiling: one HIP event pair per op while enabled
+    bool prof = false;
+    struct Rec { hipEvent_t a, b; int cls; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
     std::map<int, TRef> taps;            // module idx -> output tensor
     int64_t ws_per_image = 0, packed_bytes = 0;
     const unsigned char* packed = nullptr;
@@ -139,6 +146,7 @@ struct Builder {
 
     explicit Builder(natinf_ncsnpp& e) : E(e) { arena.keep = (e.flags & NATINF_NCSNPP_KEEP_ACTIVATIONS) != 0; }
 
+    void op(int cls, OpFn f) { E.ops.push_back(std::move(f)); E.op_cls.push_back(cls); }
     int64_t wres(int64_t bytes) { const int64_t o = wtop; wtop += align_up(bytes, 256); return o; }
     int64_t take(int64_t n) { const int64_t o = poff; poff += n; return o; }
 
@@ -181,7 +189,7 @@ struct Builder {
     // GroupNorm statistics of x -> (scale, shift) per (image, channel); returns their arena offsets
     void emit_gn_stats(const TRef& x, GN gn, int64_t sc, int64_t sh) {
         const int HW = x.res * x.res;
-        E.ops.push_back([=](const Ctx& c) {
+        op(CLS_OTHER, [=](const Ctx& c) {
             hipLaunchKernelGGL(k_gn_stats, dim3(c.B), dim3(256), 0, c.stream, c.act(x), x.ld, x.C, HW,
                                c.w<float>(gn.gamma), c.w<float>(gn.beta), c.at<float>(sc), c.at<float>(sh), GN_EPS);
         });
@@ -191,7 +199,7 @@ struct Builder {
         const int64_t chunks_per_img = (int64_t)(mode == RS_DOWN ? HW / 4 : HW) * (x.C / 8);
         const int logW = ilog2(x.res), logHW = 2 * logW;
         const TRef xrr = xr ? *xr : TRef();
-        E.ops.push_back([=](const Ctx& c) {
+        op(CLS_OTHER, [=](const Ctx& c) {
             const int64_t total = chunks_per_img * c.B;
             hipLaunchKernelGGL(k_gn_apply, dim3(grid1d(total, 256, 8192)), dim3(256), 0, c.stream, c.act(x), x.ld, x.C,
                                logW, logHW, c.at<float>(sc), c.at<float>(sh), c.act(y),
@@ -233,7 +241,7 @@ struct Builder {
         TRef t = new_act(ro, cout);
         const int logW = ilog2(ro), logHW = 2 * logW, HWo = ro * ro;
         const int dtotal = dense_total; const int64_t dout = dense_out;
-        E.ops.push_back([=](const Ctx& c) {
+        op(CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
             g.a0 = c.act(h); g.a0_ld = h.ld; g.a0_C = cin; g.taps = 9; g.logW = logW; g.logHW = logHW;
             g.M = c.B * HWo; g.N = cout; g.b = c.w<bf16>(w0); g.b_ld = K0a;
@@ -248,7 +256,7 @@ struct Builder {
         emit_gn_apply(t, sc, sh, u, nullptr, ACT_SILU, RS_NONE);
         arena.release(t.off);
         const TRef xs = (m.up || m.down) ? xr : x;           // shortcut source at the output resolution
-        E.ops.push_back([=](const Ctx& c) {
+        op(CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
             g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_C = cout; g.taps = 9; g.logW = logW; g.logHW = logHW;
             if (shortcut) { g.a1 = c.act(xs); g.a1_ld = xs.ld; g.a1_C = cin; }
@@ -283,14 +291,14 @@ struct Builder {
         TRef h = new_act(m.res, C);
         emit_gn_apply(x, sc, sh, h, nullptr, ACT_NONE, RS_NONE);
         const int64_t qk = arena.alloc((int64_t)T * 2 * C * 2), vT = arena.alloc((int64_t)C * T * 2);
-        E.ops.push_back([=](const Ctx& c) {             // q | k  = h Wq | h Wk
+        op(CLS_GEMM, [=](const Ctx& c) {             // q | k  = h Wq | h Wk
             GemmArgs g = gemm_defaults();
             g.a0 = c.act(h); g.a0_ld = C; g.a0_C = C; g.M = c.B * T; g.N = 2 * C;
             g.b = c.w<bf16>(wqk); g.b_ld = C; g.bias_n = c.w<float>(bqk);
             g.c = c.at<bf16>(qk); g.c_ld = 2 * C;
             launch_gemm(g, c.stream);
         });
-        E.ops.push_back([=](const Ctx& c) {             // V^T[b] = Wv^T h[b]^T  (so that P V is an "A B^T" product)
+        op(CLS_GEMM, [=](const Ctx& c) {             // V^T[b] = Wv^T h[b]^T  (so that P V is an "A B^T" product)
             GemmArgs g = gemm_defaults();
             g.a0 = c.w<bf16>(wv); g.a0_ld = C; g.a0_C = C; g.a_bs = 0; g.M = C; g.N = T;
             g.b = c.act(h); g.b_ld = C; g.b_bs = (int64_t)T * C; g.bias_m = c.w<float>(bv);
@@ -299,7 +307,7 @@ struct Builder {
         });
         arena.release(h.off);
         const int64_t S = arena.alloc((int64_t)T * T * 4);
-        E.ops.push_back([=](const Ctx& c) {             // S[b] = q[b] k[b]^T / sqrt(C)
+        op(CLS_GEMM, [=](const Ctx& c) {             // S[b] = q[b] k[b]^T / sqrt(C)
             GemmArgs g = gemm_defaults();
             g.a0 = c.at<bf16>(qk); g.a0_ld = 2 * C; g.a0_C = C; g.a_bs = (int64_t)T * 2 * C; g.M = T; g.N = T;
             g.b = c.at<bf16>(qk) + C; g.b_ld = 2 * C; g.b_bs = (int64_t)T * 2 * C;
@@ -308,14 +316,14 @@ struct Builder {
             launch_gemm(g, c.stream);
         });
         const int64_t P = arena.alloc((int64_t)T * T * 2);
-        E.ops.push_back([=](const Ctx& c) {
+        op(CLS_OTHER, [=](const Ctx& c) {
             const int64_t rows = (int64_t)c.B * T;
             hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c.stream,
                                c.at<float>(S), c.at<bf16>(P), T, rows);
         });
         arena.release(S);
         TRef O = new_act(m.res, C);
-        E.ops.push_back([=](const Ctx& c) {             // O[b] = P[b] V[b]
+        op(CLS_GEMM, [=](const Ctx& c) {             // O[b] = P[b] V[b]
             GemmArgs g = gemm_defaults();
             g.a0 = c.at<bf16>(P); g.a0_ld = T; g.a0_C = T; g.a_bs = (int64_t)T * T; g.M = T; g.N = C;
             g.b = c.at<bf16>(vT); g.b_ld = T; g.b_bs = (int64_t)C * T;
@@ -323,7 +331,7 @@ struct Builder {
             launch_gemm(g, c.stream);
         });
         arena.release(P); arena.release(vT); arena.release(qk);
-        E.ops.push_back([=](const Ctx& c) {             // out = (x + O W3 + b3) / sqrt(2)
+        op(CLS_GEMM, [=](const Ctx& c) {             // out = (x + O W3 + b3) / sqrt(2)
             GemmArgs g = gemm_defaults();
             g.a0 = c.act(O); g.a0_ld = C; g.a0_C = C; g.M = c.B * T; g.N = C;
             g.b = c.w<bf16>(w3); g.b_ld = C; g.bias_n = c.w<float>(b3);
@@ -407,8 +415,10 @@ struct Builder {
             pack_conv(pw0, w0, TEMB, NF, 1, NF, 0, NF); pack_conv(pw1, w1, TEMB, TEMB, 1, TEMB, 0, TEMB);
             const int64_t b0 = pack_f32(pb0, TEMB), b1 = pack_f32(pb1, TEMB);
             const int64_t dw = dense_w, db = dense_b, dout = dense_out; const int dtot = dense_total;
-            E.ops.push_back([=](const Ctx& c) {
+            op(CLS_OTHER, [=](const Ctx& c) {
                 hipLaunchKernelGGL(k_time_embed, dim3(grid1d((int64_t)c.B * 128)), dim3(256), 0, c.stream, c.labels, c.at<bf16>(emb), c.B);
+            });
+            op(CLS_GEMM, [=](const Ctx& c) {
                 GemmArgs g = gemm_defaults();                        // act(Linear_0(emb))
                 g.a0 = c.at<bf16>(emb); g.a0_ld = NF; g.a0_C = NF; g.M = c.B; g.N = TEMB;
                 g.b = c.w<bf16>(w0); g.b_ld = NF; g.bias_n = c.w<float>(b0); g.act = ACT_SILU;
@@ -438,9 +448,12 @@ struct Builder {
             const int64_t b = pack_f32(pb, NF);
             const int64_t a0 = arena.alloc((int64_t)IMG * IMG * 64 * 2);
             const TRef dst = cur;
-            E.ops.push_back([=](const Ctx& c) {
+            op(CLS_OTHER, [=](const Ctx& c) {
                 const int64_t rows = (int64_t)c.B * IMG * IMG;
                 hipLaunchKernelGGL(k_stem_im2col, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, c.stream, c.x, c.at<bf16>(a0), rows);
+            });
+            op(CLS_GEMM, [=](const Ctx& c) {
+                const int64_t rows = (int64_t)c.B * IMG * IMG;
                 GemmArgs g = gemm_defaults();
                 g.a0 = c.at<bf16>(a0); g.a0_ld = 64; g.a0_C = 64; g.M = (int)rows; g.N = NF;
                 g.b = c.w<bf16>(w); g.b_ld = 64; g.bias_n = c.w<float>(b);
@@ -522,7 +535,7 @@ struct Builder {
             TRef u = new_act(res, mg.cin);
             emit_gn_apply(last, sc, sh, u, nullptr, ACT_SILU, RS_NONE);
             const int logW = ilog2(res), cinf = mc.cin;
-            E.ops.push_back([=](const Ctx& c) {
+            op(CLS_GEMM, [=](const Ctx& c) {
                 GemmArgs g = gemm_defaults();
                 g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_C = cinf; g.taps = 9; g.logW = logW; g.logHW = 2 * logW;
                 g.M = c.B * res * res; g.N = 3; g.b = c.w<bf16>(w); g.b_ld = Kf; g.bias_n = c.w<float>(b);
@@ -589,6 +602,8 @@ int natinf_ncsnpp_create(natinf_ncsnpp_t* out, int flags) {
 
 int natinf_ncsnpp_destroy(natinf_ncsnpp_t h) {
     if (!h) return NATINF_EINVAL;
+    for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : h->pool) (void)hipEventDestroy(e);
     delete h;
     return NATINF_OK;
 }
@@ -627,9 +642,45 @@ int natinf_ncsnpp_forward(natinf_ncsnpp_t h, const float* x, const float* labels
         h->attr_set = true;
     }
     Ctx c{B, reinterpret_cast<unsigned char*>(workspace), h->packed, (hipStream_t)stream, x, labels, out};
-    for (const auto& f : h->ops) f(c);
+    if (!h->prof) {
+        for (const auto& f : h->ops) f(c);
+    } else {
+        for (size_t i = 0; i < h->ops.size(); ++i) {
+            natinf_ncsnpp::Rec r; r.cls = h->op_cls[i];
+            for (hipEvent_t* e : {&r.a, &r.b}) {
+                if (!h->pool.empty()) { *e = h->pool.back(); h->pool.pop_back(); }
+                else if (hipEventCreate(e) != hipSuccess) return NATINF_ELAUNCH;
+            }
+            (void)hipEventRecord(r.a, c.stream);
+            h->ops[i](c);
+            (void)hipEventRecord(r.b, c.stream);
+            h->recs.push_back(r);
+        }
+    }
     h->last_B = B; h->last_ws = c.ws;
     return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
+}
+
+int natinf_ncsnpp_profile(natinf_ncsnpp_t h, int enable) {
+    if (!h) return NATINF_EINVAL;
+    h->prof = enable != 0;
+    return NATINF_OK;
+}
+
+int natinf_ncsnpp_profile_read(natinf_ncsnpp_t h, double* ms_by_class, int64_t* launches_by_class) {
+    if (!h || !ms_by_class || !launches_by_class) return NATINF_EINVAL;
+    for (int i = 0; i < N_CLS; ++i) { ms_by_class[i] = 0.0; launches_by_class[i] = 0; }
+    for (const auto& r : h->recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) {
+            (void)hipGetLastError();
+            return NATINF_ELAUNCH;
+        }
+        ms_by_class[r.cls] += ms; launches_by_class[r.cls] += 1;
+        h->pool.push_back(r.a); h->pool.push_back(r.b);
+    }
+    h->recs.clear();
+    return NATINF_OK;
 }
 
 int natinf_ncsnpp_debug_tap(natinf_ncsnpp_t h, int module_idx, float* out, int64_t capacity_elems, natinf_stream_t stream) {

@@ -268,16 +268,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const GemmArgs g)
 // GroupNorm (32 groups, eps 1e-6): statistics pass -> per-(sample, channel) scale / shift
 // ------------------------------------------------------------------------------------------------
 // One 256-thread block per sample.  scale[b][c] = rstd*gamma[c], shift[b][c] = beta[c] - mean*scale.
+// Deterministic: per-thread partial sums are parked in LDS and reduced in a fixed order (no atomics), so a
+// sample's statistics do not depend on timing, batch size or batch neighbours.
 __global__ __launch_bounds__(256) void k_gn_stats(const bf16* __restrict__ x, int ld, int C, int HW,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   float* __restrict__ scale, float* __restrict__ shift, float eps)
 {
+    __shared__ float s_part[2][16 * 128 + 64];     // [sum|sq][lane * C + c]; lanes*C <= 2048 for every C in use
     __shared__ float s_sum[512], s_sq[512], s_mean[32], s_rstd[32];
     const int tid = threadIdx.x, b = blockIdx.x;
-    for (int c = tid; c < C; c += 256) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
-    __syncthreads();
     const int cpp = C >> 3;                        // 16-byte chunks per pixel
-    const int lanes = 256 / cpp;                   // pixel lanes
+    const int lanes = 256 / cpp;                   // pixel lanes (16 / 8 / 5 / 4 for C = 128 / 256 / 384 / 512)
     if (tid < cpp * lanes) {
         const int chunk = tid % cpp, pl = tid / cpp;
         float s[8], q[8];
@@ -290,7 +291,13 @@ __global__ __launch_bounds__(256) void k_gn_stats(const bf16* __restrict__ x, in
             for (int i = 0; i < 8; ++i) { const float f = (float)v[i]; s[i] += f; q[i] += f * f; }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { atomicAdd(&s_sum[chunk * 8 + i], s[i]); atomicAdd(&s_sq[chunk * 8 + i], q[i]); }
+        for (int i = 0; i < 8; ++i) { s_part[0][pl * C + chunk * 8 + i] = s[i]; s_part[1][pl * C + chunk * 8 + i] = q[i]; }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f, q = 0.f;
+        for (int l = 0; l < lanes; ++l) { s += s_part[0][l * C + c]; q += s_part[1][l * C + c]; }
+        s_sum[c] = s; s_sq[c] = q;
     }
     __syncthreads();
     const int cg = C >> 5;

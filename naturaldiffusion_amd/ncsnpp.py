@@ -139,6 +139,16 @@ class NCSNppEngine:
                                         stream_ptr()), "natinf_ncsnpp_forward")
         return out
 
+    def profile(self, enable: bool) -> None:
+        check(lib.natinf_ncsnpp_profile(self._h, 1 if enable else 0), "natinf_ncsnpp_profile")
+
+    def profile_read(self):
+        """-> {"gemm": (ms, launches), "other": (ms, launches)} since the last read (synchronises)."""
+        ms = (C.c_double * 2)()
+        n = (C.c_int64 * 2)()
+        check(lib.natinf_ncsnpp_profile_read(self._h, ms, n), "natinf_ncsnpp_profile_read")
+        return {"gemm": (ms[0], n[0]), "other": (ms[1], n[1])}
+
     def tap(self, module_idx: int, shape) -> torch.Tensor:
         out = torch.empty(shape, dtype=torch.float32, device=self.device)
         check(lib.natinf_ncsnpp_debug_tap(self._h, module_idx, ptr(out), out.numel(), stream_ptr()), "natinf_ncsnpp_debug_tap")
