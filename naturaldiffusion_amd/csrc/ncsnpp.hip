@@ -45,7 +45,8 @@ const char* kind_name(int k) { static const char* n[] = {"lin", "conv", "res", "
 struct Mod { int idx, kind, cin, cout, up, down, res; int64_t poff; };
 
 // tensor reference inside the workspace: `off` is BYTES PER IMAGE (actual = off * B)
-struct TRef { int64_t off = -1; int C = 0, ld = 0, res = 0, coff = 0; };   // coff: channel offset inside a wider buffer
+// coff: channel offset inside a wider buffer; pad = 1: stored with a one-pixel zero border (3x3 GEMM inputs)
+struct TRef { int64_t off = -1; int C = 0, ld = 0, res = 0, coff = 0, pad = 0; };
 
 struct Ctx {                     // per-forward launch context
     int B; unsigned char* ws; const unsigned char* wp; hipStream_t stream;
@@ -125,9 +126,14 @@ GemmArgs gemm_defaults() {
     g.taps = 1; g.batch = 1; g.scale = 1.0f; g.act = ACT_NONE; g.c_mode = OUT_BF16;
     return g;
 }
+// LDS-DMA kernel whenever its preconditions hold (K a multiple of 64 per segment, 3x3 operands zero-bordered);
+// the register-staged, fully masked kernel otherwise (4x4 attention: K or N = 16).
 void launch_gemm(const GemmArgs& g, hipStream_t s) {
     const int nM = (g.M + BM - 1) / BM, nN = (g.N + BN - 1) / BN;
-    hipLaunchKernelGGL(k_gemm_bf16, dim3(nM * nN, 1, g.batch), dim3(256), GEMM_LDS_BYTES, s, g);
+    const int K0 = g.taps * g.a0_C, K1 = g.a1 ? g.a1_C : 0;
+    const bool dma = K0 % BK == 0 && K1 % BK == 0 && (g.taps == 1 || g.a0_padded) && (g.taps == 1 || g.a0_C % BK == 0);
+    if (dma) hipLaunchKernelGGL(k_gemm_bf16_dma, dim3(nM * nN, 1, g.batch), dim3(256), GEMM_LDS_BYTES, s, g);
+    else     hipLaunchKernelGGL(k_gemm_bf16, dim3(nM * nN, 1, g.batch), dim3(256), GEMM_LDS_BYTES, s, g);
 }
 inline int grid1d(int64_t n, int block = 256, int cap = 4096) {
     int64_t g = (n + block - 1) / block; return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -195,18 +201,20 @@ struct Builder {
         });
     }
     void emit_gn_apply(const TRef& x, int64_t sc, int64_t sh, const TRef& y, const TRef* xr, int act, int mode) {
-        const int HW = x.res * x.res;
-        const int64_t chunks_per_img = (int64_t)(mode == RS_DOWN ? HW / 4 : HW) * (x.C / 8);
         const int logW = ilog2(x.res), logHW = 2 * logW;
+        const int rd = mode == RS_UP ? 2 * x.res : (mode == RS_DOWN ? x.res / 2 : x.res);
+        const int rows_per_img = rd + 2 * y.pad;
         const TRef xrr = xr ? *xr : TRef();
         op(CLS_OTHER, [=](const Ctx& c) {
-            const int64_t total = chunks_per_img * c.B;
-            hipLaunchKernelGGL(k_gn_apply, dim3(grid1d(total, 256, 8192)), dim3(256), 0, c.stream, c.act(x), x.ld, x.C,
+            hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)(c.B * rows_per_img)), dim3(256), 0, c.stream, c.act(x), x.ld, x.C,
                                logW, logHW, c.at<float>(sc), c.at<float>(sh), c.act(y),
-                               xrr.off >= 0 ? c.act(xrr) : (bf16*)nullptr, act, mode, total);
+                               xrr.off >= 0 ? c.act(xrr) : (bf16*)nullptr, act, mode, y.pad);
         });
     }
-    TRef new_act(int res, int C) { TRef t; t.off = arena.alloc((int64_t)res * res * C * 2); t.C = C; t.ld = C; t.res = res; return t; }
+    TRef new_act(int res, int C, int pad = 0) {
+        TRef t; t.off = arena.alloc((int64_t)(res + 2 * pad) * (res + 2 * pad) * C * 2); t.C = C; t.ld = C; t.res = res; t.pad = pad;
+        return t;
+    }
 
     void emit_res(const Mod& m, const TRef& x, const TRef& out) {
         const int cin = m.cin, cout = m.cout;
@@ -234,7 +242,7 @@ struct Builder {
 
         const int64_t sc = arena.alloc((int64_t)std::max(cin, cout) * 4), sh = arena.alloc((int64_t)std::max(cin, cout) * 4);
         emit_gn_stats(x, gn0, sc, sh);
-        TRef h = new_act(ro, cin), xr;
+        TRef h = new_act(ro, cin, 1), xr;
         if (m.up || m.down) xr = new_act(ro, cin);
         emit_gn_apply(x, sc, sh, h, (m.up || m.down) ? &xr : nullptr, ACT_SILU, m.up ? RS_UP : (m.down ? RS_DOWN : RS_NONE));
 
@@ -243,7 +251,7 @@ struct Builder {
         const int dtotal = dense_total; const int64_t dout = dense_out;
         op(CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
-            g.a0 = c.act(h); g.a0_ld = h.ld; g.a0_C = cin; g.taps = 9; g.logW = logW; g.logHW = logHW;
+            g.a0 = c.act(h); g.a0_ld = h.ld; g.a0_C = cin; g.taps = 9; g.logW = logW; g.logHW = logHW; g.a0_padded = 1;
             g.M = c.B * HWo; g.N = cout; g.b = c.w<bf16>(w0); g.b_ld = K0a;
             g.bias_n = c.w<float>(b0);
             g.rowvec = c.at<float>(dout) + drow; g.rowvec_ld = dtotal; g.log_rows_per_sample = logHW;
@@ -252,13 +260,13 @@ struct Builder {
         });
         arena.release(h.off);
         emit_gn_stats(t, gn1, sc, sh);
-        TRef u = new_act(ro, cout);
+        TRef u = new_act(ro, cout, 1);
         emit_gn_apply(t, sc, sh, u, nullptr, ACT_SILU, RS_NONE);
         arena.release(t.off);
         const TRef xs = (m.up || m.down) ? xr : x;           // shortcut source at the output resolution
         op(CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
-            g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_C = cout; g.taps = 9; g.logW = logW; g.logHW = logHW;
+            g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_C = cout; g.taps = 9; g.logW = logW; g.logHW = logHW; g.a0_padded = 1;
             if (shortcut) { g.a1 = c.act(xs); g.a1_ld = xs.ld; g.a1_C = cin; }
             else { g.resid = c.act(xs); g.resid_ld = xs.ld; }
             g.M = c.B * HWo; g.N = cout; g.b = c.w<bf16>(w1); g.b_ld = K1tot;
@@ -532,12 +540,12 @@ struct Builder {
             const int64_t b = pack_f32(pb, 3);
             const int64_t sc = arena.alloc((int64_t)mg.cin * 4), sh = arena.alloc((int64_t)mg.cin * 4);
             emit_gn_stats(last, gn, sc, sh);
-            TRef u = new_act(res, mg.cin);
+            TRef u = new_act(res, mg.cin, 1);
             emit_gn_apply(last, sc, sh, u, nullptr, ACT_SILU, RS_NONE);
             const int logW = ilog2(res), cinf = mc.cin;
             op(CLS_GEMM, [=](const Ctx& c) {
                 GemmArgs g = gemm_defaults();
-                g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_C = cinf; g.taps = 9; g.logW = logW; g.logHW = 2 * logW;
+                g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_C = cinf; g.taps = 9; g.logW = logW; g.logHW = 2 * logW; g.a0_padded = 1;
                 g.M = c.B * res * res; g.N = 3; g.b = c.w<bf16>(w); g.b_ld = Kf; g.bias_n = c.w<float>(b);
                 g.c = c.out; g.c_mode = OUT_F32_NCHW;
                 launch_gemm(g, c.stream);
@@ -638,6 +646,8 @@ int natinf_ncsnpp_forward(natinf_ncsnpp_t h, const float* x, const float* labels
     if (workspace_bytes < h->ws_per_image * (int64_t)B || (int64_t)B * IMG * IMG >= (1LL << 31)) return NATINF_EINVAL;
     if (!h->attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GEMM_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16_dma), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GEMM_LDS_BYTES) != hipSuccess) { (void)hipGetLastError(); return NATINF_ENODEV; }
         h->attr_set = true;
     }

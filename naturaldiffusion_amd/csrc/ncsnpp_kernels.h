@@ -38,6 +38,7 @@ struct GemmArgs {
     const bf16* a0; int a0_ld; int a0_C;
     const bf16* a1; int a1_ld; int a1_C;
     int taps; int logW; int logHW;                    // spatial decode of m for taps == 9 (power-of-two H, W)
+    int a0_padded;                                    // taps == 9: a0 is [B][H+2][W+2][C] with a zero border (k_gemm_bf16_dma only)
     int M, N;
     const bf16* b; int b_ld;                          // [N][K0+K1], K contiguous
     int64_t a_bs, b_bs, c_bs; int batch;              // per-batch element strides (blockIdx.z)
@@ -55,6 +56,92 @@ __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)
 __device__ __forceinline__ int xcd_remap(int bid, int n) {
     const int q = n >> 3, r = n & 7, x = bid & 7, l = bid >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
+}
+
+// Shared epilogue: accumulators -> LDS (fp32) -> fused adds -> coalesced stores.  All waves must have finished
+// reading the operand tiles (the caller's last barrier) before this overwrites the same LDS.
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, unsigned char* smem, f32x4 (&acc)[4][4],
+                                              int m0, int n0, int z, int tid, int lane, int wm, int wn)
+{
+    float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                sC[(wm * 64 + i * 16 + (lane >> 4) * 4 + r) * C_ROW + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
+
+    if (g.c_mode == OUT_F32_NCHW) {
+        // out[b][n][p] fp32, N small (final 3-channel conv): consecutive threads -> consecutive pixels
+        float* out = reinterpret_cast<float*>(g.c);
+        const int nvalid = min(BN, g.N - n0);
+        for (int e = tid; e < BM * nvalid; e += 256) {
+            const int r = e & (BM - 1), n = e >> 7;
+            const int m = m0 + r;
+            if (m < g.M) {
+                float v = sC[r * C_ROW + n];
+                if (g.bias_n) v += g.bias_n[n0 + n];
+                v *= g.scale;
+                const int b = m >> g.logHW, p = m & ((1 << g.logHW) - 1);
+                out[((int64_t)b * g.N + n0 + n) * ((int64_t)1 << g.logHW) + p] = v;
+            }
+        }
+        return;
+    }
+
+    const int cchunk = tid & 15;                   // 8 consecutive columns
+    const int n = n0 + cchunk * 8;
+    const bool n_in = n < g.N;                     // N is a multiple of 8 whenever this path is used
+    float bn[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bn[q] = 0.f;
+    if (g.bias_n && n_in) {
+        const float4 u = *reinterpret_cast<const float4*>(g.bias_n + n), w = *reinterpret_cast<const float4*>(g.bias_n + n + 4);
+        bn[0] = u.x; bn[1] = u.y; bn[2] = u.z; bn[3] = u.w; bn[4] = w.x; bn[5] = w.y; bn[6] = w.z; bn[7] = w.w;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int r = pass * 16 + (tid >> 4);
+        const int m = m0 + r;
+        if (m >= g.M || !n_in) continue;
+        const float4 u = *reinterpret_cast<const float4*>(sC + r * C_ROW + cchunk * 8);
+        const float4 w = *reinterpret_cast<const float4*>(sC + r * C_ROW + cchunk * 8 + 4);
+        float v[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += bn[q];
+        if (g.bias_m) {
+            const float bm = g.bias_m[m];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += bm;
+        }
+        if (g.rowvec) {
+            const float* rv = g.rowvec + (int64_t)(m >> g.log_rows_per_sample) * g.rowvec_ld + n;
+            const float4 s = *reinterpret_cast<const float4*>(rv), t = *reinterpret_cast<const float4*>(rv + 4);
+            v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w; v[4] += t.x; v[5] += t.y; v[6] += t.z; v[7] += t.w;
+        }
+        if (g.resid) {
+            const bf16x8 rs = *reinterpret_cast<const bf16x8*>(g.resid + (int64_t)z * g.c_bs + (int64_t)m * g.resid_ld + n);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += (float)rs[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            v[q] *= g.scale;
+            if (g.act == ACT_SILU) v[q] = silu_f(v[q]);
+        }
+        if (g.c_mode == OUT_BF16) {
+            bf16x8 o;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = (bf16)v[q];
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(g.c) + (int64_t)z * g.c_bs + (int64_t)m * g.c_ld + n) = o;
+        } else {
+            float* o = reinterpret_cast<float*>(g.c) + (int64_t)z * g.c_bs + (int64_t)m * g.c_ld + n;
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
 }
 
 // Branch-free masked 16-byte load: the address is always a readable one (the operand's base when
@@ -182,86 +269,121 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const GemmArgs g)
         __syncthreads();
     }
 
-    // ---- epilogue: accumulators -> LDS (fp32) -> fused adds -> coalesced stores
-    float* sC = reinterpret_cast<float*>(smem);
+    gemm_epilogue(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_gemm_bf16_dma: the same tile / fragment / epilogue structure, fed by LDS-DMA.
+//
+// Operand tiles go HBM/L2 -> LDS with `global_load_lds_dwordx4` (no VGPR staging, no ds_write pass -- the
+// ds_write_b128 path moves only ~79 B/clk/CU and was the busiest pipe of the register-staged kernel).  One
+// wave-instruction lands 64 lanes x 16 B = 8 consecutive 128-byte LDS rows; the XOR swizzle therefore sits on the
+// SOURCE address (lane l of a piece fetches logical chunk (l&7) ^ ((row>>1)&7) of row l>>3) and on the fragment
+// read, never on the LDS destination.  Loads are unconditional, which the callers make legal:
+//   * taps == 9 operands are stored with a one-pixel zero border ([B][H+2][W+2][C], written by k_gn_apply),
+//     so a shifted tap never leaves the tensor and no zero-fill is needed;
+//   * rows beyond M (or N) are clamped to the last valid row -- computed, never stored;
+//   * K0 and K1 are multiples of 64 (checked on the host; other shapes use k_gemm_bf16).
+// Pipeline: 2 LDS buffers; tile k+1's DMA is issued before tile k's MFMAs and retired by the vmcnt(0) that
+// __syncthreads() carries, one barrier per K-tile; 2 blocks/CU overlap each other's barrier stalls.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_gemm_bf16_dma(const GemmArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nN = (g.N + BN - 1) / BN, nM = (g.M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, nM * nN);
+    const int m0 = (tile / nN) * BM, n0 = (tile % nN) * BN;
+    const int z = blockIdx.z;
+
+    const bf16* a0 = g.a0 + (int64_t)z * g.a_bs;
+    const bf16* a1 = g.a1 ? g.a1 + (int64_t)z * g.a_bs : nullptr;
+    const bf16* bp = g.b + (int64_t)z * g.b_bs;
+    const int K0 = g.taps * g.a0_C, K1 = g.a1 ? g.a1_C : 0;
+    const int nk0 = K0 / BK, nk = nk0 + K1 / BK;
+    const int Wp = (1 << g.logW) + 2, Hp = (1 << (g.logHW - g.logW)) + 2;     // padded extent (taps == 9)
+
+    // this lane's source rows in the 4 DMA pieces (8 rows each) its wave issues per operand per K-tile
+    // (byte addresses; the segment-1 operand is reached through a per-row delta so that the K loop selects between
+    // VALUES, never between array slots -- a select of slots would push these arrays to scratch)
+    uint64_t a_row[4], a_delta[4], b_row[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + (lane >> 3);
+        const int lchunk = ((lane & 7) ^ ((r >> 1) & 7)) << 3;
+        const int m = min(m0 + r, g.M - 1);
+        int64_t off0;
+        if (g.taps == 9) {
+            const int b = m >> g.logHW, p = m & ((1 << g.logHW) - 1), y = p >> g.logW, x = p & ((1 << g.logW) - 1);
+            off0 = ((int64_t)(b * Hp + y + 1) * Wp + x + 1) * g.a0_ld;
+        } else {
+            off0 = (int64_t)m * g.a0_ld;
+        }
+        a_row[j] = reinterpret_cast<uint64_t>(a0 + off0 + lchunk);
+        a_delta[j] = a1 ? reinterpret_cast<uint64_t>(a1 + (int64_t)m * g.a1_ld + lchunk) - a_row[j] : 0;
+        b_row[j] = reinterpret_cast<uint64_t>(bp + (int64_t)min(n0 + r, g.N - 1) * g.b_ld + lchunk);
+    }
+
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto issue_tile = [&](int kt, int buf) __attribute__((always_inline)) {
+        unsigned char* dA = smem + buf * (2 * TILE_ELEMS * 2) + wave * 4096;
+        unsigned char* dB = dA + TILE_ELEMS * 2;
+        const bool seg0 = kt < nk0;
+        int64_t ashift;                                     // bytes, wave-uniform
+        int kk;
+        if (seg0) {
+            const int kbase = kt * BK;
+            int tap = 0, c0 = kbase;
+            if (g.taps == 9) { tap = kbase / g.a0_C; c0 = kbase - tap * g.a0_C; }
+            const int dy = g.taps == 9 ? tap / 3 - 1 : 0, dx = g.taps == 9 ? tap % 3 - 1 : 0;
+            ashift = ((int64_t)(dy * Wp + dx) * g.a0_ld + c0) * 2; kk = kbase;
+        } else {
+            ashift = (int64_t)(kt - nk0) * BK * 2; kk = K0 + (kt - nk0) * BK;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t pa = a_row[j] + (seg0 ? 0 : a_delta[j]) + (uint64_t)ashift;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pa), (lds_void*)(dA + j * 1024), 16, 0, 0);
+            const uint64_t pb = b_row[j] + (uint64_t)kk * 2;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pb), (lds_void*)(dB + j * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                sC[(wm * 64 + i * 16 + (lane >> 4) * 4 + r) * C_ROW + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue_tile(0, 0);
     __syncthreads();
 
-    if (g.c_mode == OUT_F32_NCHW) {
-        // out[b][n][p] fp32, N small (final 3-channel conv): consecutive threads -> consecutive pixels
-        float* out = reinterpret_cast<float*>(g.c);
-        const int nvalid = min(BN, g.N - n0);
-        for (int e = tid; e < BM * nvalid; e += 256) {
-            const int r = e & (BM - 1), n = e >> 7;
-            const int m = m0 + r;
-            if (m < g.M) {
-                float v = sC[r * C_ROW + n];
-                if (g.bias_n) v += g.bias_n[n0 + n];
-                v *= g.scale;
-                const int b = m >> g.logHW, p = m & ((1 << g.logHW) - 1);
-                out[((int64_t)b * g.N + n0 + n) * ((int64_t)1 << g.logHW) + p] = v;
+    const int frow = lane & 15, fq = lane >> 4, fswz = (frow >> 1) & 7;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue_tile(kt + 1, cur ^ 1);
+        const bf16* ta = reinterpret_cast<const bf16*>(smem + cur * (2 * TILE_ELEMS * 2)) + (wm * 64 + frow) * LDS_ROW;
+        const bf16* tb = reinterpret_cast<const bf16*>(smem + cur * (2 * TILE_ELEMS * 2) + TILE_ELEMS * 2) + (wn * 64 + frow) * LDS_ROW;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+            const int ko = (((ks << 2) | fq) ^ fswz) << 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = *reinterpret_cast<const bf16x8*>(ta + i * 16 * LDS_ROW + ko);
+                fb[i] = *reinterpret_cast<const bf16x8*>(tb + i * 16 * LDS_ROW + ko);
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        return;
+        __syncthreads();          // vmcnt(0) + barrier: tile kt+1 has landed, everyone is done with buffer `cur`
     }
-
-    const int cchunk = tid & 15;                   // 8 consecutive columns
-    const int n = n0 + cchunk * 8;
-    const bool n_in = n < g.N;                     // N is a multiple of 8 whenever this path is used
-    float bn[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) bn[q] = 0.f;
-    if (g.bias_n && n_in) {
-        const float4 u = *reinterpret_cast<const float4*>(g.bias_n + n), w = *reinterpret_cast<const float4*>(g.bias_n + n + 4);
-        bn[0] = u.x; bn[1] = u.y; bn[2] = u.z; bn[3] = u.w; bn[4] = w.x; bn[5] = w.y; bn[6] = w.z; bn[7] = w.w;
-    }
-#pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-        const int r = pass * 16 + (tid >> 4);
-        const int m = m0 + r;
-        if (m >= g.M || !n_in) continue;
-        const float4 u = *reinterpret_cast<const float4*>(sC + r * C_ROW + cchunk * 8);
-        const float4 w = *reinterpret_cast<const float4*>(sC + r * C_ROW + cchunk * 8 + 4);
-        float v[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] += bn[q];
-        if (g.bias_m) {
-            const float bm = g.bias_m[m];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] += bm;
-        }
-        if (g.rowvec) {
-            const float* rv = g.rowvec + (int64_t)(m >> g.log_rows_per_sample) * g.rowvec_ld + n;
-            const float4 s = *reinterpret_cast<const float4*>(rv), t = *reinterpret_cast<const float4*>(rv + 4);
-            v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w; v[4] += t.x; v[5] += t.y; v[6] += t.z; v[7] += t.w;
-        }
-        if (g.resid) {
-            const bf16x8 rs = *reinterpret_cast<const bf16x8*>(g.resid + (int64_t)z * g.c_bs + (int64_t)m * g.resid_ld + n);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] += (float)rs[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            v[q] *= g.scale;
-            if (g.act == ACT_SILU) v[q] = silu_f(v[q]);
-        }
-        if (g.c_mode == OUT_BF16) {
-            bf16x8 o;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) o[q] = (bf16)v[q];
-            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(g.c) + (int64_t)z * g.c_bs + (int64_t)m * g.c_ld + n) = o;
-        } else {
-            float* o = reinterpret_cast<float*>(g.c) + (int64_t)z * g.c_bs + (int64_t)m * g.c_ld + n;
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        }
-    }
+    gemm_epilogue(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -322,71 +444,75 @@ __global__ __launch_bounds__(256) void k_gn_stats(const bf16* __restrict__ x, in
 
 // y = act(x*scale + shift) with optional 2x nearest up-sampling / 2x2 mean down-sampling of BOTH the
 // activated tensor (-> y) and the raw input (-> xr), as ResnetBlockBigGANpp does (layerspp.py:245-257).
+// Destination-centric: one block per destination pixel ROW (blockIdx.x = b*Hp + yy), threads over that row's
+// 16-byte chunks.  With pad = 1 the destination carries a one-pixel zero border ([B][Hd+2][Wd+2][C]) which this
+// kernel writes too, so the 3x3 implicit GEMM that consumes y can fetch every tap unconditionally.
+// xr (raw input at the output resolution, feeds the 1x1 shortcut) is never padded.
 enum { RS_NONE = 0, RS_UP = 1, RS_DOWN = 2 };
 __global__ __launch_bounds__(256) void k_gn_apply(const bf16* __restrict__ x, int ld, int C, int logW, int logHW,
                                                   const float* __restrict__ scale, const float* __restrict__ shift,
-                                                  bf16* __restrict__ y, bf16* __restrict__ xr, int act, int mode,
-                                                  int64_t total_chunks)
+                                                  bf16* __restrict__ y, bf16* __restrict__ xr, int act, int mode, int pad)
 {
     const int cpp = C >> 3;
-    const int W = 1 << logW, HW = 1 << logHW;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total_chunks; idx += (int64_t)gridDim.x * 256) {
-        const int chunk = (int)(idx % cpp);
-        const int64_t pix = idx / cpp;             // pixel index in the SOURCE (none/up) or DEST (down) grid
+    const int Ws = 1 << logW, Hs = 1 << (logHW - logW);
+    const int Wd = mode == RS_UP ? 2 * Ws : (mode == RS_DOWN ? Ws >> 1 : Ws);
+    const int Hd = mode == RS_UP ? 2 * Hs : (mode == RS_DOWN ? Hs >> 1 : Hs);
+    const int Wp = Wd + 2 * pad, Hp = Hd + 2 * pad;
+    const int b = blockIdx.x / Hp, yy = blockIdx.x - b * Hp;
+    const int Y = yy - pad;
+    bf16* yrow = y + ((int64_t)b * Hp + yy) * Wp * C;
+    const bool row_in = Y >= 0 && Y < Hd;
+    const float* ps = scale + (int64_t)b * C;
+    const float* ph = shift + (int64_t)b * C;
+    const bf16* xb = x + (int64_t)b * Hs * Ws * ld;
+    for (int i = threadIdx.x; i < Wp * cpp; i += 256) {
+        const int xx = i / cpp, chunk = i - xx * cpp;
+        const int X = xx - pad;
+        bf16x8 o;
+        if (!row_in || X < 0 || X >= Wd) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = (bf16)0.0f;
+            *reinterpret_cast<bf16x8*>(yrow + (int64_t)xx * C + chunk * 8) = o;
+            continue;
+        }
         float sc[8], sh[8];
+        {
+            const float4 s0 = *reinterpret_cast<const float4*>(ps + chunk * 8), s1 = *reinterpret_cast<const float4*>(ps + chunk * 8 + 4);
+            const float4 h0 = *reinterpret_cast<const float4*>(ph + chunk * 8), h1 = *reinterpret_cast<const float4*>(ph + chunk * 8 + 4);
+            sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+            sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+        }
         if (mode != RS_DOWN) {
-            const int b = (int)(pix >> logHW);
-            const float* ps = scale + (int64_t)b * C + chunk * 8; const float* ph = shift + (int64_t)b * C + chunk * 8;
+            const int sy = mode == RS_UP ? Y >> 1 : Y, sx = mode == RS_UP ? X >> 1 : X;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(xb + ((int64_t)sy * Ws + sx) * ld + chunk * 8);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { sc[i] = ps[i]; sh[i] = ph[i]; }
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + pix * ld + chunk * 8);
-            bf16x8 o;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float f = (float)v[i] * sc[i] + sh[i];
+            for (int q = 0; q < 8; ++q) {
+                float f = (float)v[q] * sc[q] + sh[q];
                 if (act == ACT_SILU) f = silu_f(f);
-                o[i] = (bf16)f;
+                o[q] = (bf16)f;
             }
-            if (mode == RS_NONE) {
-                *reinterpret_cast<bf16x8*>(y + pix * C + chunk * 8) = o;
-            } else {
-                const int p = (int)(pix & (HW - 1)), yy = p >> logW, xx = p & (W - 1);
-                const int64_t ob = (pix >> logHW) * 4 * HW;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int64_t op = ob + (int64_t)(2 * yy + (d >> 1)) * (2 * W) + 2 * xx + (d & 1);
-                    *reinterpret_cast<bf16x8*>(y + op * C + chunk * 8) = o;
-                    if (xr) *reinterpret_cast<bf16x8*>(xr + op * C + chunk * 8) = v;
-                }
-            }
+            if (xr) *reinterpret_cast<bf16x8*>(xr + (((int64_t)b * Hd + Y) * Wd + X) * C + chunk * 8) = v;
         } else {
-            // dest grid is (H/2, W/2): logHW/logW describe the SOURCE grid
-            const int HWd = HW >> 2, Wd = W >> 1;
-            const int b = (int)(pix / HWd), p = (int)(pix % HWd), yy = p / Wd, xx = p % Wd;
-            const float* ps = scale + (int64_t)b * C + chunk * 8; const float* ph = shift + (int64_t)b * C + chunk * 8;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { sc[i] = ps[i]; sh[i] = ph[i]; }
             float ay[8], ax[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { ay[i] = 0.f; ax[i] = 0.f; }
+            for (int q = 0; q < 8; ++q) { ay[q] = 0.f; ax[q] = 0.f; }
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const int64_t sp = (int64_t)b * HW + (int64_t)(2 * yy + (d >> 1)) * W + 2 * xx + (d & 1);
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + sp * ld + chunk * 8);
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(xb + ((int64_t)(2 * Y + (d >> 1)) * Ws + 2 * X + (d & 1)) * ld + chunk * 8);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float raw = (float)v[i];
-                    float f = raw * sc[i] + sh[i];
+                for (int q = 0; q < 8; ++q) {
+                    const float raw = (float)v[q];
+                    float f = raw * sc[q] + sh[q];
                     if (act == ACT_SILU) f = silu_f(f);
-                    ay[i] += f; ax[i] += raw;
+                    ay[q] += f; ax[q] += raw;
                 }
             }
-            bf16x8 oy, ox;
+            bf16x8 ox;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { oy[i] = (bf16)(ay[i] * 0.25f); ox[i] = (bf16)(ax[i] * 0.25f); }
-            *reinterpret_cast<bf16x8*>(y + pix * C + chunk * 8) = oy;
-            if (xr) *reinterpret_cast<bf16x8*>(xr + pix * C + chunk * 8) = ox;
+            for (int q = 0; q < 8; ++q) { o[q] = (bf16)(ay[q] * 0.25f); ox[q] = (bf16)(ax[q] * 0.25f); }
+            if (xr) *reinterpret_cast<bf16x8*>(xr + (((int64_t)b * Hd + Y) * Wd + X) * C + chunk * 8) = ox;
         }
+        *reinterpret_cast<bf16x8*>(yrow + (int64_t)xx * C + chunk * 8) = o;
     }
 }
 
