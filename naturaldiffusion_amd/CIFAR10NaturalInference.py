@@ -74,10 +74,10 @@ def weighted_sum(past_x0_coeff: Sequence[float], seq_x0: Sequence[torch.Tensor])
 
 @torch.no_grad()
 def natural_inference(model_fn: Callable, noise: torch.Tensor, weight_path, dense: bool = False,
-                      fast_f32: bool = False, return_all: bool = False):
+                      fast_f32: bool = False, return_all: bool = False, stds=None):
     """The loop body of ``natural_inference_tx`` (:292-304) for one batch of initial noise."""
     C, B, node = load_coeff_npz(weight_path)
-    ni = CifarNI(C, B, node, noise.numel(), device=noise.device, dense=dense, fast_f32=fast_f32)
+    ni = CifarNI(C, B, node, noise.numel(), device=noise.device, dense=dense, fast_f32=fast_f32, stds=stds)
     return ni.run(model_fn, noise, return_all=return_all)
 
 

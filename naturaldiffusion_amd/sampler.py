@@ -34,7 +34,7 @@ class CifarNI:
     """x_{k+1} = fp32(sum_j C[k,j]*x0_j) + fp32(B[k,0])*noise with x0_k = ((-out/std)*sigma^2 + x_k)/alpha."""
 
     def __init__(self, C: np.ndarray, B: np.ndarray, node: np.ndarray, n_elem: int, device="cuda:0",
-                 dense: bool = False, fast_f32: bool = False):
+                 dense: bool = False, fast_f32: bool = False, stds=None):
         _lib.require_gpu()
         if n_elem % 4:
             raise ValueError("element count must be a multiple of 4")
@@ -49,7 +49,9 @@ class CifarNI:
         self.rows = SparseRows(self.C, lambda k: k + 1, hdt, self.device, dense=dense)
         self.hist = torch.empty((self.n_step, self.E), dtype=hdt, device=self.device)
         self._x = [torch.empty(self.E, dtype=torch.float32, device=self.device) for _ in range(2)]
-        self.std = [vp_std_f32(self.node[k, 0]) for k in range(self.n_step)]
+        # fp32 VP std per step, evaluated on the host like score_fn does; `stds` lets a caller pin them
+        # (torch.exp on CPU differs in the last ulp between hosts -- so does the reference's own value)
+        self.std = [vp_std_f32(self.node[k, 0]) for k in range(self.n_step)] if stds is None else [float(v) for v in stds]
         self.labels = [float(np.float32(self.node[k, 0]) * np.float32(999)) for k in range(self.n_step)]
 
     def step(self, k: int, x_k: torch.Tensor, model_out: torch.Tensor, noise: torch.Tensor,

@@ -93,11 +93,13 @@ def x0_from_score(xt: torch.Tensor, score: torch.Tensor, alpha: float, sigma: fl
     return (sc64 * (s * s) + xt64) / a
 
 
-def cifar_data_fn(model_fn: Callable, xt: torch.Tensor, t: float, alpha: float, sigma: float) -> torch.Tensor:
-    """A1+A2.  ``model_fn(x, labels)`` is the raw network (labels = t*999, fp32)."""
+def cifar_data_fn(model_fn: Callable, xt: torch.Tensor, t: float, alpha: float, sigma: float,
+                  std: Optional[float] = None) -> torch.Tensor:
+    """A1+A2.  ``model_fn(x, labels)`` is the raw network (labels = t*999, fp32).  ``std`` overrides the fp32
+    VP std (torch.exp is machine-dependent in the last ulp; fixtures carry the value they were made with)."""
     vec_t = torch.ones(xt.shape[0], dtype=F32) * t
     out = model_fn(xt, vec_t * 999)
-    std = vp_std_f32(t)
+    std = vp_std_f32(t) if std is None else torch.tensor(std, dtype=F32)
     return x0_from_score(xt, score_from_model_out(out, std), alpha, sigma)
 
 
@@ -110,13 +112,14 @@ def cifar_weighted_sum(coeff_row: Sequence[float], seq_x0: Sequence[torch.Tensor
 
 
 def cifar_ni_trajectory(model_fn: Callable, noise: torch.Tensor, C: np.ndarray, B: np.ndarray,
-                        node: np.ndarray) -> List[torch.Tensor]:
+                        node: np.ndarray, stds: Optional[Sequence[float]] = None) -> List[torch.Tensor]:
     """A5 (CIFAR10...:292-304).  Returns [x_0 (=noise), x_1, ..., x_N] (fp32)."""
     n_step = node.shape[0] - 1
     xs, hist = [noise], []
     x = noise
     for k in range(n_step):
-        hist.append(cifar_data_fn(model_fn, x, node[k, 0], node[k, 1], node[k, 2]))
+        hist.append(cifar_data_fn(model_fn, x, node[k, 0], node[k, 1], node[k, 2],
+                                  None if stds is None else float(stds[k])))
         nxt = cifar_weighted_sum(C[k], hist)
         eps = noise * float(np.float32(B[k, 0]))                    # fp32 scalar * fp32 tensor
         x = nxt + eps
@@ -290,40 +293,49 @@ def sd3_euler_ni(velocity_fn: Callable, noises: torch.Tensor, sigmas: torch.Tens
 
 
 # --------------------------------------------------------------------------- #
-# analytic stand-in denoisers used by the fixtures
+# stand-in denoisers used by the fixtures
+#
+# Built ONLY from +, -, *, / and sqrt on fp32 CPU tensors: those are correctly rounded by IEEE-754 on every
+# machine, so the build container (where the fixtures were captured) and the GPU box feed ni_step the same
+# bits.  torch.exp / sin / cos are NOT used: their vectorised CPU implementations differ in the last ulp between
+# CPU generations (observed: the fp32 VP std of step 0 is 0.99997836 on one host, 0.99997842 on another).
 # --------------------------------------------------------------------------- #
-def analytic_vp_model(mu: float = 0.25, s: float = 0.5, wobble: float = 0.05,
-                      beta_0: float = 0.1, beta_1: float = 20.0) -> Callable:
-    """eps-hat of N(mu, s^2) data under the VP SDE plus a small non-linear term;
-    all arithmetic in fp32 on CPU so that every platform feeds ni_step the
-    same bits."""
+def _bump(x: torch.Tensor) -> torch.Tensor:
+    """smooth bounded non-linearity x / (1 + x^2)."""
+    return x / (1.0 + x * x)
+
+
+def analytic_vp_model(mu: float = 0.25, s: float = 0.5, wobble: float = 0.05) -> Callable:
+    """eps-hat of N(mu, s^2) data under a variance-preserving schedule a(t) = 1/(1+4t^2), sg = sqrt(1-a^2),
+    plus a small non-linear term.  ``labels = t*999``."""
     def model_fn(x: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         xc = x.detach().to("cpu", F32)
         t = labels.detach().to("cpu", F32) / 999
-        lmc = -0.25 * t ** 2 * (beta_1 - beta_0) - 0.5 * t * beta_0
-        a = torch.exp(lmc)[:, None, None, None]
-        sg = torch.sqrt(1.0 - torch.exp(2.0 * lmc))[:, None, None, None]
-        out = sg * (xc - a * mu) / (a * a * s * s + sg * sg) + wobble * torch.sin(xc)
+        a = (1.0 / (1.0 + 4.0 * t * t))[:, None, None, None]
+        sg = torch.sqrt(1.0 - a * a)
+        out = sg * (xc - a * mu) / (a * a * (s * s) + sg * sg) + wobble * _bump(xc)
         return out.to(x.device)
     return model_fn
 
 
 def analytic_eps_model(wobble: float = 0.1) -> Callable:
     """fused-eps stand-in for the DiT+CFG call of the Validate form (fp32, CPU)."""
+    abar_tab = np.cumprod(1.0 - np.linspace(1e-4, 2e-2, 1000))
+
     def eps_fn(z: torch.Tensor, timestep: int) -> torch.Tensor:
         zc = z.detach().to("cpu", F32)
-        abar = float(np.cumprod(1.0 - np.linspace(1e-4, 2e-2, 1000))[max(int(timestep), 0)])
-        out = zc * float(np.float32(math.sqrt(1 - abar))) + wobble * torch.cos(3.0 * zc)
+        abar = float(abar_tab[max(int(timestep), 0)])
+        out = zc * float(np.float32(np.sqrt(1 - abar))) + wobble * _bump(3.0 * zc)
         return out.to(z.device)
     return eps_fn
 
 
 def analytic_velocity_model() -> Callable:
-    """velocity stand-in for the two MMDiT calls of the SD3 form (fp16 in/out)."""
+    """velocity stand-in for the two MMDiT calls of the SD3 form (fp16 in/out, fp32 arithmetic)."""
     def vel_fn(x: torch.Tensor, t: torch.Tensor, cond: bool) -> torch.Tensor:
         xc = x.detach().to("cpu", F32)
         tt = float(t) / 1000.0
         tgt = 0.3 if cond else -0.1
-        v = (xc - tgt) * (0.5 + 0.5 * tt) + 0.05 * torch.sin(2.0 * xc + (1.0 if cond else 0.0))
+        v = (xc - tgt) * (0.5 + 0.5 * tt) + 0.05 * _bump(2.0 * xc + (1.0 if cond else 0.0))
         return v.to(x.dtype).to(x.device)
     return vel_fn

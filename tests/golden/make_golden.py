@@ -107,10 +107,14 @@ def group_cifar():
 
     out = {}
     g = torch.Generator().manual_seed(1234)
+
+    def stds_of(node):          # the fp32 std the reference's score_fn used on THIS host (sde_lib.py:141-145)
+        return np.array([float(sde.marginal_prob(torch.zeros(1), torch.ones(1) * t)[1][0]) for t in node[:-1, 0]], np.float32)
     # K2 data_fn at three rows of step_15
     C, B, node = np.load(REF / "weights/step_15_weight_173.npz").values()
     xt = torch.randn(2, 3, 32, 32, generator=g)
     out["k2_xt"] = xt.numpy()
+    out["k2_stds"] = stds_of(node)
     for r in (0, 7, 14):
         out[f"k2_row{r}"] = R.data_fn(score_fn, xt, node[r, 0], node[r, 1], node[r, 2], "cpu").numpy()
     # K3 weighted_sum incl. negative / zero coefficients
@@ -132,6 +136,7 @@ def group_cifar():
             x = R.weighted_sum(C[kk], seq_x0) + B[kk, 0] * noise
             xs.append(x)
         out[f"k4_{name}_xs"] = np.stack([t.numpy() for t in xs])
+        out[f"k4_{name}_stds"] = stds_of(node)
         out[f"k4_{name}_pix"] = R.to_pixel(R.datasets.get_data_inverse_scaler(_AttrDict(data=_AttrDict(centered=True)))(x)).numpy()
     # K5 (continuous grid): coefficient-matrix equivalents of classical samplers shipped under results/
     for rel in ("dpmsolverpp/dpmsolverpp2s_018", "euler_heun/ode_euler_018"):
@@ -144,6 +149,7 @@ def group_cifar():
             x = R.weighted_sum(C[kk], seq_x0) + B[kk, 0] * noise
         key = rel.split("/")[1]
         out[f"k5_{key}_noise"] = noise.numpy()
+        out[f"k5_{key}_stds"] = stds_of(node)
         out[f"k5_{key}_final"] = x.numpy()
     np.savez_compressed(HERE / "cifar_form.npz", **out)
     print("cifar:", len(out), "arrays")

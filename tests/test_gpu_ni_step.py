@@ -43,7 +43,8 @@ def test_cifar_trajectory_bit_exact(dev, cifar, repo_root, name, dense):
     from naturaldiffusion_amd.CIFAR10NaturalInference import natural_inference, to_pixel_from_centered
     ref = cifar[f"k4_{name}_xs"]
     noise = torch.from_numpy(ref[0]).to(dev)
-    xs = natural_inference(O.analytic_vp_model(), noise, repo_root / f"weights/{name}.npz", dense=dense, return_all=True)
+    xs = natural_inference(O.analytic_vp_model(), noise, repo_root / f"weights/{name}.npz", dense=dense, return_all=True,
+                           stds=cifar[f"k4_{name}_stds"])     # host-dependent fp32 std pinned to the fixture's
     assert len(xs) == ref.shape[0]
     for k, x in enumerate(xs):
         assert np.array_equal(x.cpu().numpy(), ref[k]), f"x_{k} differs from the reference"
@@ -55,7 +56,7 @@ def test_classical_sampler_matrices(dev, cifar, repo_root, rel):
     from naturaldiffusion_amd.CIFAR10NaturalInference import natural_inference
     key = rel.split("/")[1]
     noise = torch.from_numpy(cifar[f"k5_{key}_noise"]).to(dev)
-    out = natural_inference(O.analytic_vp_model(), noise, repo_root / f"results/{rel}.npz")
+    out = natural_inference(O.analytic_vp_model(), noise, repo_root / f"results/{rel}.npz", stds=cifar[f"k5_{key}_stds"])
     assert np.array_equal(out.cpu().numpy(), cifar[f"k5_{key}_final"])
 
 
@@ -65,11 +66,10 @@ def test_data_fn_and_weighted_sum_mirrors(dev, cifar, repo_root):
     xt = torch.from_numpy(cifar["k2_xt"]).to(dev)
     model = O.analytic_vp_model()
 
-    def score_fn(x, vec_t):                      # models/utils.py:144-160 with the analytic network, fp32
-        out = model(x, vec_t * 999)
-        std = O.vp_std_f32(float(vec_t[0].cpu())).to(x.device)
-        return -out / std
     for r in (0, 7, 14):
+        def score_fn(x, vec_t, r=r):             # models/utils.py:144-160 with the stand-in network, fp32
+            out = model(x, vec_t * 999).cpu()      # the division is done on the CPU (IEEE) so the score bits are the fixture's
+            return ((-out) / torch.tensor(float(cifar["k2_stds"][r]))).to(x.device)
         got = M.data_fn(score_fn, xt, node[r, 0], node[r, 1], node[r, 2], dev)
         assert got.dtype == torch.float64
         assert np.array_equal(got.cpu().numpy(), cifar[f"k2_row{r}"])
