@@ -177,7 +177,9 @@ def main():
         # ---- recurrence) on this host's cores, bounded sample of the same workload
         from oracle import ni_oracle as O, ncsnpp_oracle as N
         from naturaldiffusion_amd.synth import synthetic_state_dict
-        threads = torch.get_num_threads()
+        # 4 images x 15 forwards is a small problem: more than ~32 OpenMP threads only add synchronisation cost
+        threads = min(32, torch.get_num_threads())
+        torch.set_num_threads(threads)
         P = synthetic_state_dict(0)
         model = N.model_fn_from_params(P)
         nb = 4

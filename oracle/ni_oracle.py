@@ -295,10 +295,11 @@ def sd3_euler_ni(velocity_fn: Callable, noises: torch.Tensor, sigmas: torch.Tens
 # --------------------------------------------------------------------------- #
 # stand-in denoisers used by the fixtures
 #
-# Built ONLY from +, -, *, / and sqrt on fp32 CPU tensors: those are correctly rounded by IEEE-754 on every
-# machine, so the build container (where the fixtures were captured) and the GPU box feed ni_step the same
-# bits.  torch.exp / sin / cos are NOT used: their vectorised CPU implementations differ in the last ulp between
-# CPU generations (observed: the fp32 VP std of step 0 is 0.99997836 on one host, 0.99997842 on another).
+# Built ONLY from +, -, *, / on fp32 CPU tensors: those are correctly rounded by IEEE-754 on every machine, so
+# the build container (where the fixtures were captured) and the GPU box feed ni_step the same bits.
+# torch.exp / sin / cos / sqrt are NOT used: their vectorised CPU implementations differ in the last ulp
+# between hosts (observed: the fp32 VP std of step 0 is 0.99997836 on one host and 0.99997842 on another, and
+# torch.sqrt of an 8-element fp32 tensor differed between two AVX512 hosts).
 # --------------------------------------------------------------------------- #
 def _bump(x: torch.Tensor) -> torch.Tensor:
     """smooth bounded non-linearity x / (1 + x^2)."""
@@ -306,13 +307,13 @@ def _bump(x: torch.Tensor) -> torch.Tensor:
 
 
 def analytic_vp_model(mu: float = 0.25, s: float = 0.5, wobble: float = 0.05) -> Callable:
-    """eps-hat of N(mu, s^2) data under a variance-preserving schedule a(t) = 1/(1+4t^2), sg = sqrt(1-a^2),
-    plus a small non-linear term.  ``labels = t*999``."""
+    """eps-hat of N(mu, s^2) data under the variance-preserving schedule a(t) = (1-t^2)/(1+t^2),
+    sg(t) = 2t/(1+t^2) (a^2 + sg^2 = 1 without a square root), plus a small non-linear term.  ``labels = t*999``."""
     def model_fn(x: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         xc = x.detach().to("cpu", F32)
         t = labels.detach().to("cpu", F32) / 999
-        a = (1.0 / (1.0 + 4.0 * t * t))[:, None, None, None]
-        sg = torch.sqrt(1.0 - a * a)
+        a = ((1.0 - t * t) / (1.0 + t * t))[:, None, None, None]
+        sg = ((2.0 * t) / (1.0 + t * t))[:, None, None, None]
         out = sg * (xc - a * mu) / (a * a * (s * s) + sg * sg) + wobble * _bump(xc)
         return out.to(x.device)
     return model_fn
@@ -325,7 +326,7 @@ def analytic_eps_model(wobble: float = 0.1) -> Callable:
     def eps_fn(z: torch.Tensor, timestep: int) -> torch.Tensor:
         zc = z.detach().to("cpu", F32)
         abar = float(abar_tab[max(int(timestep), 0)])
-        out = zc * float(np.float32(np.sqrt(1 - abar))) + wobble * _bump(3.0 * zc)
+        out = zc * float(np.float32(1 - abar)) + wobble * _bump(3.0 * zc)
         return out.to(z.device)
     return eps_fn
 

@@ -11,6 +11,9 @@ GOLDEN = REPO / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    # the CPU oracle works on small tensors: a 256-thread OpenMP team (GPU box host) makes every op slower
+    import torch
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
 
 
 @pytest.fixture(scope="session")

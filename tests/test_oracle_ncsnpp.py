@@ -15,7 +15,6 @@ def fx(golden_dir):
 
 @pytest.fixture(scope="module")
 def run(fx):
-    torch.set_num_threads(8)
     P = N.make_params(seed=0)
     taps = {}
     y = N.forward(P, torch.from_numpy(fx["x"]), torch.from_numpy(fx["labels"]), taps)
