@@ -57,7 +57,8 @@ def euler_weighted_sum(seq_xstarts, cliplen=0):
     acc = torch.empty(E, dtype=torch.float16, device=slab.device)
     mean = torch.empty(E, dtype=torch.float16, device=slab.device)
     check(lib.natinf_weighted_mean_f16(ptr(slab), ptr(acc), idx, val, nt, 1.0, E, stream_ptr()), "natinf_weighted_mean_f16")
-    check(lib.natinf_weighted_mean_f16(ptr(slab), ptr(mean), idx, val, nt, h(tot), E, stream_ptr()), "natinf_weighted_mean_f16")
+    # `acc / acc_weight`: a 0-d fp32 divisor keeps its fp32 value (it is only cast to fp16 as a FIRST operand)
+    check(lib.natinf_weighted_mean_f16(ptr(slab), ptr(mean), idx, val, nt, float(tot), E, stream_ptr()), "natinf_weighted_mean_f16")
     shape = seq[0][1].shape
     return acc.view(shape), mean.view(shape)
 

@@ -126,14 +126,40 @@ GemmArgs gemm_defaults() {
     g.taps = 1; g.batch = 1; g.scale = 1.0f; g.act = ACT_NONE; g.c_mode = OUT_BF16;
     return g;
 }
-// LDS-DMA kernel whenever its preconditions hold (K a multiple of 64 per segment, 3x3 operands zero-bordered);
-// the register-staged, fully masked kernel otherwise (4x4 attention: K or N = 16).
+// Kernel choice.  LDS-DMA kernels whenever their preconditions hold (K a multiple of 64 per segment, 3x3
+// operands zero-bordered), in the largest block tile that still gives every CU at least one tile; the
+// register-staged, fully masked kernel otherwise (4x4 attention: K = 16).
+constexpr int NUM_CU = 256;
+using Cfg256x256 = DmaCfg<2, 4, 8, 4>;
+using Cfg256x128 = DmaCfg<4, 2, 4, 4>;
+using Cfg128x128 = DmaCfg<2, 2, 4, 4>;
+int g_force_tile = 0;        // 0 = automatic; 128 / 256 force a tile (tuning / tests)
+
 void launch_gemm(const GemmArgs& g, hipStream_t s) {
-    const int nM = (g.M + BM - 1) / BM, nN = (g.N + BN - 1) / BN;
     const int K0 = g.taps * g.a0_C, K1 = g.a1 ? g.a1_C : 0;
     const bool dma = K0 % BK == 0 && K1 % BK == 0 && (g.taps == 1 || g.a0_padded) && (g.taps == 1 || g.a0_C % BK == 0);
-    if (dma) hipLaunchKernelGGL(k_gemm_bf16_dma, dim3(nM * nN, 1, g.batch), dim3(256), GEMM_LDS_BYTES, s, g);
-    else     hipLaunchKernelGGL(k_gemm_bf16, dim3(nM * nN, 1, g.batch), dim3(256), GEMM_LDS_BYTES, s, g);
+    if (!dma) {
+        const int nM = (g.M + BM - 1) / BM, nN = (g.N + BN - 1) / BN;
+        hipLaunchKernelGGL(k_gemm_bf16, dim3(nM * nN, 1, g.batch), dim3(256), GEMM_LDS_BYTES, s, g);
+        return;
+    }
+    const int64_t t256 = (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.batch;
+    const int64_t t256x128 = (int64_t)((g.M + 255) / 256) * ((g.N + 127) / 128) * g.batch;
+    int pick = 128;
+    if (g.N % 256 == 0 && t256 >= NUM_CU) pick = 256;
+    else if (g.N % 128 == 0 && g.N % 256 != 0 && t256x128 >= NUM_CU) pick = 257;      // 256 x 128
+    if (g_force_tile == 128) pick = 128;
+    if (pick == 256) {
+        hipLaunchKernelGGL((k_gemm_dma<2, 4, 8, 4>), dim3((unsigned)(t256 / g.batch), 1, g.batch), dim3(Cfg256x256::THREADS),
+                           Cfg256x256::LDS_BYTES, s, g);
+    } else if (pick == 257) {
+        hipLaunchKernelGGL((k_gemm_dma<4, 2, 4, 4>), dim3((unsigned)(t256x128 / g.batch), 1, g.batch), dim3(Cfg256x128::THREADS),
+                           Cfg256x128::LDS_BYTES, s, g);
+    } else {
+        const int nM = (g.M + 127) / 128, nN = (g.N + 127) / 128;
+        hipLaunchKernelGGL((k_gemm_dma<2, 2, 4, 4>), dim3(nM * nN, 1, g.batch), dim3(Cfg128x128::THREADS),
+                           Cfg128x128::LDS_BYTES, s, g);
+    }
 }
 inline int grid1d(int64_t n, int block = 256, int cap = 4096) {
     int64_t g = (n + block - 1) / block; return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -645,10 +671,14 @@ int natinf_ncsnpp_forward(natinf_ncsnpp_t h, const float* x, const float* labels
     if (!h->packed) return NATINF_ESTATE;
     if (workspace_bytes < h->ws_per_image * (int64_t)B || (int64_t)B * IMG * IMG >= (1LL << 31)) return NATINF_EINVAL;
     if (!h->attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                GEMM_LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16_dma), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                GEMM_LDS_BYTES) != hipSuccess) { (void)hipGetLastError(); return NATINF_ENODEV; }
+        const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16), at, GEMM_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<2, 4, 8, 4>), at, Cfg256x256::LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<4, 2, 4, 4>), at, Cfg256x128::LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<2, 2, 4, 4>), at, Cfg128x128::LDS_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            return NATINF_ENODEV;
+        }
         h->attr_set = true;
     }
     Ctx c{B, reinterpret_cast<unsigned char*>(workspace), h->packed, (hipStream_t)stream, x, labels, out};

@@ -137,8 +137,9 @@ class SD3NI:
         sig = sigmas.detach().to("cpu", torch.float32)
         h = lambda t: float(t.to(torch.float16))                     # 0-d fp32 tensor -> fp16 value, as torch casts it
         if euler:
-            # weights w_j = sigma_j - sigma_{j+1} (fp32 0-d tensors, cast to fp16 when multiplied); the row
-            # total is the fp32 running sum, cast to fp16 when dividing (SD3...:61-69)
+            # weights w_j = sigma_j - sigma_{j+1} are fp32 0-d tensors: as the FIRST operand of `w * x` eager
+            # PyTorch casts them to fp16, but as the SECOND operand of `acc / total` the CPU kernel keeps the
+            # fp32 value (original_scalar_value); the row total is the fp32 running sum (SD3...:61-69)
             n = sig.numel() - 1
             w32 = [-1 * (sig[i + 1] - sig[i]) for i in range(n)]
             W = np.zeros((n, n))
@@ -148,7 +149,7 @@ class SD3NI:
                 for j in range(k + 1):
                     W[k, j] = h(w32[j])
                     acc = acc + w32[j]
-                tot.append(h(acc))
+                tot.append(float(acc))
             self.rows = SparseRows(W, lambda k: k + 1, torch.float32, self.device, dense=dense)
             self.totals = tot
         else:
