@@ -60,6 +60,10 @@ int natinf_ncsnpp_load(natinf_ncsnpp_t h, const float* params_f32, int64_t n_par
 int natinf_ncsnpp_forward(natinf_ncsnpp_t h, const float* x, const float* labels, float* out, int B,
                           void* workspace, int64_t workspace_bytes, natinf_stream_t stream);
 
+/* One line per GEMM launch of a forward at batch B, in launch order: "M N K0 K1 taps batch kernel".
+ * Host only (nothing is launched); used to attribute rocprofv3 kernel-trace rows to layer shapes. */
+int natinf_ncsnpp_describe_gemms(natinf_ncsnpp_t h, int B, char* buf, int cap);
+
 /* Measurement hooks (bench.py): while enabled, every launch group of a forward is bracketed by a HIP event
  * pair on `stream`.  natinf_ncsnpp_profile_read waits for the recorded events and returns, per class
  * (0 = the MFMA GEMM kernel k_gemm_bf16: all convolutions / NIN / linear / attention products;

@@ -47,6 +47,7 @@ SIGNATURES = {
     "natinf_ncsnpp_load": (C.c_int, [_p, _p, _i64, _p, _i64, _p]),
     "natinf_ncsnpp_forward": (C.c_int, [_p, _p, _p, _p, _i32, _p, _i64, _p]),
     "natinf_ncsnpp_debug_tap": (C.c_int, [_p, _i32, _p, _i64, _p]),
+    "natinf_ncsnpp_describe_gemms": (C.c_int, [_p, _i32, C.c_char_p, _i32]),
     "natinf_ncsnpp_profile": (C.c_int, [_p, _i32]),
     "natinf_ncsnpp_profile_read": (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

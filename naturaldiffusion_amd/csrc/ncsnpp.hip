@@ -134,10 +134,21 @@ using Cfg256x256 = DmaCfg<2, 4, 8, 4>;
 using Cfg256x128 = DmaCfg<4, 2, 4, 4>;
 using Cfg128x128 = DmaCfg<2, 2, 4, 4>;
 int g_force_tile = 0;        // 0 = automatic; 128 / 256 force a tile (tuning / tests)
+std::string* g_record = nullptr;   // when set, launch_gemm describes the launch instead of issuing it
 
 void launch_gemm(const GemmArgs& g, hipStream_t s) {
     const int K0 = g.taps * g.a0_C, K1 = g.a1 ? g.a1_C : 0;
     const bool dma = K0 % BK == 0 && K1 % BK == 0 && (g.taps == 1 || g.a0_padded) && (g.taps == 1 || g.a0_C % BK == 0);
+    if (g_record) {
+        const int64_t t256 = (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.batch;
+        const int64_t t256x128 = (int64_t)((g.M + 255) / 256) * ((g.N + 127) / 128) * g.batch;
+        const char* k = !dma ? "generic128" : (g.N % 256 == 0 && t256 >= NUM_CU && g_force_tile != 128) ? "dma256x256"
+                        : (g.N % 128 == 0 && g.N % 256 != 0 && t256x128 >= NUM_CU && g_force_tile != 128) ? "dma256x128" : "dma128x128";
+        char line[160];
+        snprintf(line, sizeof(line), "%d %d %d %d %d %d %s\n", g.M, g.N, K0, K1, g.taps, g.batch, k);
+        *g_record += line;
+        return;
+    }
     if (!dma) {
         const int nM = (g.M + BM - 1) / BM, nN = (g.N + BN - 1) / BN;
         hipLaunchKernelGGL(k_gemm_bf16, dim3(nM * nN, 1, g.batch), dim3(256), GEMM_LDS_BYTES, s, g);
@@ -184,10 +195,11 @@ struct Builder {
 
     // ---- weight packing recipes -------------------------------------------------------------
     void pack_conv(int64_t src, int64_t dst, int N, int Cin, int taps, int dst_ld, int koff, int tapstride) {
+        const int chunked = taps == 9 && Cin % BK == 0;      // every 3x3 conv except the 3-channel stem
         E.packs.push_back([=](const PackCtx& p) {
             const int64_t n = (int64_t)N * Cin * taps;
             hipLaunchKernelGGL(k_pack_conv, dim3(grid1d(n, 256, 1 << 30)), dim3(256), 0, p.stream, p.params + src,
-                               reinterpret_cast<bf16*>(p.packed + dst), N, Cin, taps, dst_ld, koff, tapstride);
+                               reinterpret_cast<bf16*>(p.packed + dst), N, Cin, taps, dst_ld, koff, tapstride, chunked);
         });
     }
     void pack_transpose(int64_t src, int64_t dst, int K, int N, int dst_ld) {
@@ -699,6 +711,19 @@ int natinf_ncsnpp_forward(natinf_ncsnpp_t h, const float* x, const float* labels
     }
     h->last_B = B; h->last_ws = c.ws;
     return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
+}
+
+int natinf_ncsnpp_describe_gemms(natinf_ncsnpp_t h, int B, char* buf, int cap) {
+    if (!h || !buf || cap <= 0 || B <= 0) return NATINF_EINVAL;
+    std::string out;
+    g_record = &out;
+    Ctx c{B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (size_t i = 0; i < h->ops.size(); ++i)
+        if (h->op_cls[i] == CLS_GEMM) h->ops[i](c);          // GEMM ops only compute pointers and call launch_gemm
+    g_record = nullptr;
+    if ((int)out.size() + 1 > cap) return NATINF_EINVAL;
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return (int)out.size();
 }
 
 int natinf_ncsnpp_profile(natinf_ncsnpp_t h, int enable) {

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const GemmArgs g)
         if (kt < nk0) {
             const int kbase = kt * BK;
             int tap = 0, c0 = kbase;
-            if (g.taps == 9) { tap = kbase / g.a0_C; c0 = kbase - tap * g.a0_C; }
+            if (g.taps == 9) { const int cch = kt / 9; tap = kt - 9 * cch; c0 = cch * BK; }   // chunk outer, tap inner
             const int dy = g.taps == 9 ? tap / 3 - 1 : 0, dx = g.taps == 9 ? tap % 3 - 1 : 0;
             const int cc = c0 + colc * 8;
             const bool kin = cc < (g.taps == 9 ? g.a0_C : K0);
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16_dma(const GemmArgs g)
         if (seg0) {
             const int kbase = kt * BK;
             int tap = 0, c0 = kbase;
-            if (g.taps == 9) { tap = kbase / g.a0_C; c0 = kbase - tap * g.a0_C; }
+            if (g.taps == 9) { const int cch = kt / 9; tap = kt - 9 * cch; c0 = cch * BK; }   // chunk outer, tap inner
             const int dy = g.taps == 9 ? tap / 3 - 1 : 0, dx = g.taps == 9 ? tap % 3 - 1 : 0;
             ashift = ((int64_t)(dy * Wp + dx) * g.a0_ld + c0) * 2; kk = kbase;
         } else {
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
         if (seg0) {
             const int kbase = kt * BK;
             int tap = 0, c0 = kbase;
-            if (g.taps == 9) { tap = kbase / g.a0_C; c0 = kbase - tap * g.a0_C; }
+            if (g.taps == 9) { const int cch = kt / 9; tap = kt - 9 * cch; c0 = cch * BK; }   // chunk outer, tap inner
             const int dy = g.taps == 9 ? tap / 3 - 1 : 0, dx = g.taps == 9 ? tap % 3 - 1 : 0;
             ashift = ((int64_t)(dy * Wp + dx) * g.a0_ld + c0) * 2; kk = kbase;
         } else {
@@ -802,14 +802,18 @@ __global__ __launch_bounds__(256) void k_stem_im2col(const float* __restrict__ x
 // ------------------------------------------------------------------------------------------------
 // weight packing (fp32 reference layouts -> bf16 GEMM layouts), run once per load
 // ------------------------------------------------------------------------------------------------
-// src [N][Cin][taps] (OIHW flattened) -> dst[n*dst_ld + koff + tap*Cin + c]
+// src [N][Cin][taps] (OIHW flattened) -> packed K order.
+//   chunked = 0: k = tap*tap_stride_c + c                       (stem: 27 taps*channels padded to 64; 1x1; linear)
+//   chunked = 1: k = ((c/64)*taps + tap)*64 + c%64              (3x3 convs: 64-channel chunk OUTER, tap INNER, so the
+//                nine shifted reads of one chunk are back to back in the K loop and hit L1/L2 instead of thrashing it)
 __global__ void k_pack_conv(const float* __restrict__ src, bf16* __restrict__ dst, int N, int Cin, int taps,
-                            int dst_ld, int koff, int tap_stride_c)
+                            int dst_ld, int koff, int tap_stride_c, int chunked)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)N * Cin * taps) return;
     const int tap = (int)(i % taps); const int64_t r = i / taps; const int c = (int)(r % Cin); const int n = (int)(r / Cin);
-    dst[(int64_t)n * dst_ld + koff + tap * tap_stride_c + c] = (bf16)src[i];
+    const int k = chunked ? ((c >> 6) * taps + tap) * 64 + (c & 63) : tap * tap_stride_c + c;
+    dst[(int64_t)n * dst_ld + koff + k] = (bf16)src[i];
 }
 // src [K][N] (NIN.W) -> dst[n*dst_ld + k]
 __global__ void k_pack_transpose(const float* __restrict__ src, bf16* __restrict__ dst, int K, int N, int dst_ld)
