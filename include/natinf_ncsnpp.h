@@ -64,6 +64,17 @@ int natinf_ncsnpp_forward(natinf_ncsnpp_t h, const float* x, const float* labels
  * Host only (nothing is launched); used to attribute rocprofv3 kernel-trace rows to layer shapes. */
 int natinf_ncsnpp_describe_gemms(natinf_ncsnpp_t h, int B, char* buf, int cap);
 
+/* Tuning hooks.  natinf_debug_gemm runs `iters` launches of one GEMM-kernel variant on caller-supplied operands
+ * (A [batch][M][K0/taps channels] bf16 -- zero-bordered [B][H+2][W+2][C] when taps == 9, W = 1 << logW --,
+ * optional 1x1 segment a1 [M][K1], B [N][K0+K1] bf16 in the engine's K order, optional fp32 bias, C [M][N] bf16 or
+ * fp32).  Variants: 0 auto, 1 generic, 2/3/4 two-stage DMA 256x256 / 256x128 / 128x128, 5/6/7/8 ring
+ * 256x256 / 256x128 / 128x128 / 64x128.  natinf_set_gemm_variant forces a variant for every DMA-eligible launch of
+ * subsequent forwards (0 = automatic). */
+int natinf_debug_gemm(int variant, int M, int N, int K0, int K1, int taps, int logW, int batch,
+                      const void* a0, const void* a1, const void* b, const float* bias_n, void* c, int c_f32, float scale,
+                      int iters, natinf_stream_t stream);
+int natinf_set_gemm_variant(int variant);
+
 /* Measurement hooks (bench.py): while enabled, every launch group of a forward is bracketed by a HIP event
  * pair on `stream`.  natinf_ncsnpp_profile_read waits for the recorded events and returns, per class
  * (0 = the MFMA GEMM kernel k_gemm_bf16: all convolutions / NIN / linear / attention products;

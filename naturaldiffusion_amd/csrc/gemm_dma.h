@@ -1,0 +1,393 @@
+// gemm_dma.h -- LDS-DMA implicit-GEMM kernels of the NCSN++ engine (included by ncsnpp_kernels.h users).
+//
+// Operand tiles go HBM/L2 -> LDS with `global_load_lds_dwordx4` (no VGPR staging, no ds_write pass -- the
+// ds_write_b128 path moves only ~79 B/clk/CU and was the busiest pipe of the register-staged kernel).  One
+// wave-instruction lands 64 lanes x 16 B = 1 KiB of consecutive LDS; the XOR swizzle therefore sits on the SOURCE
+// address and on the fragment read, never on the LDS destination.  Loads are unconditional, which the callers
+// make legal:
+//   * taps == 9 operands are stored with a one-pixel zero border ([B][H+2][W+2][C], written by k_gn_apply),
+//     so a shifted tap never leaves the tensor and no zero-fill is needed;
+//   * rows beyond M (or N) are clamped to the last valid row -- computed, never stored;
+//   * K0 and K1 are multiples of 64 (checked on the host; other shapes use k_gemm_bf16).
+#pragma once
+#include "ncsnpp_kernels.h"
+
+namespace ncsn {
+
+// ------------------------------------------------------------------------------------------------
+// k_gemm_dma<WM, WN, TM, TN>: LDS-DMA GEMM with a configurable block tile.
+//
+//   block tile BM x BN = (WM*TM*16) x (WN*TN*16), WM*WN waves, each wave TM x TN tiles of 16x16 (x32 in K),
+//   BK = 64, two LDS stages of (BM + BN) x 128 B.
+//
+// Why bigger tiles: every K-tile moves (BM+BN)*128 B from L2 into LDS for 2*BM*BN*64 flops.  At 128x128 that is
+// 64 flop/B, i.e. ~39 TB/s of L2->LDS traffic at the 2.5 PFLOP/s MFMA peak -- more than the ~34 TB/s the L2s
+// deliver; 256x256 halves it (128 flop/B) and, with 2048 MFMA-cycles of work per K-tile per CU, the single
+// prefetched tile covers the DMA latency even at one block per CU.  Same preconditions as k_gemm_bf16_dma
+// (zero-bordered 3x3 operands, K multiples of 64, clamped M/N edges).
+//   <2,4,8,4> 256x256, 512 threads, 128 KB LDS   (N = 256 layers with >= 1 tile per CU)
+//   <4,2,4,4> 256x128, 512 threads,  96 KB LDS   (N = 128 layers)
+//   <2,2,4,4> 128x128, 256 threads,  66 KB LDS   (small grids: 8x8 / 4x4 levels, attention, embeddings)
+// ------------------------------------------------------------------------------------------------
+// Epilogue staging geometry for a (WM x WN waves) x (TM x TN 16x16 tiles) block with AVAIL bytes of LDS.
+template <int WM, int WN, int TM, int TN, int AVAIL>
+struct EpiCfg {
+    static constexpr int CROW = WN * TN * 16 + 4;                          // fp32 staging row stride
+    static constexpr int bytes(int rb) { return WM * rb * 16 * CROW * 4; }
+    // row-tiles (of 16) staged per pass: the most that fits
+    static constexpr int RB = bytes(TM) <= AVAIL ? TM : (bytes(TM / 2) <= AVAIL ? TM / 2 : (bytes(TM / 4) <= AVAIL ? TM / 4 : 1));
+    static constexpr int SLAB_ROWS = WM * RB * 16;
+    static constexpr int SLAB_BYTES = bytes(RB);
+    static_assert(TM % RB == 0 && SLAB_BYTES <= AVAIL, "epilogue staging does not fit");
+};
+
+template <int WM, int WN, int TM, int TN>
+struct DmaCfg {
+    static constexpr int NW = WM * WN, THREADS = NW * 64;
+    static constexpr int BM_ = WM * TM * 16, BN_ = WN * TN * 16;
+    static constexpr int STAGE_BYTES = (BM_ + BN_) * BK * 2;
+    static constexpr int PA = BM_ / 8 / NW, PB = BN_ / 8 / NW;            // 1-KiB DMA pieces per wave per K-tile
+    using Epi = EpiCfg<WM, WN, TM, TN, 2 * STAGE_BYTES + 4096>;
+    static constexpr int LDS_BYTES = Epi::SLAB_BYTES > 2 * STAGE_BYTES ? Epi::SLAB_BYTES : 2 * STAGE_BYTES;
+    static_assert(BM_ % (8 * NW) == 0 && BN_ % (8 * NW) == 0, "DMA pieces must divide evenly over the waves");
+};
+
+// Epilogue shared by the DMA kernels: in TM/RB passes, RB row-tiles of every wave -> LDS (fp32) -> fused adds
+// (bias, per-sample row vector, residual, scale, SiLU) in fp32 -> 16-byte coalesced stores.
+template <int WM, int WN, int TM, int TN, class Cfg>
+__device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned char* smem, f32x4 (&acc)[TM][TN],
+                                                  int m0, int n0, int z, int tid, int lane, int wm, int wn)
+{
+    constexpr int BN_ = WN * TN * 16, THREADS = WM * WN * 64;
+    float* sC = reinterpret_cast<float*>(smem);
+    constexpr int CROW = Cfg::CROW, RB = Cfg::RB, CPR = BN_ / 8;            // 16-byte output chunks per row
+    constexpr int ROWS_PER_SWEEP = THREADS / CPR;
+    const int cchunk = tid % CPR, rsub = tid / CPR;
+    const int n = n0 + cchunk * 8;
+    const bool n_in = n < g.N;
+    float bn[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bn[q] = 0.f;
+    if (g.bias_n && n_in && g.c_mode != OUT_F32_NCHW) {
+        const float4 u = *reinterpret_cast<const float4*>(g.bias_n + n), w = *reinterpret_cast<const float4*>(g.bias_n + n + 4);
+        bn[0] = u.x; bn[1] = u.y; bn[2] = u.z; bn[3] = u.w; bn[4] = w.x; bn[5] = w.y; bn[6] = w.z; bn[7] = w.w;
+    }
+#pragma unroll
+    for (int pass = 0; pass < TM / RB; ++pass) {
+        if (pass) __syncthreads();                 // previous pass fully read
+#pragma unroll
+        for (int ii = 0; ii < RB; ++ii)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sC[(wm * RB * 16 + ii * 16 + (lane >> 4) * 4 + r) * CROW + wn * TN * 16 + j * 16 + (lane & 15)] = acc[pass * RB + ii][j][r];
+        __syncthreads();
+        // slab row s  <->  tile row  (s / (RB*16)) * TM*16 + pass*RB*16 + s % (RB*16)
+        if (g.c_mode == OUT_F32_NCHW) {
+            float* out = reinterpret_cast<float*>(g.c);
+            const int nvalid = min(BN_, g.N - n0);
+            for (int e = tid; e < Cfg::SLAB_ROWS * nvalid; e += THREADS) {
+                const int s = e % Cfg::SLAB_ROWS, nn = e / Cfg::SLAB_ROWS;
+                const int m = m0 + (s / (RB * 16)) * (TM * 16) + pass * RB * 16 + s % (RB * 16);
+                if (m < g.M) {
+                    float v = sC[s * CROW + nn];
+                    if (g.bias_n) v += g.bias_n[n0 + nn];
+                    v *= g.scale;
+                    const int b = m >> g.logHW, p = m & ((1 << g.logHW) - 1);
+                    out[((int64_t)b * g.N + n0 + nn) * ((int64_t)1 << g.logHW) + p] = v;
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int sw = 0; sw < Cfg::SLAB_ROWS / ROWS_PER_SWEEP; ++sw) {
+            const int s = sw * ROWS_PER_SWEEP + rsub;
+            const int m = m0 + (s / (RB * 16)) * (TM * 16) + pass * RB * 16 + s % (RB * 16);
+            if (m >= g.M || !n_in) continue;
+            const float4 u = *reinterpret_cast<const float4*>(sC + s * CROW + cchunk * 8);
+            const float4 w = *reinterpret_cast<const float4*>(sC + s * CROW + cchunk * 8 + 4);
+            float v[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += bn[q];
+            if (g.bias_m) {
+                const float bm = g.bias_m[m];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += bm;
+            }
+            if (g.rowvec) {
+                const float* rv = g.rowvec + (int64_t)(m >> g.log_rows_per_sample) * g.rowvec_ld + n;
+                const float4 s4 = *reinterpret_cast<const float4*>(rv), t4 = *reinterpret_cast<const float4*>(rv + 4);
+                v[0] += s4.x; v[1] += s4.y; v[2] += s4.z; v[3] += s4.w; v[4] += t4.x; v[5] += t4.y; v[6] += t4.z; v[7] += t4.w;
+            }
+            if (g.resid) {
+                const bf16x8 rs = *reinterpret_cast<const bf16x8*>(g.resid + (int64_t)z * g.c_bs + (int64_t)m * g.resid_ld + n);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += (float)rs[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                v[q] *= g.scale;
+                if (g.act == ACT_SILU) v[q] = silu_f(v[q]);
+            }
+            if (g.c_mode == OUT_BF16) {
+                bf16x8 o;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[q] = (bf16)v[q];
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(g.c) + (int64_t)z * g.c_bs + (int64_t)m * g.c_ld + n) = o;
+            } else {
+                float* o = reinterpret_cast<float*>(g.c) + (int64_t)z * g.c_bs + (int64_t)m * g.c_ld + n;
+                *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
+{
+    using Cfg = DmaCfg<WM, WN, TM, TN>;
+    constexpr int BM_ = Cfg::BM_, BN_ = Cfg::BN_, THREADS = Cfg::THREADS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nN = (g.N + BN_ - 1) / BN_, nM = (g.M + BM_ - 1) / BM_;
+    const int tile = xcd_remap(blockIdx.x, nM * nN);
+    const int m0 = (tile / nN) * BM_, n0 = (tile % nN) * BN_;
+    const int z = blockIdx.z;
+
+    const bf16* a0 = g.a0 + (int64_t)z * g.a_bs;
+    const bf16* a1 = g.a1 ? g.a1 + (int64_t)z * g.a_bs : nullptr;
+    const bf16* bp = g.b + (int64_t)z * g.b_bs;
+    const int K0 = g.taps * g.a0_C, K1 = g.a1 ? g.a1_C : 0;
+    const int nk0 = K0 / BK, nk = nk0 + K1 / BK;
+    const int Wp = (1 << g.logW) + 2, Hp = (1 << (g.logHW - g.logW)) + 2;
+
+    uint64_t a_row[Cfg::PA], a_delta[Cfg::PA], b_row[Cfg::PB];
+#pragma unroll
+    for (int j = 0; j < Cfg::PA; ++j) {
+        const int r = (wave * Cfg::PA + j) * 8 + (lane >> 3);
+        const int lchunk = ((lane & 7) ^ ((r >> 1) & 7)) << 3;
+        const int m = min(m0 + r, g.M - 1);
+        int64_t off0;
+        if (g.taps == 9) {
+            const int b = m >> g.logHW, p = m & ((1 << g.logHW) - 1), y = p >> g.logW, x = p & ((1 << g.logW) - 1);
+            off0 = ((int64_t)(b * Hp + y + 1) * Wp + x + 1) * g.a0_ld;
+        } else {
+            off0 = (int64_t)m * g.a0_ld;
+        }
+        a_row[j] = reinterpret_cast<uint64_t>(a0 + off0 + lchunk);
+        a_delta[j] = a1 ? reinterpret_cast<uint64_t>(a1 + (int64_t)m * g.a1_ld + lchunk) - a_row[j] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < Cfg::PB; ++j) {
+        const int r = (wave * Cfg::PB + j) * 8 + (lane >> 3);
+        const int lchunk = ((lane & 7) ^ ((r >> 1) & 7)) << 3;
+        b_row[j] = reinterpret_cast<uint64_t>(bp + (int64_t)min(n0 + r, g.N - 1) * g.b_ld + lchunk);
+    }
+
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto issue_tile = [&](int kt, int buf) __attribute__((always_inline)) {
+        unsigned char* dA = smem + buf * Cfg::STAGE_BYTES + wave * (Cfg::PA * 1024);
+        unsigned char* dB = smem + buf * Cfg::STAGE_BYTES + BM_ * BK * 2 + wave * (Cfg::PB * 1024);
+        const bool seg0 = kt < nk0;
+        int64_t ashift;
+        int kk;
+        if (seg0) {
+            const int kbase = kt * BK;
+            int tap = 0, c0 = kbase;
+            if (g.taps == 9) { const int cch = kt / 9; tap = kt - 9 * cch; c0 = cch * BK; }   // chunk outer, tap inner
+            const int dy = g.taps == 9 ? tap / 3 - 1 : 0, dx = g.taps == 9 ? tap % 3 - 1 : 0;
+            ashift = ((int64_t)(dy * Wp + dx) * g.a0_ld + c0) * 2; kk = kbase;
+        } else {
+            ashift = (int64_t)(kt - nk0) * BK * 2; kk = K0 + (kt - nk0) * BK;
+        }
+#pragma unroll
+        for (int j = 0; j < Cfg::PA; ++j) {
+            const uint64_t pa = a_row[j] + (seg0 ? 0 : a_delta[j]) + (uint64_t)ashift;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pa), (lds_void*)(dA + j * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < Cfg::PB; ++j) {
+            const uint64_t pb = b_row[j] + (uint64_t)kk * 2;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pb), (lds_void*)(dB + j * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue_tile(0, 0);
+    __syncthreads();
+
+    const int frow = lane & 15, fq = lane >> 4, fswz = (frow >> 1) & 7;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue_tile(kt + 1, cur ^ 1);
+        const bf16* ta = reinterpret_cast<const bf16*>(smem + cur * Cfg::STAGE_BYTES) + (wm * TM * 16 + frow) * LDS_ROW;
+        const bf16* tb = reinterpret_cast<const bf16*>(smem + cur * Cfg::STAGE_BYTES + BM_ * BK * 2) + (wn * TN * 16 + frow) * LDS_ROW;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ko = (((ks << 2) | fq) ^ fswz) << 3;
+            bf16x8 fb[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(tb + j * 16 * LDS_ROW + ko);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(ta + i * 16 * LDS_ROW + ko);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    dma_tile_epilogue<WM, WN, TM, TN, typename Cfg::Epi>(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// k_gemm_ring<WM, WN, TM, TN, NS>: the same block geometry with a deeper pipeline.
+//
+// The 2-stage kernel keeps at most one K-tile of DMA in flight per CU, and LDS-DMA ingest is latency-bound:
+// sustained bytes/s = bytes in flight / round-trip time.  Here the K loop advances in 32-wide tiles through a
+// ring of NS LDS slots (64-byte rows); NS-1 tiles are requested ahead and a COUNTED `s_waitcnt vmcnt` retires
+// only the oldest one, so NS-2 tiles stay in flight across every barrier (raw s_barrier, never
+// __syncthreads(), whose vmcnt(0) would drain the queue).  One barrier per 32-wide tile.
+//   per iteration kt:  wait(tile kt landed) -> barrier -> request tile kt+NS-1 into slot (kt-1)%NS -> MFMAs on kt
+// The barrier both publishes tile kt (every wave waited for its own pieces first) and proves that every wave is
+// done reading slot (kt-1)%NS (its ds_reads fed MFMAs issued before the barrier).
+// LDS image: 64-byte rows, 16-byte chunk q of row r stored at chunk q ^ T[(r>>2)&3], T = {0,2,3,1}: conflict-free
+// for ds_read_b128's lane groups (4 rows share a 256-byte bank line).
+// ------------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN, int NS>
+struct RingCfg {
+    static constexpr int BKR = 32;
+    static constexpr int NW = WM * WN, THREADS = NW * 64;
+    static constexpr int BM_ = WM * TM * 16, BN_ = WN * TN * 16;
+    static constexpr int STAGE_BYTES = (BM_ + BN_) * BKR * 2;
+    static constexpr int PA = BM_ / 16 / NW, PB = BN_ / 16 / NW;          // 1-KiB pieces (16 rows x 64 B) per wave per tile
+    static constexpr int DPT = PA + PB;                                    // DMA instructions per wave per tile
+    using Epi = EpiCfg<WM, WN, TM, TN, NS * STAGE_BYTES + 4096>;
+    static constexpr int LDS_BYTES = Epi::SLAB_BYTES > NS * STAGE_BYTES ? Epi::SLAB_BYTES : NS * STAGE_BYTES;
+    static_assert(BM_ % (16 * NW) == 0 && BN_ % (16 * NW) == 0, "DMA pieces must divide evenly over the waves");
+    static_assert((NS - 2) * DPT <= 63 && NS >= 3, "vmcnt immediate is 6 bits");
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(N) : "memory");
+}
+
+template <int WM, int WN, int TM, int TN, int NS>
+__global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_ring(const GemmArgs g)
+{
+    using Cfg = RingCfg<WM, WN, TM, TN, NS>;
+    constexpr int BM_ = Cfg::BM_, BN_ = Cfg::BN_, BKR = Cfg::BKR, ROW = 32;      // ROW: bf16 per LDS row
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nN = (g.N + BN_ - 1) / BN_, nM = (g.M + BM_ - 1) / BM_;
+    const int tile = xcd_remap(blockIdx.x, nM * nN);
+    const int m0 = (tile / nN) * BM_, n0 = (tile % nN) * BN_;
+    const int z = blockIdx.z;
+
+    const bf16* a0 = g.a0 + (int64_t)z * g.a_bs;
+    const bf16* a1 = g.a1 ? g.a1 + (int64_t)z * g.a_bs : nullptr;
+    const bf16* bp = g.b + (int64_t)z * g.b_bs;
+    const int K0 = g.taps * g.a0_C, K1 = g.a1 ? g.a1_C : 0;
+    const int nk0 = K0 / BKR, nk = nk0 + K1 / BKR;
+    const int Wp = (1 << g.logW) + 2, Hp = (1 << (g.logHW - g.logW)) + 2;
+
+    uint64_t a_row[Cfg::PA], a_delta[Cfg::PA], b_row[Cfg::PB];
+#pragma unroll
+    for (int j = 0; j < Cfg::PA; ++j) {
+        const int r = (wave * Cfg::PA + j) * 16 + (lane >> 2);
+        const int t4 = (r >> 2) & 3;
+        const int lchunk = ((lane & 3) ^ ((0x1320 >> (t4 * 4)) & 3)) << 3;          // T = {0,2,3,1}
+        const int m = min(m0 + r, g.M - 1);
+        int64_t off0;
+        if (g.taps == 9) {
+            const int b = m >> g.logHW, p = m & ((1 << g.logHW) - 1), y = p >> g.logW, x = p & ((1 << g.logW) - 1);
+            off0 = ((int64_t)(b * Hp + y + 1) * Wp + x + 1) * g.a0_ld;
+        } else {
+            off0 = (int64_t)m * g.a0_ld;
+        }
+        a_row[j] = reinterpret_cast<uint64_t>(a0 + off0 + lchunk);
+        a_delta[j] = a1 ? reinterpret_cast<uint64_t>(a1 + (int64_t)m * g.a1_ld + lchunk) - a_row[j] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < Cfg::PB; ++j) {
+        const int r = (wave * Cfg::PB + j) * 16 + (lane >> 2);
+        const int t4 = (r >> 2) & 3;
+        const int lchunk = ((lane & 3) ^ ((0x1320 >> (t4 * 4)) & 3)) << 3;
+        b_row[j] = reinterpret_cast<uint64_t>(bp + (int64_t)min(n0 + r, g.N - 1) * g.b_ld + lchunk);
+    }
+
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto issue_tile = [&](int kt) __attribute__((always_inline)) {
+        const int slot = kt % NS;
+        unsigned char* dA = smem + slot * Cfg::STAGE_BYTES + wave * (Cfg::PA * 1024);
+        unsigned char* dB = smem + slot * Cfg::STAGE_BYTES + BM_ * BKR * 2 + wave * (Cfg::PB * 1024);
+        const bool seg0 = kt < nk0;
+        int64_t ashift;
+        if (seg0) {
+            int tap = 0, c0 = kt * BKR;
+            if (g.taps == 9) { const int q = kt >> 1, cch = q / 9; tap = q - 9 * cch; c0 = cch * 64 + (kt & 1) * BKR; }
+            const int dy = g.taps == 9 ? tap / 3 - 1 : 0, dx = g.taps == 9 ? tap % 3 - 1 : 0;
+            ashift = ((int64_t)(dy * Wp + dx) * g.a0_ld + c0) * 2;
+        } else {
+            ashift = (int64_t)(kt - nk0) * BKR * 2;
+        }
+        const uint64_t kk2 = (uint64_t)kt * BKR * 2;           // B columns are packed in K-loop order
+#pragma unroll
+        for (int j = 0; j < Cfg::PA; ++j) {
+            const uint64_t pa = a_row[j] + (seg0 ? 0 : a_delta[j]) + (uint64_t)ashift;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pa), (lds_void*)(dA + j * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < Cfg::PB; ++j)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(b_row[j] + kk2), (lds_void*)(dB + j * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nk) issue_tile(t);
+
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fko = (fq ^ ((0x1320 >> (((frow >> 2) & 3) * 4)) & 3)) << 3;       // swizzled chunk of this lane's 8 k-values
+    for (int kt = 0; kt < nk; ++kt) {
+        // tiles requested so far: 0 .. min(nk, kt+NS-1)-1; retire tile kt, keep the younger ones in flight
+        if (kt + NS - 1 <= nk) wait_vmcnt_barrier<(NS - 2) * Cfg::DPT>();
+        else                   wait_vmcnt_barrier<0>();
+        if (kt + NS - 1 < nk) issue_tile(kt + NS - 1);
+        const int slot = kt % NS;
+        const bf16* ta = reinterpret_cast<const bf16*>(smem + slot * Cfg::STAGE_BYTES) + (wm * TM * 16 + frow) * ROW + fko;
+        const bf16* tb = reinterpret_cast<const bf16*>(smem + slot * Cfg::STAGE_BYTES + BM_ * BKR * 2) + (wn * TN * 16 + frow) * ROW + fko;
+        bf16x8 fb[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(tb + j * 16 * ROW);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const bf16x8 fa = *reinterpret_cast<const bf16x8*>(ta + i * 16 * ROW);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();               // every wave is done with the ring before the epilogue reuses it
+    dma_tile_epilogue<WM, WN, TM, TN, typename Cfg::Epi>(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
+}
+
+}  // namespace ncsn

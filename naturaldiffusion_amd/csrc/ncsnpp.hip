@@ -26,6 +26,7 @@
 
 #include "natinf_ncsnpp.h"
 #include "ncsnpp_kernels.h"
+#include "gemm_dma.h"
 
 using namespace ncsn;
 
@@ -126,50 +127,84 @@ GemmArgs gemm_defaults() {
     g.taps = 1; g.batch = 1; g.scale = 1.0f; g.act = ACT_NONE; g.c_mode = OUT_BF16;
     return g;
 }
-// Kernel choice.  LDS-DMA kernels whenever their preconditions hold (K a multiple of 64 per segment, 3x3
-// operands zero-bordered), in the largest block tile that still gives every CU at least one tile; the
-// register-staged, fully masked kernel otherwise (4x4 attention: K = 16).
+// ------------------------------------------------------------------------------------------------
+// GEMM kernel variants and the choice among them
+// ------------------------------------------------------------------------------------------------
 constexpr int NUM_CU = 256;
-using Cfg256x256 = DmaCfg<2, 4, 8, 4>;
-using Cfg256x128 = DmaCfg<4, 2, 4, 4>;
-using Cfg128x128 = DmaCfg<2, 2, 4, 4>;
-int g_force_tile = 0;        // 0 = automatic; 128 / 256 force a tile (tuning / tests)
+enum GemmVariant {
+    V_AUTO = 0, V_GENERIC = 1,
+    V_DMA_256x256 = 2, V_DMA_256x128 = 3, V_DMA_128x128 = 4,          // 2-stage, BK = 64
+    V_RING_256x256 = 5, V_RING_256x128 = 6, V_RING_128x128 = 7, V_RING_64x128 = 8,   // NS-slot ring, BK = 32
+    V_COUNT
+};
+const char* variant_name(int v) {
+    static const char* n[] = {"auto", "generic128", "dma256x256", "dma256x128", "dma128x128", "ring256x256", "ring256x128",
+                              "ring128x128", "ring64x128"};
+    return v >= 0 && v < V_COUNT ? n[v] : "?";
+}
+int g_force_variant = V_AUTO;      // tuning / tests: force one variant for every DMA-eligible launch
 std::string* g_record = nullptr;   // when set, launch_gemm describes the launch instead of issuing it
 
-void launch_gemm(const GemmArgs& g, hipStream_t s) {
+template <class Cfg, class K>
+inline void launch_tiles(K kernel, const GemmArgs& g, hipStream_t s) {
+    const int nM = (g.M + Cfg::BM_ - 1) / Cfg::BM_, nN = (g.N + Cfg::BN_ - 1) / Cfg::BN_;
+    hipLaunchKernelGGL(kernel, dim3(nM * nN, 1, g.batch), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, g);
+}
+template <class Cfg, class K>
+inline bool set_lds(K kernel) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) == hipSuccess;
+}
+using CfgD256x256 = DmaCfg<2, 4, 8, 4>;  using CfgD256x128 = DmaCfg<4, 2, 4, 4>;  using CfgD128x128 = DmaCfg<2, 2, 4, 4>;
+using CfgR256x256 = RingCfg<2, 4, 8, 4, 4>; using CfgR256x128 = RingCfg<4, 2, 4, 4, 6>;
+using CfgR128x128 = RingCfg<2, 2, 4, 4, 4>; using CfgR64x128 = RingCfg<2, 2, 2, 4, 4>;
+
+bool configure_gemm_kernels() {
+    bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  GEMM_LDS_BYTES) == hipSuccess;
+    ok = ok && set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4>) && set_lds<CfgD256x128>(&k_gemm_dma<4, 2, 4, 4>) &&
+         set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4>) && set_lds<CfgR256x256>(&k_gemm_ring<2, 4, 8, 4, 4>) &&
+         set_lds<CfgR256x128>(&k_gemm_ring<4, 2, 4, 4, 6>) && set_lds<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4>) &&
+         set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4>);
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
+
+// Automatic choice: the largest block tile that still gives every CU a tile (DMA kernels need K a multiple of
+// 64 per segment and zero-bordered 3x3 operands); the register-staged, fully masked kernel otherwise (4x4
+// attention: K = 16).
+int choose_variant(const GemmArgs& g) {
     const int K0 = g.taps * g.a0_C, K1 = g.a1 ? g.a1_C : 0;
-    const bool dma = K0 % BK == 0 && K1 % BK == 0 && (g.taps == 1 || g.a0_padded) && (g.taps == 1 || g.a0_C % BK == 0);
+    const bool dma = K0 % BK == 0 && K1 % BK == 0 && (g.taps == 1 || (g.a0_padded && g.a0_C % BK == 0));
+    if (!dma) return V_GENERIC;
+    if (g_force_variant > V_GENERIC) return g_force_variant;
+    const int64_t mt = (g.M + 255) / 256;
+    if (g.N % 256 == 0 && mt * (g.N / 256) * g.batch >= NUM_CU) return V_DMA_256x256;
+    if (g.N % 128 == 0 && g.N % 256 != 0 && mt * (g.N / 128) * g.batch >= NUM_CU) return V_DMA_256x128;
+    return V_DMA_128x128;
+}
+
+void launch_gemm(const GemmArgs& g, hipStream_t s) {
+    const int v = choose_variant(g);
     if (g_record) {
-        const int64_t t256 = (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.batch;
-        const int64_t t256x128 = (int64_t)((g.M + 255) / 256) * ((g.N + 127) / 128) * g.batch;
-        const char* k = !dma ? "generic128" : (g.N % 256 == 0 && t256 >= NUM_CU && g_force_tile != 128) ? "dma256x256"
-                        : (g.N % 128 == 0 && g.N % 256 != 0 && t256x128 >= NUM_CU && g_force_tile != 128) ? "dma256x128" : "dma128x128";
         char line[160];
-        snprintf(line, sizeof(line), "%d %d %d %d %d %d %s\n", g.M, g.N, K0, K1, g.taps, g.batch, k);
+        snprintf(line, sizeof(line), "%d %d %d %d %d %d %s\n", g.M, g.N, g.taps * g.a0_C, g.a1 ? g.a1_C : 0, g.taps, g.batch, variant_name(v));
         *g_record += line;
         return;
     }
-    if (!dma) {
-        const int nM = (g.M + BM - 1) / BM, nN = (g.N + BN - 1) / BN;
-        hipLaunchKernelGGL(k_gemm_bf16, dim3(nM * nN, 1, g.batch), dim3(256), GEMM_LDS_BYTES, s, g);
-        return;
-    }
-    const int64_t t256 = (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.batch;
-    const int64_t t256x128 = (int64_t)((g.M + 255) / 256) * ((g.N + 127) / 128) * g.batch;
-    int pick = 128;
-    if (g.N % 256 == 0 && t256 >= NUM_CU) pick = 256;
-    else if (g.N % 128 == 0 && g.N % 256 != 0 && t256x128 >= NUM_CU) pick = 257;      // 256 x 128
-    if (g_force_tile == 128) pick = 128;
-    if (pick == 256) {
-        hipLaunchKernelGGL((k_gemm_dma<2, 4, 8, 4>), dim3((unsigned)(t256 / g.batch), 1, g.batch), dim3(Cfg256x256::THREADS),
-                           Cfg256x256::LDS_BYTES, s, g);
-    } else if (pick == 257) {
-        hipLaunchKernelGGL((k_gemm_dma<4, 2, 4, 4>), dim3((unsigned)(t256x128 / g.batch), 1, g.batch), dim3(Cfg256x128::THREADS),
-                           Cfg256x128::LDS_BYTES, s, g);
-    } else {
-        const int nM = (g.M + 127) / 128, nN = (g.N + 127) / 128;
-        hipLaunchKernelGGL((k_gemm_dma<2, 2, 4, 4>), dim3(nM * nN, 1, g.batch), dim3(Cfg128x128::THREADS),
-                           Cfg128x128::LDS_BYTES, s, g);
+    switch (v) {
+        case V_GENERIC: {
+            const int nM = (g.M + BM - 1) / BM, nN = (g.N + BN - 1) / BN;
+            hipLaunchKernelGGL(k_gemm_bf16, dim3(nM * nN, 1, g.batch), dim3(256), GEMM_LDS_BYTES, s, g);
+            break;
+        }
+        case V_DMA_256x256: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4>, g, s); break;
+        case V_DMA_256x128: launch_tiles<CfgD256x128>(&k_gemm_dma<4, 2, 4, 4>, g, s); break;
+        case V_DMA_128x128: launch_tiles<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4>, g, s); break;
+        case V_RING_256x256: launch_tiles<CfgR256x256>(&k_gemm_ring<2, 4, 8, 4, 4>, g, s); break;
+        case V_RING_256x128: launch_tiles<CfgR256x128>(&k_gemm_ring<4, 2, 4, 4, 6>, g, s); break;
+        case V_RING_128x128: launch_tiles<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4>, g, s); break;
+        case V_RING_64x128: launch_tiles<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4>, g, s); break;
+        default: break;
     }
 }
 inline int grid1d(int64_t n, int block = 256, int cap = 4096) {
@@ -683,14 +718,7 @@ int natinf_ncsnpp_forward(natinf_ncsnpp_t h, const float* x, const float* labels
     if (!h->packed) return NATINF_ESTATE;
     if (workspace_bytes < h->ws_per_image * (int64_t)B || (int64_t)B * IMG * IMG >= (1LL << 31)) return NATINF_EINVAL;
     if (!h->attr_set) {
-        const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16), at, GEMM_LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<2, 4, 8, 4>), at, Cfg256x256::LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<4, 2, 4, 4>), at, Cfg256x128::LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<2, 2, 4, 4>), at, Cfg128x128::LDS_BYTES) != hipSuccess) {
-            (void)hipGetLastError();
-            return NATINF_ENODEV;
-        }
+        if (!configure_gemm_kernels()) return NATINF_ENODEV;
         h->attr_set = true;
     }
     Ctx c{B, reinterpret_cast<unsigned char*>(workspace), h->packed, (hipStream_t)stream, x, labels, out};
@@ -724,6 +752,31 @@ int natinf_ncsnpp_describe_gemms(natinf_ncsnpp_t h, int B, char* buf, int cap) {
     if ((int)out.size() + 1 > cap) return NATINF_EINVAL;
     memcpy(buf, out.c_str(), out.size() + 1);
     return (int)out.size();
+}
+
+int natinf_debug_gemm(int variant, int M, int N, int K0, int K1, int taps, int logW, int batch,
+                      const void* a0, const void* a1, const void* b, const float* bias_n, void* c, int c_f32, float scale,
+                      int iters, natinf_stream_t stream) {
+    if (variant < 0 || variant >= V_COUNT || !a0 || !b || !c || M <= 0 || N <= 0 || iters <= 0 || (taps != 1 && taps != 9)) return NATINF_EINVAL;
+    static bool configured = false;
+    if (!configured) { if (!configure_gemm_kernels()) return NATINF_ENODEV; configured = true; }
+    GemmArgs g = gemm_defaults();
+    g.a0 = (const bf16*)a0; g.a0_C = K0 / taps; g.a0_ld = g.a0_C; g.taps = taps; g.logW = logW; g.logHW = 2 * logW; g.a0_padded = taps == 9;
+    if (a1) { g.a1 = (const bf16*)a1; g.a1_C = K1; g.a1_ld = K1; }
+    g.M = M; g.N = N; g.b = (const bf16*)b; g.b_ld = K0 + (a1 ? K1 : 0); g.batch = batch;
+    if (batch > 1) { g.a_bs = (int64_t)M * g.a0_ld; g.b_bs = (int64_t)N * g.b_ld; g.c_bs = (int64_t)M * N; }
+    g.bias_n = bias_n; g.scale = scale; g.c = c; g.c_ld = N; g.c_mode = c_f32 ? OUT_F32 : OUT_BF16;
+    const int saved = g_force_variant;
+    g_force_variant = variant;
+    for (int i = 0; i < iters; ++i) launch_gemm(g, (hipStream_t)stream);
+    g_force_variant = saved;
+    return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
+}
+
+int natinf_set_gemm_variant(int variant) {
+    if (variant < 0 || variant >= V_COUNT) return NATINF_EINVAL;
+    g_force_variant = variant;
+    return NATINF_OK;
 }
 
 int natinf_ncsnpp_profile(natinf_ncsnpp_t h, int enable) {

@@ -1,0 +1,59 @@
+"""Micro-benchmark of the GEMM kernel variants on the engine's dominant layer shapes (GPU box).
+usage: bench_gemm.py [variant ids ...]      (default: all DMA / ring variants)"""
+import sys, ctypes as C
+from pathlib import Path
+import torch
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from naturaldiffusion_amd._lib import lib, check, stream_ptr
+
+NAMES = {1: "generic128", 2: "dma256x256", 3: "dma256x128", 4: "dma128x128", 5: "ring256x256", 6: "ring256x128", 7: "ring128x128", 8: "ring64x128"}
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+
+def run(variant, M, N, K0, K1, taps, res, iters=20, check_ref=False):
+    C0 = K0 // taps
+    if taps == 9:
+        Bn = M // (res * res)
+        a = torch.zeros(Bn, res + 2, res + 2, C0, dtype=torch.bfloat16, device=dev)
+        a[:, 1:-1, 1:-1] = torch.randn(Bn, res, res, C0, device=dev).to(torch.bfloat16)
+        logW = res.bit_length() - 1
+    else:
+        a = torch.randn(M, C0, device=dev).to(torch.bfloat16); logW = 0
+    a1 = torch.randn(M, K1, device=dev).to(torch.bfloat16) if K1 else None
+    b = (torch.randn(N, K0 + K1, device=dev) * 0.05).to(torch.bfloat16)
+    c = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    args = lambda it: (variant, M, N, K0, K1, taps, logW, 1, a.data_ptr(), a1.data_ptr() if K1 else None, b.data_ptr(), None,
+                       c.data_ptr(), 0, 1.0, it, stream_ptr())
+    check(lib.natinf_debug_gemm(*args(3)), "debug_gemm")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); check(lib.natinf_debug_gemm(*args(iters)), "debug_gemm"); e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    err = None
+    if check_ref and taps == 1:
+        ref = a.float() @ b[:, :K0].float().t()
+        if K1: ref = ref + a1.float() @ b[:, K0:].float().t()
+        err = ((c.float() - ref).abs().max() / ref.abs().max()).item()
+    return ms, 2.0 * M * N * (K0 + K1) / ms / 1e9, err
+
+SHAPES = [  # (M, N, K0, K1, taps, res)  -- B=512 layer shapes, largest time first
+    (524288, 128, 1152, 0, 9, 32), (524288, 128, 2304, 128, 9, 32), (131072, 256, 2304, 0, 9, 16), (131072, 256, 4608, 0, 9, 16),
+    (524288, 256, 2304, 256, 9, 32), (32768, 256, 2304, 0, 9, 8), (8192, 256, 2304, 0, 9, 4), (131072, 256, 256, 0, 1, 0),
+    (131072, 512, 256, 0, 1, 0),
+]
+variants = [int(v) for v in sys.argv[1:]] or [2, 3, 4, 5, 6, 7, 8]
+# correctness (plain GEMM with both K segments) for every variant first
+for v in variants:
+    ms, tf, err = run(v, 1000, 384, 256, 128, 1, 0, iters=2, check_ref=True)
+    print(f"check {NAMES[v]:>12}: rel err {err:.2e}")
+print(f"{'shape':>34} " + " ".join(f"{NAMES[v]:>12}" for v in variants))
+for (M, N, K0, K1, taps, res) in SHAPES:
+    cells = []
+    for v in variants:
+        try:
+            ms, tf, _ = run(v, M, N, K0, K1, taps, res)
+            cells.append(f"{tf:7.0f}TF/s")
+        except Exception as e:
+            cells.append("       error")
+    print(f"{str((M, N, K0 + K1, taps)):>34} " + " ".join(f"{c:>12}" for c in cells), flush=True)
