@@ -58,8 +58,9 @@ template <int WM, int WN, int TM, int TN, class Cfg>
 __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned char* smem, f32x4 (&acc)[TM][TN],
                                                   int m0, int n0, int z, int tid, int lane, int wm, int wn)
 {
-    constexpr int BN_ = WN * TN * 16, THREADS = WM * WN * 64;
+    constexpr int BN_ = WN * TN * 16, BM_ = WM * TM * 16, THREADS = WM * WN * 64;
     float* sC = reinterpret_cast<float*>(smem);
+    float st[4] = {0.f, 0.f, 0.f, 0.f};            // fused GroupNorm partials of this thread's two 4-channel quads
     constexpr int CROW = Cfg::CROW, RB = Cfg::RB, CPR = BN_ / 8;            // 16-byte output chunks per row
     constexpr int ROWS_PER_SWEEP = THREADS / CPR;
     const int cchunk = tid % CPR, rsub = tid / CPR;
@@ -130,6 +131,10 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
                 v[q] *= g.scale;
                 if (g.act == ACT_SILU) v[q] = silu_f(v[q]);
             }
+            if (g.gn_part) {
+                st[0] += (v[0] + v[1]) + (v[2] + v[3]); st[1] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                st[2] += (v[4] + v[5]) + (v[6] + v[7]); st[3] += (v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]);
+            }
             if (g.c_mode == OUT_BF16) {
                 bf16x8 o;
 #pragma unroll
@@ -140,6 +145,20 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
                 *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
+        }
+    }
+    if (g.gn_part) {
+        // block reduction in a fixed order: [row-thread][chunk][4] through LDS, then one thread per quad
+        __syncthreads();
+        float* sred = reinterpret_cast<float*>(smem);
+        *reinterpret_cast<float4*>(sred + (rsub * CPR + cchunk) * 4) = make_float4(st[0], st[1], st[2], st[3]);
+        __syncthreads();
+        if (tid < CPR * 2 && n0 + tid * 4 < g.N) {
+            const int ch = tid >> 1, hf = (tid & 1) * 2;
+            float s = 0.f, q = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < ROWS_PER_SWEEP; ++r) { s += sred[(r * CPR + ch) * 4 + hf]; q += sred[(r * CPR + ch) * 4 + hf + 1]; }
+            reinterpret_cast<float2*>(g.gn_part)[(int64_t)(m0 / BM_) * g.gn_quads + (n0 >> 2) + tid] = make_float2(s, q);
         }
     }
 }

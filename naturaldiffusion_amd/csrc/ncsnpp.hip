@@ -52,6 +52,7 @@ struct TRef { int64_t off = -1; int C = 0, ld = 0, res = 0, coff = 0, pad = 0; }
 struct Ctx {                     // per-forward launch context
     int B; unsigned char* ws; const unsigned char* wp; hipStream_t stream;
     const float* x; const float* labels; float* out;
+    int* part_bm;                // [n_parts] block-tile rows (BM) of the GEMM variant that wrote each partial table
     bf16* act(const TRef& t) const { return reinterpret_cast<bf16*>(ws + t.off * B) + t.coff; }
     template <class T> T* at(int64_t off) const { return reinterpret_cast<T*>(ws + off * B); }
     template <class T> const T* w(int64_t off) const { return reinterpret_cast<const T*>(wp + off); }
@@ -114,6 +115,7 @@ struct natinf_ncsnpp {
     const unsigned char* packed = nullptr;
     bool attr_set = false;
     int last_B = 0; unsigned char* last_ws = nullptr;
+    std::vector<int> part_bm;            // see Ctx::part_bm
 };
 
 namespace {
@@ -135,11 +137,12 @@ enum GemmVariant {
     V_AUTO = 0, V_GENERIC = 1,
     V_DMA_256x256 = 2, V_DMA_256x128 = 3, V_DMA_128x128 = 4,          // 2-stage, BK = 64
     V_RING_256x256 = 5, V_RING_256x128 = 6, V_RING_128x128 = 7, V_RING_64x128 = 8,   // NS-slot ring, BK = 32
+    V_RING_256x128_W4 = 9, V_DMA_256x128_W4 = 10,                     // 4 waves, wave tile 128x64 (less LDS read traffic per MFMA)
     V_COUNT
 };
 const char* variant_name(int v) {
     static const char* n[] = {"auto", "generic128", "dma256x256", "dma256x128", "dma128x128", "ring256x256", "ring256x128",
-                              "ring128x128", "ring64x128"};
+                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4"};
     return v >= 0 && v < V_COUNT ? n[v] : "?";
 }
 int g_force_variant = V_AUTO;      // tuning / tests: force one variant for every DMA-eligible launch
@@ -157,6 +160,7 @@ inline bool set_lds(K kernel) {
 using CfgD256x256 = DmaCfg<2, 4, 8, 4>;  using CfgD256x128 = DmaCfg<4, 2, 4, 4>;  using CfgD128x128 = DmaCfg<2, 2, 4, 4>;
 using CfgR256x256 = RingCfg<2, 4, 8, 4, 4>; using CfgR256x128 = RingCfg<4, 2, 4, 4, 6>;
 using CfgR128x128 = RingCfg<2, 2, 4, 4, 4>; using CfgR64x128 = RingCfg<2, 2, 2, 4, 4>;
+using CfgR256x128W4 = RingCfg<2, 2, 8, 4, 3>; using CfgD256x128W4 = DmaCfg<2, 2, 8, 4>;
 
 bool configure_gemm_kernels() {
     bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -164,7 +168,8 @@ bool configure_gemm_kernels() {
     ok = ok && set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4>) && set_lds<CfgD256x128>(&k_gemm_dma<4, 2, 4, 4>) &&
          set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4>) && set_lds<CfgR256x256>(&k_gemm_ring<2, 4, 8, 4, 4>) &&
          set_lds<CfgR256x128>(&k_gemm_ring<4, 2, 4, 4, 6>) && set_lds<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4>) &&
-         set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4>);
+         set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4>) && set_lds<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3>) &&
+         set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4>);
     if (!ok) (void)hipGetLastError();
     return ok;
 }
@@ -177,19 +182,33 @@ int choose_variant(const GemmArgs& g) {
     const bool dma = K0 % BK == 0 && K1 % BK == 0 && (g.taps == 1 || (g.a0_padded && g.a0_C % BK == 0));
     if (!dma) return V_GENERIC;
     if (g_force_variant > V_GENERIC) return g_force_variant;
-    const int64_t mt = (g.M + 255) / 256;
-    if (g.N % 256 == 0 && mt * (g.N / 256) * g.batch >= NUM_CU) return V_DMA_256x256;
-    if (g.N % 128 == 0 && g.N % 256 != 0 && mt * (g.N / 128) * g.batch >= NUM_CU) return V_DMA_256x128;
-    return V_DMA_128x128;
+    // measured on the engine's layer shapes (tools/bench_gemm.py, profiles/r01): 256x256 two-stage for wide-N,
+    // long-K layers; the 4-wave 256x128 ring (wave tile 128x64, 2 blocks/CU) for N = 128 and short-K layers;
+    // 128x128 when 256-row tiles would leave CUs idle; 64x128 for the 4x4 level
+    const int64_t mt256 = (g.M + 255) / 256, mt128 = (g.M + 127) / 128;
+    const int64_t nt128 = (g.N + 127) / 128;
+    if (g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) * g.batch >= NUM_CU) return V_DMA_256x256;
+    if (mt256 * nt128 * g.batch >= 2 * NUM_CU) return V_RING_256x128_W4;        // it runs two blocks per CU
+    if (mt128 * nt128 * g.batch >= NUM_CU) return V_DMA_128x128;
+    return V_RING_64x128;
 }
 
-void launch_gemm(const GemmArgs& g, hipStream_t s) {
+int variant_bm(int v) {
+    switch (v) {
+        case V_DMA_256x256: case V_DMA_256x128: case V_RING_256x256: case V_RING_256x128: case V_RING_256x128_W4: case V_DMA_256x128_W4: return 256;
+        case V_RING_64x128: return 64;
+        default: return 128;
+    }
+}
+
+// returns the block-tile row count of the variant used
+int launch_gemm(const GemmArgs& g, hipStream_t s) {
     const int v = choose_variant(g);
     if (g_record) {
         char line[160];
         snprintf(line, sizeof(line), "%d %d %d %d %d %d %s\n", g.M, g.N, g.taps * g.a0_C, g.a1 ? g.a1_C : 0, g.taps, g.batch, variant_name(v));
         *g_record += line;
-        return;
+        return variant_bm(v);
     }
     switch (v) {
         case V_GENERIC: {
@@ -204,8 +223,11 @@ void launch_gemm(const GemmArgs& g, hipStream_t s) {
         case V_RING_256x128: launch_tiles<CfgR256x128>(&k_gemm_ring<4, 2, 4, 4, 6>, g, s); break;
         case V_RING_128x128: launch_tiles<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4>, g, s); break;
         case V_RING_64x128: launch_tiles<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4>, g, s); break;
+        case V_RING_256x128_W4: launch_tiles<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3>, g, s); break;
+        case V_DMA_256x128_W4: launch_tiles<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4>, g, s); break;
         default: break;
     }
+    return variant_bm(v);
 }
 inline int grid1d(int64_t n, int block = 256, int cap = 4096) {
     int64_t g = (n + block - 1) / block; return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -267,6 +289,7 @@ struct Builder {
 
     // GroupNorm statistics of x -> (scale, shift) per (image, channel); returns their arena offsets
     void emit_gn_stats(const TRef& x, GN gn, int64_t sc, int64_t sh) {
+        if (emit_gn_from_parts(x, gn, sc, sh)) return;
         const int HW = x.res * x.res;
         op(CLS_OTHER, [=](const Ctx& c) {
             hipLaunchKernelGGL(k_gn_stats, dim3(c.B), dim3(256), 0, c.stream, c.act(x), x.ld, x.C, HW,
@@ -320,6 +343,7 @@ struct Builder {
         emit_gn_apply(x, sc, sh, h, (m.up || m.down) ? &xr : nullptr, ACT_SILU, m.up ? RS_UP : (m.down ? RS_DOWN : RS_NONE));
 
         TRef t = new_act(ro, cout);
+        const Part pt = register_output(t);
         const int logW = ilog2(ro), logHW = 2 * logW, HWo = ro * ro;
         const int dtotal = dense_total; const int64_t dout = dense_out;
         op(CLS_GEMM, [=](const Ctx& c) {
@@ -329,14 +353,18 @@ struct Builder {
             g.bias_n = c.w<float>(b0);
             g.rowvec = c.at<float>(dout) + drow; g.rowvec_ld = dtotal; g.log_rows_per_sample = logHW;
             g.c = c.act(t); g.c_ld = t.ld;
-            launch_gemm(g, c.stream);
+            if (pt.valid) { g.gn_part = c.at<float>(pt.off); g.gn_quads = pt.quads; }
+            const int bm = launch_gemm(g, c.stream);
+            if (pt.valid) c.part_bm[pt.id] = bm;
         });
         arena.release(h.off);
         emit_gn_stats(t, gn1, sc, sh);
         TRef u = new_act(ro, cout, 1);
         emit_gn_apply(t, sc, sh, u, nullptr, ACT_SILU, RS_NONE);
         arena.release(t.off);
+        if (pt.valid) arena.release(pt.off);
         const TRef xs = (m.up || m.down) ? xr : x;           // shortcut source at the output resolution
+        const Part po = register_output(out);
         op(CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
             g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_C = cout; g.taps = 9; g.logW = logW; g.logHW = logHW; g.a0_padded = 1;
@@ -345,7 +373,9 @@ struct Builder {
             g.M = c.B * HWo; g.N = cout; g.b = c.w<bf16>(w1); g.b_ld = K1tot;
             g.bias_n = c.w<float>(b1); g.scale = INV_SQRT2;
             g.c = c.act(out); g.c_ld = out.ld;
-            launch_gemm(g, c.stream);
+            if (po.valid) { g.gn_part = c.at<float>(po.off); g.gn_quads = po.quads; }
+            const int bm = launch_gemm(g, c.stream);
+            if (po.valid) c.part_bm[po.id] = bm;
         });
         arena.release(u.off);
         if (m.up || m.down) arena.release(xr.off);
@@ -412,19 +442,61 @@ struct Builder {
             launch_gemm(g, c.stream);
         });
         arena.release(P); arena.release(vT); arena.release(qk);
+        const Part po = register_output(out);
         op(CLS_GEMM, [=](const Ctx& c) {             // out = (x + O W3 + b3) / sqrt(2)
             GemmArgs g = gemm_defaults();
             g.a0 = c.act(O); g.a0_ld = C; g.a0_C = C; g.M = c.B * T; g.N = C;
             g.b = c.w<bf16>(w3); g.b_ld = C; g.bias_n = c.w<float>(b3);
             g.resid = c.act(x); g.resid_ld = x.ld; g.scale = INV_SQRT2;
             g.c = c.act(out); g.c_ld = out.ld;
-            launch_gemm(g, c.stream);
+            if (po.valid) { g.gn_part = c.at<float>(po.off); g.gn_quads = po.quads; }
+            const int bm = launch_gemm(g, c.stream);
+            if (po.valid) c.part_bm[po.id] = bm;
         });
         arena.release(O.off); arena.release(sc); arena.release(sh);
         E.taps[m.idx] = out;
     }
 
     int dense_rows_next = 0;
+
+    // ---- fused GroupNorm statistics: partial tables written by GEMM epilogues ------------------------
+    struct Part { int64_t off = -1; int quads = 0, id = -1, res = 0; bool valid = false; };
+    std::map<std::pair<int64_t, int>, Part> parts;      // (tensor offset, channel offset) -> latest producer's table
+    int n_parts = 0;
+    static bool fusable(int res) { return res >= 16; }   // every block tile (<= 256 rows) lies inside one sample
+    Part new_part(int res, int C) {
+        Part p; p.quads = C / 4; p.res = res; p.id = n_parts++; p.valid = true;
+        p.off = arena.alloc((int64_t)(res * res / 64) * p.quads * 8);       // worst case: 64-row block tiles
+        return p;
+    }
+    // called for EVERY module output so that a stale table can never be matched to a later tensor at the same place
+    Part register_output(const TRef& out) {
+        Part p;
+        if (fusable(out.res)) p = new_part(out.res, out.C);
+        parts[{out.off, out.coff}] = p;
+        return p;
+    }
+    // statistics of x from partial tables if every channel slice of x has a valid one; otherwise the streaming kernel
+    bool emit_gn_from_parts(const TRef& x, GN gn, int64_t sc, int64_t sh) {
+        std::vector<Part> src;
+        int ch = 0;
+        while (ch < x.C) {
+            auto it = parts.find({x.off, x.coff + ch});
+            if (it == parts.end() || !it->second.valid || it->second.res != x.res) return false;
+            src.push_back(it->second);
+            ch += it->second.quads * 4;
+        }
+        if (ch != x.C || src.empty() || src.size() > 2) return false;
+        const Part p0 = src[0], p1 = src.size() > 1 ? src[1] : Part();
+        const int HW = x.res * x.res, C = x.C;
+        op(CLS_OTHER, [=](const Ctx& c) {
+            const int tps0 = HW / c.part_bm[p0.id], tps1 = p1.valid ? HW / c.part_bm[p1.id] : 0;
+            hipLaunchKernelGGL(k_gn_finalize, dim3(c.B), dim3(256), 0, c.stream, c.at<float2>(p0.off), tps0, p0.quads,
+                               p1.valid ? c.at<float2>(p1.off) : (const float2*)nullptr, tps1, p1.valid ? p1.quads : 0, C, HW,
+                               c.w<float>(gn.gamma), c.w<float>(gn.beta), c.at<float>(sc), c.at<float>(sh), GN_EPS);
+        });
+        return true;
+    }
 
     // ---- module list (ncsnpp.py:66-230) ----------------------------------------------------
     void list_modules() {
@@ -529,6 +601,7 @@ struct Builder {
             const int64_t b = pack_f32(pb, NF);
             const int64_t a0 = arena.alloc((int64_t)IMG * IMG * 64 * 2);
             const TRef dst = cur;
+            const Part po = register_output(dst);
             op(CLS_OTHER, [=](const Ctx& c) {
                 const int64_t rows = (int64_t)c.B * IMG * IMG;
                 hipLaunchKernelGGL(k_stem_im2col, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, c.stream, c.x, c.at<bf16>(a0), rows);
@@ -539,7 +612,9 @@ struct Builder {
                 g.a0 = c.at<bf16>(a0); g.a0_ld = 64; g.a0_C = 64; g.M = (int)rows; g.N = NF;
                 g.b = c.w<bf16>(w); g.b_ld = 64; g.bias_n = c.w<float>(b);
                 g.c = c.act(dst); g.c_ld = dst.ld;
-                launch_gemm(g, c.stream);
+                if (po.valid) { g.gn_part = c.at<float>(po.off); g.gn_quads = po.quads; }
+                const int bm = launch_gemm(g, c.stream);
+                if (po.valid) c.part_bm[po.id] = bm;
             });
             arena.release(a0);
             E.taps[m.idx] = dst;
@@ -626,6 +701,7 @@ struct Builder {
             E.taps[mg.idx] = last;          // (pre-norm tensor; the GN module's own output is internal)
         }
         E.n_params = poff;
+        E.part_bm.assign(n_parts > 0 ? n_parts : 1, 128);
         E.ws_per_image = arena.peak;
         E.packed_bytes = wtop;
         // parameter offsets for describe(): recompute by module in order
@@ -721,7 +797,7 @@ int natinf_ncsnpp_forward(natinf_ncsnpp_t h, const float* x, const float* labels
         if (!configure_gemm_kernels()) return NATINF_ENODEV;
         h->attr_set = true;
     }
-    Ctx c{B, reinterpret_cast<unsigned char*>(workspace), h->packed, (hipStream_t)stream, x, labels, out};
+    Ctx c{B, reinterpret_cast<unsigned char*>(workspace), h->packed, (hipStream_t)stream, x, labels, out, h->part_bm.data()};
     if (!h->prof) {
         for (const auto& f : h->ops) f(c);
     } else {
@@ -745,7 +821,8 @@ int natinf_ncsnpp_describe_gemms(natinf_ncsnpp_t h, int B, char* buf, int cap) {
     if (!h || !buf || cap <= 0 || B <= 0) return NATINF_EINVAL;
     std::string out;
     g_record = &out;
-    Ctx c{B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<int> scratch_bm(h->part_bm.size(), 128);
+    Ctx c{B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, scratch_bm.data()};
     for (size_t i = 0; i < h->ops.size(); ++i)
         if (h->op_cls[i] == CLS_GEMM) h->ops[i](c);          // GEMM ops only compute pointers and call launch_gemm
     g_record = nullptr;

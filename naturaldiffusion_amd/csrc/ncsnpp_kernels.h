@@ -47,6 +47,9 @@ struct GemmArgs {
     const bf16* resid; int resid_ld;                  // + resid[m*ld + n]
     float scale; int act;
     void* c; int c_ld; int c_mode;
+    // fused GroupNorm statistics of the OUTPUT (DMA kernels, block tile inside one sample): per block tile and per
+    // 4-channel quad, (sum, sum of squares) of the fp32 results -> gn_part[(m0/BM)*gn_quads + n/4] (float2)
+    float* gn_part; int gn_quads;
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
@@ -312,6 +315,46 @@ __global__ __launch_bounds__(256) void k_gn_stats(const bf16* __restrict__ x, in
     if (tid < 32) {
         float s = 0.f, q = 0.f;
         for (int i = 0; i < cg; ++i) { s += s_sum[tid * cg + i]; q += s_sq[tid * cg + i]; }
+        const float inv = 1.0f / (float)(cg * HW);
+        const float mean = s * inv;
+        float var = q * inv - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        s_mean[tid] = mean;
+        s_rstd[tid] = 1.0f / sqrtf(var + eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int gi = c / cg;
+        const float sc = s_rstd[gi] * gamma[c];
+        scale[(int64_t)b * C + c] = sc;
+        shift[(int64_t)b * C + c] = beta[c] - s_mean[gi] * sc;
+    }
+}
+
+// GroupNorm statistics from the per-tile quad partials the producing GEMM(s) wrote (up to two channel-wise
+// concatenated sources, e.g. [h, skip] of an up-path block): fixed summation order -> deterministic.
+// One block per sample.  P*: float2 [tiles][quads*]; sample b owns tiles b*tps* .. (b+1)*tps*-1.
+__global__ __launch_bounds__(256) void k_gn_finalize(const float2* __restrict__ P0, int tps0, int quads0,
+                                                     const float2* __restrict__ P1, int tps1, int quads1, int C, int HW,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ scale, float* __restrict__ shift, float eps)
+{
+    __shared__ float s_s[128], s_q[128], s_mean[32], s_rstd[32];
+    const int tid = threadIdx.x, b = blockIdx.x, nq = quads0 + quads1;
+    for (int q = tid; q < nq; q += 256) {
+        float s = 0.f, qq = 0.f;
+        if (q < quads0) {
+            for (int t = 0; t < tps0; ++t) { const float2 v = P0[((int64_t)b * tps0 + t) * quads0 + q]; s += v.x; qq += v.y; }
+        } else {
+            for (int t = 0; t < tps1; ++t) { const float2 v = P1[((int64_t)b * tps1 + t) * quads1 + (q - quads0)]; s += v.x; qq += v.y; }
+        }
+        s_s[q] = s; s_q[q] = qq;
+    }
+    __syncthreads();
+    const int cg = C >> 5, qpg = cg >> 2;
+    if (tid < 32) {
+        float s = 0.f, q = 0.f;
+        for (int i = 0; i < qpg; ++i) { s += s_s[tid * qpg + i]; q += s_q[tid * qpg + i]; }
         const float inv = 1.0f / (float)(cg * HW);
         const float mean = s * inv;
         float var = q * inv - mean * mean;
