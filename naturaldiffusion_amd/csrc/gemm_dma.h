@@ -12,6 +12,10 @@
 #pragma once
 #include "ncsnpp_kernels.h"
 
+#ifndef NATINF_SETPRIO
+#define NATINF_SETPRIO 0
+#endif
+
 namespace ncsn {
 
 // ------------------------------------------------------------------------------------------------
@@ -256,6 +260,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
             bf16x8 fb[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(tb + j * 16 * LDS_ROW + ko);
+#if NATINF_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const bf16x8 fa = *reinterpret_cast<const bf16x8*>(ta + i * 16 * LDS_ROW + ko);
@@ -263,6 +270,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
             }
+#if NATINF_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         __syncthreads();
     }
@@ -397,6 +407,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_ring(const GemmArgs g)
         bf16x8 fb[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(tb + j * 16 * ROW);
+#if NATINF_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const bf16x8 fa = *reinterpret_cast<const bf16x8*>(ta + i * 16 * ROW);
@@ -404,6 +417,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_ring(const GemmArgs g)
             for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
         }
+#if NATINF_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
     __syncthreads();               // every wave is done with the ring before the epilogue reuses it
     dma_tile_epilogue<WM, WN, TM, TN, typename Cfg::Epi>(g, smem, acc, m0, n0, z, tid, lane, wm, wn);

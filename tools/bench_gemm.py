@@ -42,6 +42,15 @@ SHAPES = [  # (M, N, K0, K1, taps, res)  -- B=512 layer shapes, largest time fir
     (524288, 256, 2304, 256, 9, 32), (32768, 256, 2304, 0, 9, 8), (8192, 256, 2304, 0, 9, 4), (131072, 256, 256, 0, 1, 0),
     (131072, 512, 256, 0, 1, 0),
 ]
+if __name__ != "__main__":
+    SHAPES = []
+if len(sys.argv) > 1 and sys.argv[1] == "one":
+    # bench_gemm.py one <variant> <M> <N> <K0> <K1> <taps> <res> [iters]
+    v, M, N, K0, K1, taps, res = map(int, sys.argv[2:9])
+    it = int(sys.argv[9]) if len(sys.argv) > 9 else 5
+    ms, tf, _ = run(v, M, N, K0, K1, taps, res, iters=it)
+    print(f"{NAMES[v]} {(M, N, K0 + K1, taps)}: {ms*1e3:.1f} us  {tf:.0f} TF/s")
+    sys.exit(0)
 variants = [int(v) for v in sys.argv[1:]] or [2, 3, 4, 5, 6, 7, 8]
 # correctness (plain GEMM with both K segments) for every variant first
 for v in variants:
