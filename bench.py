@@ -43,6 +43,21 @@ def ni_step_bytes_per_element(C, s_x=4, s_h=8):
     return out
 
 
+def profiled_traffic(match):
+    """HBM bytes per launch from the newest committed rocprofv3 PMC summary (profiles/rNN/*_hbm_traffic.json:
+    separate FETCH_SIZE / WRITE_SIZE passes over this very command, gfx950 x2 read correction applied by
+    tools/summarize_profile.py).  bench.py cannot run rocprofv3 itself; returns None when no summary exists."""
+    files = sorted(ROOT.glob("profiles/r*/*_hbm_traffic.json"))
+    if not files:
+        return None, None
+    tab = json.loads(files[-1].read_text())
+    rows = [v for k, v in tab.items() if match in k]
+    n = sum(v["launches"] for v in rows)
+    if not n:
+        return None, None
+    return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in rows) / n, str(files[-1].relative_to(ROOT))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,9 +168,11 @@ def main():
         flops_per_launch = flops_total / gemm_n
         mean_ms = gemm_ms / gemm_n
         ach = flops_per_launch / (mean_ms * 1e-3) / 1e12
+        tr_gemm, tr_src = profiled_traffic("k_gemm")
         line["roofline"] = {
-            "kernel": "k_gemm_bf16", "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": "k_gemm_* (k_gemm_dma / k_gemm_ring tile variants of one implicit-GEMM kernel)", "bound": "mfma",
+            "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": tr_gemm, "traffic_source": tr_src,
             "launches": int(gemm_n), "mean_launch_ms": round(mean_ms, 5),
             "flops_per_launch": flops_per_launch, "device_ms_total": round(gemm_ms, 3),
             "other_kernels_device_ms": round(other_ms, 3), "other_launches": int(other_n),
@@ -165,9 +182,10 @@ def main():
         tot_ms = sum(a0.elapsed_time(a1) for _, a0, a1 in ev)
         tot_bytes = sum(bpe[k] * E for k, _, _ in ev)
         ach_gbs = tot_bytes / (tot_ms * 1e-3) / 1e9
+        tr_ni, tr_src = profiled_traffic("k_step_f64hist")
         line["roofline_ni_step"] = {
             "kernel": "k_step_f64hist", "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(ach_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "unit": "GB/s", "frac": round(ach_gbs / HBM_PEAK_GBS, 4), "traffic": tr_ni, "traffic_source": tr_src,
             "launches": len(ev), "mean_launch_ms": round(tot_ms / len(ev), 5),
             "bytes_per_launch": tot_bytes / len(ev), "bytes_per_element_by_step": bpe,
         }
@@ -182,7 +200,7 @@ def main():
         torch.set_num_threads(threads)
         P = synthetic_state_dict(0)
         model = N.model_fn_from_params(P)
-        nb = 4
+        nb = 16
         z = torch.randn(nb, 3, 32, 32, generator=torch.Generator().manual_seed(888))
         model(z[:1], torch.zeros(1))                       # page in / warm the thread pool
         tc = time.perf_counter()

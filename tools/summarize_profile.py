@@ -10,8 +10,8 @@ dst.mkdir(parents=True, exist_ok=True)
 shutil.copy(glob.glob(str(src / "stats/*/*_kernel_stats.csv"))[0], dst / f"{tag}_kernel_stats.csv")
 shutil.copy(str(src) + ".bench.json", dst / f"{tag}_bench.json")
 def short(n):
-    n = n.split("(")[0]
-    return n.replace("ncsn::", "").replace("(anonymous namespace)::", "").replace("void ", "")[:48]
+    n = n.replace("(anonymous namespace)::", "").replace("ncsn::", "").replace("void ", "")
+    return n.split("(")[0][:48]
 traffic = defaultdict(lambda: dict(launches=0, fetch_kb=0.0, write_kb=0.0))
 for kind, key in (("fetch", "fetch_kb"), ("write", "write_kb")):
     f = glob.glob(str(src / kind / "*/*_counter_collection.csv"))[0]
