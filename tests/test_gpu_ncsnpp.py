@@ -103,3 +103,37 @@ def test_ni_end_to_end_with_engine(dev, params, flat, repo_root):
     errs = [_rel(a.cpu(), b) for a, b in zip(xs[1:], ref[1:])]
     print("trajectory max-rel errors per step:", errs)
     assert max(errs) <= 5e-2          # bf16 denoiser error propagated through 5 NI steps (|C| rows sum up to 3.8)
+
+
+def test_every_gemm_variant_gives_the_same_network(dev, flat, golden_dir):
+    """force each DMA/ring tile variant for all eligible launches: outputs agree to bf16 rounding noise (the
+    variants only differ in tiling / pipeline depth; accumulation order inside a K loop is identical)."""
+    from naturaldiffusion_amd.ncsnpp import NCSNppEngine
+    from naturaldiffusion_amd._lib import lib
+    fx = np.load(golden_dir / "ncsnpp_forward.npz")
+    x, labels = torch.from_numpy(fx["x"]).to(dev), torch.from_numpy(fx["labels"]).to(dev)
+    eng = NCSNppEngine(flat, max_batch=2, device=dev)
+    outs = {}
+    try:
+        for v in (0, 2, 3, 4, 5, 6, 7, 8, 9, 10):
+            assert lib.natinf_set_gemm_variant(v) == 0
+            outs[v] = eng(x, labels).clone()
+            torch.cuda.synchronize()
+    finally:
+        lib.natinf_set_gemm_variant(0)
+    ref = torch.from_numpy(fx["y"])
+    for v, y in outs.items():
+        assert _rel(y.cpu(), ref) <= TOL, (v, _rel(y.cpu(), ref))
+        assert torch.equal(y, outs[0]) or _rel(y.cpu(), outs[0].cpu()) < 2e-2
+
+
+def test_workspace_too_small_is_an_error(dev, flat):
+    from naturaldiffusion_amd.ncsnpp import NCSNppEngine
+    from naturaldiffusion_amd._lib import lib, ptr, stream_ptr
+    eng = NCSNppEngine(flat, max_batch=2, device=dev)
+    x = torch.zeros(4, 3, 32, 32, device=dev)
+    with pytest.raises(ValueError):
+        eng(x, torch.zeros(4, device=dev))
+    out = torch.empty_like(x)
+    rc = lib.natinf_ncsnpp_forward(eng._h, ptr(x), ptr(torch.zeros(4, device=dev)), ptr(out), 4, ptr(eng._ws), eng._ws.numel(), stream_ptr())
+    assert rc == -1

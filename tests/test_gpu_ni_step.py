@@ -241,3 +241,61 @@ def test_sd3_full_size_step_matches_oracle(dev, repo_root):
     assert torch.equal(ni.hist[k].cpu(), f)
     assert torch.equal(mean.cpu(), want_mean)
     assert torch.equal(xn.cpu(), want_next)
+
+
+# ------------------------------------------------------------------------------ edge cases
+def test_long_stochastic_history_matches_oracle(dev):
+    """a 120-step matrix with a dense lower triangle AND a dense noise matrix (every column used) in the
+    Validate form: the term loops run far past their unroll factor; kernel == oracle on every element."""
+    from naturaldiffusion_amd.sampler import ValidateNI
+    rs = np.random.RandomState(7)
+    N, E = 120, 4 * 1024
+    C = np.tril(rs.randn(N, N) * 0.2)
+    Bm = np.zeros((N, N + 1))
+    for k in range(N):
+        Bm[k, :k + 2] = rs.randn(k + 2) * 0.1
+    C[5, 2] = 0.0; Bm[9, 3] = 0.0; C[17, 17] = 0.0                     # zero entries incl. a zero diagonal
+    node = np.zeros((N + 1, 3))
+    c1 = rs.rand(N) + 0.5; c2 = rs.rand(N) * 0.5
+    g = torch.Generator().manual_seed(3)
+    z0 = torch.randn(E, generator=g)
+    eps = [torch.randn(E, generator=g) for _ in range(N)]
+    noi = [torch.randn(E, generator=g) for _ in range(N + 1)]
+    for dense in (False, True):
+        ni = ValidateNI(C, Bm, node, c1.astype(np.float32), c2.astype(np.float32), E, device=dev, dense=dense)
+        for j in range(N + 1):
+            ni.hist_eps[j].copy_(noi[j])
+        z = z0.to(dev)
+        seq_x0, zo = [], z0
+        for k in range(N):
+            z = ni.step(k, z, eps[k].to(dev), None, 0.0)
+            x0 = float(np.float32(c1[k])) * zo - float(np.float32(c2[k])) * eps[k]
+            seq_x0.append(x0)
+            zo = O.validate_weighted_sum(C[k], seq_x0) + O.validate_weighted_sum(Bm[k, :k + 2], noi[:k + 2])
+            if k % 40 == 39 or k == N - 1:
+                assert torch.equal(z.cpu(), zo), f"step {k} (dense={dense})"
+        assert torch.isfinite(zo).all()
+
+
+def test_degenerate_rows_and_sizes(dev):
+    """single-step matrix (no history terms at all), the smallest legal E, and E not a multiple of the vector width."""
+    from naturaldiffusion_amd.sampler import CifarNI
+    C = np.array([[0.75]]); Bm = np.array([[0.5]]); node = np.array([[1.0, 0.3, 0.9], [0.0, 1.0, 0.0]])
+    for E in (4, 8, 4 * 1031):
+        g = torch.Generator().manual_seed(E)
+        x, out = torch.randn(E, generator=g), torch.randn(E, generator=g)
+        ni = CifarNI(C, Bm, node, E, device=dev, stds=[0.97])
+        got = ni.step(0, x.to(dev), out.to(dev), x.to(dev)).cpu()
+        x0 = O.x0_from_score(x, O.score_from_model_out(out, torch.tensor(0.97)), 0.3, 0.9)
+        want = O.cifar_weighted_sum(C[0], [x0]) + x * 0.5
+        assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        CifarNI(C, Bm, node, 6, device=dev)
+    # non-finite data: dense rows reproduce the reference's NaN propagation (inf * 0 = nan), sparse rows do not
+    C2 = np.array([[1.0, 0.0], [0.0, 1.0]]); B2 = np.zeros((2, 2)); node2 = np.array([[1.0, 1.0, 0.0], [0.5, 1.0, 0.0], [0.0, 1.0, 0.0]])
+    x = torch.zeros(4); bad = torch.tensor([float("inf"), 1.0, 2.0, 3.0])
+    for dense, expect_nan in ((True, True), (False, False)):
+        ni = CifarNI(C2, B2, node2, 4, device=dev, dense=dense, stds=[1.0, 1.0])
+        ni.step(0, bad.to(dev), x.to(dev), x.to(dev))          # x0_0 = [inf, 1, 2, 3]
+        r = ni.step(1, x.to(dev), x.to(dev), x.to(dev)).cpu()  # row 1 = [0, 1]: inf*0 term present only when dense
+        assert bool(torch.isnan(r[0])) == expect_nan
