@@ -80,6 +80,15 @@ int natinf_weighted_sum_f64(const double* hist, float* out,
                             const int32_t* idx, const double* val, int n_terms,
                             int64_t E, natinf_stream_t stream);
 
+/* Initial noise for batch-sharded generation (replaces the sequential torch.manual_seed(888) + torch.randn of
+ * src/CIFAR10NaturalInference.py:285-290, which cannot be split over GPUs): out[i][e], i < n_images, e <
+ * elems_per_image, ~ N(0,1) from Philox4x32-10 with key = seed and counter = (global image index, e/4), Box-Muller.
+ * The global index of row i is image_index[i] (device array) or, when image_index is NULL, first_index +
+ * i*index_stride.  The same (seed, global index) gives the same image for any GPU count or batch split.
+ * elems_per_image % 4 == 0. */
+int natinf_randn_philox_f32(float* out, int64_t n_images, int64_t elems_per_image, const int64_t* image_index,
+                            int64_t first_index, int64_t index_stride, uint64_t seed, natinf_stream_t stream);
+
 /* src/CIFAR10NaturalInference.py:212-216 (to_pixel): x [B,C,H,W] fp32 -> uint8 [B,H,W,C] =
  * trunc(clip(x*255, 0, 255)); with centered != 0 the inverse scaler of datasets.py:32-38,
  * x <- (x+1)/2, is applied first (the reference calls the two back to back, :308-309). */

@@ -81,6 +81,41 @@ def natural_inference(model_fn: Callable, noise: torch.Tensor, weight_path, dens
     return ni.run(model_fn, noise, return_all=return_all)
 
 
+def philox_noise(indices, shape_per_image, seed: int, device="cuda:0") -> torch.Tensor:
+    """[len(indices), *shape_per_image] fp32 N(0,1), image i keyed by its GLOBAL index (include/natinf.h,
+    natinf_randn_philox_f32): identical for any GPU count / batch split."""
+    _lib.require_gpu()
+    idx = torch.as_tensor(list(indices), dtype=torch.int64, device=device)
+    per = int(np.prod(shape_per_image))
+    out = torch.empty((idx.numel(),) + tuple(shape_per_image), dtype=torch.float32, device=device)
+    check(lib.natinf_randn_philox_f32(ptr(out), idx.numel(), per, ptr(idx), 0, 0, int(seed) & (2 ** 64 - 1), stream_ptr()),
+          "natinf_randn_philox_f32")
+    return out
+
+
+@torch.no_grad()
+def generate_sharded(model_fn: Callable, weight_path, sample_count: int, batch_size: int, rank: int = 0, world: int = 1,
+                     seed: int = 888, device="cuda:0"):
+    """Batch-sharded generation (BASELINE config 3): this rank generates the images whose
+    global index is rank, rank+world, ... in batches of ``batch_size`` -- no collective on the data path.
+    Returns (uint8 images [n_local, 32, 32, 3] on the CPU, their global indices)."""
+    from .shard import rank_batches
+    C, B, node = load_coeff_npz(weight_path)
+    samplers = {}
+    imgs, idxs = [], []
+    for batch in rank_batches(sample_count, batch_size, rank, world):
+        n = len(batch)
+        if n not in samplers:                                   # the ragged last batch gets its own slabs
+            samplers[n] = CifarNI(C, B, node, n * 3 * 32 * 32, device=device)
+        noise = philox_noise(batch, (3, 32, 32), seed, device)
+        out = samplers[n].run(model_fn, noise)
+        imgs.append(to_pixel_from_centered(out))
+        idxs.append(torch.tensor(batch, dtype=torch.int64))
+    if not imgs:
+        return torch.empty((0, 32, 32, 3), dtype=torch.uint8), torch.empty(0, dtype=torch.int64)
+    return torch.cat(imgs), torch.cat(idxs)
+
+
 def calc_fid(imgs, ref_path, device):
     """Reference :73-86 (InceptionV3 pool3 + Frechet distance).  Needs ``pytorch_fid`` and the
     ``cifar10_mu_sigma.npz`` statistics, neither of which ships with the reference."""

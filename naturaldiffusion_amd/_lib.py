@@ -29,6 +29,7 @@ SIGNATURES = {
     "natinf_step_f64hist": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _f64, _i32, _f64, _f64, _f32, _f32, _i64, _p]),
     "natinf_step_f32hist": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _f32, _i32, _f32, _f32, _f32, _f32, _i64, _p]),
     "natinf_weighted_sum_f64": (C.c_int, [_p, _p, _p, _p, _i32, _i64, _p]),
+    "natinf_randn_philox_f32": (C.c_int, [_p, _i64, _i64, _p, _i64, _i64, C.c_uint64, _p]),
     "natinf_to_pixel_u8": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "natinf_step_f32prod": (C.c_int, [_p, _p, _p, _f32, _i64, _i64, _p, _p, _p, _p, _p, _i32, _f32, _p, _p, _i32,
                                       _i32, _f32, _f32, _i64, _p]),

@@ -349,6 +349,49 @@ __global__ __launch_bounds__(kBlock) void k_wmean_f16(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Counter-based initial noise: Philox4x32-10 keyed by (seed, global image index).  The reference draws one
+// sequential torch.randn stream (src/CIFAR10NaturalInference.py:285-290), which cannot be sharded; keying
+// the generator by the image's GLOBAL index makes image i identical for any GPU count / batch split.
+// counter = (index lo, index hi, element quad, 0), key = (seed lo, seed hi); 4 x uint32 -> 4 normals (Box-Muller).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&o)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+__global__ __launch_bounds__(kBlock) void k_randn_philox(
+    float4* __restrict__ out, const int64_t* __restrict__ index, int64_t first_index, int64_t index_stride,
+    int64_t quads_per_image, int64_t total_quads, uint32_t k0, uint32_t k1)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < total_quads; v += stride) {
+        const int64_t img = v / quads_per_image, q = v - img * quads_per_image;
+        const uint64_t gi = (uint64_t)(index ? index[img] : first_index + img * index_stride);
+        uint32_t r[4];
+        philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)q, (uint32_t)(q >> 32), k0, k1, r);
+        float z[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = ((float)(r[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);       // (0, 1), 24 bits
+            const float u2 = ((float)(r[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const float rad = sqrtf(-2.0f * logf(u1));
+            float sn, cs;
+            sincosf(6.28318530717958647692f * u2, &sn, &cs);
+            z[2 * h] = rad * cs; z[2 * h + 1] = rad * sn;
+        }
+        out[v] = make_float4(z[0], z[1], z[2], z[3]);
+    }
+}
+
 inline int launched() { return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH; }
 inline bool terms_ok(const void* idx, const void* val, int n) { return n >= 0 && (n == 0 || (idx && val)); }
 
@@ -407,6 +450,16 @@ int natinf_step_f32hist(const float* x_k, const float* model_out, const float* n
     hipLaunchKernelGGL(k_step_f32hist, dim3(grid_for(nvec)), dim3(kBlock), 0, (hipStream_t)stream,
                        (const float4*)x_k, (const float4*)model_out, (const float4*)noise, hist, (float4*)x_next,
                        idx, val, n_terms, c_diag, k, 1.0f / alpha, sigma * sigma / std_f32, b0_f32, nvec, E);
+    return launched();
+}
+
+int natinf_randn_philox_f32(float* out, int64_t n_images, int64_t elems_per_image, const int64_t* image_index,
+                            int64_t first_index, int64_t index_stride, uint64_t seed, natinf_stream_t stream)
+{
+    if (!out || n_images <= 0 || elems_per_image <= 0 || (elems_per_image & 3)) return NATINF_EINVAL;
+    const int64_t qpi = elems_per_image / 4, total = qpi * n_images;
+    hipLaunchKernelGGL(k_randn_philox, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, (float4*)out,
+                       image_index, first_index, index_stride, qpi, total, (uint32_t)seed, (uint32_t)(seed >> 32));
     return launched();
 }
 
