@@ -167,7 +167,10 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
     }
 }
 
-template <int WM, int WN, int TM, int TN>
+// SPREAD = 1: the DMA requests of tile k+1 are not issued in one burst after the barrier (every wave of the block
+// would then be issuing ~100-cycle LDS-DMA instructions at the same moment, with the matrix pipe idle) but one at
+// a time between the MFMA groups of tile k.
+template <int WM, int WN, int TM, int TN, int SPREAD = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
 {
     using Cfg = DmaCfg<WM, WN, TM, TN>;
@@ -249,9 +252,37 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
     __syncthreads();
 
     const int frow = lane & 15, fq = lane >> 4, fswz = (frow >> 1) & 7;
+    constexpr int NP = Cfg::PA + Cfg::PB, SLOTS = 2 * TM, STEP = SLOTS / NP > 0 ? SLOTS / NP : 1;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) issue_tile(kt + 1, cur ^ 1);
+        const bool more = kt + 1 < nk;
+        // tile-uniform part of the next tile's addresses (scalar registers)
+        const int kn = kt + 1;
+        const bool seg0n = kn < nk0;
+        int64_t ashiftn; int kkn;
+        if (seg0n) {
+            int tap = 0, c0 = kn * BK;
+            if (g.taps == 9) { const int cch = kn / 9; tap = kn - 9 * cch; c0 = cch * BK; }
+            const int dy = g.taps == 9 ? tap / 3 - 1 : 0, dx = g.taps == 9 ? tap % 3 - 1 : 0;
+            ashiftn = ((int64_t)(dy * Wp + dx) * g.a0_ld + c0) * 2; kkn = kn * BK;
+        } else {
+            ashiftn = (int64_t)(kn - nk0) * BK * 2; kkn = K0 + (kn - nk0) * BK;
+        }
+        unsigned char* dAn = smem + (cur ^ 1) * Cfg::STAGE_BYTES + wave * (Cfg::PA * 1024);
+        unsigned char* dBn = smem + (cur ^ 1) * Cfg::STAGE_BYTES + BM_ * BK * 2 + wave * (Cfg::PB * 1024);
+        auto issue_piece = [&](int p) __attribute__((always_inline)) {
+            if (p < Cfg::PA) {
+                const uint64_t pa = a_row[p] + (seg0n ? 0 : a_delta[p]) + (uint64_t)ashiftn;
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pa), (lds_void*)(dAn + p * 1024), 16, 0, 0);
+            } else {
+                const uint64_t pb = b_row[p - Cfg::PA] + (uint64_t)kkn * 2;
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pb), (lds_void*)(dBn + (p - Cfg::PA) * 1024), 16, 0, 0);
+            }
+        };
+        if (!SPREAD && more) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) issue_piece(p);
+        }
         const bf16* ta = reinterpret_cast<const bf16*>(smem + cur * Cfg::STAGE_BYTES) + (wm * TM * 16 + frow) * LDS_ROW;
         const bf16* tb = reinterpret_cast<const bf16*>(smem + cur * Cfg::STAGE_BYTES + BM_ * BK * 2) + (wn * TN * 16 + frow) * LDS_ROW;
 #pragma unroll
@@ -260,19 +291,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
             bf16x8 fb[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(tb + j * 16 * LDS_ROW + ko);
-#if NATINF_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const bf16x8 fa = *reinterpret_cast<const bf16x8*>(ta + i * 16 * LDS_ROW + ko);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+                if (SPREAD) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int slot = ks * TM + i;
+                    if (more && slot % STEP == 0 && slot / STEP < NP) issue_piece(slot / STEP);
+                }
             }
-#if NATINF_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
         }
         __syncthreads();
     }

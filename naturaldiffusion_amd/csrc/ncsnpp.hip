@@ -138,11 +138,12 @@ enum GemmVariant {
     V_DMA_256x256 = 2, V_DMA_256x128 = 3, V_DMA_128x128 = 4,          // 2-stage, BK = 64
     V_RING_256x256 = 5, V_RING_256x128 = 6, V_RING_128x128 = 7, V_RING_64x128 = 8,   // NS-slot ring, BK = 32
     V_RING_256x128_W4 = 9, V_DMA_256x128_W4 = 10,                     // 4 waves, wave tile 128x64 (less LDS read traffic per MFMA)
+    V_DMA_256x256_S = 11, V_DMA_128x128_S = 12,                       // two-stage with the DMA issue spread between MFMA groups
     V_COUNT
 };
 const char* variant_name(int v) {
     static const char* n[] = {"auto", "generic128", "dma256x256", "dma256x128", "dma128x128", "ring256x256", "ring256x128",
-                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4"};
+                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s"};
     return v >= 0 && v < V_COUNT ? n[v] : "?";
 }
 int g_force_variant = V_AUTO;      // tuning / tests: force one variant for every DMA-eligible launch
@@ -169,7 +170,8 @@ bool configure_gemm_kernels() {
          set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4>) && set_lds<CfgR256x256>(&k_gemm_ring<2, 4, 8, 4, 4>) &&
          set_lds<CfgR256x128>(&k_gemm_ring<4, 2, 4, 4, 6>) && set_lds<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4>) &&
          set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4>) && set_lds<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3>) &&
-         set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4>);
+         set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4>) && set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 1>) &&
+         set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 1>);
     if (!ok) (void)hipGetLastError();
     return ok;
 }
@@ -195,7 +197,8 @@ int choose_variant(const GemmArgs& g) {
 
 int variant_bm(int v) {
     switch (v) {
-        case V_DMA_256x256: case V_DMA_256x128: case V_RING_256x256: case V_RING_256x128: case V_RING_256x128_W4: case V_DMA_256x128_W4: return 256;
+        case V_DMA_256x256: case V_DMA_256x128: case V_RING_256x256: case V_RING_256x128: case V_RING_256x128_W4: case V_DMA_256x128_W4:
+        case V_DMA_256x256_S: return 256;
         case V_RING_64x128: return 64;
         default: return 128;
     }
@@ -225,6 +228,8 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
         case V_RING_64x128: launch_tiles<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4>, g, s); break;
         case V_RING_256x128_W4: launch_tiles<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3>, g, s); break;
         case V_DMA_256x128_W4: launch_tiles<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4>, g, s); break;
+        case V_DMA_256x256_S: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 1>, g, s); break;
+        case V_DMA_128x128_S: launch_tiles<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 1>, g, s); break;
         default: break;
     }
     return variant_bm(v);
