@@ -27,6 +27,7 @@
 #include "natinf_ncsnpp.h"
 #include "ncsnpp_kernels.h"
 #include "gemm_dma.h"
+#include "conv_patch.h"
 
 using namespace ncsn;
 
@@ -139,11 +140,13 @@ enum GemmVariant {
     V_RING_256x256 = 5, V_RING_256x128 = 6, V_RING_128x128 = 7, V_RING_64x128 = 8,   // NS-slot ring, BK = 32
     V_RING_256x128_W4 = 9, V_DMA_256x128_W4 = 10,                     // 4 waves, wave tile 128x64 (less LDS read traffic per MFMA)
     V_DMA_256x256_S = 11, V_DMA_128x128_S = 12,                       // two-stage with the DMA issue spread between MFMA groups
+    V_DMA_512x128 = 13,                                                // 8 waves x (128x64), all 160 KiB of LDS
+    V_PATCH_256x256 = 14, V_PATCH_256x128 = 15,                        // 3x3 conv with an LDS-resident input patch
     V_COUNT
 };
 const char* variant_name(int v) {
     static const char* n[] = {"auto", "generic128", "dma256x256", "dma256x128", "dma128x128", "ring256x256", "ring256x128",
-                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s"};
+                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s", "dma512x128", "patch256x256", "patch256x128"};
     return v >= 0 && v < V_COUNT ? n[v] : "?";
 }
 int g_force_variant = V_AUTO;      // tuning / tests: force one variant for every DMA-eligible launch
@@ -162,6 +165,8 @@ using CfgD256x256 = DmaCfg<2, 4, 8, 4>;  using CfgD256x128 = DmaCfg<4, 2, 4, 4>;
 using CfgR256x256 = RingCfg<2, 4, 8, 4, 4>; using CfgR256x128 = RingCfg<4, 2, 4, 4, 6>;
 using CfgR128x128 = RingCfg<2, 2, 4, 4, 4>; using CfgR64x128 = RingCfg<2, 2, 2, 4, 4>;
 using CfgR256x128W4 = RingCfg<2, 2, 8, 4, 3>; using CfgD256x128W4 = DmaCfg<2, 2, 8, 4>;
+using CfgD512x128 = DmaCfg<4, 2, 8, 4>;
+using CfgP256x256 = PatchCfg<2, 4, 8, 4, 344>; using CfgP256x128 = PatchCfg<4, 2, 4, 4, 400>;
 
 bool configure_gemm_kernels() {
     bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -171,7 +176,8 @@ bool configure_gemm_kernels() {
          set_lds<CfgR256x128>(&k_gemm_ring<4, 2, 4, 4, 6>) && set_lds<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4>) &&
          set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4>) && set_lds<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3>) &&
          set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4>) && set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 1>) &&
-         set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 1>);
+         set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 1>) && set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4>) &&
+         set_lds<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>) && set_lds<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>);
     if (!ok) (void)hipGetLastError();
     return ok;
 }
@@ -183,7 +189,10 @@ int choose_variant(const GemmArgs& g) {
     const int K0 = g.taps * g.a0_C, K1 = g.a1 ? g.a1_C : 0;
     const bool dma = K0 % BK == 0 && K1 % BK == 0 && (g.taps == 1 || (g.a0_padded && g.a0_C % BK == 0));
     if (!dma) return V_GENERIC;
-    if (g_force_variant > V_GENERIC) return g_force_variant;
+    const bool patch_ok = g.taps == 9 && g.batch == 1 && g.logW >= 3;
+    if (g_force_variant == V_PATCH_256x256 || g_force_variant == V_PATCH_256x128) {
+        if (patch_ok && (g_force_variant == V_PATCH_256x128 || g.logW >= 4)) return g_force_variant;
+    } else if (g_force_variant > V_GENERIC) return g_force_variant;
     // measured on the engine's layer shapes (tools/bench_gemm.py, profiles/r01): 256x256 two-stage for wide-N,
     // long-K layers; the 4-wave 256x128 ring (wave tile 128x64, 2 blocks/CU) for N = 128 and short-K layers;
     // 128x128 when 256-row tiles would leave CUs idle; 64x128 for the 4x4 level
@@ -198,7 +207,8 @@ int choose_variant(const GemmArgs& g) {
 int variant_bm(int v) {
     switch (v) {
         case V_DMA_256x256: case V_DMA_256x128: case V_RING_256x256: case V_RING_256x128: case V_RING_256x128_W4: case V_DMA_256x128_W4:
-        case V_DMA_256x256_S: return 256;
+        case V_DMA_256x256_S: case V_PATCH_256x256: case V_PATCH_256x128: return 256;
+        case V_DMA_512x128: return 512;
         case V_RING_64x128: return 64;
         default: return 128;
     }
@@ -230,6 +240,9 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
         case V_DMA_256x128_W4: launch_tiles<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4>, g, s); break;
         case V_DMA_256x256_S: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 1>, g, s); break;
         case V_DMA_128x128_S: launch_tiles<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 1>, g, s); break;
+        case V_DMA_512x128: launch_tiles<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4>, g, s); break;
+        case V_PATCH_256x256: launch_tiles<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>, g, s); break;
+        case V_PATCH_256x128: launch_tiles<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>, g, s); break;
         default: break;
     }
     return variant_bm(v);

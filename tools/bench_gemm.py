@@ -7,7 +7,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from naturaldiffusion_amd._lib import lib, check, stream_ptr
 
-NAMES = {1: "generic128", 2: "dma256x256", 3: "dma256x128", 4: "dma128x128", 5: "ring256x256", 6: "ring256x128", 7: "ring128x128", 8: "ring64x128", 9: "ring256x128w4", 10: "dma256x128w4", 11: "dma256x256s", 12: "dma128x128s"}
+NAMES = {1: "generic128", 2: "dma256x256", 3: "dma256x128", 4: "dma128x128", 5: "ring256x256", 6: "ring256x128", 7: "ring128x128", 8: "ring64x128", 9: "ring256x128w4", 10: "dma256x128w4", 11: "dma256x256s", 12: "dma128x128s", 13: "dma512x128", 14: "patch256x256", 15: "patch256x128"}
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 
@@ -37,6 +37,34 @@ def run(variant, M, N, K0, K1, taps, res, iters=20, check_ref=False):
         err = ((c.float() - ref).abs().max() / ref.abs().max()).item()
     return ms, 2.0 * M * N * (K0 + K1) / ms / 1e9, err
 
+def check_conv(variant, Bn, res, Cin, N, K1):
+    """3x3 conv (+ optional 1x1 shortcut over K1 channels) against torch.nn.functional.conv2d (fp32)."""
+    import torch.nn.functional as F
+    x = torch.randn(Bn, Cin, res, res, device=dev)
+    w = torch.randn(N, Cin, 3, 3, device=dev) * 0.05
+    xb = x.to(torch.bfloat16); wb = w.to(torch.bfloat16)
+    a = torch.zeros(Bn, res + 2, res + 2, Cin, dtype=torch.bfloat16, device=dev)
+    a[:, 1:-1, 1:-1] = xb.permute(0, 2, 3, 1)
+    # engine K order: 64-channel chunk outer, tap, channel
+    wp = wb.reshape(N, Cin // 64, 64, 9).permute(0, 1, 3, 2).reshape(N, Cin * 9)
+    ref = F.conv2d(xb.float(), wb.float(), padding=1)
+    a1 = None
+    if K1:
+        s = torch.randn(Bn, K1, res, res, device=dev); w1 = torch.randn(N, K1, device=dev) * 0.05
+        sb = s.to(torch.bfloat16); w1b = w1.to(torch.bfloat16)
+        a1 = sb.permute(0, 2, 3, 1).contiguous().reshape(-1, K1)
+        wp = torch.cat([wp, w1b], dim=1)
+        ref = ref + torch.einsum("bkhw,nk->bnhw", sb.float(), w1b.float())
+    wp = wp.contiguous()
+    M = Bn * res * res
+    c = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    check(lib.natinf_debug_gemm(variant, M, N, Cin * 9, K1, 9, res.bit_length() - 1, 1, a.data_ptr(), a1.data_ptr() if K1 else None,
+                                wp.data_ptr(), None, c.data_ptr(), 0, 1.0, 1, stream_ptr()), "debug_gemm")
+    torch.cuda.synchronize()
+    got = c.float().reshape(Bn, res, res, N).permute(0, 3, 1, 2)
+    return ((got - ref).abs().max() / ref.abs().max()).item()
+
+
 SHAPES = [  # (M, N, K0, K1, taps, res)  -- B=512 layer shapes, largest time first
     (524288, 128, 1152, 0, 9, 32), (524288, 128, 2304, 128, 9, 32), (131072, 256, 2304, 0, 9, 16), (131072, 256, 4608, 0, 9, 16),
     (524288, 256, 2304, 256, 9, 32), (32768, 256, 2304, 0, 9, 8), (8192, 256, 2304, 0, 9, 4), (131072, 256, 256, 0, 1, 0),
@@ -56,6 +84,13 @@ variants = [int(v) for v in sys.argv[1:]] or [2, 3, 4, 5, 6, 7, 8]
 for v in variants:
     ms, tf, err = run(v, 1000, 384, 256, 128, 1, 0, iters=2, check_ref=True)
     print(f"check {NAMES[v]:>12}: rel err {err:.2e}")
+for v in variants:
+    errs = []
+    for (Bn, res, Cin, N, K1) in ((5, 32, 128, 128, 0), (3, 16, 256, 256, 128), (9, 8, 128, 256, 64), (2, 32, 192, 128, 64)):
+        if v == 14 and res < 16:
+            continue
+        errs.append(check_conv(v, Bn, res, Cin, N, K1))
+    print(f"conv check {NAMES[v]:>12}: " + " ".join(f"{e:.2e}" for e in errs))
 print(f"{'shape':>34} " + " ".join(f"{NAMES[v]:>12}" for v in variants))
 for (M, N, K0, K1, taps, res) in SHAPES:
     cells = []
