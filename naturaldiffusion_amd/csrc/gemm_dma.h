@@ -167,6 +167,52 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
     }
 }
 
+// ---- hand-counted LDS fragment pipeline (k_gemm_dma<..., 2>) ------------------------------------------------
+// hipcc schedules "ds_read xN; s_waitcnt lgkmcnt(0); MFMA xM" batches: inside one wave LDS latency and the matrix
+// pipe never overlap.  Here the fragment reads are inline-asm ds_read_b128 (invisible to hipcc's waitcnt pass) issued
+// two steps ahead of their use, retired by COUNTED lgkmcnt waits, with sched_barrier(0) pinning each MFMA group
+// behind its wait (guide 5.4 rule 18 / 5.7 form iii).  A step = one A row-tile x TN B tiles of one k-step.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF> __device__ __forceinline__ u32x4 lds_read16(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// reads still allowed in flight when step `st` starts its MFMAs.  Issue order: [B(ks0) x4, A0, A1], then per step s:
+// A(s+2) if it exists, then -- during the last four steps of k-step 0 -- one B fragment of k-step 1.
+constexpr int pipe_lgkm_after(int TM, int st) {
+    int n = 6, pos_fa[40] = {4, 5}, pos_fb1_last = -1;
+    for (int s = 0; s <= st; ++s) {
+        if (s + 2 < 2 * TM) pos_fa[s + 2] = n++;
+        if (s / TM == 0 && s % TM >= TM - 4) pos_fb1_last = n++;
+    }
+    int need = pos_fa[st];
+    if (st >= TM && pos_fb1_last > need) need = pos_fb1_last;
+    return n - 1 - need;
+}
+template <int TM, int ST>
+struct PipeStep {
+    static __device__ __forceinline__ void run(u32x4 (&fa)[3], u32x4 (&fb)[2][4], f32x4 (&acc)[TM][4],
+                                               unsigned a0, unsigned a1, unsigned b1) {
+        constexpr int S = 2 * TM, ks = ST / TM, i = ST % TM;
+        if constexpr (ST + 2 < S) {
+            constexpr int ks2 = (ST + 2) / TM, i2 = (ST + 2) % TM;
+            fa[(ST + 2) % 3] = lds_read16<i2 * 2048>(ks2 ? a1 : a0);
+        }
+        if constexpr (ks == 0 && i >= TM - 4) fb[1][i - (TM - 4)] = lds_read16<(i - (TM - 4)) * 2048>(b1);
+        wait_lgkmcnt<pipe_lgkm_after(TM, ST)>();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[ST % 3]),
+                                                                __builtin_bit_cast(bf16x8, fb[ks][j]), acc[i][j], 0, 0, 0);
+        if constexpr (ST + 1 < S) PipeStep<TM, ST + 1>::run(fa, fb, acc, a0, a1, b1);
+    }
+};
+
 // SPREAD = 1: the DMA requests of tile k+1 are not issued in one burst after the barrier (every wave of the block
 // would then be issuing ~100-cycle LDS-DMA instructions at the same moment, with the matrix pipe idle) but one at
 // a time between the MFMA groups of tile k.
@@ -285,24 +331,36 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
         }
         const bf16* ta = reinterpret_cast<const bf16*>(smem + cur * Cfg::STAGE_BYTES) + (wm * TM * 16 + frow) * LDS_ROW;
         const bf16* tb = reinterpret_cast<const bf16*>(smem + cur * Cfg::STAGE_BYTES + BM_ * BK * 2) + (wn * TN * 16 + frow) * LDS_ROW;
+        if constexpr (SPREAD != 2) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ko = (((ks << 2) | fq) ^ fswz) << 3;
-            bf16x8 fb[TN];
+            for (int ks = 0; ks < 2; ++ks) {
+                const int ko = (((ks << 2) | fq) ^ fswz) << 3;
+                bf16x8 fb[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(tb + j * 16 * LDS_ROW + ko);
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(tb + j * 16 * LDS_ROW + ko);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(ta + i * 16 * LDS_ROW + ko);
+                for (int i = 0; i < TM; ++i) {
+                    const bf16x8 fa = *reinterpret_cast<const bf16x8*>(ta + i * 16 * LDS_ROW + ko);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
-                if (SPREAD) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int slot = ks * TM + i;
-                    if (more && slot % STEP == 0 && slot / STEP < NP) issue_piece(slot / STEP);
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+                    if (SPREAD == 1) {
+                        const int slot = ks * TM + i;
+                        if (more && slot % STEP == 0 && slot / STEP < NP) issue_piece(slot / STEP);
+                    }
                 }
             }
+        } else {
+            static_assert(SPREAD != 2 || TN == 4, "the hand-counted pipeline is written for TN = 4");
+            typedef __attribute__((address_space(3))) unsigned char lds_u8;
+            const unsigned a_lds = (unsigned)(uintptr_t)((lds_u8*)(unsigned char*)const_cast<bf16*>(ta));
+            const unsigned b_lds = (unsigned)(uintptr_t)((lds_u8*)(unsigned char*)const_cast<bf16*>(tb));
+            const unsigned ko0 = ((0 | fq) ^ fswz) << 4, ko1 = ((4 | fq) ^ fswz) << 4;      // bytes
+            u32x4 fa[3], fb[2][4];
+            fb[0][0] = lds_read16<0>(b_lds + ko0); fb[0][1] = lds_read16<2048>(b_lds + ko0);
+            fb[0][2] = lds_read16<4096>(b_lds + ko0); fb[0][3] = lds_read16<6144>(b_lds + ko0);
+            fa[0] = lds_read16<0>(a_lds + ko0); fa[1] = lds_read16<2048>(a_lds + ko0);
+            PipeStep<TM, 0>::run(fa, fb, acc, a_lds + ko0, a_lds + ko1, b_lds + ko1);
         }
         __syncthreads();
     }

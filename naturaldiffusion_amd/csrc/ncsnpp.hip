@@ -142,11 +142,12 @@ enum GemmVariant {
     V_DMA_256x256_S = 11, V_DMA_128x128_S = 12,                       // two-stage with the DMA issue spread between MFMA groups
     V_DMA_512x128 = 13,                                                // 8 waves x (128x64), all 160 KiB of LDS
     V_PATCH_256x256 = 14, V_PATCH_256x128 = 15,                        // 3x3 conv with an LDS-resident input patch
+    V_DMA_256x256_P = 16, V_DMA_128x128_P = 17, V_DMA_256x128W4_P = 18,  // two-stage + hand-counted LDS fragment pipeline
     V_COUNT
 };
 const char* variant_name(int v) {
     static const char* n[] = {"auto", "generic128", "dma256x256", "dma256x128", "dma128x128", "ring256x256", "ring256x128",
-                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s", "dma512x128", "patch256x256", "patch256x128"};
+                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s", "dma512x128", "patch256x256", "patch256x128", "dma256x256p", "dma128x128p", "dma256x128w4p"};
     return v >= 0 && v < V_COUNT ? n[v] : "?";
 }
 int g_force_variant = V_AUTO;      // tuning / tests: force one variant for every DMA-eligible launch
@@ -177,7 +178,9 @@ bool configure_gemm_kernels() {
          set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4>) && set_lds<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3>) &&
          set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4>) && set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 1>) &&
          set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 1>) && set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4>) &&
-         set_lds<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>) && set_lds<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>);
+         set_lds<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>) && set_lds<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>) &&
+         set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2>) && set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2>) &&
+         set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>);
     if (!ok) (void)hipGetLastError();
     return ok;
 }
@@ -207,7 +210,7 @@ int choose_variant(const GemmArgs& g) {
 int variant_bm(int v) {
     switch (v) {
         case V_DMA_256x256: case V_DMA_256x128: case V_RING_256x256: case V_RING_256x128: case V_RING_256x128_W4: case V_DMA_256x128_W4:
-        case V_DMA_256x256_S: case V_PATCH_256x256: case V_PATCH_256x128: return 256;
+        case V_DMA_256x256_S: case V_PATCH_256x256: case V_PATCH_256x128: case V_DMA_256x256_P: case V_DMA_256x128W4_P: return 256;
         case V_DMA_512x128: return 512;
         case V_RING_64x128: return 64;
         default: return 128;
@@ -243,6 +246,9 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
         case V_DMA_512x128: launch_tiles<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4>, g, s); break;
         case V_PATCH_256x256: launch_tiles<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>, g, s); break;
         case V_PATCH_256x128: launch_tiles<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>, g, s); break;
+        case V_DMA_256x256_P: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2>, g, s); break;
+        case V_DMA_128x128_P: launch_tiles<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2>, g, s); break;
+        case V_DMA_256x128W4_P: launch_tiles<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>, g, s); break;
         default: break;
     }
     return variant_bm(v);
