@@ -325,7 +325,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pb), (lds_void*)(dBn + (p - Cfg::PA) * 1024), 16, 0, 0);
             }
         };
-        if (!SPREAD && more) {
+        if (SPREAD != 1 && more) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) issue_piece(p);
         }
