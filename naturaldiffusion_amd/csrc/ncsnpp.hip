@@ -201,9 +201,9 @@ int choose_variant(const GemmArgs& g) {
     // 128x128 when 256-row tiles would leave CUs idle; 64x128 for the 4x4 level
     const int64_t mt256 = (g.M + 255) / 256, mt128 = (g.M + 127) / 128;
     const int64_t nt128 = (g.N + 127) / 128;
-    if (g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) * g.batch >= NUM_CU) return V_DMA_256x256;
+    if (g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) * g.batch >= NUM_CU) return V_DMA_256x256_P;
     if (mt256 * nt128 * g.batch >= 2 * NUM_CU) return V_RING_256x128_W4;        // it runs two blocks per CU
-    if (mt128 * nt128 * g.batch >= NUM_CU) return V_DMA_128x128;
+    if (mt128 * nt128 * g.batch >= NUM_CU) return V_DMA_128x128_P;
     return V_RING_64x128;
 }
 
