@@ -326,7 +326,7 @@ struct Builder {
         const int rows_per_img = rd + 2 * y.pad;
         const TRef xrr = xr ? *xr : TRef();
         op(CLS_OTHER, [=](const Ctx& c) {
-            hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)(c.B * rows_per_img)), dim3(256), 0, c.stream, c.act(x), x.ld, x.C,
+            hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)((rows_per_img + GN_ROWS - 1) / GN_ROWS), (unsigned)c.B), dim3(256), 0, c.stream, c.act(x), x.ld, x.C,
                                logW, logHW, c.at<float>(sc), c.at<float>(sh), c.act(y),
                                xrr.off >= 0 ? c.act(xrr) : (bf16*)nullptr, act, mode, y.pad);
         });

@@ -373,61 +373,63 @@ __global__ __launch_bounds__(256) void k_gn_finalize(const float2* __restrict__ 
 
 // y = act(x*scale + shift) with optional 2x nearest up-sampling / 2x2 mean down-sampling of BOTH the
 // activated tensor (-> y) and the raw input (-> xr), as ResnetBlockBigGANpp does (layerspp.py:245-257).
-// Destination-centric: one block per destination pixel ROW (blockIdx.x = b*Hp + yy), threads over that row's
-// 16-byte chunks.  With pad = 1 the destination carries a one-pixel zero border ([B][Hd+2][Wd+2][C]) which this
-// kernel writes too, so the 3x3 implicit GEMM that consumes y can fetch every tap unconditionally.
+// Destination-centric: a block owns GN_ROWS consecutive destination pixel rows of one sample (gridDim.y = B); a thread
+// owns ONE 16-byte channel chunk for the whole block -- its 8 scale / 8 shift values live in registers -- and walks
+// the pixels of those rows.  With pad = 1 the destination carries a one-pixel zero border ([B][Hd+2][Wd+2][C]) which
+// this kernel writes too, so the 3x3 implicit GEMM that consumes y can fetch every tap unconditionally.
 // xr (raw input at the output resolution, feeds the 1x1 shortcut) is never padded.
 enum { RS_NONE = 0, RS_UP = 1, RS_DOWN = 2 };
+constexpr int GN_ROWS = 4;
 __global__ __launch_bounds__(256) void k_gn_apply(const bf16* __restrict__ x, int ld, int C, int logW, int logHW,
                                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                                   bf16* __restrict__ y, bf16* __restrict__ xr, int act, int mode, int pad)
 {
-    const int cpp = C >> 3;
+    const int cpp = C >> 3, lanes = 256 / cpp;
+    const int chunk = threadIdx.x % cpp, pl = threadIdx.x / cpp;
+    if (pl >= lanes) return;                          // C = 384: 5 pixel lanes x 48 chunks = 240 active threads
     const int Ws = 1 << logW, Hs = 1 << (logHW - logW);
     const int Wd = mode == RS_UP ? 2 * Ws : (mode == RS_DOWN ? Ws >> 1 : Ws);
     const int Hd = mode == RS_UP ? 2 * Hs : (mode == RS_DOWN ? Hs >> 1 : Hs);
     const int Wp = Wd + 2 * pad, Hp = Hd + 2 * pad;
-    const int b = blockIdx.x / Hp, yy = blockIdx.x - b * Hp;
-    const int Y = yy - pad;
-    bf16* yrow = y + ((int64_t)b * Hp + yy) * Wp * C;
-    const bool row_in = Y >= 0 && Y < Hd;
-    const float* ps = scale + (int64_t)b * C;
-    const float* ph = shift + (int64_t)b * C;
-    const bf16* xb = x + (int64_t)b * Hs * Ws * ld;
-    for (int i = threadIdx.x; i < Wp * cpp; i += 256) {
-        const int xx = i / cpp, chunk = i - xx * cpp;
-        const int X = xx - pad;
+    const int b = blockIdx.y, row0 = blockIdx.x * GN_ROWS;
+    const int nrows = min(GN_ROWS, Hp - row0);
+    float sc[8], sh[8];
+    {
+        const float* ps = scale + (int64_t)b * C + chunk * 8;
+        const float* ph = shift + (int64_t)b * C + chunk * 8;
+        const float4 s0 = *reinterpret_cast<const float4*>(ps), s1 = *reinterpret_cast<const float4*>(ps + 4);
+        const float4 h0 = *reinterpret_cast<const float4*>(ph), h1 = *reinterpret_cast<const float4*>(ph + 4);
+        sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+        sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+    }
+    const bf16* xb = x + (int64_t)b * Hs * Ws * ld + chunk * 8;
+    bf16* yb = y + ((int64_t)b * Hp + row0) * Wp * C + chunk * 8;
+    bf16* xrb = xr ? xr + (int64_t)b * Hd * Wd * C + chunk * 8 : nullptr;
+    int rr = 0, xx = pl;
+    while (xx >= Wp) { xx -= Wp; ++rr; }
+    for (; rr < nrows; ) {
+        const int Y = row0 + rr - pad, X = xx - pad;
         bf16x8 o;
-        if (!row_in || X < 0 || X >= Wd) {
+        if (Y < 0 || Y >= Hd || X < 0 || X >= Wd) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) o[q] = (bf16)0.0f;
-            *reinterpret_cast<bf16x8*>(yrow + (int64_t)xx * C + chunk * 8) = o;
-            continue;
-        }
-        float sc[8], sh[8];
-        {
-            const float4 s0 = *reinterpret_cast<const float4*>(ps + chunk * 8), s1 = *reinterpret_cast<const float4*>(ps + chunk * 8 + 4);
-            const float4 h0 = *reinterpret_cast<const float4*>(ph + chunk * 8), h1 = *reinterpret_cast<const float4*>(ph + chunk * 8 + 4);
-            sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
-            sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
-        }
-        if (mode != RS_DOWN) {
+        } else if (mode != RS_DOWN) {
             const int sy = mode == RS_UP ? Y >> 1 : Y, sx = mode == RS_UP ? X >> 1 : X;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(xb + ((int64_t)sy * Ws + sx) * ld + chunk * 8);
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(xb + ((int64_t)sy * Ws + sx) * ld);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 float f = (float)v[q] * sc[q] + sh[q];
                 if (act == ACT_SILU) f = silu_f(f);
                 o[q] = (bf16)f;
             }
-            if (xr) *reinterpret_cast<bf16x8*>(xr + (((int64_t)b * Hd + Y) * Wd + X) * C + chunk * 8) = v;
+            if (xrb) *reinterpret_cast<bf16x8*>(xrb + ((int64_t)Y * Wd + X) * C) = v;
         } else {
             float ay[8], ax[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) { ay[q] = 0.f; ax[q] = 0.f; }
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(xb + ((int64_t)(2 * Y + (d >> 1)) * Ws + 2 * X + (d & 1)) * ld + chunk * 8);
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(xb + ((int64_t)(2 * Y + (d >> 1)) * Ws + 2 * X + (d & 1)) * ld);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const float raw = (float)v[q];
@@ -439,9 +441,11 @@ __global__ __launch_bounds__(256) void k_gn_apply(const bf16* __restrict__ x, in
             bf16x8 ox;
 #pragma unroll
             for (int q = 0; q < 8; ++q) { o[q] = (bf16)(ay[q] * 0.25f); ox[q] = (bf16)(ax[q] * 0.25f); }
-            if (xr) *reinterpret_cast<bf16x8*>(xr + (((int64_t)b * Hd + Y) * Wd + X) * C + chunk * 8) = ox;
+            if (xrb) *reinterpret_cast<bf16x8*>(xrb + ((int64_t)Y * Wd + X) * C) = ox;
         }
-        *reinterpret_cast<bf16x8*>(yrow + (int64_t)xx * C + chunk * 8) = o;
+        *reinterpret_cast<bf16x8*>(yb + ((int64_t)rr * Wp + xx) * C) = o;
+        xx += lanes;
+        while (xx >= Wp) { xx -= Wp; ++rr; }
     }
 }
 
