@@ -405,24 +405,53 @@ __global__ __launch_bounds__(256) void k_gn_apply(const bf16* __restrict__ x, in
     const bf16* xb = x + (int64_t)b * Hs * Ws * ld + chunk * 8;
     bf16* yb = y + ((int64_t)b * Hp + row0) * Wp * C + chunk * 8;
     bf16* xrb = xr ? xr + (int64_t)b * Hd * Wd * C + chunk * 8 : nullptr;
+    // pixel walk, two pixels per iteration so that two independent 16-byte loads are in flight per thread
     int rr = 0, xx = pl;
     while (xx >= Wp) { xx -= Wp; ++rr; }
-    for (; rr < nrows; ) {
-        const int Y = row0 + rr - pad, X = xx - pad;
+    auto advance = [&](int& r, int& c) __attribute__((always_inline)) { c += lanes; while (c >= Wp) { c -= Wp; ++r; } };
+    auto interior = [&](int r, int c) __attribute__((always_inline)) {
+        const int Y = row0 + r - pad, X = c - pad;
+        return r < nrows && Y >= 0 && Y < Hd && X >= 0 && X < Wd;
+    };
+    auto finish = [&](int r, int c, bool in, const bf16x8& v) __attribute__((always_inline)) {
+        if (r >= nrows) return;
         bf16x8 o;
-        if (Y < 0 || Y >= Hd || X < 0 || X >= Wd) {
+        if (!in) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) o[q] = (bf16)0.0f;
-        } else if (mode != RS_DOWN) {
-            const int sy = mode == RS_UP ? Y >> 1 : Y, sx = mode == RS_UP ? X >> 1 : X;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(xb + ((int64_t)sy * Ws + sx) * ld);
+        } else {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 float f = (float)v[q] * sc[q] + sh[q];
                 if (act == ACT_SILU) f = silu_f(f);
                 o[q] = (bf16)f;
             }
-            if (xrb) *reinterpret_cast<bf16x8*>(xrb + ((int64_t)Y * Wd + X) * C) = v;
+            if (xrb) *reinterpret_cast<bf16x8*>(xrb + ((int64_t)(row0 + r - pad) * Wd + (c - pad)) * C) = v;
+        }
+        *reinterpret_cast<bf16x8*>(yb + ((int64_t)r * Wp + c) * C) = o;
+    };
+    if (mode != RS_DOWN) {
+        const int sh_ = mode == RS_UP ? 1 : 0;
+        while (rr < nrows) {
+            int r1 = rr, c1 = xx;
+            advance(r1, c1);
+            const bool in0 = interior(rr, xx), in1 = interior(r1, c1);
+            bf16x8 v0, v1;
+            if (in0) v0 = *reinterpret_cast<const bf16x8*>(xb + ((int64_t)((row0 + rr - pad) >> sh_) * Ws + ((xx - pad) >> sh_)) * ld);
+            if (in1) v1 = *reinterpret_cast<const bf16x8*>(xb + ((int64_t)((row0 + r1 - pad) >> sh_) * Ws + ((c1 - pad) >> sh_)) * ld);
+            finish(rr, xx, in0, v0);
+            finish(r1, c1, in1, v1);
+            rr = r1; xx = c1;
+            advance(rr, xx);
+        }
+        return;
+    }
+    for (; rr < nrows; ) {
+        const int Y = row0 + rr - pad, X = xx - pad;
+        bf16x8 o;
+        if (Y < 0 || Y >= Hd || X < 0 || X >= Wd) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = (bf16)0.0f;
         } else {
             float ay[8], ax[8];
 #pragma unroll
