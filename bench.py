@@ -195,12 +195,12 @@ def main():
         # ---- recurrence) on this host's cores, bounded sample of the same workload
         from oracle import ni_oracle as O, ncsnpp_oracle as N
         from naturaldiffusion_amd.synth import synthetic_state_dict
-        # 4 images x 15 forwards is a small problem: more than ~32 OpenMP threads only add synchronisation cost
+        # 64 images x 15 forwards is a small problem: more than ~32 OpenMP threads only add synchronisation cost
         threads = min(32, torch.get_num_threads())
         torch.set_num_threads(threads)
         P = synthetic_state_dict(0)
         model = N.model_fn_from_params(P)
-        nb = 16
+        nb = 64
         z = torch.randn(nb, 3, 32, 32, generator=torch.Generator().manual_seed(888))
         model(z[:1], torch.zeros(1))                       # page in / warm the thread pool
         tc = time.perf_counter()
