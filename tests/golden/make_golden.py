@@ -364,7 +364,77 @@ def group_ncsnpp():
     print("ncsnpp: params", n_param, "| y absmax", float(np.abs(out["y"]).max()), "| taps", len(taps))
 
 
-GROUPS = dict(loaders=group_loaders, cifar=group_cifar, validate=group_validate, sd3=group_sd3, ncsnpp=group_ncsnpp)
+def group_dit():
+    """deps/DiT/models.py's own DiT class (timm's PatchEmbed / Attention / Mlp stubbed by their published
+    definitions) on the oracle's synthetic weights: two small configurations (head_dim 64 and 72) in full, DiT-XL/2
+    as output statistics."""
+    import numpy as np
+    import torch
+    import torch.nn as nn
+
+    class PatchEmbed(nn.Module):
+        def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, bias=True):
+            super().__init__()
+            self.patch_size = (patch_size, patch_size)
+            self.num_patches = (img_size // patch_size) ** 2
+            self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=bias)
+
+        def forward(self, x):
+            return self.proj(x).flatten(2).transpose(1, 2)
+
+    class Attention(nn.Module):
+        def __init__(self, dim, num_heads=8, qkv_bias=False):
+            super().__init__()
+            self.num_heads, self.scale = num_heads, (dim // num_heads) ** -0.5
+            self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+            self.proj = nn.Linear(dim, dim)
+
+        def forward(self, x):
+            B, N, C = x.shape
+            qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+            q, k, v = qkv.unbind(0)
+            attn = ((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1)
+            return self.proj((attn @ v).transpose(1, 2).reshape(B, N, C))
+
+    class Mlp(nn.Module):
+        def __init__(self, in_features, hidden_features=None, act_layer=nn.GELU, drop=0.0):
+            super().__init__()
+            self.fc1 = nn.Linear(in_features, hidden_features)
+            self.act = act_layer()
+            self.fc2 = nn.Linear(hidden_features, in_features)
+
+        def forward(self, x):
+            return self.fc2(self.act(self.fc1(x)))
+
+    tm = _stub("timm"); tm.models = _stub("timm.models")
+    tm.models.vision_transformer = _stub("timm.models.vision_transformer", PatchEmbed=PatchEmbed, Attention=Attention, Mlp=Mlp)
+    sys.path.insert(0, str(REF / "deps/DiT"))
+    import models as M
+    from oracle import dit_oracle as D
+    torch.set_num_threads(8)
+    out = {}
+    g = torch.Generator().manual_seed(99)
+    for tag, depth, hid, heads, B in (("s64", 2, 128, 2, 3), ("s72", 1, 576, 8, 2), ("xl2", 28, 1152, 16, 1)):
+        net = M.DiT(depth=depth, hidden_size=hid, num_heads=heads).eval()
+        P = D.make_params(depth, hid, seed=7)
+        net.load_state_dict(P, strict=True)
+        x = torch.randn(B, 4, 32, 32, generator=g)
+        t = torch.tensor([999.0, 500.0, 41.0][:B])
+        y = torch.tensor([207, 1000, 3][:B])
+        with torch.no_grad():
+            r = net(x, t, y)
+        out[f"{tag}_x"], out[f"{tag}_t"], out[f"{tag}_y"] = x.numpy(), t.numpy(), y.numpy()
+        if tag == "xl2":
+            out[f"{tag}_stats"] = np.array([r.mean().item(), r.std().item(), r.abs().max().item()])
+            out[f"{tag}_head"] = r.flatten()[:256].numpy()
+            out[f"{tag}_nparam"] = np.int64(sum(p.numel() for p in net.parameters()))
+        else:
+            out[f"{tag}_out"] = r.numpy()
+    np.savez_compressed(HERE / "dit_forward.npz", **out)
+    print("dit:", {k: getattr(v, "shape", v) for k, v in out.items() if k.endswith(("out", "stats", "nparam"))})
+
+
+GROUPS = dict(dit=group_dit, loaders=group_loaders, cifar=group_cifar, validate=group_validate, sd3=group_sd3, ncsnpp=group_ncsnpp)
 
 if __name__ == "__main__":
     assert REF.exists(), "the reference is only mounted in the build container"
