@@ -31,7 +31,7 @@ constexpr int GEMM_LDS_BYTES = BM * C_ROW * 4;        // 67,584 B: max(tiles 65,
 static_assert(4 * TILE_ELEMS * 2 <= GEMM_LDS_BYTES, "tile buffers must fit");
 
 enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_NCHW = 2 };
-enum { ACT_NONE = 0, ACT_SILU = 1 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU_TANH = 2 };
 
 struct GemmArgs {
     // A operand: segment 0 = `taps` (1 or 9) shifted views of a0, segment 1 = a1 (1x1), concatenated along K
@@ -44,7 +44,9 @@ struct GemmArgs {
     int64_t a_bs, b_bs, c_bs; int batch;              // per-batch element strides (blockIdx.z)
     const float* bias_n; const float* bias_m;
     const float* rowvec; int rowvec_ld; int log_rows_per_sample;   // + rowvec[(m >> log)*ld + n]
+    const float* gate; int gate_ld;                   // * gate[(m >> log)*ld + n]   (adaLN-Zero gates; applied before the residual)
     const bf16* resid; int resid_ld;                  // + resid[m*ld + n]
+    const float* resid_f32; int resid_f32_ld;         // + resid_f32[m*ld + n]       (fp32 residual stream)
     float scale; int act;
     void* c; int c_ld; int c_mode;
     // fused GroupNorm statistics of the OUTPUT (DMA kernels, block tile inside one sample): per block tile and per
@@ -53,6 +55,14 @@ struct GemmArgs {
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float gelu_tanh_f(float v) {             // nn.GELU(approximate="tanh")
+    const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+    const float e = __expf(2.0f * u);                               // tanh(u) = 1 - 2/(e^{2u}+1)
+    return 0.5f * v * (2.0f - 2.0f / (e + 1.0f));
+}
+__device__ __forceinline__ float apply_act(float v, int act) {
+    return act == ACT_SILU ? silu_f(v) : (act == ACT_GELU_TANH ? gelu_tanh_f(v) : v);
+}
 
 // XCD-aware bijective remap of a linear block id: consecutive ids land on different XCDs (round-robin
 // dispatch), so give every XCD a contiguous run of tiles.
@@ -124,15 +134,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, unsigned char* 
             const float4 s = *reinterpret_cast<const float4*>(rv), t = *reinterpret_cast<const float4*>(rv + 4);
             v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w; v[4] += t.x; v[5] += t.y; v[6] += t.z; v[7] += t.w;
         }
+        if (g.gate) {
+            const float* gv = g.gate + (int64_t)(m >> g.log_rows_per_sample) * g.gate_ld + n;
+            const float4 s = *reinterpret_cast<const float4*>(gv), t = *reinterpret_cast<const float4*>(gv + 4);
+            v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w; v[4] *= t.x; v[5] *= t.y; v[6] *= t.z; v[7] *= t.w;
+        }
         if (g.resid) {
             const bf16x8 rs = *reinterpret_cast<const bf16x8*>(g.resid + (int64_t)z * g.c_bs + (int64_t)m * g.resid_ld + n);
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] += (float)rs[q];
         }
+        if (g.resid_f32) {
+            const float* rp = g.resid_f32 + (int64_t)m * g.resid_f32_ld + n;
+            const float4 s = *reinterpret_cast<const float4*>(rp), t = *reinterpret_cast<const float4*>(rp + 4);
+            v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w; v[4] += t.x; v[5] += t.y; v[6] += t.z; v[7] += t.w;
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             v[q] *= g.scale;
-            if (g.act == ACT_SILU) v[q] = silu_f(v[q]);
+            v[q] = apply_act(v[q], g.act);
         }
         if (g.c_mode == OUT_BF16) {
             bf16x8 o;

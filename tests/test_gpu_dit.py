@@ -1,0 +1,68 @@
+"""HIP DiT engine (include/natinf_dit.h) against the CPU oracle (oracle/dit_oracle.py, pinned to the reference's
+DiT class by tests/golden/dit_forward.npz).  bf16 operands / fp32 accumulation against an fp32 oracle: tolerance is
+relative to the output's max magnitude, as for the NCSN++ engine."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 3e-2          # max |engine - oracle| / max |oracle|
+
+
+def _flat(P, depth, hid):
+    from naturaldiffusion_amd.dit import flatten_state_dict
+    return flatten_state_dict(P, depth, hid)
+
+
+@pytest.fixture(scope="module")
+def fx(golden_dir):
+    return np.load(golden_dir / "dit_forward.npz")
+
+
+@pytest.mark.parametrize("tag,depth,hid,heads", [("s64", 2, 128, 2), ("s72", 1, 576, 8)])
+def test_small_configs_match_golden(fx, tag, depth, hid, heads):
+    from oracle import dit_oracle as D
+    from naturaldiffusion_amd.dit import DiTEngine
+    P = D.make_params(depth, hid, seed=7)
+    eng = DiTEngine(_flat(P, depth, hid), max_batch=4, depth=depth, hidden=hid, heads=heads)
+    x, t, y = (torch.from_numpy(fx[f"{tag}_{k}"]) for k in ("x", "t", "y"))
+    out = eng(x.cuda(), t.cuda(), y.cuda()).cpu().numpy()
+    ref = fx[f"{tag}_out"]
+    assert out.shape == ref.shape
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    assert err <= TOL, err
+
+
+def test_xl2_matches_oracle_and_batch_independent():
+    from oracle import dit_oracle as D
+    from naturaldiffusion_amd.dit import DiTEngine
+    P = D.make_params(28, 1152, seed=3)
+    eng = DiTEngine(_flat(P, 28, 1152), max_batch=8)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 4, 32, 32, generator=g)
+    t = torch.tensor([999.0, 500.0, 3.0])
+    y = torch.tensor([1000, 207, 0])
+    ref = D.forward(P, x, t, y, 16).numpy()
+    out = eng(x.cuda(), t.cuda(), y.cuda()).cpu().numpy()
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    assert err <= TOL, err
+    # a sample's output does not depend on what else is in the batch, nor on its position
+    xb = torch.cat([x[2:3], torch.randn(5, 4, 32, 32, generator=g)]).cuda()
+    tb = torch.cat([t[2:3], torch.full((5,), 77.0)]).cuda()
+    yb = torch.cat([y[2:3], torch.tensor([3, 4, 5, 6, 7])]).cuda()
+    out8 = eng(xb, tb, yb).cpu().numpy()
+    assert np.abs(out8[0] - out[2]).max() <= 1e-2 * np.abs(ref).max()
+
+
+def test_argument_errors():
+    from oracle import dit_oracle as D
+    from naturaldiffusion_amd.dit import DiTEngine
+    P = D.make_params(1, 128, seed=1)
+    with pytest.raises(ValueError):
+        DiTEngine(_flat(P, 1, 128)[:-1], max_batch=2, depth=1, hidden=128, heads=2)
+    eng = DiTEngine(_flat(P, 1, 128), max_batch=2, depth=1, hidden=128, heads=2)
+    with pytest.raises(ValueError):
+        eng(torch.zeros(3, 4, 32, 32).cuda(), torch.zeros(3), torch.zeros(3, dtype=torch.int64))
+    with pytest.raises(ValueError):
+        DiTEngine(_flat(P, 1, 128), max_batch=2, depth=1, hidden=100, heads=2)
