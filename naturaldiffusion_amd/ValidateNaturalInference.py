@@ -6,9 +6,9 @@ Same public names as the reference (``space_timesteps``, ``create_ddpm_coeff``, 
 ``ddpm_skip_sample``, ``ddim_skip_sample``, ``natural_inference``, ``compare_output_tx``; globals
 ``vae_path``, ``model_path``).  ``natural_inference`` -- the path being accelerated -- runs one fused
 ``natinf_step_f32prod`` launch per step.  The two *original* samplers are the baselines it is compared
-with and stay host-sequenced tensor algebra.  The DiT-XL/2 denoiser and the VAE come from un-vendored
-packages (``timm``/``diffusers``, reference requirements.txt:13-14); they are injected through
-``denoiser_factory`` / ``decoder_factory`` so the samplers can be exercised without them.
+with and stay host-sequenced tensor algebra.  The DiT-XL/2 denoiser is the gfx950 engine of
+``include/natinf_dit.h`` loaded from ``model_path`` (or whatever ``denoiser_factory`` returns); the VAE comes
+from the un-vendored ``diffusers`` (reference requirements.txt:13) and is injected through ``decoder_factory``.
 """
 from __future__ import annotations
 
@@ -144,13 +144,30 @@ def weighted_sum(weights, seq_elem):
     return out.view(seq_elem[0].shape)
 
 
+_engine_cache = {}
+
+
+def load_dit_engine(path, max_batch=8):
+    """Reference :150-154 (``DiT_models['DiT-XL/2'](input_size=32, num_classes=1000)`` + ``load_state_dict``) on the
+    gfx950 engine: the checkpoint's tensors go straight into ``natinf_dit_load``; one engine per checkpoint path."""
+    from .dit import DiTEngine, flatten_state_dict, XL2
+    key = (str(path), max_batch)
+    if key not in _engine_cache:
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        _engine_cache[key] = DiTEngine(flatten_state_dict(sd, XL2["depth"], XL2["hidden"]), max_batch, device=device, **XL2)
+    return _engine_cache[key]
+
+
 def _setup(seed):
     torch.manual_seed(seed)
     torch.set_grad_enabled(False)
-    if denoiser_factory is None:
-        raise RuntimeError("set ValidateNaturalInference.denoiser_factory (DiT-XL/2 needs the un-vendored `timm`; "
-                           "see INTEGRATION.md)")
-    model = denoiser_factory()
+    if denoiser_factory is not None:
+        model = denoiser_factory()
+    elif model_path is not None:
+        model = load_dit_engine(model_path)
+    else:
+        raise RuntimeError("set ValidateNaturalInference.model_path (a DiT-XL/2 state dict, reference :152-154) or "
+                           "ValidateNaturalInference.denoiser_factory; see INTEGRATION.md")
     labels = torch.tensor([207, 360, 387, 974, 88, 979, 417, 279], device=device)
     return model, labels, len(labels)
 

@@ -32,3 +32,31 @@ def synthetic_state_dict(seed: int = 0, perturb: float = 0.01) -> Dict[str, torc
 
 def synthetic_flat_params(seed: int = 0, perturb: float = 0.01) -> torch.Tensor:
     return torch.cat([t.reshape(-1) for t in synthetic_state_dict(seed, perturb).values()])
+
+
+def dit_pos_embed(dim: int, grid: int = 16) -> torch.Tensor:
+    """Fixed 2-D sin-cos position table [grid*grid, dim] (deps/DiT/models.py:279-326): first half encodes the w index,
+    second half the h index, each half = [sin | cos] over dim/4 frequencies 10000^(-i/(dim/4))."""
+    def one(d, pos):
+        omega = 1.0 / 10000 ** (np.arange(d // 2, dtype=np.float64) / (d / 2.0))
+        a = pos.reshape(-1)[:, None] * omega[None]
+        return np.concatenate([np.sin(a), np.cos(a)], axis=1)
+    gw, gh = np.meshgrid(np.arange(grid, dtype=np.float32), np.arange(grid, dtype=np.float32))
+    return torch.from_numpy(np.concatenate([one(dim // 2, gw), one(dim // 2, gh)], axis=1)).float()
+
+
+def synthetic_dit_state_dict(depth: int = 28, hidden: int = 1152, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Synthetic DiT weights (``DiT-XL-2-256x256.pt`` is a download the image lacks): xavier-uniform matrices --
+    including the adaLN / output layers the reference zero-initialises --, N(0, 0.02) embeddings and biases."""
+    from .dit import param_layout as dit_layout
+    g = torch.Generator().manual_seed(seed)
+    out: Dict[str, torch.Tensor] = {}
+    for name, shp in dit_layout(depth, hidden):
+        if name == "pos_embed":
+            out[name] = dit_pos_embed(hidden).unsqueeze(0)
+        elif len(shp) >= 2 and "embedding_table" not in name:
+            lim = math.sqrt(6.0 / (int(np.prod(shp[1:])) + shp[0]))
+            out[name] = (torch.rand(shp, generator=g) * 2 - 1) * lim
+        else:
+            out[name] = torch.randn(shp, generator=g) * 0.02
+    return out

@@ -146,3 +146,13 @@ def test_synthetic_weights_match_the_oracle_recipe():
     a, b = synthetic_state_dict(0), N.make_params(0)
     assert list(a) == list(b)
     assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_synthetic_dit_weights_match_the_oracle_recipe():
+    from oracle import dit_oracle as D
+    from naturaldiffusion_amd.synth import synthetic_dit_state_dict
+    from naturaldiffusion_amd.dit import param_layout
+    a, b = synthetic_dit_state_dict(2, 128, seed=7), D.make_params(2, 128, seed=7)
+    assert list(a) == list(b) == [n for n, _ in param_layout(2, 128)]
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

@@ -66,3 +66,36 @@ def test_argument_errors():
         eng(torch.zeros(3, 4, 32, 32).cuda(), torch.zeros(3), torch.zeros(3, dtype=torch.int64))
     with pytest.raises(ValueError):
         DiTEngine(_flat(P, 1, 128), max_batch=2, depth=1, hidden=100, heads=2)
+
+
+def test_validate_natural_inference_end_to_end(monkeypatch):
+    """src/ValidateNaturalInference.py:311-372 with the HIP DiT engine as the denoiser (two CFG forwards per step, one
+    fused natinf_step_f32prod launch per step) against the oracle's restatement driven by the DiT oracle."""
+    from oracle import dit_oracle as D, ni_oracle as O
+    from naturaldiffusion_amd import ValidateNaturalInference as V
+    from naturaldiffusion_amd.dit import DiTEngine
+    from naturaldiffusion_amd.coeff import load_coeff_npz
+    depth, hid, heads = 2, 128, 2
+    P = D.make_params(depth, hid, seed=11)
+    eng = DiTEngine(_flat(P, depth, hid), max_batch=8, depth=depth, hidden=hid, heads=heads)
+    g = torch.Generator().manual_seed(0)
+    draws = [torch.randn(8, 4, 32, 32, generator=g) for _ in range(25)]
+    it = iter(draws)
+    monkeypatch.setattr(V.torch, "randn", lambda *a, **k: next(it).cuda())
+    monkeypatch.setattr(V.torch, "randn_like", lambda *a, **k: next(it).cuda())
+    monkeypatch.setattr(V, "denoiser_factory", lambda: eng)
+    monkeypatch.setattr(V, "device", "cuda:0")
+    z = V.natural_inference("ddim", 24).cpu()
+
+    labels = torch.tensor([207, 360, 387, 974, 88, 979, 417, 279])
+    nulls = torch.full((8,), 1000)
+
+    def eps_fn(x, t):
+        tt = torch.full((8,), float(t))
+        c = D.forward(P, x, tt, labels, heads)[:, :4]
+        u = D.forward(P, x, tt, nulls, heads)[:, :4]
+        return O.cfg_fuse(c, u, 4.0)
+    C, B, node = load_coeff_npz(V.root_path / "results/ddim/ddim_024.npz")
+    ref = O.validate_ni(eps_fn, draws[0], draws[1:], C, B, node)
+    rel = ((z - ref).abs().max() / ref.abs().max()).item()
+    assert rel <= 5e-2, rel
