@@ -23,8 +23,12 @@ extern "C" {
 
 typedef struct natinf_dit* natinf_dit_t;
 
-/* hidden % 64 == 0, hidden % heads == 0, (hidden / heads) % 8 == 0 */
-int natinf_dit_create(natinf_dit_t* out, int depth, int hidden, int heads);
+/* Attention runs as one fused launch per block when head_dim <= 96; this flag selects the per-head GEMM / softmax /
+ * GEMM path instead (the one used for larger heads), for testing one against the other. */
+#define NATINF_DIT_UNFUSED_ATTENTION 1
+
+/* hidden % 64 == 0, hidden <= 1536, hidden % heads == 0, (hidden / heads) % 8 == 0 */
+int natinf_dit_create(natinf_dit_t* out, int depth, int hidden, int heads, int flags);
 int natinf_dit_destroy(natinf_dit_t h);
 int64_t natinf_dit_param_count(natinf_dit_t h);           /* incl. the frozen pos_embed */
 int64_t natinf_dit_packed_bytes(natinf_dit_t h);

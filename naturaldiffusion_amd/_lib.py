@@ -54,7 +54,7 @@ SIGNATURES = {
     "natinf_ncsnpp_profile": (C.c_int, [_p, _i32]),
     "natinf_ncsnpp_profile_read": (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     # include/natinf_dit.h
-    "natinf_dit_create": (C.c_int, [C.POINTER(_p), _i32, _i32, _i32]),
+    "natinf_dit_create": (C.c_int, [C.POINTER(_p), _i32, _i32, _i32, _i32]),
     "natinf_dit_destroy": (C.c_int, [_p]),
     "natinf_dit_param_count": (C.c_int64, [_p]),
     "natinf_dit_packed_bytes": (C.c_int64, [_p]),

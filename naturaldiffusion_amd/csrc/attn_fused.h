@@ -1,0 +1,135 @@
+// attn_fused.h -- one-launch multi-head attention for 256 tokens and head_dim <= 96 (DiT).
+//
+// One block = one (sample, head): its K [256][hd] and V^T [hd][256] live in LDS (95 KB), eight waves each own 32
+// queries.  No S / P round trip through memory, and no LDS round trip either:
+//   S^T = K Q^T        A operand = K rows from LDS, B operand = the wave's Q rows (registers, loaded once).  The MFMA
+//                      result layout gives each lane, for query (lane & 15), keys 4*(lane>>4)+i of every 16-key tile.
+//   softmax            per query: the lane's 64 values + xor-shuffles over lane>>4 (two steps)
+//   O^T = V^T P^T      B operand = P for (query = lane & 15, 8 keys): exactly the values the lane already holds from S^T
+//                      tiles 2c and 2c+1, i.e. keys {32c+4q+i} u {32c+16+4q+i}.  The contraction does not care about
+//                      the key order as long as A agrees, so V^T is written to LDS with that permutation inside every
+//                      32-key chunk and its fragments stay single ds_read_b128s.
+//   store              O^T's layout gives a lane 4 consecutive head channels of one query: 8-byte stores.
+// LDS rows are padded by 16 B so that the 16 rows of a fragment read start in 16 distinct 4-bank groups.
+// Reference: timm Attention as used by deps/DiT/models.py:16,113 (softmax(q k^T * hd^-0.5) v per head).
+#pragma once
+#include "ncsnpp_kernels.h"
+
+namespace ncsn {
+
+template <int NQK, int ND>
+struct AttnCfg {
+    static constexpr int T = 256, THREADS = 512;
+    static constexpr int KSTR = NQK * 64 + 16;            // bytes per K row (NQK*32 bf16 + pad)
+    static constexpr int VSTR = T * 2 + 16;               // bytes per V^T row
+    static constexpr int LDS_BYTES = T * KSTR + ND * 16 * VSTR;
+    static_assert(LDS_BYTES <= 163840, "LDS budget");
+};
+
+// qk: [B*256][qk_ld] bf16 with q at column 0 and k at column k_off (+ head*hd); vT: [B][H*hd][256]; o: [B*256][o_ld]
+template <int NQK, int ND>
+__global__ __launch_bounds__(512) void k_attn_fused(const bf16* __restrict__ qk, int qk_ld, int k_off, const bf16* __restrict__ vT,
+                                                    bf16* __restrict__ o, int o_ld, int H, int hd, float scale)
+{
+    using Cfg = AttnCfg<NQK, ND>;
+    constexpr int T = Cfg::T, KSTR = Cfg::KSTR, VSTR = Cfg::VSTR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sK = smem;
+    unsigned char* sV = smem + T * KSTR;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
+    const bf16* qbase = qk + (int64_t)b * T * qk_ld + hh * hd;
+    const bf16* kbase = qbase + k_off;
+    const bf16* vbase = vT + ((int64_t)b * H + hh) * hd * T;
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+
+    for (int idx = tid; idx < T * NQK * 4; idx += 512) {                       // K rows, zero-padded to NQK*32 channels
+        const int row = idx / (NQK * 4), ch = idx - row * (NQK * 4);
+        const uint4 v = ch * 8 < hd ? *reinterpret_cast<const uint4*>(kbase + (int64_t)row * qk_ld + ch * 8) : zero4;
+        *reinterpret_cast<uint4*>(sK + row * KSTR + ch * 16) = v;
+    }
+    for (int idx = tid; idx < ND * 16 * 32; idx += 512) {                      // V^T rows, keys permuted inside 32-key chunks
+        const int d = idx >> 5, m8 = idx & 31, c = m8 >> 2, m = m8 & 3;
+        const uint4 v = d < hd ? *reinterpret_cast<const uint4*>(vbase + (int64_t)d * T + m8 * 8) : zero4;
+        const int qa = (m & 1) * 2, jo = (m >> 1) * 4;
+        unsigned char* row = sV + d * VSTR + (32 * c + jo) * 2;
+        *reinterpret_cast<uint2*>(row + 8 * qa * 2) = make_uint2(v.x, v.y);
+        *reinterpret_cast<uint2*>(row + 8 * (qa + 1) * 2) = make_uint2(v.z, v.w);
+    }
+    bf16x8 qf[2][NQK];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int c = 0; c < NQK; ++c) {
+            const int dcol = 32 * c + 8 * q;
+            const uint4 v = dcol < hd ? *reinterpret_cast<const uint4*>(qbase + (int64_t)(wave * 32 + 16 * g + r) * qk_ld + dcol) : zero4;
+            qf[g][c] = __builtin_bit_cast(bf16x8, v);
+        }
+    __syncthreads();
+
+    f32x4 acc[2][16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { acc[0][t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int c = 0; c < NQK; ++c) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + (16 * t + r) * KSTR + (32 * c + 8 * q) * 2);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[0][c], acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[1][c], acc[1][t], 0, 0, 0);
+        }
+
+    float inv[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mx = fmaxf(mx, acc[g][t][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float p = __expf((acc[g][t][i] - mx) * scale); acc[g][t][i] = p; sum += p; }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        inv[g] = 1.0f / sum;
+    }
+
+    f32x4 oacc[2][ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) { oacc[0][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc[1][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        bf16x8 pf[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { pf[g][i] = (bf16)acc[g][2 * c][i]; pf[g][4 + i] = (bf16)acc[g][2 * c + 1][i]; }
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(sV + (16 * dt + r) * VSTR + (32 * c + 8 * q) * 2);
+            oacc[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[0], oacc[0][dt], 0, 0, 0);
+            oacc[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[1], oacc[1][dt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            const int d0 = 16 * dt + 4 * q;
+            if (d0 < hd) {
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                bf16x4 w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = (bf16)(oacc[g][dt][i] * inv[g]);
+                *reinterpret_cast<bf16x4*>(o + ((int64_t)b * T + wave * 32 + 16 * g + r) * o_ld + hh * hd + d0) = w;
+            }
+        }
+}
+
+}  // namespace ncsn

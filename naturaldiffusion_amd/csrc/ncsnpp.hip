@@ -28,6 +28,7 @@
 #include "ncsnpp_kernels.h"
 #include "gemm_dma.h"
 #include "conv_patch.h"
+#include "attn_fused.h"
 
 using namespace ncsn;
 
@@ -180,7 +181,9 @@ bool configure_gemm_kernels() {
          set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 1>) && set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4>) &&
          set_lds<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>) && set_lds<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>) &&
          set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2>) && set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2>) &&
-         set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>);
+         set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>) &&
+         set_lds<AttnCfg<2, 4>>(&k_attn_fused<2, 4>) && set_lds<AttnCfg<3, 6>>(&k_attn_fused<3, 6>) &&
+         set_lds<AttnCfg<3, 5>>(&k_attn_fused<3, 5>);
     if (!ok) (void)hipGetLastError();
     return ok;
 }

@@ -14,6 +14,7 @@ import torch
 from . import _lib
 from ._lib import lib, check, ptr, stream_ptr
 
+UNFUSED_ATTENTION = 1
 XL2 = dict(depth=28, hidden=1152, heads=16)          # deps/DiT/models.py:333-334
 
 
@@ -50,14 +51,14 @@ def flatten_state_dict(sd: Dict[str, torch.Tensor], depth: int, hidden: int) -> 
 
 class DiTEngine:
     def __init__(self, flat_params: torch.Tensor, max_batch: int, depth: int = 28, hidden: int = 1152, heads: int = 16,
-                 device="cuda:0"):
+                 device="cuda:0", unfused_attention: bool = False):
         _lib.require_gpu()
         if depth <= 0 or hidden <= 0 or heads <= 0 or hidden % 64 or hidden > 1536 or hidden % heads or (hidden // heads) % 8:
             raise ValueError("hidden must be a multiple of 64 (<= 1536) and of heads, head_dim a multiple of 8")
         self.device = torch.device(device)
         self.max_batch = int(max_batch)
         self._h = C.c_void_p()
-        check(lib.natinf_dit_create(C.byref(self._h), depth, hidden, heads), "natinf_dit_create")
+        check(lib.natinf_dit_create(C.byref(self._h), depth, hidden, heads, UNFUSED_ATTENTION if unfused_attention else 0), "natinf_dit_create")
         n = lib.natinf_dit_param_count(self._h)
         if flat_params.numel() != n:
             raise ValueError(f"expected {n} parameters, got {flat_params.numel()}")

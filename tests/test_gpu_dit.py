@@ -20,12 +20,13 @@ def fx(golden_dir):
     return np.load(golden_dir / "dit_forward.npz")
 
 
+@pytest.mark.parametrize("unfused", [False, True])
 @pytest.mark.parametrize("tag,depth,hid,heads", [("s64", 2, 128, 2), ("s72", 1, 576, 8)])
-def test_small_configs_match_golden(fx, tag, depth, hid, heads):
+def test_small_configs_match_golden(fx, tag, depth, hid, heads, unfused):
     from oracle import dit_oracle as D
     from naturaldiffusion_amd.dit import DiTEngine
     P = D.make_params(depth, hid, seed=7)
-    eng = DiTEngine(_flat(P, depth, hid), max_batch=4, depth=depth, hidden=hid, heads=heads)
+    eng = DiTEngine(_flat(P, depth, hid), max_batch=4, depth=depth, hidden=hid, heads=heads, unfused_attention=unfused)
     x, t, y = (torch.from_numpy(fx[f"{tag}_{k}"]) for k in ("x", "t", "y"))
     out = eng(x.cuda(), t.cuda(), y.cuda()).cpu().numpy()
     ref = fx[f"{tag}_out"]
@@ -53,6 +54,25 @@ def test_xl2_matches_oracle_and_batch_independent():
     yb = torch.cat([y[2:3], torch.tensor([3, 4, 5, 6, 7])]).cuda()
     out8 = eng(xb, tb, yb).cpu().numpy()
     assert np.abs(out8[0] - out[2]).max() <= 1e-2 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("hid,heads", [(128, 2), (576, 8), (192, 2), (768, 8)])      # head_dim 64, 72, 96 (fused) and 96
+def test_fused_attention_equals_per_head_path(hid, heads):
+    """One block: the fused attention launch against the per-head GEMM / softmax / GEMM path on the same weights.  Both
+    round P to bf16 (the fused kernel before, the other after the 1/sum), so they agree to bf16 resolution."""
+    from oracle import dit_oracle as D
+    from naturaldiffusion_amd.dit import DiTEngine
+    P = D.make_params(1, hid, seed=2)
+    flat = _flat(P, 1, hid)
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(3, 4, 32, 32, generator=g) * 2).cuda()
+    t = torch.tensor([10.0, 400.0, 900.0]).cuda()
+    y = torch.tensor([1, 2, 1000]).cuda()
+    a = DiTEngine(flat, 3, depth=1, hidden=hid, heads=heads)(x, t, y)
+    b = DiTEngine(flat, 3, depth=1, hidden=hid, heads=heads, unfused_attention=True)(x, t, y)
+    ref = D.forward(P, x.cpu(), t.cpu(), y.cpu(), heads)
+    assert ((a - b).abs().max() / b.abs().max()).item() <= 1e-2
+    assert ((a.cpu() - ref).abs().max() / ref.abs().max()).item() <= TOL
 
 
 def test_argument_errors():
