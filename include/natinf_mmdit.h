@@ -1,0 +1,63 @@
+/*
+ * natinf_mmdit.h -- C ABI of the SD3 MMDiT denoiser engine inside libnatinf.so.
+ *
+ * Replaces `pipe.transformer(hidden_states, timestep, encoder_hidden_states, pooled_projections)` at
+ * src/SD3NaturalInference.py:111-114,210-213.  The reference takes that module from the un-vendored, un-pinned
+ * `diffusers` (requirements.txt:13: SD3Transformer2DModel of stable-diffusion-3-medium); its arithmetic is restated in
+ * oracle/mmdit_oracle.py from the published architecture (PARITY UNPINNED -- see that file's header) and this engine is
+ * tested against that restatement.  Joint (image + text) transformer blocks with adaLN-Zero modulation, head_dim 64,
+ * patch 2, latent channels `in_ch`; layers / heads / text dims / token counts are create-time parameters
+ * (SD3-medium at 1024x1024: 24 layers, 24 heads, joint_dim 4096, pooled_dim 2048, in_ch 16, grid 64, 333 text tokens).
+ *
+ * Arithmetic: bf16 operands on the matrix cores, fp32 accumulation, fp32 residual streams, LayerNorm / softmax /
+ * modulation in fp32.  Conventions of natinf.h (device pointers, explicit stream, int return codes, caller-owned
+ * packed-weight buffer and workspace).
+ */
+#ifndef NATINF_MMDIT_H
+#define NATINF_MMDIT_H
+
+#include <stdint.h>
+#include "natinf.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct natinf_mmdit* natinf_mmdit_t;
+
+/* grid = image tokens per side (latent side / 2), grid*grid % 8 == 0; ctx_tokens = text tokens per sequence;
+ * hidden = 64*heads <= 1536; joint_dim % 8 == 0, pooled_dim % 8 == 0. */
+int natinf_mmdit_create(natinf_mmdit_t* out, int layers, int heads, int joint_dim, int pooled_dim, int in_ch, int grid,
+                        int ctx_tokens);
+int natinf_mmdit_destroy(natinf_mmdit_t h);
+int64_t natinf_mmdit_param_count(natinf_mmdit_t h);
+int64_t natinf_mmdit_packed_bytes(natinf_mmdit_t h);
+int64_t natinf_mmdit_workspace_bytes(natinf_mmdit_t h, int max_batch);
+
+/* params_f32: fp32, concatenated in this order (diffusers state-dict names; D = 64*heads):
+ *   pos_embed.pos_embed CROPPED to the grid ([grid*grid][D], the centre window of the checkpoint's table),
+ *   pos_embed.proj.{weight,bias}, time_text_embed.timestep_embedder.linear_1.{weight,bias}, .linear_2.{weight,bias},
+ *   time_text_embed.text_embedder.linear_1.{weight,bias}, .linear_2.{weight,bias}, context_embedder.{weight,bias},
+ *   per block i: norm1.linear.{w,b}, norm1_context.linear.{w,b}, attn.to_q, to_k, to_v, add_k_proj, add_v_proj, add_q_proj,
+ *                to_out.0 (each {w,b}), [attn.to_add_out.{w,b}], ff.net.0.proj.{w,b}, ff.net.2.{w,b},
+ *                [ff_context.net.0.proj.{w,b}, ff_context.net.2.{w,b}]      ([..]: absent in the last block),
+ *   norm_out.linear.{weight,bias}, proj_out.{weight,bias}. */
+int natinf_mmdit_load(natinf_mmdit_t h, const float* params_f32, int64_t n_params, void* packed, int64_t packed_bytes,
+                      natinf_stream_t stream);
+
+/* out = transformer(latents, timestep, text, pooled): latents / out [B, in_ch, 2*grid, 2*grid] fp32 NCHW,
+ * timestep [B] fp32, text [B, ctx_tokens, joint_dim] fp32, pooled [B, pooled_dim] fp32. */
+int natinf_mmdit_forward(natinf_mmdit_t h, const float* latents, const float* timestep, const float* text, const float* pooled,
+                         float* out, int B, void* workspace, int64_t workspace_bytes, natinf_stream_t stream);
+
+/* The attention kernel on its own: o = softmax(q k^T * scale) v per (sequence, head), head_dim 64, bf16.
+ * q, k: [B][Tp][ld_qk] (head h at columns 64h..64h+63; per-sequence stride qk_bs elements); vT: [B][64*H][Tp] (V
+ * TRANSPOSED: keys contiguous; must be finite at keys >= T); o: [B][Tp][ld_o].  Tp % 128 == 0, 0 < T <= Tp; keys >= T
+ * are ignored, query rows >= T produce unspecified values. */
+int natinf_attention_hd64_bf16(const void* q, const void* k, int ld_qk, int64_t qk_bs, const void* vT, void* o, int ld_o,
+                               int64_t o_bs, int B, int H, int Tp, int T, float scale, natinf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NATINF_MMDIT_H */

@@ -61,6 +61,15 @@ SIGNATURES = {
     "natinf_dit_workspace_bytes": (C.c_int64, [_p, _i32]),
     "natinf_dit_load": (C.c_int, [_p, _p, _i64, _p, _i64, _p]),
     "natinf_dit_forward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _p, _i64, _p]),
+    # include/natinf_mmdit.h
+    "natinf_mmdit_create": (C.c_int, [C.POINTER(_p), _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "natinf_mmdit_destroy": (C.c_int, [_p]),
+    "natinf_mmdit_param_count": (C.c_int64, [_p]),
+    "natinf_mmdit_packed_bytes": (C.c_int64, [_p]),
+    "natinf_mmdit_workspace_bytes": (C.c_int64, [_p, _i32]),
+    "natinf_mmdit_load": (C.c_int, [_p, _p, _i64, _p, _i64, _p]),
+    "natinf_mmdit_forward": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _p, _i64, _p]),
+    "natinf_attention_hd64_bf16": (C.c_int, [_p, _p, _i32, _i64, _p, _p, _i32, _i64, _i32, _i32, _i32, _i32, C.c_float, _p]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

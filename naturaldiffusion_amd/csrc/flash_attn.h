@@ -1,0 +1,160 @@
+// flash_attn.h -- softmax attention over long (joint) sequences, head_dim 64: the SD3 MMDiT attention.
+//
+// One block = 128 queries of one (sequence, head): 4 waves x 32 queries.  Keys are walked in tiles of 128; the K tile
+// [128][64] and the V^T tile [64][128] of step kt+1 stream into LDS by direct global->LDS DMA while step kt is being
+// multiplied (two buffers, one barrier per tile).  S and P never leave the registers (same operand trick as
+// attn_fused.h): S^T = K Q^T leaves a lane with four keys of its query column per 16-key tile, and O^T = V^T P^T wants,
+// per lane, eight consecutive keys of that query -- so the A-operand ROWS of S^T tile (2c+h) are taken from the K tile
+// in the order  key = 32c + 8(r>>2) + 4h + (r&3),  which makes the lane's values of tiles 2c and 2c+1 exactly keys
+// 32c+8q .. 32c+8q+7, the 16 bytes its V^T fragment read covers.
+//   online softmax: running max m and (per-lane partial) sum l per query; exp2 with scale*log2(e) folded into one fma;
+//   the O^T accumulators are rescaled by exp2((m_old-m_new)c) once per key tile.
+//   LDS: 128-byte rows, 16-byte chunk index XOR-ed with a 3-bit row hash on the DMA source side and on the fragment
+//   read: K uses bits (1,3,4) of the row (its rows are read in the permuted order above), V^T bits (1,2,3).
+//   XCD-aware block order: the 35 query blocks of one (sequence, head) run back to back on one XCD, so its K / V^T
+//   (1.1 MB at 4,429 tokens) are fetched from HBM once and re-read from that XCD's L2.
+// Keys >= T_total (the padding up to a multiple of 128) are masked in the last tile; V^T must be finite there.
+// Reference: diffusers JointAttnProcessor2_0 as called by pipe.transformer (src/SD3NaturalInference.py:210-213).
+#pragma once
+#include "ncsnpp_kernels.h"
+
+namespace ncsn {
+
+constexpr int FA_KT = 128, FA_QB = 128, FA_STAGE = 32768, FA_LDS_BYTES = 2 * FA_STAGE;
+
+struct FlashArgs {
+    const bf16* q; const bf16* k; int ld_qk; int64_t qk_bs;        // [B][Tp][ld_qk], head h at column 64h
+    const bf16* vT; int64_t vT_bs;                                 // [B][H*64][Tp]
+    bf16* o; int ld_o; int64_t o_bs;                               // [B][Tp][ld_o]
+    int H, Tp, Ttot; float c1;                                     // c1 = softmax scale * log2(e)
+};
+
+__global__ __launch_bounds__(256, 2) void k_flash_attn64(const FlashArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nQ = a.Tp / FA_QB, nK = a.Tp / FA_KT;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = tile / nQ, qb = tile - bh * nQ, b = bh / a.H, head = bh - b * a.H;
+    const bf16* qbase = a.q + (int64_t)b * a.qk_bs + head * 64;
+    const bf16* kbase = a.k + (int64_t)b * a.qk_bs + head * 64;
+    const bf16* vbase = a.vT + (int64_t)b * a.vT_bs + (int64_t)head * 64 * a.Tp;
+
+    // DMA: per wave and stage 4 K pieces + 4 V^T pieces of 1 KiB (8 rows x 128 B)
+    const int prow = lane >> 3, pch = lane & 7;
+    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+        unsigned char* st = smem + buf * FA_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = wave * 4 + j, row = 8 * p + prow;
+            const int f = ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
+            __builtin_amdgcn_global_load_lds(kbase + (int64_t)(kt * FA_KT + row) * a.ld_qk + ((pch ^ f) << 3), (lds_void*)(st + p * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = wave * 4 + j, sub = p >> 3, d = 8 * (p & 7) + prow;
+            __builtin_amdgcn_global_load_lds(vbase + (int64_t)d * a.Tp + kt * FA_KT + sub * 64 + ((pch ^ ((d >> 1) & 7)) << 3),
+                                             (lds_void*)(st + 16384 + p * 1024), 16, 0, 0);
+        }
+    };
+
+    bf16x8 qf[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[g][ks] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)(qb * FA_QB + wave * 32 + 16 * g + r) * a.ld_qk + 32 * ks + 8 * q);
+
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    f32x4 oacc[2][4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { oacc[0][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc[1][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int krow = 8 * (r >> 2) + (r & 3), swz = r >> 1;
+    issue(0, 0);
+    for (int kt = 0; kt < nK; ++kt) {
+        __syncthreads();                                   // tile kt landed (vmcnt(0)), every wave is done with tile kt-1
+        if (kt + 1 < nK) issue(kt + 1, (kt + 1) & 1);
+        const unsigned char* sK = smem + (kt & 1) * FA_STAGE;
+        const unsigned char* sV = sK + 16384;
+
+        f32x4 acc[2][8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { acc[0][t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int row = 32 * (t >> 1) + 4 * (t & 1) + krow;
+                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(sK + row * 128 + (((4 * ks + q) ^ swz) << 4));
+                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, qf[0][ks], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, qf[1][ks], acc[1][t], 0, 0, 0);
+            }
+        if (kt == nK - 1 && a.Ttot < a.Tp) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = kt * FA_KT + 32 * (t >> 1) + 8 * q + 4 * (t & 1) + i < a.Ttot;
+                    acc[0][t][i] = ok ? acc[0][t][i] : -INFINITY;
+                    acc[1][t][i] = ok ? acc[1][t][i] : -INFINITY;
+                }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float mx = m[g];
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, acc[g][t][i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float alpha = __builtin_amdgcn_exp2f((m[g] - mx) * a.c1), mc = mx * a.c1;
+            m[g] = mx;
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const float p = __builtin_amdgcn_exp2f(fmaf(acc[g][t][i], a.c1, -mc)); acc[g][t][i] = p; s += p; }
+            l[g] = l[g] * alpha + s;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) oacc[g][dt][i] *= alpha;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x8 pf[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { pf[g][i] = (bf16)acc[g][2 * c][i]; pf[g][4 + i] = (bf16)acc[g][2 * c + 1][i]; }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 fv = *reinterpret_cast<const bf16x8*>(sV + (c >> 1) * 8192 + (16 * dt + r) * 128 + (((4 * (c & 1) + q) ^ swz) << 4));
+                oacc[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pf[0], oacc[0][dt], 0, 0, 0);
+                oacc[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pf[1], oacc[1][dt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float s = l[g];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const float inv = 1.0f / s;
+        bf16* orow = a.o + (int64_t)b * a.o_bs + (int64_t)(qb * FA_QB + wave * 32 + 16 * g + r) * a.ld_o + head * 64 + 4 * q;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = (bf16)(oacc[g][dt][i] * inv);
+            *reinterpret_cast<bf16x4*>(orow + 16 * dt) = w;
+        }
+    }
+}
+
+}  // namespace ncsn

@@ -121,12 +121,12 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
                 for (int q = 0; q < 8; ++q) v[q] += bm;
             }
             if (g.rowvec) {
-                const float* rv = g.rowvec + (int64_t)(m >> g.log_rows_per_sample) * g.rowvec_ld + n;
+                const float* rv = g.rowvec + (int64_t)((m >> g.log_rows_per_sample) + z * g.z_samples) * g.rowvec_ld + n;
                 const float4 s4 = *reinterpret_cast<const float4*>(rv), t4 = *reinterpret_cast<const float4*>(rv + 4);
                 v[0] += s4.x; v[1] += s4.y; v[2] += s4.z; v[3] += s4.w; v[4] += t4.x; v[5] += t4.y; v[6] += t4.z; v[7] += t4.w;
             }
             if (g.gate) {
-                const float* gv = g.gate + (int64_t)(m >> g.log_rows_per_sample) * g.gate_ld + n;
+                const float* gv = g.gate + (int64_t)((m >> g.log_rows_per_sample) + z * g.z_samples) * g.gate_ld + n;
                 const float4 s4 = *reinterpret_cast<const float4*>(gv), t4 = *reinterpret_cast<const float4*>(gv + 4);
                 v[0] *= s4.x; v[1] *= s4.y; v[2] *= s4.z; v[3] *= s4.w; v[4] *= t4.x; v[5] *= t4.y; v[6] *= t4.z; v[7] *= t4.w;
             }
@@ -136,7 +136,7 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
                 for (int q = 0; q < 8; ++q) v[q] += (float)rs[q];
             }
             if (g.resid_f32) {
-                const float* rp = g.resid_f32 + (int64_t)m * g.resid_f32_ld + n;
+                const float* rp = g.resid_f32 + (int64_t)z * g.c_bs + (int64_t)m * g.resid_f32_ld + n;
                 const float4 s4 = *reinterpret_cast<const float4*>(rp), t4 = *reinterpret_cast<const float4*>(rp + 4);
                 v[0] += s4.x; v[1] += s4.y; v[2] += s4.z; v[3] += s4.w; v[4] += t4.x; v[5] += t4.y; v[6] += t4.z; v[7] += t4.w;
             }

@@ -29,6 +29,7 @@
 #include "gemm_dma.h"
 #include "conv_patch.h"
 #include "attn_fused.h"
+#include "flash_attn.h"
 
 using namespace ncsn;
 
@@ -183,7 +184,8 @@ bool configure_gemm_kernels() {
          set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2>) && set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2>) &&
          set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>) &&
          set_lds<AttnCfg<2, 4>>(&k_attn_fused<2, 4>) && set_lds<AttnCfg<3, 6>>(&k_attn_fused<3, 6>) &&
-         set_lds<AttnCfg<3, 5>>(&k_attn_fused<3, 5>);
+         set_lds<AttnCfg<3, 5>>(&k_attn_fused<3, 5>) &&
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess;
     if (!ok) (void)hipGetLastError();
     return ok;
 }
@@ -921,3 +923,4 @@ int natinf_ncsnpp_debug_tap(natinf_ncsnpp_t h, int module_idx, float* out, int64
 
 }  // extern "C"
 #include "dit_engine.inc"
+#include "mmdit_engine.inc"

@@ -43,10 +43,11 @@ struct GemmArgs {
     const bf16* b; int b_ld;                          // [N][K0+K1], K contiguous
     int64_t a_bs, b_bs, c_bs; int batch;              // per-batch element strides (blockIdx.z)
     const float* bias_n; const float* bias_m;
-    const float* rowvec; int rowvec_ld; int log_rows_per_sample;   // + rowvec[(m >> log)*ld + n]
+    const float* rowvec; int rowvec_ld; int log_rows_per_sample;   // + rowvec[((m >> log) + z*z_samples)*ld + n]
+    int z_samples;                                    // samples per batch index z (0: rowvec / gate ignore z)
     const float* gate; int gate_ld;                   // * gate[(m >> log)*ld + n]   (adaLN-Zero gates; applied before the residual)
     const bf16* resid; int resid_ld;                  // + resid[m*ld + n]
-    const float* resid_f32; int resid_f32_ld;         // + resid_f32[m*ld + n]       (fp32 residual stream)
+    const float* resid_f32; int resid_f32_ld;         // + resid_f32[z*c_bs + m*ld + n]  (fp32 residual stream, batch stride of c)
     float scale; int act;
     void* c; int c_ld; int c_mode;
     // fused GroupNorm statistics of the OUTPUT (DMA kernels, block tile inside one sample): per block tile and per
@@ -130,12 +131,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, unsigned char* 
             for (int q = 0; q < 8; ++q) v[q] += bm;
         }
         if (g.rowvec) {
-            const float* rv = g.rowvec + (int64_t)(m >> g.log_rows_per_sample) * g.rowvec_ld + n;
+            const float* rv = g.rowvec + (int64_t)((m >> g.log_rows_per_sample) + z * g.z_samples) * g.rowvec_ld + n;
             const float4 s = *reinterpret_cast<const float4*>(rv), t = *reinterpret_cast<const float4*>(rv + 4);
             v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w; v[4] += t.x; v[5] += t.y; v[6] += t.z; v[7] += t.w;
         }
         if (g.gate) {
-            const float* gv = g.gate + (int64_t)(m >> g.log_rows_per_sample) * g.gate_ld + n;
+            const float* gv = g.gate + (int64_t)((m >> g.log_rows_per_sample) + z * g.z_samples) * g.gate_ld + n;
             const float4 s = *reinterpret_cast<const float4*>(gv), t = *reinterpret_cast<const float4*>(gv + 4);
             v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w; v[4] *= t.x; v[5] *= t.y; v[6] *= t.z; v[7] *= t.w;
         }
@@ -145,7 +146,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, unsigned char* 
             for (int q = 0; q < 8; ++q) v[q] += (float)rs[q];
         }
         if (g.resid_f32) {
-            const float* rp = g.resid_f32 + (int64_t)m * g.resid_f32_ld + n;
+            const float* rp = g.resid_f32 + (int64_t)z * g.c_bs + (int64_t)m * g.resid_f32_ld + n;
             const float4 s = *reinterpret_cast<const float4*>(rp), t = *reinterpret_cast<const float4*>(rp + 4);
             v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w; v[4] += t.x; v[5] += t.y; v[6] += t.z; v[7] += t.w;
         }
