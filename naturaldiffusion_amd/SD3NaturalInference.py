@@ -3,8 +3,10 @@
 Public names as in the reference: ``weighted_sum(seq_xstarts, weights=None)``, ``euler_weighted_sum``,
 ``sd_natural_inference_tx()``, ``sd_euler_natural_inference_tx()``.  Per step the two MMDiT calls are
 followed by ONE fused launch (``natinf_step_f16chain``: x0 from velocity, CFG fuse, append, row-normalised
-fp16 weighted mean, next model input).  The MMDiT / text encoders / VAE are third-party (``diffusers``,
-un-vendored and unpinned in the reference); a ``pipe`` object with the same attributes can be passed in.
+fp16 weighted mean, next model input).  The text encoders / scheduler / VAE are third-party (``diffusers``,
+un-vendored and unpinned in the reference); a ``pipe`` object with the same attributes can be passed in.  The
+denoiser ``pipe.transformer`` is replaced by the gfx950 MMDiT engine (``use_native_transformer``; on by default when
+the pipe is loaded here): text and null prompts then go through ONE batched forward per step.
 The reference's 28x5x4 intermediate VAE decodes (:223-236, visualisation only) are off by default.
 """
 from __future__ import annotations
@@ -63,7 +65,27 @@ def euler_weighted_sum(seq_xstarts, cliplen=0):
     return acc.view(shape), mean.view(shape)
 
 
-def _load_pipe(pipe, device, dtype):
+def use_native_transformer(pipe, n: int, latent_side: int = 128, ctx_tokens: Optional[int] = None, device="cuda:0"):
+    """Swap ``pipe.transformer`` (diffusers ``SD3Transformer2DModel``) for the HIP engine built from its own weights
+    (include/natinf_mmdit.h).  ``n`` = images per batch; the engine is sized for the 2n sequences of a CFG step."""
+    from .mmdit import MMDiTEngine, flatten_state_dict
+    tr = pipe.transformer
+    if isinstance(tr, MMDiTEngine):
+        return pipe
+    cfg = tr.config
+    kw = dict(layers=cfg.num_layers, heads=cfg.num_attention_heads, joint_dim=cfg.joint_attention_dim,
+              pooled_dim=cfg.pooled_projection_dim, in_ch=cfg.in_channels)
+    if cfg.attention_head_dim != 64 or cfg.patch_size != 2:
+        raise ValueError("the engine supports head_dim 64 / patch 2 (SD3-medium)")
+    grid = latent_side // 2
+    if ctx_tokens is None:
+        ctx_tokens = 77 + 256                               # CLIP (77) + T5 (max_sequence_length 256): encode_prompt's default
+    flat = flatten_state_dict(tr.state_dict(), grid, **kw)
+    pipe.transformer = MMDiTEngine(flat, max_batch=2 * n, grid=grid, ctx_tokens=ctx_tokens, device=device, **kw)
+    return pipe
+
+
+def _load_pipe(pipe, device, dtype, n=4):
     if pipe is not None:
         return pipe
     try:
@@ -71,8 +93,9 @@ def _load_pipe(pipe, device, dtype):
     except ImportError as e:
         raise ImportError("SD3 needs the `diffusers` package and the stabilityai/stable-diffusion-3-medium-diffusers "
                           "weights (un-vendored in the reference); pass pipe=... to use another denoiser") from e
-    return StableDiffusion3Pipeline.from_pretrained("stabilityai/stable-diffusion-3-medium-diffusers",
+    pipe = StableDiffusion3Pipeline.from_pretrained("stabilityai/stable-diffusion-3-medium-diffusers",
                                                     torch_dtype=dtype, local_files_only=True).to(device)
+    return use_native_transformer(pipe, n, device=device)
 
 
 def _prepare(pipe, device, dtype, n, seed, num_step, noises):
@@ -94,6 +117,11 @@ def _decode(pipe, latents):
 
 def _velocities(pipe, x, ts, emb):
     pe, ne, ppe, npe = emb
+    from .mmdit import MMDiTEngine
+    if isinstance(pipe.transformer, MMDiTEngine) and pipe.transformer.max_batch >= 2 * x.shape[0]:
+        n = x.shape[0]                                      # text and null prompts of a step in one batched forward
+        v = pipe.transformer.forward(torch.cat([x, x]), torch.cat([ts, ts]), torch.cat([pe, ne]), torch.cat([ppe, npe]))
+        return v[:n].contiguous(), v[n:].contiguous()
     vt = pipe.transformer(hidden_states=x, timestep=ts, encoder_hidden_states=pe, pooled_projections=ppe, return_dict=False)[0]
     vn = pipe.transformer(hidden_states=x, timestep=ts, encoder_hidden_states=ne, pooled_projections=npe, return_dict=False)[0]
     return vt.contiguous(), vn.contiguous()
@@ -106,7 +134,7 @@ def sd_natural_inference_tx(pipe=None, device="cuda", noises: Optional[torch.Ten
     """Reference :172-245.  Returns the final latents per weight file (and writes ``results/sd3/sgl_*.png``
     when ``decode``)."""
     dtype = torch.float16
-    pipe = _load_pipe(pipe, device, dtype)
+    pipe = _load_pipe(pipe, device, dtype, n)
     noises, emb, timesteps, sigmas = _prepare(pipe, device, dtype, n, seed, num_step, noises)
     shape, finals = noises.shape, []
     for weight_name in weight_names:
@@ -135,7 +163,7 @@ def sd_euler_natural_inference_tx(pipe=None, device="cuda", noises: Optional[tor
                                   seed: int = 10, num_step: int = 28, decode: bool = True) -> torch.Tensor:
     """Reference :81-154 with ``is_vanilla_update = False``: flow-Euler written as Natural Inference."""
     dtype = torch.float16
-    pipe = _load_pipe(pipe, device, dtype)
+    pipe = _load_pipe(pipe, device, dtype, n)
     noises, emb, timesteps, sigmas = _prepare(pipe, device, dtype, n, seed, num_step, noises)
     shape = noises.shape
     ni = SD3NI(None, sigmas, noises.numel(), device=noises.device, cfg=7.0, euler=True)

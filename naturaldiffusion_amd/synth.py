@@ -60,3 +60,29 @@ def synthetic_dit_state_dict(depth: int = 28, hidden: int = 1152, seed: int = 0)
         else:
             out[name] = torch.randn(shp, generator=g) * 0.02
     return out
+
+
+def synthetic_mmdit_flat(grid: int, layers: int, heads: int, joint_dim: int, pooled_dim: int, in_ch: int = 16, seed: int = 0,
+                         pos_max: int = 192, pos_base: int = 64) -> torch.Tensor:
+    """Synthetic SD3 MMDiT weights as the flat vector ``MMDiTEngine`` consumes (the SD3-medium checkpoint is a gated
+    download): xavier-uniform matrices, N(0, 0.02) biases, the cropped sin-cos position table."""
+    from .mmdit import param_layout as mm_layout
+    g = torch.Generator().manual_seed(seed)
+    parts = []
+    D = heads * 64
+    for name, shp in mm_layout(layers, heads, joint_dim, pooled_dim, in_ch):
+        if name == "pos_embed.pos_embed":
+            def one(d, pos):
+                omega = 1.0 / 10000 ** (np.arange(d // 2, dtype=np.float64) / (d / 2.0))
+                a = pos.reshape(-1)[:, None] * omega[None]
+                return np.concatenate([np.sin(a), np.cos(a)], axis=1)
+            top = (pos_max - grid) // 2
+            ax = (np.arange(pos_max, dtype=np.float32) / (pos_max / pos_base))[top:top + grid]
+            gw, gh = np.meshgrid(ax, ax)
+            parts.append(torch.from_numpy(np.concatenate([one(D // 2, gw), one(D // 2, gh)], axis=1)).float().reshape(-1))
+        elif len(shp) >= 2:
+            lim = math.sqrt(6.0 / (int(np.prod(shp[1:])) + shp[0]))
+            parts.append(((torch.rand(shp, generator=g) * 2 - 1) * lim).reshape(-1))
+        else:
+            parts.append((torch.randn(shp, generator=g) * 0.02).reshape(-1))
+    return torch.cat(parts)

@@ -156,3 +156,13 @@ def test_synthetic_dit_weights_match_the_oracle_recipe():
     assert list(a) == list(b) == [n for n, _ in param_layout(2, 128)]
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_synthetic_mmdit_weights_match_the_oracle_recipe():
+    from oracle import mmdit_oracle as M
+    from naturaldiffusion_amd.synth import synthetic_mmdit_flat
+    from naturaldiffusion_amd.mmdit import flatten_state_dict
+    cfg = dict(layers=2, heads=2, joint_dim=64, pooled_dim=32)
+    a = synthetic_mmdit_flat(grid=8, seed=5, pos_max=24, pos_base=8, **cfg)
+    b = flatten_state_dict(M.make_params(seed=5, pos_max=24, pos_base=8, **cfg), 8, **cfg)
+    assert torch.equal(a, b)

@@ -81,3 +81,44 @@ def test_argument_errors():
         eng.forward(z, torch.zeros(2), torch.zeros(2, 13, 64), torch.zeros(2, 32))          # batch > max_batch
     with pytest.raises(ValueError):
         eng.forward(z[:1], torch.zeros(1), torch.zeros(1, 12, 64), torch.zeros(1, 32))      # wrong text length
+
+
+def test_sd3_natural_inference_with_the_engine_as_pipe_transformer(repo_root):
+    """src/SD3NaturalInference.py:172-245 with ``pipe.transformer`` = the HIP engine (text + null prompts batched into
+    one forward per step), against the oracle's restatement of the loop driven by the MMDiT oracle.  fp16 chain with a
+    bf16-operand denoiser vs an fp32 one: tolerance on the final latents, not bit equality."""
+    from oracle import ni_oracle as O
+    from naturaldiffusion_amd import SD3NaturalInference as S
+    from naturaldiffusion_amd.mmdit import MMDiTEngine, flatten_state_dict
+    M, cfg, P = _small()
+    n, grid, tc = 2, 8, 13
+    # a denoiser with O(1) velocities of the right sign keeps the 28-step fp16 chain well conditioned: scale the output layer
+    P = dict(P); P["proj_out.weight"] = P["proj_out.weight"] * 0.2
+    eng = MMDiTEngine(flatten_state_dict(P, grid, **cfg), max_batch=2 * n, grid=grid, ctx_tokens=tc, **cfg)
+    g = torch.Generator().manual_seed(3)
+    pe, ne = torch.randn(n, tc, 64, generator=g).half(), torch.randn(n, tc, 64, generator=g).half()
+    ppe, npe = torch.randn(n, 32, generator=g).half(), torch.randn(n, 32, generator=g).half()
+    noises = torch.randn(n, 16, 16, 16, generator=g).half()
+
+    class Sched:
+        def set_timesteps(self, k, device=None):
+            self.timesteps, self.sigmas = O.sd3_sigma_schedule(k)
+
+    class Pipe:
+        scheduler = Sched()
+        transformer = eng
+
+        def encode_prompt(self, prompt, **k):
+            return (pe.cuda(), ne.cuda(), ppe.cuda(), npe.cuda())
+    finals = S.sd_natural_inference_tx(pipe=Pipe(), device="cuda:0", noises=noises.cuda(), n=n, decode=False,
+                                       weight_names=("sd3_step_28_weight.csv",))
+    W = O.load_sd3_csv(repo_root / "weights/sd3_step_28_weight.csv")
+    ts, sig = O.sd3_sigma_schedule(28)
+
+    def vel(x, t, cond):
+        tt = torch.as_tensor(t, dtype=torch.float32).expand(n)
+        return M.forward(P, x.float(), tt, (pe if cond else ne).float(), (ppe if cond else npe).float()).half()
+    ref = O.sd3_ni(vel, noises, W, sig, ts)
+    out = finals[0].cpu().float()
+    assert torch.isfinite(out).all()
+    assert ((out - ref.float()).abs().max() / ref.float().abs().max()).item() <= 5e-2
