@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--weights", default=str(ROOT / "weights" / "step_15_weight_173.npz"))
+    ap.add_argument("--workload", choices=["cifar10", "sd3"], default="cifar10",
+                    help="cifar10 = the BASELINE.json metric (default); sd3 = config 4 (SD3 1024x1024 28-step NI, MMDiT bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the event-instrumented replica (for rocprof runs)")
     args = ap.parse_args()
@@ -83,6 +85,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.workload == "sd3":
+        return bench_sd3(args, world, rank, dev)
 
     from naturaldiffusion_amd import _lib
     from naturaldiffusion_amd.coeff import load_coeff_npz
@@ -210,6 +215,77 @@ def main():
                                 "sample": f"{nb} images x {n_step} steps, same coefficient file and synthetic weights "
                                           f"(fp32 NCSN++ oracle + fp64 recurrence), {dc:.1f} s; host has {os.cpu_count()} logical CPUs"}
 
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_sd3(args, world, rank, dev):
+    """BASELINE config 4: SD3NaturalInference 28-step (weights/sd3_step_28_weight.csv), 1024x1024 (latents
+    [4,16,128,128] fp16), CFG 7 -> per step ONE batched MMDiT forward of 8 sequences (4,096 image + 333 text tokens) +
+    one fused natinf_step_f16chain launch.  A "step" of this bench = one 4-image batch through all 28 steps.
+    SD3-medium-shaped synthetic weights and synthetic text embeddings (the checkpoint / text encoders are downloads)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from naturaldiffusion_amd import _lib
+    from naturaldiffusion_amd.coeff import load_sd3_csv
+    from naturaldiffusion_amd.mmdit import MMDiTEngine, SD3_MEDIUM
+    from naturaldiffusion_amd.sampler import SD3NI
+    from naturaldiffusion_amd.synth import synthetic_mmdit_flat
+    _lib.require_gpu()
+    n, tc, nstep = 4, 333, 28
+    W = load_sd3_csv(ROOT / "weights" / "sd3_step_28_weight.csv")
+    u = np.linspace(1.0, 3 * 0.001 / (1 + 2 * 0.001), nstep)          # FlowMatchEulerDiscreteScheduler, shift 3 (SURVEY 8a A9)
+    sig = np.append(3 * u / (1 + 2 * u), 0.0).astype(np.float32)
+    sigmas, timesteps = torch.from_numpy(sig).to(dev), torch.from_numpy(sig[:-1] * 1000).to(dev)
+    eng = MMDiTEngine(synthetic_mmdit_flat(grid=64, seed=0, **SD3_MEDIUM), max_batch=2 * n, grid=64, ctx_tokens=tc, device=dev, **SD3_MEDIUM)
+    g = torch.Generator(device=dev).manual_seed(10 + rank)
+    noises = torch.randn(n, 16, 128, 128, device=dev, dtype=torch.float16, generator=g)
+    text = torch.randn(2 * n, tc, 4096, device=dev, generator=g)
+    pooled = torch.randn(2 * n, 2048, device=dev, generator=g)
+    ni = SD3NI(W, sigmas, noises.numel(), device=dev, cfg=7.0)
+    flat = noises.reshape(-1)
+
+    def one_step():
+        x = ni.first_input(flat)
+        for k in range(nstep):
+            xx = x.view(n, 16, 128, 128)
+            v = eng.forward(torch.cat([xx, xx]), timesteps[k].expand(2 * n), text, pooled)
+            mean, x = ni.step(k, x, v[:n].reshape(-1), v[n:].reshape(-1), flat, want_next=k + 1 < nstep)
+        return mean
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    assert torch.isfinite(out.float()).all()
+    D, L, tx = 1536, 24, 4096
+    T = tx + tc
+    flops_fwd_seq = L * (2.0 * T * 3 * D * D + 4.0 * T * T * D + 2.0 * T * D * D + 2.0 * T * 8 * D * D) - 2.0 * tc * 9 * D * D + 2.0 * tc * 4096 * D
+    tf = flops_fwd_seq * 2 * n * nstep * args.steps / dt / 1e12
+    line = {"metric": "images/sec at 28-step Natural Inference (SD3 1024x1024, MMDiT)", "value": round(world * n * args.steps / dt, 4),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "SD3 Natural Inference 28-step (sd3_step_28_weight.csv), 4 images x CFG per GPU = 8 sequences of 4096+333 "
+                                   "tokens per forward, SD3-medium-shaped MMDiT (2.03 B params, synthetic weights) bf16 MFMA / fp32 acc, "
+                                   "ni_step fp16 chain", "nfe": 2 * nstep, "images_per_gpu": n, "sharding": f"batch-sharded x{world}, no collective"},
+            "roofline": {"kernel": "whole forward (k_gemm_dma + k_flash_attn64), 2*MAC flops / wall time", "bound": "mfma", "achieved": round(tf, 1),
+                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

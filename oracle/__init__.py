@@ -10,7 +10,9 @@ function cites the reference ``file:line`` it follows.
 Parity status: PINNED for the sampler half (A1-A10 of SURVEY.md section 8) and
 for the NCSN++ denoiser (A4) by the fixtures under ``tests/golden/`` that
 ``tests/golden/make_golden.py`` captured from the reference itself, imported
-on CPU in the build container.  The SD3 MMDiT / DiT-XL/2 denoiser arithmetic
-lives in un-vendored, un-pinned third-party packages (``diffusers``, ``timm``)
-and is "parity unpinned" (see DESIGN.md).
+on CPU in the build container; ``dit_oracle`` is pinned to the reference's own
+``DiT`` class for everything DiT-specific.  PARITY UNPINNED: ``mmdit_oracle``
+(the SD3 MMDiT is ``diffusers``' -- un-vendored, un-pinned, absent here; the
+file restates the published architecture) and the three ``timm`` building
+blocks inside DiT.
 """
