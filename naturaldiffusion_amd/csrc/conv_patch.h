@@ -135,6 +135,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_conv_patch(const GemmArgs g
 #pragma unroll
     for (int j = 0; j < Cfg::PP; ++j) issue_patch_piece(j, 0, 0);
     issue_b(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     int kt = 0;                                                     // K-tile counter in packed order
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_conv_patch(const GemmArgs g
 #pragma unroll
                 for (int i = 0; i < TM; ++i) arow[i] = pc[i] + off;
                 compute(arow, pbuf, kt & 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA completions are not tracked across the back-edge
                 __syncthreads();
             }
         }
@@ -166,6 +168,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_conv_patch(const GemmArgs g
 #pragma unroll
         for (int i = 0; i < TM; ++i) arow[i] = wm * TM * 16 + i * 16 + frow;
         compute(arow, pbuf, kt & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     dma_tile_epilogue<WM, WN, TM, TN, typename Cfg::Epi>(g, smem, acc, m0, n0, 0, tid, lane, wm, wn);

@@ -75,7 +75,10 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64(const FlashArgs a)
     const int krow = 8 * (r >> 2) + (r & 3), swz = r >> 1;
     issue(0, 0);
     for (int kt = 0; kt < nK; ++kt) {
-        __syncthreads();                                   // tile kt landed (vmcnt(0)), every wave is done with tile kt-1
+        // tile kt landed: the compiler does not track LDS-DMA completions across the loop back-edge, so wait explicitly;
+        // the barrier then also proves every wave is done with tile kt-1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (kt + 1 < nK) issue(kt + 1, (kt + 1) & 1);
         const unsigned char* sK = smem + (kt & 1) * FA_STAGE;
         const unsigned char* sV = sK + 16384;

@@ -305,6 +305,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int frow = lane & 15, fq = lane >> 4, fswz = (frow >> 1) & 7;
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
             fa[0] = lds_read16<0>(a_lds + ko0); fa[1] = lds_read16<2048>(a_lds + ko0);
             PipeStep<TM, 0>::run(fa, fb, acc, a_lds + ko0, a_lds + ko1, b_lds + ko1);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's LDS-DMA has landed (explicit: not left to the compiler's tracking)
         __syncthreads();
     }
     dma_tile_epilogue<WM, WN, TM, TN, typename Cfg::Epi>(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
