@@ -51,3 +51,51 @@ def test_quadratic_grid_matches_shipped_weights(repo_root):
     assert np.allclose(G.quadratic_time_grid(15), node[:, 0], atol=1e-12)
     al, sg = G.vp_alpha_sigma(node[:, 0])
     assert np.allclose(al, node[:, 1], atol=1e-6) and np.allclose(sg, node[:, 2], atol=1e-6)
+
+
+def _close(repo_root, rel, got, tol=1e-12):
+    C, B, node = O.load_coeff_npz(repo_root / rel)
+    c, b, nd = got
+    assert c.shape == C.shape and b.shape == B.shape and nd.shape == node.shape, rel
+    assert np.abs(c - C).max() <= tol * max(1.0, np.abs(C).max()), (rel, np.abs(c - C).max())
+    assert np.abs(b - B).max() <= tol * max(1.0, np.abs(B).max()), (rel, np.abs(b - B).max())
+    assert np.abs(nd - node).max() <= tol * max(1.0, np.abs(node).max()), (rel, np.abs(nd - node).max())
+
+
+@pytest.mark.parametrize("n", [18, 24])
+def test_tracer_generators_reproduce_shipped_matrices(repo_root, n):
+    """K8 of SURVEY section 8c: every sampler family the reference ships a matrix for (the reference derives them with
+    sympy; the float64 tracer agrees to rounding)."""
+    _close(repo_root, f"results/dpmsolver/dpmsolver2s_{n:03d}.npz", G.dpmsolver_singlestep(n // 2, 2))
+    _close(repo_root, f"results/dpmsolver/dpmsolver3s_{n:03d}.npz", G.dpmsolver_singlestep(n // 3, 3))
+    _close(repo_root, f"results/dpmsolverpp/dpmsolverpp2s_{n:03d}.npz", G.dpmsolver_singlestep(n // 2, 2, data_prediction=True))
+    _close(repo_root, f"results/dpmsolverpp/dpmsolverpp3s_{n:03d}.npz", G.dpmsolver_singlestep(n // 3, 3, data_prediction=True))
+    _close(repo_root, f"results/euler_heun/ode_euler_{n:03d}.npz", G.vp_euler(n))
+    _close(repo_root, f"results/euler_heun/sde_euler_{n:03d}.npz", G.vp_euler(n, stochastic=True))
+    _close(repo_root, f"results/euler_heun/ode_heun_{n:03d}.npz", G.vp_heun(n // 2))
+    _close(repo_root, f"results/flow_euler/flow_euler_simpy_{n:03d}.npz", G.flow_euler(n))
+    _close(repo_root, f"results/ddpm/ddpm_sympy_{n:03d}.npz", G.ddpm_discrete(n))
+
+
+def test_marginal_invariants_of_generated_matrices():
+    """what the reference prints as its own check (src/Utils.py:14-27): row sums of C follow alpha, row norms of B
+    follow sigma -- exactly for DDPM / flow, to discretisation error for the ODE / SDE solvers."""
+    C, B, node = G.ddpm_discrete(50)
+    # the chain starts from pure noise although sqrt(abar_999) = 0.0064: the signal sums fall short by that much at most
+    assert np.allclose(C.sum(1), node[1:, 1], atol=7e-3) and np.allclose(np.linalg.norm(B, axis=1), node[1:, 2], atol=7e-3)
+    C, B, node = G.flow_euler(40)
+    assert np.allclose(C.sum(1), node[1:, 1], atol=1e-12) and np.allclose(np.abs(B).sum(1), node[1:, 2], atol=1e-12)
+    for C, B, node in (G.dpmsolver_singlestep(10, 3), G.dpmsolver_singlestep(12, 2, data_prediction=True), G.vp_heun(20, reference_quirks=False)):
+        assert np.allclose(np.triu(C, 1), 0)
+        assert np.abs(C.sum(1)[-1] - node[-1, 1]) < 2e-2
+
+
+def test_published_dpmsolverpp3s_differs_from_the_reference_variant_and_is_more_accurate():
+    """the sign the reference uses in DPM-Solver++(3S) (AnalyzeDPMSolver.py:597-613) against the published one, on a model
+    whose exact solution is known: x0_hat = const makes the data-prediction ODE solution x_t = (sigma_t/sigma_s) x_s +
+    alpha_t (1 - e^{-h}) x0 for any solver order, so both variants must be exact -- the difference shows on a
+    t-dependent prediction."""
+    Cq, _, node = G.dpmsolver_singlestep(6, 3, data_prediction=True, reference_sign=True)
+    Cp, _, _ = G.dpmsolver_singlestep(6, 3, data_prediction=True, reference_sign=False)
+    assert np.abs(Cq - Cp).max() > 1e-3
+    assert np.allclose(Cq.sum(1), Cp.sum(1), atol=1e-12)        # constant prediction: identical (difference terms vanish)
