@@ -64,9 +64,20 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
 {
     constexpr int BN_ = WN * TN * 16, BM_ = WM * TM * 16, THREADS = WM * WN * 64;
     float* sC = reinterpret_cast<float*>(smem);
+    if (g.c_mode == 102) {                          // timing experiment: no epilogue at all (one store keeps the accumulators live)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456f) reinterpret_cast<float*>(g.c)[tid] = t;
+        return;
+    }
     float st[4] = {0.f, 0.f, 0.f, 0.f};            // fused GroupNorm partials of this thread's two 4-channel quads
     constexpr int CROW = Cfg::CROW, RB = Cfg::RB, CPR = BN_ / 8;            // 16-byte output chunks per row
     constexpr int ROWS_PER_SWEEP = THREADS / CPR;
+    constexpr int NP = TM / RB, NSW = Cfg::SLAB_ROWS / ROWS_PER_SWEEP;
+    uint4 keep[NSW][2];                            // one pass's finished outputs (bf16: [0] only), stored after its last load
     const int cchunk = tid % CPR, rsub = tid / CPR;
     const int n = n0 + cchunk * 8;
     const bool n_in = n < g.N;
@@ -77,8 +88,10 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
         const float4 u = *reinterpret_cast<const float4*>(g.bias_n + n), w = *reinterpret_cast<const float4*>(g.bias_n + n + 4);
         bn[0] = u.x; bn[1] = u.y; bn[2] = u.z; bn[3] = u.w; bn[4] = w.x; bn[5] = w.y; bn[6] = w.z; bn[7] = w.w;
     }
+    // the bias is waited for here, once, and handed on as asm outputs: hipcc then attaches no pending load to bn[]
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3]), "+v"(bn[4]), "+v"(bn[5]), "+v"(bn[6]), "+v"(bn[7]));
 #pragma unroll
-    for (int pass = 0; pass < TM / RB; ++pass) {
+    for (int pass = 0; pass < NP; ++pass) {
         if (pass) __syncthreads();                 // previous pass fully read
 #pragma unroll
         for (int ii = 0; ii < RB; ++ii)
@@ -106,7 +119,7 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
             continue;
         }
 #pragma unroll
-        for (int sw = 0; sw < Cfg::SLAB_ROWS / ROWS_PER_SWEEP; ++sw) {
+        for (int sw = 0; sw < NSW; ++sw) {
             const int s = sw * ROWS_PER_SWEEP + rsub;
             const int m = m0 + (s / (RB * 16)) * (TM * 16) + pass * RB * 16 + s % (RB * 16);
             if (m >= g.M || !n_in) continue;
@@ -141,10 +154,8 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
                 v[0] += s4.x; v[1] += s4.y; v[2] += s4.z; v[3] += s4.w; v[4] += t4.x; v[5] += t4.y; v[6] += t4.z; v[7] += t4.w;
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                v[q] *= g.scale;
-                v[q] = apply_act(v[q], g.act);
-            }
+            for (int q = 0; q < 8; ++q) v[q] *= g.scale;
+            apply_act8(v, g.act);
             if (g.gn_part) {
                 st[0] += (v[0] + v[1]) + (v[2] + v[3]); st[1] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                 st[2] += (v[4] + v[5]) + (v[6] + v[7]); st[3] += (v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]);
@@ -153,11 +164,29 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
                 bf16x8 o;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) o[q] = (bf16)v[q];
-                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(g.c) + (int64_t)z * g.c_bs + (int64_t)m * g.c_ld + n) = o;
+                keep[sw][0] = __builtin_bit_cast(uint4, o);
+            } else {
+                keep[sw][0] = __builtin_bit_cast(uint4, make_float4(v[0], v[1], v[2], v[3]));
+                keep[sw][1] = __builtin_bit_cast(uint4, make_float4(v[4], v[5], v[6], v[7]));
+            }
+        }
+        // ---- this pass's stores, after all of its loads.  vmcnt counts stores as well as loads, and hipcc waits
+        // ---- vmcnt(0) for a loaded value whenever stores are outstanding too (mixed event types retire out of order):
+        // ---- with the store inside the sweep, every sweep's bias / row-vector / gate / residual use waited for the
+        // ---- previous sweep's store round trip -- 11.8 us of epilogue per 256x256 tile (K-scan in profiles/r01 notes).
+#pragma unroll
+        for (int sw = 0; sw < NSW; ++sw) {
+            const int s = sw * ROWS_PER_SWEEP + rsub;
+            const int m = m0 + (s / (RB * 16)) * (TM * 16) + pass * RB * 16 + s % (RB * 16);
+            if (m >= g.M || !n_in) continue;
+            if (g.c_mode == 103) {                  // timing experiment: everything but the global stores
+                if (keep[sw][0].x == 0x12345678u) *reinterpret_cast<uint4*>(g.c) = keep[sw][0];
+            } else if (g.c_mode == OUT_BF16) {
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(g.c) + (int64_t)z * g.c_bs + (int64_t)m * g.c_ld + n) = keep[sw][0];
             } else {
                 float* o = reinterpret_cast<float*>(g.c) + (int64_t)z * g.c_bs + (int64_t)m * g.c_ld + n;
-                *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                *reinterpret_cast<uint4*>(o) = keep[sw][0];
+                *reinterpret_cast<uint4*>(o + 4) = keep[sw][1];
             }
         }
     }

@@ -28,6 +28,7 @@
 #include "ncsnpp_kernels.h"
 #include "gemm_dma.h"
 #include "conv_patch.h"
+#include "gemm_8phase.h"
 #include "attn_fused.h"
 #include "flash_attn.h"
 
@@ -145,11 +146,12 @@ enum GemmVariant {
     V_DMA_512x128 = 13,                                                // 8 waves x (128x64), all 160 KiB of LDS
     V_PATCH_256x256 = 14, V_PATCH_256x128 = 15,                        // 3x3 conv with an LDS-resident input patch
     V_DMA_256x256_P = 16, V_DMA_128x128_P = 17, V_DMA_256x128W4_P = 18,  // two-stage + hand-counted LDS fragment pipeline
+    V_8PH_256x256 = 19, V_8PH_NOPRIO = 20, V_8PH_READFIRST = 21, V_8PH_BOTH = 22,   // phase-interleaved schedule, counted vmcnt (gemm_8phase.h)
     V_COUNT
 };
 const char* variant_name(int v) {
     static const char* n[] = {"auto", "generic128", "dma256x256", "dma256x128", "dma128x128", "ring256x256", "ring256x128",
-                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s", "dma512x128", "patch256x256", "patch256x128", "dma256x256p", "dma128x128p", "dma256x128w4p"};
+                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s", "dma512x128", "patch256x256", "patch256x128", "dma256x256p", "dma128x128p", "dma256x128w4p", "gemm8ph", "gemm8ph_np", "gemm8ph_rf", "gemm8ph_nprf"};
     return v >= 0 && v < V_COUNT ? n[v] : "?";
 }
 int g_force_variant = V_AUTO;      // tuning / tests: force one variant for every DMA-eligible launch
@@ -183,6 +185,7 @@ bool configure_gemm_kernels() {
          set_lds<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>) && set_lds<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>) &&
          set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2>) && set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2>) &&
          set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>) &&
+         set_lds<Cfg8ph>(&k_gemm_8ph<0>) && set_lds<Cfg8ph>(&k_gemm_8ph<1>) && set_lds<Cfg8ph>(&k_gemm_8ph<2>) && set_lds<Cfg8ph>(&k_gemm_8ph<3>) &&
          set_lds<AttnCfg<2, 4>>(&k_attn_fused<2, 4>) && set_lds<AttnCfg<3, 6>>(&k_attn_fused<3, 6>) &&
          set_lds<AttnCfg<3, 5>>(&k_attn_fused<3, 5>) &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess;
@@ -193,6 +196,9 @@ bool configure_gemm_kernels() {
 // Automatic choice: the largest block tile that still gives every CU a tile (DMA kernels need K a multiple of
 // 64 per segment and zero-bordered 3x3 operands); the register-staged, fully masked kernel otherwise (4x4
 // attention: K = 16).
+// k_gemm_8ph has no edge clamping and addresses the 1x1 segment row-linearly
+inline bool eligible_8ph(const GemmArgs& g) { return g.M % 256 == 0 && g.N % 256 == 0; }
+
 int choose_variant(const GemmArgs& g) {
     const int K0 = g.taps * g.a0_C, K1 = g.a1 ? g.a1_C : 0;
     const bool dma = K0 % BK == 0 && K1 % BK == 0 && (g.taps == 1 || (g.a0_padded && g.a0_C % BK == 0));
@@ -200,6 +206,8 @@ int choose_variant(const GemmArgs& g) {
     const bool patch_ok = g.taps == 9 && g.batch == 1 && g.logW >= 3;
     if (g_force_variant == V_PATCH_256x256 || g_force_variant == V_PATCH_256x128) {
         if (patch_ok && (g_force_variant == V_PATCH_256x128 || g.logW >= 4)) return g_force_variant;
+    } else if (g_force_variant >= V_8PH_256x256 && g_force_variant <= V_8PH_BOTH) {
+        if (eligible_8ph(g)) return g_force_variant;
     } else if (g_force_variant > V_GENERIC) return g_force_variant;
     // measured on the engine's layer shapes (tools/bench_gemm.py, profiles/r01): 256x256 two-stage for wide-N,
     // long-K layers; the 4-wave 256x128 ring (wave tile 128x64, 2 blocks/CU) for N = 128 and short-K layers;
@@ -215,7 +223,7 @@ int choose_variant(const GemmArgs& g) {
 int variant_bm(int v) {
     switch (v) {
         case V_DMA_256x256: case V_DMA_256x128: case V_RING_256x256: case V_RING_256x128: case V_RING_256x128_W4: case V_DMA_256x128_W4:
-        case V_DMA_256x256_S: case V_PATCH_256x256: case V_PATCH_256x128: case V_DMA_256x256_P: case V_DMA_256x128W4_P: return 256;
+        case V_DMA_256x256_S: case V_PATCH_256x256: case V_PATCH_256x128: case V_DMA_256x256_P: case V_DMA_256x128W4_P: case V_8PH_256x256: case V_8PH_NOPRIO: case V_8PH_READFIRST: case V_8PH_BOTH: return 256;
         case V_DMA_512x128: return 512;
         case V_RING_64x128: return 64;
         default: return 128;
@@ -254,6 +262,10 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
         case V_DMA_256x256_P: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2>, g, s); break;
         case V_DMA_128x128_P: launch_tiles<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2>, g, s); break;
         case V_DMA_256x128W4_P: launch_tiles<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>, g, s); break;
+        case V_8PH_256x256: launch_tiles<Cfg8ph>(&k_gemm_8ph<0>, g, s); break;
+        case V_8PH_NOPRIO: launch_tiles<Cfg8ph>(&k_gemm_8ph<1>, g, s); break;
+        case V_8PH_READFIRST: launch_tiles<Cfg8ph>(&k_gemm_8ph<2>, g, s); break;
+        case V_8PH_BOTH: launch_tiles<Cfg8ph>(&k_gemm_8ph<3>, g, s); break;
         default: break;
     }
     return variant_bm(v);
@@ -871,7 +883,7 @@ int natinf_debug_gemm(int variant, int M, int N, int K0, int K1, int taps, int l
     if (a1) { g.a1 = (const bf16*)a1; g.a1_C = K1; g.a1_ld = K1; }
     g.M = M; g.N = N; g.b = (const bf16*)b; g.b_ld = K0 + (a1 ? K1 : 0); g.batch = batch;
     if (batch > 1) { g.a_bs = (int64_t)M * g.a0_ld; g.b_bs = (int64_t)N * g.b_ld; g.c_bs = (int64_t)M * N; }
-    g.bias_n = bias_n; g.scale = scale; g.c = c; g.c_ld = N; g.c_mode = c_f32 ? OUT_F32 : OUT_BF16;
+    g.bias_n = bias_n; g.scale = scale; g.c = c; g.c_ld = N; g.c_mode = c_f32 == 1 ? OUT_F32 : (c_f32 >= 2 ? 100 + c_f32 : OUT_BF16);      // >= 2: timing experiments (tools/bench_gemm.py)
     const int saved = g_force_variant;
     g_force_variant = variant;
     for (int i = 0; i < iters; ++i) launch_gemm(g, (hipStream_t)stream);

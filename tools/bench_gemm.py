@@ -7,10 +7,11 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from naturaldiffusion_amd._lib import lib, check, stream_ptr
 
-NAMES = {1: "generic128", 2: "dma256x256", 3: "dma256x128", 4: "dma128x128", 5: "ring256x256", 6: "ring256x128", 7: "ring128x128", 8: "ring64x128", 9: "ring256x128w4", 10: "dma256x128w4", 11: "dma256x256s", 12: "dma128x128s", 13: "dma512x128", 14: "patch256x256", 15: "patch256x128", 16: "dma256x256p", 17: "dma128x128p", 18: "dma256x128w4p"}
+NAMES = {1: "generic128", 2: "dma256x256", 3: "dma256x128", 4: "dma128x128", 5: "ring256x256", 6: "ring256x128", 7: "ring128x128", 8: "ring64x128", 9: "ring256x128w4", 10: "dma256x128w4", 11: "dma256x256s", 12: "dma128x128s", 13: "dma512x128", 14: "patch256x256", 15: "patch256x128", 16: "dma256x256p", 17: "dma128x128p", 18: "dma256x128w4p", 19: "gemm8ph", 20: "gemm8ph_np", 21: "gemm8ph_rf", 22: "gemm8ph_nprf"}
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 
+CMODE = 0
 def run(variant, M, N, K0, K1, taps, res, iters=20, check_ref=False):
     C0 = K0 // taps
     if taps == 9:
@@ -24,7 +25,7 @@ def run(variant, M, N, K0, K1, taps, res, iters=20, check_ref=False):
     b = (torch.randn(N, K0 + K1, device=dev) * 0.05).to(torch.bfloat16)
     c = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     args = lambda it: (variant, M, N, K0, K1, taps, logW, 1, a.data_ptr(), a1.data_ptr() if K1 else None, b.data_ptr(), None,
-                       c.data_ptr(), 0, 1.0, it, stream_ptr())
+                       c.data_ptr(), CMODE, 1.0, it, stream_ptr())
     check(lib.natinf_debug_gemm(*args(3)), "debug_gemm")
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -72,10 +73,37 @@ SHAPES = [  # (M, N, K0, K1, taps, res)  -- B=512 layer shapes, largest time fir
 ]
 if __name__ != "__main__":
     SHAPES = []
+if len(sys.argv) > 1 and sys.argv[1] == "8ph":
+    # correctness of the 256x256 variants on 256-aligned shapes (many repeats: the schedule is race-prone by nature), then speed
+    vs = [16, 19, 20, 21, 22]
+    for v in vs:
+        for rep in range(1):
+            errs = [run(v, 1024, 512, 256, 128, 1, 0, iters=2, check_ref=True)[2], run(v, 2048, 256, 1536, 0, 1, 0, iters=2, check_ref=True)[2],
+                    run(v, 512, 768, 64, 0, 1, 0, iters=2, check_ref=True)[2], run(v, 256, 256, 128, 64, 1, 0, iters=2, check_ref=True)[2]]
+            cerr = [check_conv(v, *c) for c in ((4, 16, 256, 256, 128), (8, 8, 128, 256, 64), (1, 32, 192, 256, 64), (2, 32, 64, 512, 0))]
+            print(f"check {NAMES[v]:>12}: gemm " + " ".join(f"{e:.1e}" for e in errs) + " | conv " + " ".join(f"{e:.1e}" for e in cerr), flush=True)
+    shapes = [(131072, 256, 2304, 0, 9, 16), (131072, 256, 4608, 0, 9, 16), (524288, 256, 2304, 256, 9, 32), (32768, 256, 2304, 0, 9, 8),
+              (32768, 1536, 1536, 0, 1, 0), (32768, 6144, 1536, 0, 1, 0), (32768, 1536, 6144, 0, 1, 0), (32768, 3072, 1536, 0, 1, 0),
+              (8192, 8192, 8192, 0, 1, 0), (4096, 4096, 4096, 0, 1, 0)]
+    print(f"{'shape':>34} " + " ".join(f"{NAMES[v]:>12}" for v in vs))
+    for (M, N, K0, K1, taps, res) in shapes:
+        cells = [f"{run(v, M, N, K0, K1, taps, res, iters=10)[1]:7.0f}TF/s" for v in vs]
+        print(f"{str((M, N, K0 + K1, taps)):>34} " + " ".join(f"{c:>12}" for c in cells), flush=True)
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "sd3":
+    vs = [int(v) for v in sys.argv[2:]] or [9, 10, 18, 16, 19, 13]
+    shapes = [(32768, 1536, 1536, 0, 1, 0), (32768, 3072, 1536, 0, 1, 0), (32768, 6144, 1536, 0, 1, 0), (32768, 1536, 6144, 0, 1, 0),
+              (65536, 1152, 1152, 0, 1, 0), (65536, 4608, 1152, 0, 1, 0), (65536, 1152, 4608, 0, 1, 0)]
+    print(f"{'shape':>34} " + " ".join(f"{NAMES[v]:>13}" for v in vs))
+    for (M, N, K0, K1, taps, res) in shapes:
+        cells = [f"{run(v, M, N, K0, K1, taps, res, iters=10)[1]:7.0f}TF/s" for v in vs]
+        print(f"{str((M, N, K0 + K1, taps)):>34} " + " ".join(f"{c:>13}" for c in cells), flush=True)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "one":
     # bench_gemm.py one <variant> <M> <N> <K0> <K1> <taps> <res> [iters]
     v, M, N, K0, K1, taps, res = map(int, sys.argv[2:9])
     it = int(sys.argv[9]) if len(sys.argv) > 9 else 5
+    CMODE = int(sys.argv[10]) if len(sys.argv) > 10 else 0
     ms, tf, _ = run(v, M, N, K0, K1, taps, res, iters=it)
     print(f"{NAMES[v]} {(M, N, K0 + K1, taps)}: {ms*1e3:.1f} us  {tf:.0f} TF/s")
     sys.exit(0)
