@@ -56,6 +56,8 @@ struct GemmArgs {
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// v_rcp_f32 instead of the IEEE division sequence (1 ulp; the result is rounded to bf16 right after)
+__device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 __device__ __forceinline__ float gelu_tanh_f(float v) {             // nn.GELU(approximate="tanh")
     const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
     const float e = __expf(2.0f * u);                               // tanh(u) = 1 - 2/(e^{2u}+1)
@@ -413,6 +415,9 @@ __global__ __launch_bounds__(256) void k_gn_finalize(const float2* __restrict__ 
 // xr (raw input at the output resolution, feeds the 1x1 shortcut) is never padded.
 enum { RS_NONE = 0, RS_UP = 1, RS_DOWN = 2 };
 constexpr int GN_ROWS = 4;
+#ifndef GN_UNROLL
+#define GN_UNROLL 4
+#endif
 __global__ __launch_bounds__(256) void k_gn_apply(const bf16* __restrict__ x, int ld, int C, int logW, int logHW,
                                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                                   bf16* __restrict__ y, bf16* __restrict__ xr, int act, int mode, int pad)
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const bf16* __restrict__ x, in
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 float f = (float)v[q] * sc[q] + sh[q];
-                if (act == ACT_SILU) f = silu_f(f);
+                if (act == ACT_SILU) f = silu_fast(f);
                 o[q] = (bf16)f;
             }
             if (xrb) *reinterpret_cast<bf16x8*>(xrb + ((int64_t)(row0 + r - pad) * Wd + (c - pad)) * C) = v;
@@ -465,16 +470,22 @@ __global__ __launch_bounds__(256) void k_gn_apply(const bf16* __restrict__ x, in
     };
     if (mode != RS_DOWN) {
         const int sh_ = mode == RS_UP ? 1 : 0;
+        constexpr int U = GN_UNROLL;                   // independent 16-byte loads in flight per thread
         while (rr < nrows) {
-            int r1 = rr, c1 = xx;
-            advance(r1, c1);
-            const bool in0 = interior(rr, xx), in1 = interior(r1, c1);
-            bf16x8 v0, v1;
-            if (in0) v0 = *reinterpret_cast<const bf16x8*>(xb + ((int64_t)((row0 + rr - pad) >> sh_) * Ws + ((xx - pad) >> sh_)) * ld);
-            if (in1) v1 = *reinterpret_cast<const bf16x8*>(xb + ((int64_t)((row0 + r1 - pad) >> sh_) * Ws + ((c1 - pad) >> sh_)) * ld);
-            finish(rr, xx, in0, v0);
-            finish(r1, c1, in1, v1);
-            rr = r1; xx = c1;
+            int r[U], c[U];
+            bool in[U];
+            bf16x8 v[U];
+            r[0] = rr; c[0] = xx;
+#pragma unroll
+            for (int u = 1; u < U; ++u) { r[u] = r[u - 1]; c[u] = c[u - 1]; advance(r[u], c[u]); }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                in[u] = interior(r[u], c[u]);
+                if (in[u]) v[u] = *reinterpret_cast<const bf16x8*>(xb + ((int64_t)((row0 + r[u] - pad) >> sh_) * Ws + ((c[u] - pad) >> sh_)) * ld);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) finish(r[u], c[u], in[u], v[u]);
+            rr = r[U - 1]; xx = c[U - 1];
             advance(rr, xx);
         }
         return;
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const bf16* __restrict__ x, in
                 for (int q = 0; q < 8; ++q) {
                     const float raw = (float)v[q];
                     float f = raw * sc[q] + sh[q];
-                    if (act == ACT_SILU) f = silu_f(f);
+                    if (act == ACT_SILU) f = silu_fast(f);
                     ay[q] += f; ax[q] += raw;
                 }
             }
