@@ -126,7 +126,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_conv_patch(const GemmArgs g
                 const bf16x8 fa = *reinterpret_cast<const bf16x8*>(pa + r * LDS_ROW + ((((ks << 2) | fq) ^ ((r >> 1) & 7)) << 3));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[i][j], 0, 0, 0);
             }
         }
     };

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(512) void k_gemm_8ph(const GemmArgs g)
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                           \
                     acc[IH * 4 + i][JH * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                              \
-                        __builtin_bit_cast(bf16x8, fa[ks][i]), __builtin_bit_cast(bf16x8, fb[JH][ks][j]), acc[IH * 4 + i][JH * 2 + j], 0, 0, 0); \
+                        __builtin_bit_cast(bf16x8, fb[JH][ks][j]), __builtin_bit_cast(bf16x8, fa[ks][i]), acc[IH * 4 + i][JH * 2 + j], 0, 0, 0); \
         if (!(FLAGS & 1)) __builtin_amdgcn_s_setprio(0);                                                                \
         phase_barrier();                                                                                                \
     }

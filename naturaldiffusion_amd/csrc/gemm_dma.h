@@ -56,6 +56,12 @@ struct DmaCfg {
     static_assert(BM_ % (8 * NW) == 0 && BN_ % (8 * NW) == 0, "DMA pieces must divide evenly over the waves");
 };
 
+// The main loops multiply with the operands SWAPPED (mfma(B fragment, A fragment)): a lane then holds four consecutive
+// output columns of one row, and the slab below is filled with 16-byte LDS writes (a quarter of the ds_write count).
+// (A register-only epilogue on this layout -- column terms hoisted, 8/16-byte stores straight from the accumulators or
+// through a wave-private bf16 transpose -- was built and measured: +13 % on an isolated K = 1536 GEMM, but 3 % SLOWER end
+// to end in same-box A/B runs (1,890 vs 1,950 images/s; SD3 1.57 vs 1.60), and hipcc spills the 128-register tile on
+// every run-time branch that touches it.  Not kept.)
 // Epilogue shared by the DMA kernels: in TM/RB passes, RB row-tiles of every wave -> LDS (fp32) -> fused adds
 // (bias, per-sample row vector, residual, scale, SiLU) in fp32 -> 16-byte coalesced stores.
 template <int WM, int WN, int TM, int TN, class Cfg>
@@ -96,10 +102,8 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
 #pragma unroll
         for (int ii = 0; ii < RB; ++ii)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    sC[(wm * RB * 16 + ii * 16 + (lane >> 4) * 4 + r) * CROW + wn * TN * 16 + j * 16 + (lane & 15)] = acc[pass * RB + ii][j][r];
+            for (int j = 0; j < TN; ++j)       // swapped-operand accumulators: a lane holds 4 consecutive columns of row (lane & 15)
+                *reinterpret_cast<f32x4*>(sC + (wm * RB * 16 + ii * 16 + (lane & 15)) * CROW + wn * TN * 16 + j * 16 + (lane >> 4) * 4) = acc[pass * RB + ii][j];
         __syncthreads();
         // slab row s  <->  tile row  (s / (RB*16)) * TM*16 + pass*RB*16 + s % (RB*16)
         if (g.c_mode == OUT_F32_NCHW) {
@@ -246,8 +250,8 @@ struct PipeStep {
         wait_lgkmcnt<pipe_lgkm_after(TM, ST)>();
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[ST % 3]),
-                                                                __builtin_bit_cast(bf16x8, fb[ks][j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[ks][j]),
+                                                                __builtin_bit_cast(bf16x8, fa[ST % 3]), acc[i][j], 0, 0, 0);
         if constexpr (ST + 1 < S) PipeStep<TM, ST + 1>::run(fa, fb, acc, a0, a1, b1);
     }
 };
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
                     const bf16x8 fa = *reinterpret_cast<const bf16x8*>(ta + i * 16 * LDS_ROW + ko);
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[i][j], 0, 0, 0);
                     if (SPREAD == 1) {
                         const int slot = ks * TM + i;
                         if (more && slot % STEP == 0 && slot / STEP < NP) issue_piece(slot / STEP);
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_ring(const GemmArgs g)
             const bf16x8 fa = *reinterpret_cast<const bf16x8*>(ta + i * 16 * ROW);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[i][j], 0, 0, 0);
         }
 #if NATINF_SETPRIO
         __builtin_amdgcn_s_setprio(0);
