@@ -138,6 +138,23 @@ def calc_fid(imgs, ref_path, device):
     return calculate_frechet_distance(ref["mu"], ref["sigma"], np.mean(act, axis=0), np.cov(act, rowvar=False))
 
 
+def calc_fid_sharded(imgs, ref_path, device, group=None):
+    """``calc_fid`` for a batch-sharded run: every rank scores ITS images, the (count, sum, outer-product sum) statistics
+    are summed over ranks with one all-reduce (fid_stats.ActivationStats), and every rank returns the same FID."""
+    from pytorch_fid.inception import InceptionV3
+    from .fid_stats import ActivationStats, frechet_distance
+    model = InceptionV3([InceptionV3.BLOCK_INDEX_BY_DIM[2048]]).to(device).eval()
+    st = ActivationStats(2048, device=device)
+    with torch.no_grad():
+        for i in range(0, len(imgs), 50):
+            b = imgs[i:i + 50].to(dtype=torch.float32, device=device) / 255
+            st.update(model(b.permute(0, 3, 1, 2))[0].squeeze(3).squeeze(2))
+    st.all_reduce(group)
+    mu, cov = st.mean_cov()
+    ref = np.load(ref_path)
+    return frechet_distance(ref["mu"], ref["sigma"], mu, cov)
+
+
 @torch.no_grad()
 def natural_inference_tx(batch_size: int = 500,
                          ckpt_filename: Optional[str] = None,

@@ -1,0 +1,58 @@
+"""FID statistics epilogue (naturaldiffusion_amd/fid_stats.py): sharded sufficient statistics + Frechet distance."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from naturaldiffusion_amd.fid_stats import ActivationStats, frechet_distance
+
+
+def test_stats_match_numpy_mean_and_cov():
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(500, 24, generator=g) * 3 + 1
+    st = ActivationStats(24)
+    for i in range(0, 500, 50):                        # the reference feeds Inception in batches of 50 (:47)
+        st.update(a[i:i + 50])
+    mu, cov = st.mean_cov()
+    assert np.allclose(mu, np.mean(a.double().numpy(), axis=0), atol=1e-12)
+    assert np.allclose(cov, np.cov(a.double().numpy(), rowvar=False), atol=1e-10)
+
+
+def test_frechet_distance_closed_forms():
+    mu = np.array([1.0, -2.0, 0.5])
+    s = np.diag([1.0, 4.0, 0.25])
+    assert abs(frechet_distance(mu, s, mu, s)) < 1e-9
+    # commuting (diagonal) covariances: sum (sqrt(a) - sqrt(b))^2 + |dmu|^2
+    s2 = np.diag([4.0, 1.0, 0.25])
+    mu2 = mu + np.array([0.0, 3.0, 4.0])
+    want = 25.0 + (1 - 2) ** 2 + (2 - 1) ** 2
+    assert abs(frechet_distance(mu, s, mu2, s2) - want) < 1e-8
+    # symmetric in its arguments, also for non-commuting matrices
+    r = np.random.RandomState(1)
+    a, b = r.randn(6, 6), r.randn(6, 6)
+    A, B = a @ a.T + np.eye(6), b @ b.T + np.eye(6)
+    assert abs(frechet_distance(mu[:1].repeat(6), A, mu[:1].repeat(6), B) - frechet_distance(mu[:1].repeat(6), B, mu[:1].repeat(6), A)) < 1e-8
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(5)
+    acts = torch.randn(400, 16, generator=g)                       # every rank can rebuild the full set
+    st = ActivationStats(16)
+    st.update(acts[rank::world])                                    # rank r owns images r, r+W, ... (shard.py)
+    st.all_reduce()
+    mu, cov = st.mean_cov()
+    if rank == 0:
+        np.savez(out, mu=mu, cov=cov, full_mu=np.mean(acts.double().numpy(), 0), full_cov=np.cov(acts.double().numpy(), rowvar=False))
+    dist.destroy_process_group()
+
+
+def test_sharded_statistics_equal_the_unsharded_ones(tmp_path):
+    out = str(tmp_path / "fid.npz")
+    mp.spawn(_worker, args=(2, 29641, out), nprocs=2, join=True)
+    r = np.load(out)
+    assert np.allclose(r["mu"], r["full_mu"], atol=1e-12) and np.allclose(r["cov"], r["full_cov"], atol=1e-10)
