@@ -20,8 +20,8 @@ here (SURVEY.md section 8f N1, and the DDIM matrix BASELINE config 3 needs on th
   :func:`dpmsolver_singlestep` (DPM-Solver-2/-3, DPM-Solver++(2S)/(3S); src/AnalyzeDPMSolver.py),
   :func:`vp_euler` (ODE and SDE), :func:`vp_heun` (src/AnalyzeEulerHeun.py), :func:`flow_euler`
   (src/AnalyzeFlowMatching.py), :func:`ddpm_discrete` (src/AnalyzeDDPMDDIM.py) -- each regression-tested against the
-  shipped ``results/**/*.npz`` to 1e-12 (tests/test_coeffgen.py).  Not covered: tAB-DEIS (src/AnalyzeDEIS.py needs
-  ``th_deis``'s jax quadrature).
+  shipped ``results/**/*.npz`` to 1e-12 (tests/test_coeffgen.py); :func:`deis_tab` (tAB-DEIS, src/AnalyzeDEIS.py +
+  deps/th_deis/multistep.py, without jax) to the float32 accuracy of the shipped file.
 Files written here load through the same positional reader as the shipped ones."""
 from __future__ import annotations
 
@@ -332,4 +332,45 @@ def ddpm_discrete(num_step: int):
         x = c_xt[lvl] * x + c_x0[lvl] * tr.new_y() + std[lvl] * tr.new_eps()
         a = np.sqrt(abar[lvl - 1]) if lvl > 0 else 1.0
         tr.record(idx[lvl - 1] if lvl > 0 else -1, a, np.sqrt(1.0 - a ** 2), x)
+    return tr.matrices()
+
+
+def deis_tab(num_step: int, order: int = 3, t_end: float = 1e-3, t_start: float = 1.0, n_quad: int = 10000,
+             beta_0: float = 0.1, beta_1: float = 20.0):
+    """tAB-DEIS (Zhang & Chen 2022; src/AnalyzeDEIS.py with deps/th_deis/multistep.py:6-97): exponential integrator with the
+    noise prediction extrapolated by the Lagrange polynomial through the last ``order+1`` evaluations,
+
+        x_{i+1} = Psi(t_i, t_{i+1}) x_i + sum_j C_ij eps_hat_{i-j} ,
+        C_ij = int_{t_i}^{t_{i+1}} Psi(tau, t_{i+1}) * (-1/2 dlog(abar)/dtau / sqrt(1 - abar(tau))) * L_j(tau) dtau ,
+
+    on the quadratic time grid t_i = (sqrt(T) + i/N (sqrt(eps) - sqrt(T)))^2, order ramping 0, 1, .. over the first steps.
+    The integral is taken as th_deis takes it -- a left Riemann sum over ``n_quad`` points -- but in float64 (th_deis runs
+    jax's float32), so the shipped ``results/deis/deis_tab_*.npz`` are reproduced to ~1e-5, not to rounding."""
+    def log_abar(t):
+        return -0.5 * t ** 2 * (beta_1 - beta_0) - t * beta_0
+    ts = np.linspace(np.sqrt(t_start), np.sqrt(t_end), num_step + 1) ** 2
+    tr = LinearTrace(num_step)
+    x = tr.new_eps()
+    tr.record(ts[0], *vp_alpha_sigma(ts[0], beta_0, beta_1), x)
+    hist = []                                               # predicted noises, newest first
+    for i in range(num_step):
+        t0, t1 = ts[i], ts[i + 1]
+        al, sg = vp_alpha_sigma(t0, beta_0, beta_1)
+        hist.insert(0, (x - al * tr.new_y()) / sg)
+        o = min(i, order)
+        nodes = ts[i - o:i + 1]
+        tau = np.linspace(t0, t1, n_quad, endpoint=False)
+        dt = (t1 - t0) / n_quad
+        w = np.exp(0.5 * (log_abar(t1) - log_abar(tau))) * (0.5 * (tau * (beta_1 - beta_0) + beta_0) / np.sqrt(1.0 - np.exp(log_abar(tau))))
+        xn = np.exp(0.5 * (log_abar(t1) - log_abar(t0))) * x
+        for j in range(o + 1):                              # j = 0: the newest evaluation (node t_i)
+            idx = o - j
+            L = np.ones_like(tau)
+            for k in range(o + 1):
+                if k != idx:
+                    L *= (tau - nodes[k]) / (nodes[idx] - nodes[k])
+            xn = xn + np.sum(w * L) * dt * hist[j]
+        x = xn
+        hist = hist[:order]
+        tr.record(t1, *vp_alpha_sigma(t1, beta_0, beta_1), x)
     return tr.matrices()

@@ -99,3 +99,15 @@ def test_published_dpmsolverpp3s_differs_from_the_reference_variant_and_is_more_
     Cp, _, _ = G.dpmsolver_singlestep(6, 3, data_prediction=True, reference_sign=False)
     assert np.abs(Cq - Cp).max() > 1e-3
     assert np.allclose(Cq.sum(1), Cp.sum(1), atol=1e-12)        # constant prediction: identical (difference terms vanish)
+
+
+def test_deis_tab_reproduces_shipped_matrix(repo_root):
+    """tAB-DEIS: th_deis integrates in jax float32, so agreement with the shipped file is ~1e-5, and exact on the shipped
+    3-decimal CSVs of the step counts that have no .npz."""
+    import pandas as pd
+    _close(repo_root, "results/deis/deis_tab_100.npz", G.deis_tab(100), tol=2e-5)
+    for n in (18, 24):
+        df = pd.read_csv(repo_root / f"results/deis/deis_tab_{n:03d}.csv", index_col=0)
+        C, _, _ = G.deis_tab(n)
+        assert np.array_equal(C.round(3), df.to_numpy()[:, :n])
+        assert np.allclose(C.sum(1).round(3), df["sum"].to_numpy(), atol=1.1e-3)
