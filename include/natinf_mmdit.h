@@ -25,10 +25,15 @@ extern "C" {
 
 typedef struct natinf_mmdit* natinf_mmdit_t;
 
+/* flags.  NATINF_MMDIT_FP8: the image-stream q|k, v and fc1 projections (7/12 of the image-stream GEMM flops) run on fp8 e4m3
+ * operands -- activations quantised per token by the LayerNorm-modulate kernel, weights per output channel at load time,
+ * fp32 accumulation, scales applied in the epilogue (BASELINE config 5); needs an even head count (hidden % 128 == 0). */
+#define NATINF_MMDIT_FP8 1
+
 /* grid = image tokens per side (latent side / 2), grid*grid % 8 == 0; ctx_tokens = text tokens per sequence;
  * hidden = 64*heads <= 1536; joint_dim % 8 == 0, pooled_dim % 8 == 0. */
 int natinf_mmdit_create(natinf_mmdit_t* out, int layers, int heads, int joint_dim, int pooled_dim, int in_ch, int grid,
-                        int ctx_tokens);
+                        int ctx_tokens, int flags);
 int natinf_mmdit_destroy(natinf_mmdit_t h);
 int64_t natinf_mmdit_param_count(natinf_mmdit_t h);
 int64_t natinf_mmdit_packed_bytes(natinf_mmdit_t h);

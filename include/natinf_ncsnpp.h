@@ -73,6 +73,12 @@ int natinf_ncsnpp_describe_gemms(natinf_ncsnpp_t h, int B, char* buf, int cap);
 int natinf_debug_gemm(int variant, int M, int N, int K0, int K1, int taps, int logW, int batch,
                       const void* a0, const void* a1, const void* b, const float* bias_n, void* c, int c_f32, float scale,
                       int iters, natinf_stream_t stream);
+/* fp8 (e4m3) GEMM of the transformer engines, on its own (tests / micro-benchmarks): c = (a_scale[m] * b_scale[n]) * a8 b8^T
+ * (+ bias_n); a8 [M][K], b8 [N][K] fp8 bytes with one fp32 scale per row, K % 128 == 0, N % 8 == 0.
+ * natinf_debug_quant_fp8_rows produces such a pair from fp32 rows: scale = max|row| / 448, q = e4m3(row / scale). */
+int natinf_debug_quant_fp8_rows(const float* w, void* q, float* row_scale, int rows, int cols, natinf_stream_t stream);
+int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_scale, const void* b8, const float* b_scale,
+                          const float* bias_n, void* c, int c_f32, int iters, natinf_stream_t stream);
 int natinf_set_gemm_variant(int variant);
 
 /* Measurement hooks (bench.py): while enabled, every launch group of a forward is bracketed by a HIP event

@@ -94,6 +94,15 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
         const float4 u = *reinterpret_cast<const float4*>(g.bias_n + n), w = *reinterpret_cast<const float4*>(g.bias_n + n + 4);
         bn[0] = u.x; bn[1] = u.y; bn[2] = u.z; bn[3] = u.w; bn[4] = w.x; bn[5] = w.y; bn[6] = w.z; bn[7] = w.w;
     }
+    float dn[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dn[q] = 1.f;
+    if (g.deq_n && n_in) {
+        const float* pd = g.deq_n + (int64_t)z * g.deq_n_bs + n;
+        const float4 u = *reinterpret_cast<const float4*>(pd), w = *reinterpret_cast<const float4*>(pd + 4);
+        dn[0] = u.x; dn[1] = u.y; dn[2] = u.z; dn[3] = u.w; dn[4] = w.x; dn[5] = w.y; dn[6] = w.z; dn[7] = w.w;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(dn[0]), "+v"(dn[1]), "+v"(dn[2]), "+v"(dn[3]), "+v"(dn[4]), "+v"(dn[5]), "+v"(dn[6]), "+v"(dn[7]));
     // the bias is waited for here, once, and handed on as asm outputs: hipcc then attaches no pending load to bn[]
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3]), "+v"(bn[4]), "+v"(bn[5]), "+v"(bn[6]), "+v"(bn[7]));
 #pragma unroll
@@ -130,6 +139,11 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
             const float4 u = *reinterpret_cast<const float4*>(sC + s * CROW + cchunk * 8);
             const float4 w = *reinterpret_cast<const float4*>(sC + s * CROW + cchunk * 8 + 4);
             float v[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+            if (g.deq_m || g.deq_n) {
+                const float dm = g.deq_m ? g.deq_m[(int64_t)z * g.deq_m_bs + m] : 1.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] *= dm * dn[q];
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] += bn[q];
             if (g.bias_m) {

@@ -1,0 +1,158 @@
+// gemm_fp8.h -- 256x256x128 LDS-DMA GEMM on fp8 (e4m3) operands: k_gemm_fp8.
+//
+// C[m][n] = deq_m[m] * deq_n[n] * sum_k A8[m][k] * B8[n][k]  (+ the usual epilogue terms), A8 / B8 row-major fp8 bytes
+// with one fp32 scale per row (activations: per token, written by k_ln_modulate_fp8; weights: per output channel, written
+// at load time).  A K-tile is 128 bytes per row -- the SAME LDS image, DMA pieces and swizzle as the bf16 kernel's 64-wide
+// tiles -- but it feeds v_mfma_f32_16x16x128_f8f6f4 (a lane supplies 32 consecutive K bytes of its row: two 16-byte LDS
+// reads), which does four times the K of the bf16 MFMA in twice its time: twice the flops per byte moved and per cycle.
+// Unit block scales in the MFMA (127 = 2^0); the real scales are applied once, in the epilogue.
+// Two-stage pipeline like k_gemm_dma<2,4,8,4> (one K-tile of prefetch, explicit vmcnt(0) + barrier per K-tile), swapped
+// operands, slab epilogue.  Plain GEMMs only (taps = 1, one K segment); K % 128 == 0; M / N edges clamped.
+#pragma once
+#include "gemm_dma.h"
+
+namespace ncsn {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(512, 2) void k_gemm_fp8(const GemmArgs g)
+{
+    using Cfg = DmaCfg<2, 4, 8, 4>;
+    constexpr int WN = 4, TM = 8, TN = 4, BM_ = 256, BN_ = 256, BKB = 128;       // BKB: K bytes (= elements) per tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nN = (g.N + BN_ - 1) / BN_, nM = (g.M + BM_ - 1) / BM_;
+    const int tile = xcd_remap(blockIdx.x, nM * nN);
+    const int m0 = (tile / nN) * BM_, n0 = (tile % nN) * BN_;
+    const int z = blockIdx.z;
+    const uint8_t* a0 = reinterpret_cast<const uint8_t*>(g.a0) + (int64_t)z * g.a_bs;     // strides in bytes = elements
+    const uint8_t* bp = reinterpret_cast<const uint8_t*>(g.b) + (int64_t)z * g.b_bs;
+    const int nk = g.a0_C / BKB;
+
+    uint64_t a_row[Cfg::PA], b_row[Cfg::PB];
+#pragma unroll
+    for (int j = 0; j < Cfg::PA; ++j) {
+        const int r = (wave * Cfg::PA + j) * 8 + (lane >> 3);
+        a_row[j] = reinterpret_cast<uint64_t>(a0 + (int64_t)min(m0 + r, g.M - 1) * g.a0_ld + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < Cfg::PB; ++j) {
+        const int r = (wave * Cfg::PB + j) * 8 + (lane >> 3);
+        b_row[j] = reinterpret_cast<uint64_t>(bp + (int64_t)min(n0 + r, g.N - 1) * g.b_ld + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
+    }
+    auto issue_tile = [&](int kt, int buf) __attribute__((always_inline)) {
+        unsigned char* dA = smem + buf * Cfg::STAGE_BYTES + wave * (Cfg::PA * 1024);
+        unsigned char* dB = smem + buf * Cfg::STAGE_BYTES + BM_ * 128 + wave * (Cfg::PB * 1024);
+#pragma unroll
+        for (int j = 0; j < Cfg::PA; ++j)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(a_row[j] + (uint64_t)kt * BKB), (lds_void*)(dA + j * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < Cfg::PB; ++j)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(b_row[j] + (uint64_t)kt * BKB), (lds_void*)(dB + j * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int frow = lane & 15, fq = lane >> 4, fswz = (frow >> 1) & 7;
+    const int c0 = ((2 * fq) ^ fswz) << 4, c1 = ((2 * fq + 1) ^ fswz) << 4;              // the lane's two 16-byte chunks of a row
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue_tile(kt + 1, cur ^ 1);
+        const unsigned char* ta = smem + cur * Cfg::STAGE_BYTES + (wm * TM * 16 + frow) * 128;
+        const unsigned char* tb = smem + cur * Cfg::STAGE_BYTES + BM_ * 128 + (wn * TN * 16 + frow) * 128;
+        i32x8 fb[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const uint4 lo = *reinterpret_cast<const uint4*>(tb + j * 2048 + c0), hi = *reinterpret_cast<const uint4*>(tb + j * 2048 + c1);
+            fb[j] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const uint4 lo = *reinterpret_cast<const uint4*>(ta + i * 2048 + c0), hi = *reinterpret_cast<const uint4*>(ta + i * 2048 + c1);
+            const i32x8 fa = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa, acc[i][j], 0, 0, 0, 127, 0, 127);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    dma_tile_epilogue<2, 4, 8, 4, typename Cfg::Epi>(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
+}
+
+// x fp32 [rows][D] -> LayerNorm (no affine, eps 1e-6), (1 + scale) / shift modulation, then fp8 e4m3 with one scale per row:
+// q = round(v / s), s = max|v| / 448 (the e4m3 maximum; values are clamped, v_cvt_pk_fp8_f32 does not saturate)
+__global__ __launch_bounds__(256) void k_ln_modulate_fp8(const float* __restrict__ x, const float* __restrict__ shift,
+                                                         const float* __restrict__ scale, int mod_ld, uint8_t* __restrict__ h,
+                                                         float* __restrict__ row_scale, int D, int64_t rows, int rows_per_sample)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    float v[24];                                                    // D <= 1536, D % 128 == 0: two adjacent columns per lane and step
+    const int n = D >> 6;
+    float s = 0.f;
+    for (int i = 0; i < n; i += 2) {
+        const float2 u = *reinterpret_cast<const float2*>(xr + 64 * i + 2 * lane);
+        v[i] = u.x; v[i + 1] = u.y; s += u.x + u.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)D;
+    float qq = 0.f;
+    for (int i = 0; i < n; ++i) { const float d = v[i] - mean; qq += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o);
+    const float rstd = 1.0f / sqrtf(qq / (float)D + 1e-6f);
+    const int64_t b = row / rows_per_sample;
+    const float* sh = shift + b * mod_ld; const float* sc = scale + b * mod_ld;
+    float amax = 0.f;
+    for (int i = 0; i < n; i += 2) {
+        const int d = 64 * i + 2 * lane;
+        v[i] = (v[i] - mean) * rstd * (1.0f + sc[d]) + sh[d];
+        v[i + 1] = (v[i + 1] - mean) * rstd * (1.0f + sc[d + 1]) + sh[d + 1];
+        amax = fmaxf(amax, fmaxf(fabsf(v[i]), fabsf(v[i + 1])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const float qs = amax > 0.f ? amax / 448.0f : 1.0f, inv = 1.0f / qs;
+    if (lane == 0) row_scale[row] = qs;
+    for (int i = 0; i < n; i += 2) {
+        const float a = fminf(fmaxf(v[i] * inv, -448.f), 448.f), c = fminf(fmaxf(v[i + 1] * inv, -448.f), 448.f);
+        const int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, c, 0, false);
+        *reinterpret_cast<uint16_t*>(h + row * D + 64 * i + 2 * lane) = (uint16_t)(w & 0xffff);
+    }
+}
+
+// weights: W fp32 [N][K] -> fp8 bytes [N][K] + one scale per output channel
+__global__ __launch_bounds__(256) void k_pack_fp8_rows(const float* __restrict__ W, uint8_t* __restrict__ q, float* __restrict__ row_scale, int N, int K)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float* w = W + (int64_t)row * K;
+    float amax = 0.f;
+    for (int k = lane; k < K; k += 64) amax = fmaxf(amax, fabsf(w[k]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const float qs = amax > 0.f ? amax / 448.0f : 1.0f, inv = 1.0f / qs;
+    if (lane == 0) row_scale[row] = qs;
+    for (int k = 2 * lane; k < K; k += 128) {
+        const float a = fminf(fmaxf(w[k] * inv, -448.f), 448.f), c = fminf(fmaxf(w[k + 1] * inv, -448.f), 448.f);
+        *reinterpret_cast<uint16_t*>(q + (int64_t)row * K + k) = (uint16_t)(__builtin_amdgcn_cvt_pk_fp8_f32(a, c, 0, false) & 0xffff);
+    }
+}
+
+}  // namespace ncsn

@@ -29,6 +29,7 @@
 #include "gemm_dma.h"
 #include "conv_patch.h"
 #include "gemm_8phase.h"
+#include "gemm_fp8.h"
 #include "attn_fused.h"
 #include "flash_attn.h"
 
@@ -147,11 +148,12 @@ enum GemmVariant {
     V_PATCH_256x256 = 14, V_PATCH_256x128 = 15,                        // 3x3 conv with an LDS-resident input patch
     V_DMA_256x256_P = 16, V_DMA_128x128_P = 17, V_DMA_256x128W4_P = 18,  // two-stage + hand-counted LDS fragment pipeline
     V_8PH_256x256 = 19, V_8PH_NOPRIO = 20, V_8PH_READFIRST = 21, V_8PH_BOTH = 22,   // phase-interleaved schedule, counted vmcnt (gemm_8phase.h)
+    V_FP8_256x256 = 23,                                                 // fp8 e4m3 operands (gemm_fp8.h); selected by GemmArgs::deq_m/deq_n callers only
     V_COUNT
 };
 const char* variant_name(int v) {
     static const char* n[] = {"auto", "generic128", "dma256x256", "dma256x128", "dma128x128", "ring256x256", "ring256x128",
-                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s", "dma512x128", "patch256x256", "patch256x128", "dma256x256p", "dma128x128p", "dma256x128w4p", "gemm8ph", "gemm8ph_np", "gemm8ph_rf", "gemm8ph_nprf"};
+                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s", "dma512x128", "patch256x256", "patch256x128", "dma256x256p", "dma128x128p", "dma256x128w4p", "gemm8ph", "gemm8ph_np", "gemm8ph_rf", "gemm8ph_nprf", "fp8_256x256"};
     return v >= 0 && v < V_COUNT ? n[v] : "?";
 }
 int g_force_variant = V_AUTO;      // tuning / tests: force one variant for every DMA-eligible launch
@@ -185,6 +187,7 @@ bool configure_gemm_kernels() {
          set_lds<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>) && set_lds<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>) &&
          set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2>) && set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2>) &&
          set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>) &&
+         set_lds<CfgD256x256>(&k_gemm_fp8) &&
          set_lds<Cfg8ph>(&k_gemm_8ph<0>) && set_lds<Cfg8ph>(&k_gemm_8ph<1>) && set_lds<Cfg8ph>(&k_gemm_8ph<2>) && set_lds<Cfg8ph>(&k_gemm_8ph<3>) &&
          set_lds<AttnCfg<2, 4>>(&k_attn_fused<2, 4>) && set_lds<AttnCfg<3, 6>>(&k_attn_fused<3, 6>) &&
          set_lds<AttnCfg<3, 5>>(&k_attn_fused<3, 5>) &&
@@ -223,12 +226,15 @@ int choose_variant(const GemmArgs& g) {
 int variant_bm(int v) {
     switch (v) {
         case V_DMA_256x256: case V_DMA_256x128: case V_RING_256x256: case V_RING_256x128: case V_RING_256x128_W4: case V_DMA_256x128_W4:
-        case V_DMA_256x256_S: case V_PATCH_256x256: case V_PATCH_256x128: case V_DMA_256x256_P: case V_DMA_256x128W4_P: case V_8PH_256x256: case V_8PH_NOPRIO: case V_8PH_READFIRST: case V_8PH_BOTH: return 256;
+        case V_DMA_256x256_S: case V_PATCH_256x256: case V_PATCH_256x128: case V_DMA_256x256_P: case V_DMA_256x128W4_P: case V_8PH_256x256: case V_8PH_NOPRIO: case V_8PH_READFIRST: case V_8PH_BOTH: case V_FP8_256x256: return 256;
         case V_DMA_512x128: return 512;
         case V_RING_64x128: return 64;
         default: return 128;
     }
 }
+
+// fp8 operands (a0 / b point at e4m3 bytes, a0_ld / b_ld / a_bs / b_bs in bytes, a0_C = K % 128 == 0, deq_m / deq_n set)
+void launch_gemm_fp8(const GemmArgs& g, hipStream_t s) { launch_tiles<CfgD256x256>(&k_gemm_fp8, g, s); }
 
 // returns the block-tile row count of the variant used
 int launch_gemm(const GemmArgs& g, hipStream_t s) {
@@ -263,6 +269,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
         case V_DMA_128x128_P: launch_tiles<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2>, g, s); break;
         case V_DMA_256x128W4_P: launch_tiles<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>, g, s); break;
         case V_8PH_256x256: launch_tiles<Cfg8ph>(&k_gemm_8ph<0>, g, s); break;
+        case V_FP8_256x256: launch_tiles<CfgD256x256>(&k_gemm_fp8, g, s); break;
         case V_8PH_NOPRIO: launch_tiles<Cfg8ph>(&k_gemm_8ph<1>, g, s); break;
         case V_8PH_READFIRST: launch_tiles<Cfg8ph>(&k_gemm_8ph<2>, g, s); break;
         case V_8PH_BOTH: launch_tiles<Cfg8ph>(&k_gemm_8ph<3>, g, s); break;
@@ -888,6 +895,24 @@ int natinf_debug_gemm(int variant, int M, int N, int K0, int K1, int taps, int l
     g_force_variant = variant;
     for (int i = 0; i < iters; ++i) launch_gemm(g, (hipStream_t)stream);
     g_force_variant = saved;
+    return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
+}
+
+int natinf_debug_quant_fp8_rows(const float* w, void* q, float* row_scale, int rows, int cols, natinf_stream_t stream) {
+    if (!w || !q || !row_scale || rows <= 0 || cols <= 0 || cols % 2) return NATINF_EINVAL;
+    hipLaunchKernelGGL(k_pack_fp8_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, w, (uint8_t*)q, row_scale, rows, cols);
+    return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
+}
+
+int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_scale, const void* b8, const float* b_scale,
+                          const float* bias_n, void* c, int c_f32, int iters, natinf_stream_t stream) {
+    if (!a8 || !b8 || !c || M <= 0 || N <= 0 || K <= 0 || K % 128 || N % 8 || iters <= 0) return NATINF_EINVAL;
+    static bool configured = false;
+    if (!configured) { if (!configure_gemm_kernels()) return NATINF_ENODEV; configured = true; }
+    GemmArgs g = gemm_defaults();
+    g.a0 = (const bf16*)a8; g.a0_C = K; g.a0_ld = K; g.M = M; g.N = N; g.b = (const bf16*)b8; g.b_ld = K;
+    g.deq_m = a_scale; g.deq_n = b_scale; g.bias_n = bias_n; g.c = c; g.c_ld = N; g.c_mode = c_f32 ? OUT_F32 : OUT_BF16;
+    for (int i = 0; i < iters; ++i) launch_gemm_fp8(g, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
 }
 

@@ -49,6 +49,9 @@ struct GemmArgs {
     const bf16* resid; int resid_ld;                  // + resid[m*ld + n]
     const float* resid_f32; int resid_f32_ld;         // + resid_f32[z*c_bs + m*ld + n]  (fp32 residual stream, batch stride of c)
     float scale; int act;
+    // fp8 operands (k_gemm_fp8): the accumulator is multiplied by deq_m[z*deq_m_bs + m] * deq_n[z*deq_n_bs + n] first
+    // (per-row scale of the A operand x per-row scale of the B operand); nullptr = 1
+    const float* deq_m; const float* deq_n; int64_t deq_m_bs, deq_n_bs;
     void* c; int c_ld; int c_mode;
     // fused GroupNorm statistics of the OUTPUT (DMA kernels, block tile inside one sample): per block tile and per
     // 4-channel quad, (sum, sum of squares) of the fp32 results -> gn_part[(m0/BM)*gn_quads + n/4] (float2)

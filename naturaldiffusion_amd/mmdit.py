@@ -16,6 +16,7 @@ import torch
 from . import _lib
 from ._lib import lib, check, ptr, stream_ptr
 
+FP8 = 1
 SD3_MEDIUM = dict(layers=24, heads=24, joint_dim=4096, pooled_dim=2048, in_ch=16)
 
 
@@ -68,15 +69,17 @@ def flatten_state_dict(sd: Dict[str, torch.Tensor], grid: int, layers: int, head
 
 class MMDiTEngine:
     def __init__(self, flat_params: torch.Tensor, max_batch: int, grid: int = 64, ctx_tokens: int = 333, layers: int = 24,
-                 heads: int = 24, joint_dim: int = 4096, pooled_dim: int = 2048, in_ch: int = 16, device="cuda:0"):
+                 heads: int = 24, joint_dim: int = 4096, pooled_dim: int = 2048, in_ch: int = 16, device="cuda:0", fp8: bool = False):
         _lib.require_gpu()
         if min(layers, heads, joint_dim, pooled_dim, in_ch, grid, ctx_tokens) <= 0 or heads > 24 or joint_dim % 8 or pooled_dim % 8 \
                 or in_ch % 2 or (grid * grid) % 8:
             raise ValueError("unsupported MMDiT configuration (see include/natinf_mmdit.h)")
+        if fp8 and heads % 2:
+            raise ValueError("fp8 mode needs an even head count")
         self.device = torch.device(device)
         self.max_batch, self.grid, self.ctx_tokens, self.joint_dim, self.pooled_dim, self.in_ch = int(max_batch), grid, ctx_tokens, joint_dim, pooled_dim, in_ch
         self._h = C.c_void_p()
-        check(lib.natinf_mmdit_create(C.byref(self._h), layers, heads, joint_dim, pooled_dim, in_ch, grid, ctx_tokens), "natinf_mmdit_create")
+        check(lib.natinf_mmdit_create(C.byref(self._h), layers, heads, joint_dim, pooled_dim, in_ch, grid, ctx_tokens, FP8 if fp8 else 0), "natinf_mmdit_create")
         n = lib.natinf_mmdit_param_count(self._h)
         if flat_params.numel() != n:
             raise ValueError(f"expected {n} parameters, got {flat_params.numel()}")

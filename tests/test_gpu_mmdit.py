@@ -157,3 +157,48 @@ def test_forward_is_deterministic_and_ignores_workspace_contents():
     eng._ws.zero_()
     b = eng.forward(x, t, e, p)
     assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_fp8_gemm_matches_the_dequantised_product():
+    """k_gemm_fp8 on its own: same quantised operands, fp32 reference -> only the bf16 output rounding remains."""
+    from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(3)
+    for (M, N, K) in ((512, 256, 256), (1000, 520, 384), (300, 264, 128)):
+        a = (torch.randn(M, K, generator=g) * (torch.rand(M, 1, generator=g) * 3 + 0.1)).cuda()
+        b = (torch.randn(N, K, generator=g) * 0.05).cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        qa, sa = torch.empty(M, K, dtype=torch.uint8, device="cuda"), torch.empty(M, device="cuda")
+        qb, sb = torch.empty(N, K, dtype=torch.uint8, device="cuda"), torch.empty(N, device="cuda")
+        check(lib.natinf_debug_quant_fp8_rows(ptr(a), ptr(qa), ptr(sa), M, K, stream_ptr()), "quant")
+        check(lib.natinf_debug_quant_fp8_rows(ptr(b), ptr(qb), ptr(sb), N, K, stream_ptr()), "quant")
+        c = torch.empty(M, N, device="cuda")
+        check(lib.natinf_debug_gemm_fp8(M, N, K, ptr(qa), ptr(sa), ptr(qb), ptr(sb), ptr(bias), ptr(c), 1, 1, stream_ptr()), "gemm_fp8")
+        da = qa.view(torch.float8_e4m3fn).float() * sa[:, None]
+        db = qb.view(torch.float8_e4m3fn).float() * sb[:, None]
+        ref = (da.double() @ db.double().t() + bias.double()).float()
+        assert ((c - ref).abs().max() / ref.abs().max()).item() <= 1e-4          # fp32 accumulation order only
+        # the quantiser itself: per-row scale = max|row| / 448, values within e4m3 rounding (2^-3 relative) of the input
+        assert torch.allclose(sa, a.abs().amax(dim=1) / 448.0, rtol=1e-6)
+        assert ((da - a).abs() <= 0.0625 * a.abs() + sa[:, None] * 2.0 ** -9 + 1e-12).all()
+
+
+def test_fp8_engine_close_to_bf16_engine_and_oracle():
+    """NATINF_MMDIT_FP8 (config 5): image-stream q|k, v, fc1 on e4m3 operands.  Tolerance is the fp8 one (3 significant
+    bits per operand element): 8e-2 of the output's max magnitude against the fp32 oracle."""
+    from oracle import mmdit_oracle as M
+    from naturaldiffusion_amd.mmdit import MMDiTEngine, flatten_state_dict
+    cfg = dict(layers=3, heads=2, joint_dim=64, pooled_dim=32)
+    P = M.make_params(seed=4, pos_max=24, pos_base=8, **cfg)
+    flat = flatten_state_dict(P, 8, **cfg)
+    g = torch.Generator().manual_seed(0)
+    x, t = torch.randn(3, 16, 16, 16, generator=g), torch.tensor([900.0, 10.0, 455.5])
+    e, p = torch.randn(3, 13, 64, generator=g), torch.randn(3, 32, generator=g)
+    ref = M.forward(P, x, t, e, p)
+    o8 = MMDiTEngine(flat, max_batch=3, grid=8, ctx_tokens=13, fp8=True, **cfg).forward(x.cuda(), t.cuda(), e.cuda(), p.cuda()).cpu()
+    o16 = MMDiTEngine(flat, max_batch=3, grid=8, ctx_tokens=13, **cfg).forward(x.cuda(), t.cuda(), e.cuda(), p.cuda()).cpu()
+    assert torch.isfinite(o8).all()
+    e8 = ((o8 - ref).abs().max() / ref.abs().max()).item()
+    e16 = ((o16 - ref).abs().max() / ref.abs().max()).item()
+    assert e16 <= TOL and e8 <= 8e-2, (e16, e8)
+    with pytest.raises(ValueError):
+        MMDiTEngine(flat, max_batch=1, grid=8, ctx_tokens=13, fp8=True, layers=3, heads=3, joint_dim=64, pooled_dim=32)
