@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--weights", default=str(ROOT / "weights" / "step_15_weight_173.npz"))
     ap.add_argument("--workload", choices=["cifar10", "sd3"], default="cifar10",
                     help="cifar10 = the BASELINE.json metric (default); sd3 = config 4 (SD3 1024x1024 28-step NI, MMDiT bf16)")
+    ap.add_argument("--fp8", action="store_true", help="with --workload sd3: BASELINE config 5 (sharp-variant weights, fp8 e4m3 GEMM operands)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the event-instrumented replica (for rocprof runs)")
     args = ap.parse_args()
@@ -236,11 +237,12 @@ def bench_sd3(args, world, rank, dev):
     from naturaldiffusion_amd.synth import synthetic_mmdit_flat
     _lib.require_gpu()
     n, tc, nstep = 4, 333, 28
-    W = load_sd3_csv(ROOT / "weights" / "sd3_step_28_weight.csv")
+    wname = "sd3_step_28_weight_sharp.csv" if args.fp8 else "sd3_step_28_weight.csv"
+    W = load_sd3_csv(ROOT / "weights" / wname)
     u = np.linspace(1.0, 3 * 0.001 / (1 + 2 * 0.001), nstep)          # FlowMatchEulerDiscreteScheduler, shift 3
     sig = np.append(3 * u / (1 + 2 * u), 0.0).astype(np.float32)
     sigmas, timesteps = torch.from_numpy(sig).to(dev), torch.from_numpy(sig[:-1] * 1000).to(dev)
-    eng = MMDiTEngine(synthetic_mmdit_flat(grid=64, seed=0, **SD3_MEDIUM), max_batch=2 * n, grid=64, ctx_tokens=tc, device=dev, **SD3_MEDIUM)
+    eng = MMDiTEngine(synthetic_mmdit_flat(grid=64, seed=0, **SD3_MEDIUM), max_batch=2 * n, grid=64, ctx_tokens=tc, device=dev, fp8=args.fp8, **SD3_MEDIUM)
     g = torch.Generator(device=dev).manual_seed(10 + rank)
     noises = torch.randn(n, 16, 128, 128, device=dev, dtype=torch.float16, generator=g)
     text = torch.randn(2 * n, tc, 4096, device=dev, generator=g)
@@ -280,11 +282,12 @@ def bench_sd3(args, world, rank, dev):
     tf = flops_fwd_seq * 2 * n * nstep * args.steps / dt / 1e12
     line = {"metric": "images/sec at 28-step Natural Inference (SD3 1024x1024, MMDiT)", "value": round(world * n * args.steps / dt, 4),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "SD3 Natural Inference 28-step (sd3_step_28_weight.csv), 4 images x CFG per GPU = 8 sequences of 4096+333 "
-                                   "tokens per forward, SD3-medium-shaped MMDiT (2.03 B params, synthetic weights) bf16 MFMA / fp32 acc, "
-                                   "ni_step fp16 chain", "nfe": 2 * nstep, "images_per_gpu": n, "sharding": f"batch-sharded x{world}, no collective"},
-            "roofline": {"kernel": "whole forward (k_gemm_dma + k_flash_attn64), 2*MAC flops / wall time", "bound": "mfma", "achieved": round(tf, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8+bf16" if args.fp8 else "bf16", "data": "synthetic",
+            "config": {"workload": f"SD3 Natural Inference 28-step ({wname}), 4 images x CFG per GPU = 8 sequences of 4096+333 "
+                                   "tokens per forward, SD3-medium-shaped MMDiT (2.03 B params, synthetic weights) "
+                                   + ("fp8 e4m3 operands for the image-stream q|k, v, fc1 GEMMs, bf16 elsewhere, fp32 acc, " if args.fp8 else "bf16 MFMA / fp32 acc, ")
+                                   + "ni_step fp16 chain", "nfe": 2 * nstep, "images_per_gpu": n, "sharding": f"batch-sharded x{world}, no collective"},
+            "roofline": {"kernel": "whole forward (k_gemm_dma / k_gemm_fp8 + k_flash_attn64), 2*MAC flops / wall time; peak = dense bf16", "bound": "mfma", "achieved": round(tf, 1),
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}}
     if rank == 0:
         print(json.dumps(line), flush=True)
