@@ -14,6 +14,13 @@
 //   XCD-aware block order: the 35 query blocks of one (sequence, head) run back to back on one XCD, so its K / V^T
 //   (1.1 MB at 4,429 tokens) are fetched from HBM once and re-read from that XCD's L2.
 // Keys >= T_total (the padding up to a multiple of 128) are masked in the last tile; V^T must be finite there.
+// Measured alternatives that did NOT pay (tools/bench_flash.py, same-box A/B; 8 x 24 heads x 4,429 tokens, 1.35-1.45 ms):
+// Q pre-scaled + accumulators started at -m + lazy re-referencing (no per-element fma): -1 % in the engine, +7 % alone;
+// 8-wave blocks sharing a K/V tile (half the DMA requests per wave): +-0; v_permlane16/32_swap instead of ds_bpermute for
+// the 4-lane maxima: +-0; tree instead of chain reductions: slower.  Ablation of the loop: without the softmax block
+// 0.90 ms, without P V 1.13 ms, S^T alone 0.47 ms (1.0 PFLOP/s), without the exp only: unchanged -- the serial
+// S -> softmax -> PV order inside a wave is the cost, not any single instruction class; overlapping tile t's softmax
+// with tile t+1's S^T (two S register sets) is the open step.
 // Reference: diffusers JointAttnProcessor2_0 as called by pipe.transformer (src/SD3NaturalInference.py:210-213).
 #pragma once
 #include "ncsnpp_kernels.h"
