@@ -31,7 +31,7 @@ typedef struct natinf_mmdit* natinf_mmdit_t;
 #define NATINF_MMDIT_FP8 1
 
 /* grid = image tokens per side (latent side / 2), grid*grid % 8 == 0; ctx_tokens = text tokens per sequence;
- * hidden = 64*heads <= 1536; joint_dim % 8 == 0, pooled_dim % 8 == 0. */
+ * hidden = 64*heads <= 1536; joint_dim % 8 == 0, pooled_dim % 8 == 0; in_ch even, <= 16. */
 int natinf_mmdit_create(natinf_mmdit_t* out, int layers, int heads, int joint_dim, int pooled_dim, int in_ch, int grid,
                         int ctx_tokens, int flags);
 int natinf_mmdit_destroy(natinf_mmdit_t h);
