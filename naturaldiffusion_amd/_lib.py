@@ -54,7 +54,7 @@ SIGNATURES = {
     "natinf_ncsnpp_profile": (C.c_int, [_p, _i32]),
     "natinf_ncsnpp_profile_read": (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "natinf_debug_quant_fp8_rows": (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
-    "natinf_debug_gemm_fp8": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _i32, _p]),
+    "natinf_debug_gemm_fp8": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p]),
     # include/natinf_dit.h
     "natinf_dit_create": (C.c_int, [C.POINTER(_p), _i32, _i32, _i32, _i32]),
     "natinf_dit_destroy": (C.c_int, [_p]),

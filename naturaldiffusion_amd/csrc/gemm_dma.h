@@ -183,6 +183,17 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
 #pragma unroll
                 for (int q = 0; q < 8; ++q) o[q] = (bf16)v[q];
                 keep[sw][0] = __builtin_bit_cast(uint4, o);
+            } else if (g.c_mode == OUT_FP8_MX) {
+                // a 32-column block = this thread's 8 columns and those of its three neighbours (tid ^ 1, ^ 2: same row)
+                float amax = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) amax = fmaxf(amax, fabsf(v[q]));
+                amax = fmaxf(amax, __shfl_xor(amax, 1));
+                amax = fmaxf(amax, __shfl_xor(amax, 2));
+                float inv;
+                const unsigned e8 = mx_scale_of(amax, inv);
+                keep[sw][0] = make_uint4(pack_fp8x4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv),
+                                         pack_fp8x4(v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv), e8, 0u);
             } else {
                 keep[sw][0] = __builtin_bit_cast(uint4, make_float4(v[0], v[1], v[2], v[3]));
                 keep[sw][1] = __builtin_bit_cast(uint4, make_float4(v[4], v[5], v[6], v[7]));
@@ -201,6 +212,9 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
                 if (keep[sw][0].x == 0x12345678u) *reinterpret_cast<uint4*>(g.c) = keep[sw][0];
             } else if (g.c_mode == OUT_BF16) {
                 *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(g.c) + (int64_t)z * g.c_bs + (int64_t)m * g.c_ld + n) = keep[sw][0];
+            } else if (g.c_mode == OUT_FP8_MX) {
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(g.c) + (int64_t)z * g.c_bs + (int64_t)m * g.c_ld + n) = make_uint2(keep[sw][0].x, keep[sw][0].y);
+                if ((cchunk & 3) == 0) g.c_mx[(int64_t)z * g.c_mx_bs + (int64_t)m * g.c_mx_ld + (n >> 5)] = (uint8_t)keep[sw][0].z;
             } else {
                 float* o = reinterpret_cast<float*>(g.c) + (int64_t)z * g.c_bs + (int64_t)m * g.c_ld + n;
                 *reinterpret_cast<uint4*>(o) = keep[sw][0];

@@ -3,7 +3,7 @@
 // C[m][n] = deq_m[m] * deq_n[n] * sum_k A8[m][k] * B8[n][k]  (+ the usual epilogue terms), A8 / B8 row-major fp8 bytes
 // with one fp32 scale per row (activations: per token, written by k_ln_modulate_fp8; weights: per output channel, written
 // at load time).  A K-tile is 128 bytes per row -- the SAME LDS image, DMA pieces and swizzle as the bf16 kernel's 64-wide
-// tiles -- but it feeds v_mfma_f32_16x16x128_f8f6f4 (a lane supplies 32 consecutive K bytes of its row: two 16-byte LDS
+// tiles -- but it feeds v_mfma_f32_16x16x128_f8f6f4 (a lane supplies 32 K bytes of its row: two 16-byte LDS
 // reads), which does four times the K of the bf16 MFMA in twice its time: twice the flops per byte moved and per cycle.
 // Unit block scales in the MFMA (127 = 2^0); the real scales are applied once, in the epilogue.
 // Two-stage pipeline like k_gemm_dma<2,4,8,4> (one K-tile of prefetch, explicit vmcnt(0) + barrier per K-tile), swapped
@@ -15,6 +15,7 @@ namespace ncsn {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
+template <bool MXA>     // MXA: the A operand carries E8M0 block scales (GemmArgs::a_mx), fed to the MFMA lane by lane
 __global__ __launch_bounds__(512, 2) void k_gemm_fp8(const GemmArgs g)
 {
     using Cfg = DmaCfg<2, 4, 8, 4>;
@@ -60,15 +61,37 @@ __global__ __launch_bounds__(512, 2) void k_gemm_fp8(const GemmArgs g)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const int frow = lane & 15, fq = lane >> 4, fswz = (frow >> 1) & 7;
+    // MX scales of this lane's A rows: one dword per row and K-tile holds the four 32-blocks; the lane uses byte fq.
+    // Fetched one K-tile ahead (plain loads; the per-tile vmcnt(0) below retires them together with the DMA).
+    unsigned sc[TM], scn[TM];
+    const uint8_t* mxp[TM];
+    if constexpr (MXA) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            mxp[i] = g.a_mx + (int64_t)z * g.a_mx_bs + (int64_t)min(m0 + wm * TM * 16 + i * 16 + frow, g.M - 1) * g.a_mx_ld;
+            scn[i] = *reinterpret_cast<const unsigned*>(mxp[i]);
+        }
+    }
     issue_tile(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int frow = lane & 15, fq = lane >> 4, fswz = (frow >> 1) & 7;
-    const int c0 = ((2 * fq) ^ fswz) << 4, c1 = ((2 * fq + 1) ^ fswz) << 4;              // the lane's two 16-byte chunks of a row
+    // The MFMA's K order (probed, tools/fp8_probe): lane group q supplies K bytes 16q..16q+15 in its first four registers
+    // and 64+16q..64+16q+15 in the other four -- two stacked 64-wide halves -- and MX block j (K bytes 32j..32j+31) takes
+    // its scale from lane group j.  So a lane reads the 16-byte chunks q and 4+q of its row (not 2q, 2q+1): memory-
+    // contiguous 32-blocks are then the hardware's blocks.  (Without block scales any order common to A and B would do.)
+    const int c0 = (fq ^ fswz) << 4, c1 = ((4 + fq) ^ fswz) << 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) issue_tile(kt + 1, cur ^ 1);
+        if constexpr (MXA) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                sc[i] = (scn[i] >> (8 * fq)) & 0xffu;
+                if (kt + 1 < nk) scn[i] = *reinterpret_cast<const unsigned*>(mxp[i] + (kt + 1) * 4);
+            }
+        }
         const unsigned char* ta = smem + cur * Cfg::STAGE_BYTES + (wm * TM * 16 + frow) * 128;
         const unsigned char* tb = smem + cur * Cfg::STAGE_BYTES + BM_ * 128 + (wn * TN * 16 + frow) * 128;
         i32x8 fb[TN];
@@ -83,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_fp8(const GemmArgs g)
             const i32x8 fa = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa, acc[i][j], 0, 0, 0, 127, 0, 127);
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa, acc[i][j], 0, 0, 0, 127, 0, MXA ? (int)sc[i] : 127);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

@@ -187,7 +187,7 @@ bool configure_gemm_kernels() {
          set_lds<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>) && set_lds<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>) &&
          set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2>) && set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2>) &&
          set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>) &&
-         set_lds<CfgD256x256>(&k_gemm_fp8) &&
+         set_lds<CfgD256x256>(&k_gemm_fp8<false>) && set_lds<CfgD256x256>(&k_gemm_fp8<true>) &&
          set_lds<Cfg8ph>(&k_gemm_8ph<0>) && set_lds<Cfg8ph>(&k_gemm_8ph<1>) && set_lds<Cfg8ph>(&k_gemm_8ph<2>) && set_lds<Cfg8ph>(&k_gemm_8ph<3>) &&
          set_lds<AttnCfg<2, 4>>(&k_attn_fused<2, 4>) && set_lds<AttnCfg<3, 6>>(&k_attn_fused<3, 6>) &&
          set_lds<AttnCfg<3, 5>>(&k_attn_fused<3, 5>) &&
@@ -234,7 +234,9 @@ int variant_bm(int v) {
 }
 
 // fp8 operands (a0 / b point at e4m3 bytes, a0_ld / b_ld / a_bs / b_bs in bytes, a0_C = K % 128 == 0, deq_m / deq_n set)
-void launch_gemm_fp8(const GemmArgs& g, hipStream_t s) { launch_tiles<CfgD256x256>(&k_gemm_fp8, g, s); }
+void launch_gemm_fp8(const GemmArgs& g, hipStream_t s) {
+    if (g.a_mx) launch_tiles<CfgD256x256>(&k_gemm_fp8<true>, g, s); else launch_tiles<CfgD256x256>(&k_gemm_fp8<false>, g, s);
+}
 
 // returns the block-tile row count of the variant used
 int launch_gemm(const GemmArgs& g, hipStream_t s) {
@@ -269,7 +271,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
         case V_DMA_128x128_P: launch_tiles<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2>, g, s); break;
         case V_DMA_256x128W4_P: launch_tiles<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>, g, s); break;
         case V_8PH_256x256: launch_tiles<Cfg8ph>(&k_gemm_8ph<0>, g, s); break;
-        case V_FP8_256x256: launch_tiles<CfgD256x256>(&k_gemm_fp8, g, s); break;
+        case V_FP8_256x256: launch_tiles<CfgD256x256>(&k_gemm_fp8<false>, g, s); break;
         case V_8PH_NOPRIO: launch_tiles<Cfg8ph>(&k_gemm_8ph<1>, g, s); break;
         case V_8PH_READFIRST: launch_tiles<Cfg8ph>(&k_gemm_8ph<2>, g, s); break;
         case V_8PH_BOTH: launch_tiles<Cfg8ph>(&k_gemm_8ph<3>, g, s); break;
@@ -904,14 +906,16 @@ int natinf_debug_quant_fp8_rows(const float* w, void* q, float* row_scale, int r
     return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
 }
 
-int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_scale, const void* b8, const float* b_scale,
-                          const float* bias_n, void* c, int c_f32, int iters, natinf_stream_t stream) {
+int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_scale, const void* a_mx, const void* b8, const float* b_scale,
+                          const float* bias_n, void* c, void* c_mx, int c_mode, int iters, natinf_stream_t stream) {
     if (!a8 || !b8 || !c || M <= 0 || N <= 0 || K <= 0 || K % 128 || N % 8 || iters <= 0) return NATINF_EINVAL;
     static bool configured = false;
     if (!configured) { if (!configure_gemm_kernels()) return NATINF_ENODEV; configured = true; }
     GemmArgs g = gemm_defaults();
     g.a0 = (const bf16*)a8; g.a0_C = K; g.a0_ld = K; g.M = M; g.N = N; g.b = (const bf16*)b8; g.b_ld = K;
-    g.deq_m = a_scale; g.deq_n = b_scale; g.bias_n = bias_n; g.c = c; g.c_ld = N; g.c_mode = c_f32 ? OUT_F32 : OUT_BF16;
+    g.deq_m = a_scale; g.deq_n = b_scale; g.bias_n = bias_n; g.c = c; g.c_ld = N; g.c_mode = c_mode;
+    g.a_mx = (const uint8_t*)a_mx; g.a_mx_ld = K / 32; g.c_mx = (uint8_t*)c_mx; g.c_mx_ld = N / 32;
+    if ((c_mode == OUT_FP8_MX && (!c_mx || N % 32)) || c_mode < 0 || c_mode > OUT_FP8_MX || c_mode == OUT_F32_NCHW) return NATINF_EINVAL;
     for (int i = 0; i < iters; ++i) launch_gemm_fp8(g, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
 }

@@ -30,7 +30,7 @@ constexpr int C_ROW = BN + 4;                         // fp32 epilogue staging r
 constexpr int GEMM_LDS_BYTES = BM * C_ROW * 4;        // 67,584 B: max(tiles 65,536 B, epilogue staging)
 static_assert(4 * TILE_ELEMS * 2 <= GEMM_LDS_BYTES, "tile buffers must fit");
 
-enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_NCHW = 2 };
+enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_NCHW = 2, OUT_FP8_MX = 3 };      // OUT_FP8_MX: e4m3 bytes + a block scale per 32 columns
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU_TANH = 2 };
 
 struct GemmArgs {
@@ -52,6 +52,10 @@ struct GemmArgs {
     // fp8 operands (k_gemm_fp8): the accumulator is multiplied by deq_m[z*deq_m_bs + m] * deq_n[z*deq_n_bs + n] first
     // (per-row scale of the A operand x per-row scale of the B operand); nullptr = 1
     const float* deq_m; const float* deq_n; int64_t deq_m_bs, deq_n_bs;
+    // MX block scales (one E8M0 byte per row and 32 K-elements, value 2^(e-127)): of the A operand (k_gemm_fp8<true>),
+    // [M][K/32] bytes, row stride a_mx_ld, batch stride a_mx_bs; and of the OUTPUT when c_mode == OUT_FP8_MX, [M][N/32]
+    const uint8_t* a_mx; int a_mx_ld; int64_t a_mx_bs;
+    uint8_t* c_mx; int c_mx_ld; int64_t c_mx_bs;
     void* c; int c_ld; int c_mode;
     // fused GroupNorm statistics of the OUTPUT (DMA kernels, block tile inside one sample): per block tile and per
     // 4-channel quad, (sum, sum of squares) of the fp32 results -> gn_part[(m0/BM)*gn_quads + n/4] (float2)
@@ -69,6 +73,23 @@ __device__ __forceinline__ float gelu_tanh_f(float v) {             // nn.GELU(a
 __device__ __forceinline__ float apply_act(float v, int act) {
     return act == ACT_SILU ? silu_f(v) : (act == ACT_GELU_TANH ? gelu_tanh_f(v) : v);
 }
+// E8M0 scale of a 32-value block with magnitude `amax`: the smallest power of two 2^e with amax * 2^-e <= 448 (e4m3 max).
+// Returns the biased byte (e + 127, clamped) and writes 2^-e.  amax = m * 2^x, m in [1,2): 2^(x-8) maps it into [256,512);
+// one more halving when m > 1.75.  An all-zero block gets scale 1.
+__device__ __forceinline__ unsigned mx_scale_of(float amax, float& inv) {
+    const unsigned bits = __float_as_uint(amax);
+    int e = (int)((bits >> 23) & 0xff) - 127 - 8 + ((bits & 0x7fffff) > 0x600000 ? 1 : 0);
+    e = amax > 0.f ? (e < -127 ? -127 : (e > 127 ? 127 : e)) : 0;
+    inv = __uint_as_float((unsigned)(127 - e) << 23);
+    return (unsigned)(e + 127);
+}
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {      // values already scaled; clamp: the cvt does not saturate
+    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f); c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+
 // Epilogue form: ONE uniform branch per 8 values (the per-value ternary compiles to a scalar branch chain per element)
 // and v_rcp_f32 instead of the 15-instruction IEEE division -- 1 ulp, far inside the bf16 output rounding.
 __device__ __forceinline__ void apply_act8(float (&v)[8], int act) {

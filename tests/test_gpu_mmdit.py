@@ -172,7 +172,7 @@ def test_fp8_gemm_matches_the_dequantised_product():
         check(lib.natinf_debug_quant_fp8_rows(ptr(a), ptr(qa), ptr(sa), M, K, stream_ptr()), "quant")
         check(lib.natinf_debug_quant_fp8_rows(ptr(b), ptr(qb), ptr(sb), N, K, stream_ptr()), "quant")
         c = torch.empty(M, N, device="cuda")
-        check(lib.natinf_debug_gemm_fp8(M, N, K, ptr(qa), ptr(sa), ptr(qb), ptr(sb), ptr(bias), ptr(c), 1, 1, stream_ptr()), "gemm_fp8")
+        check(lib.natinf_debug_gemm_fp8(M, N, K, ptr(qa), ptr(sa), None, ptr(qb), ptr(sb), ptr(bias), ptr(c), None, 1, 1, stream_ptr()), "gemm_fp8")
         da = qa.view(torch.float8_e4m3fn).float() * sa[:, None]
         db = qb.view(torch.float8_e4m3fn).float() * sb[:, None]
         ref = (da.double() @ db.double().t() + bias.double()).float()
@@ -180,6 +180,48 @@ def test_fp8_gemm_matches_the_dequantised_product():
         # the quantiser itself: per-row scale = max|row| / 448, values within e4m3 rounding (2^-3 relative) of the input
         assert torch.allclose(sa, a.abs().amax(dim=1) / 448.0, rtol=1e-6)
         assert ((da - a).abs() <= 0.0625 * a.abs() + sa[:, None] * 2.0 ** -9 + 1e-12).all()
+
+
+def _mx_quant(x):
+    """reference MX quantiser: per row and 32 columns, scale 2^e = the smallest power of two with amax * 2^-e <= 448."""
+    M, K = x.shape
+    b = x.reshape(M, K // 32, 32)
+    amax = b.abs().amax(dim=2)
+    e = torch.ceil(torch.log2(amax.clamp_min(1e-38) / 448.0)).clamp(-127, 127)
+    e = torch.where(amax > 0, e, torch.zeros_like(e))
+    q = (b * torch.exp2(-e)[..., None]).clamp(-448, 448).to(torch.float8_e4m3fn)
+    return q.reshape(M, K).view(torch.uint8).contiguous(), (e + 127).to(torch.uint8).contiguous()
+
+
+def _mx_dequant(q, sc):
+    M, K = q.shape
+    return (q.view(torch.float8_e4m3fn).float().reshape(M, K // 32, 32) * torch.exp2(sc.float() - 127)[..., None]).reshape(M, K)
+
+
+def test_fp8_gemm_with_mx_block_scales_in_and_out():
+    """A operand with E8M0 block scales per 32 K-elements (fed to the MFMA lane by lane), and the fp8 + block-scale OUTPUT
+    mode of the epilogue (what fc1 hands to fc2 in the fp8 engine)."""
+    from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(5)
+    for (M, N, K) in ((512, 256, 256), (700, 544, 384)):
+        a = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K // 32, 1, generator=g)).expand(M, K // 32, 32).reshape(M, K)).cuda()
+        b = (torch.randn(N, K, generator=g) * 0.05).cuda()
+        qa, ma = _mx_quant(a)
+        qb, sb = torch.empty(N, K, dtype=torch.uint8, device="cuda"), torch.empty(N, device="cuda")
+        check(lib.natinf_debug_quant_fp8_rows(ptr(b), ptr(qb), ptr(sb), N, K, stream_ptr()), "quant")
+        ref = (_mx_dequant(qa, ma).double() @ (qb.view(torch.float8_e4m3fn).float() * sb[:, None]).double().t()).float()
+        c = torch.empty(M, N, device="cuda")
+        check(lib.natinf_debug_gemm_fp8(M, N, K, ptr(qa), None, ptr(ma), ptr(qb), ptr(sb), None, ptr(c), None, 1, 1, stream_ptr()), "gemm_fp8")
+        assert ((c - ref).abs().max() / ref.abs().max()).item() <= 1e-4
+        assert ((_mx_dequant(qa, ma) - a).abs() <= 0.0625 * a.abs() + 1e-6 * a.abs().max()).all()      # the reference quantiser itself
+        # output mode: e4m3 bytes + one scale per row and 32 columns, against the fp32 output of the same launch
+        c8, cm = torch.empty(M, N, dtype=torch.uint8, device="cuda"), torch.empty(M, N // 32, dtype=torch.uint8, device="cuda")
+        check(lib.natinf_debug_gemm_fp8(M, N, K, ptr(qa), None, ptr(ma), ptr(qb), ptr(sb), None, ptr(c8), ptr(cm), 3, 1, stream_ptr()), "gemm_fp8")
+        want_q, want_m = _mx_quant(c)
+        assert torch.equal(cm, want_m)
+        dec = _mx_dequant(c8, cm)
+        blockmax = c.reshape(M, N // 32, 32).abs().amax(dim=2, keepdim=True).expand(M, N // 32, 32).reshape(M, N)
+        assert ((dec - c).abs() <= 0.0625 * c.abs() + blockmax * 2.0 ** -9 + 1e-12).all()
 
 
 def test_fp8_engine_close_to_bf16_engine_and_oracle():

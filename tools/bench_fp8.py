@@ -18,7 +18,7 @@ def run(M, N, K, iters=10, chk=False):
     bias = torch.randn(N, device=dev)
     qa, sa = quant(a); qb, sb = quant(b)
     c = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    args = lambda it: (M, N, K, ptr(qa), ptr(sa), ptr(qb), ptr(sb), ptr(bias), ptr(c), 0, it, stream_ptr())
+    args = lambda it: (M, N, K, ptr(qa), ptr(sa), None, ptr(qb), ptr(sb), ptr(bias), ptr(c), None, 0, it, stream_ptr())
     check(lib.natinf_debug_gemm_fp8(*args(2)), "gemm_fp8"); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); check(lib.natinf_debug_gemm_fp8(*args(iters)), "gemm_fp8"); e1.record(); torch.cuda.synchronize()
