@@ -25,9 +25,12 @@ extern "C" {
 
 typedef struct natinf_mmdit* natinf_mmdit_t;
 
-/* flags.  NATINF_MMDIT_FP8: the image-stream q|k, v and fc1 projections (7/12 of the image-stream GEMM flops) run on fp8 e4m3
- * operands -- activations quantised per token by the LayerNorm-modulate kernel, weights per output channel at load time,
- * fp32 accumulation, scales applied in the epilogue (BASELINE config 5); needs an even head count (hidden % 128 == 0). */
+/* flags.  NATINF_MMDIT_FP8 (BASELINE config 5): every image-stream projection -- q|k, v, attention output (both streams),
+ * fc1, fc2 -- runs on fp8 e4m3 operands with fp32 accumulation.  Weights: one scale per output channel, at load time.
+ * LayerNorm-modulate outputs: one scale per token, by the kernel that produces them.  Attention and GELU outputs: MX block
+ * scales (a power of two per row and 32 channels) written by their producers' epilogues and applied by the matrix
+ * instruction itself.  Attention (Q K^T, P V) and the text-stream projections other than the attention output stay bf16.
+ * Needs an even head count (hidden % 128 == 0). */
 #define NATINF_MMDIT_FP8 1
 
 /* grid = image tokens per side (latent side / 2), grid*grid % 8 == 0; ctx_tokens = text tokens per sequence;

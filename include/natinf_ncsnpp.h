@@ -77,8 +77,9 @@ int natinf_debug_gemm(int variant, int M, int N, int K0, int K1, int taps, int l
  * (+ bias_n); a8 [M][K], b8 [N][K] fp8 bytes with one fp32 scale per row, K % 128 == 0, N % 8 == 0.
  * natinf_debug_quant_fp8_rows produces such a pair from fp32 rows: scale = max|row| / 448, q = e4m3(row / scale). */
 int natinf_debug_quant_fp8_rows(const float* w, void* q, float* row_scale, int rows, int cols, natinf_stream_t stream);
-/* a_mx (optional): E8M0 block scales of a8, [M][K/32] bytes (then a_scale is normally NULL).  c_mode 0 bf16, 1 fp32,
- * 3 = fp8 e4m3 bytes [M][N] + E8M0 block scales c_mx [M][N/32] (N % 32 == 0). */
+/* a_mx (optional): E8M0 block scales of a8 (then a_scale is normally NULL), stored K-tile major: the byte of (row r, 32-block
+ * kb) at [(kb / 4) * M * 4 + r * 4 + kb % 4], readable up to 256-row granularity (allocate ceil(M / 256) * 256 rows per
+ * plane).  c_mode 0 bf16, 1 fp32, 3 = fp8 e4m3 bytes [M][N] + block scales c_mx in the same layout (N % 128 == 0). */
 int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_scale, const void* a_mx, const void* b8, const float* b_scale,
                           const float* bias_n, void* c, void* c_mx, int c_mode, int iters, natinf_stream_t stream);
 int natinf_set_gemm_variant(int variant);

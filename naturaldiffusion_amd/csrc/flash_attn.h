@@ -34,6 +34,7 @@ struct FlashArgs {
     const bf16* vT; int64_t vT_bs;                                 // [B][H*64][Tp]
     bf16* o; int ld_o; int64_t o_bs;                               // [B][Tp][ld_o]
     int H, Tp, Ttot; float c1;                                     // c1 = softmax scale * log2(e)
+    uint8_t* o8; uint8_t* omx;                                     // optional fp8 output instead of o: e4m3 [B][Tp][64H] + E8M0 block scales, K-tile major per sequence ([H/2][Tp][4])
 };
 
 __global__ __launch_bounds__(256, 2) void k_flash_attn64(const FlashArgs a)
@@ -155,6 +156,31 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64(const FlashArgs a)
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
         const float inv = 1.0f / s;
+        const int64_t qrow = (int64_t)b * a.Tp + qb * FA_QB + wave * 32 + 16 * g + r;
+        if (a.o8) {
+            // fp8 output for the fp8 output projection: one MX block = 32 head channels of a query = two d-tiles x the four
+            // lanes of the query column
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                float amax = 0.f;
+#pragma unroll
+                for (int dt = 2 * blk; dt < 2 * blk + 2; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fabsf(oacc[g][dt][i] * inv));
+                amax = fmaxf(amax, __shfl_xor(amax, 16));
+                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                float qinv;
+                const unsigned e8 = mx_scale_of(amax, qinv);
+                qinv *= inv;
+#pragma unroll
+                for (int dt = 2 * blk; dt < 2 * blk + 2; ++dt)
+                    *reinterpret_cast<unsigned*>(a.o8 + qrow * (a.H * 64) + head * 64 + 16 * dt + 4 * q) =
+                        pack_fp8x4(oacc[g][dt][0] * qinv, oacc[g][dt][1] * qinv, oacc[g][dt][2] * qinv, oacc[g][dt][3] * qinv);
+                if (q == 0)                           // block index kb = 2 head + blk of this row; plane of a sequence: [H/2][Tp][4]
+                    a.omx[(int64_t)b * a.Tp * (a.H * 2) + ((int64_t)(head >> 1) * a.Tp + (qrow - (int64_t)b * a.Tp)) * 4 + (head & 1) * 2 + blk] = (uint8_t)e8;
+            }
+            continue;
+        }
         bf16* orow = a.o + (int64_t)b * a.o_bs + (int64_t)(qb * FA_QB + wave * 32 + 16 * g + r) * a.ld_o + head * 64 + 4 * q;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {

@@ -214,7 +214,7 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
                 *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(g.c) + (int64_t)z * g.c_bs + (int64_t)m * g.c_ld + n) = keep[sw][0];
             } else if (g.c_mode == OUT_FP8_MX) {
                 *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(g.c) + (int64_t)z * g.c_bs + (int64_t)m * g.c_ld + n) = make_uint2(keep[sw][0].x, keep[sw][0].y);
-                if ((cchunk & 3) == 0) g.c_mx[(int64_t)z * g.c_mx_bs + (int64_t)m * g.c_mx_ld + (n >> 5)] = (uint8_t)keep[sw][0].z;
+                if ((cchunk & 3) == 0) g.c_mx[(int64_t)z * g.c_mx_bs + ((int64_t)(n >> 7) * g.c_mx_ld + m) * 4 + ((n >> 5) & 3)] = (uint8_t)keep[sw][0].z;
             } else {
                 float* o = reinterpret_cast<float*>(g.c) + (int64_t)z * g.c_bs + (int64_t)m * g.c_ld + n;
                 *reinterpret_cast<uint4*>(o) = keep[sw][0];

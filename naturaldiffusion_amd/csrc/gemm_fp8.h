@@ -62,17 +62,17 @@ __global__ __launch_bounds__(512, 2) void k_gemm_fp8(const GemmArgs g)
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4, fswz = (frow >> 1) & 7;
-    // MX scales of this lane's A rows: one dword per row and K-tile holds the four 32-blocks; the lane uses byte fq.
-    // Fetched one K-tile ahead (plain loads; the per-tile vmcnt(0) below retires them together with the DMA).
-    unsigned sc[TM], scn[TM];
-    const uint8_t* mxp[TM];
-    if constexpr (MXA) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            mxp[i] = g.a_mx + (int64_t)z * g.a_mx_bs + (int64_t)min(m0 + wm * TM * 16 + i * 16 + frow, g.M - 1) * g.a_mx_ld;
-            scn[i] = *reinterpret_cast<const unsigned*>(mxp[i]);
-        }
-    }
+    // MX scales of the A rows: stored K-TILE MAJOR (ncsnpp_kernels.h), so the 256 rows x 4 blocks of one K-tile are 1 KiB
+    // of consecutive bytes -- one more DMA piece per stage (wave 0), parked behind the operand stages.  A lane then reads
+    // the dword of each of its rows from LDS and uses byte fq.  (Plain per-lane loads of the scales in the K loop cost
+    // 35 % of the kernel: they share vmcnt with the DMA and sit on the critical path.)
+    unsigned sc[TM];
+    const uint8_t* mx_src = MXA ? g.a_mx + (int64_t)z * g.a_mx_bs + (int64_t)m0 * 4 + lane * 16 : nullptr;
+    auto issue_mx = [&](int kt, int buf) __attribute__((always_inline)) {
+        if (wave == 0)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(mx_src + (int64_t)kt * g.a_mx_ld * 4), (lds_void*)(smem + 131072 + buf * 1024), 16, 0, 0);
+    };
+    if constexpr (MXA) issue_mx(0, 0);
     issue_tile(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -86,11 +86,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_fp8(const GemmArgs g)
         const int cur = kt & 1;
         if (kt + 1 < nk) issue_tile(kt + 1, cur ^ 1);
         if constexpr (MXA) {
+            if (kt + 1 < nk) issue_mx(kt + 1, cur ^ 1);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                sc[i] = (scn[i] >> (8 * fq)) & 0xffu;
-                if (kt + 1 < nk) scn[i] = *reinterpret_cast<const unsigned*>(mxp[i] + (kt + 1) * 4);
-            }
+            for (int i = 0; i < TM; ++i)
+                sc[i] = (*reinterpret_cast<const unsigned*>(smem + 131072 + cur * 1024 + (wm * TM * 16 + i * 16 + frow) * 4) >> (8 * fq)) & 0xffu;
         }
         const unsigned char* ta = smem + cur * Cfg::STAGE_BYTES + (wm * TM * 16 + frow) * 128;
         const unsigned char* tb = smem + cur * Cfg::STAGE_BYTES + BM_ * 128 + (wn * TN * 16 + frow) * 128;

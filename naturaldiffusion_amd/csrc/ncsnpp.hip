@@ -914,7 +914,7 @@ int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_sc
     GemmArgs g = gemm_defaults();
     g.a0 = (const bf16*)a8; g.a0_C = K; g.a0_ld = K; g.M = M; g.N = N; g.b = (const bf16*)b8; g.b_ld = K;
     g.deq_m = a_scale; g.deq_n = b_scale; g.bias_n = bias_n; g.c = c; g.c_ld = N; g.c_mode = c_mode;
-    g.a_mx = (const uint8_t*)a_mx; g.a_mx_ld = K / 32; g.c_mx = (uint8_t*)c_mx; g.c_mx_ld = N / 32;
+    g.a_mx = (const uint8_t*)a_mx; g.a_mx_ld = M; g.c_mx = (uint8_t*)c_mx; g.c_mx_ld = M;       // K-tile-major planes of M rows
     if ((c_mode == OUT_FP8_MX && (!c_mx || N % 32)) || c_mode < 0 || c_mode > OUT_FP8_MX || c_mode == OUT_F32_NCHW) return NATINF_EINVAL;
     for (int i = 0; i < iters; ++i) launch_gemm_fp8(g, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;

@@ -52,8 +52,10 @@ struct GemmArgs {
     // fp8 operands (k_gemm_fp8): the accumulator is multiplied by deq_m[z*deq_m_bs + m] * deq_n[z*deq_n_bs + n] first
     // (per-row scale of the A operand x per-row scale of the B operand); nullptr = 1
     const float* deq_m; const float* deq_n; int64_t deq_m_bs, deq_n_bs;
-    // MX block scales (one E8M0 byte per row and 32 K-elements, value 2^(e-127)): of the A operand (k_gemm_fp8<true>),
-    // [M][K/32] bytes, row stride a_mx_ld, batch stride a_mx_bs; and of the OUTPUT when c_mode == OUT_FP8_MX, [M][N/32]
+    // MX block scales (one E8M0 byte per row and 32 elements, value 2^(e-127)), stored K-TILE MAJOR: the byte of
+    // (row r, block kb) is at [(kb >> 2) * R * 4 + r * 4 + (kb & 3)], R = rows per batch plane (*_mx_ld), so that the scales
+    // one 128-wide K-tile needs for 256 rows are 1 KiB of consecutive bytes (one DMA piece).  a_mx: of the A operand
+    // (k_gemm_fp8<true>; the plane must be readable up to row m0 + 255); c_mx: of the OUTPUT when c_mode == OUT_FP8_MX.
     const uint8_t* a_mx; int a_mx_ld; int64_t a_mx_bs;
     uint8_t* c_mx; int c_mx_ld; int64_t c_mx_bs;
     void* c; int c_ld; int c_mode;

@@ -198,12 +198,19 @@ def _mx_dequant(q, sc):
     return (q.view(torch.float8_e4m3fn).float().reshape(M, K // 32, 32) * torch.exp2(sc.float() - 127)[..., None]).reshape(M, K)
 
 
+def _ktile_major(sc):
+    """[M][K/32] scale bytes -> the kernel's K-tile-major layout [(K/128)][M][4] (flattened), padded by 1 KiB"""
+    M, nb = sc.shape
+    t = sc.reshape(M, nb // 4, 4).permute(1, 0, 2).contiguous().reshape(-1)
+    return torch.cat([t, torch.full((1024,), 127, dtype=torch.uint8, device=sc.device)])
+
+
 def test_fp8_gemm_with_mx_block_scales_in_and_out():
     """A operand with E8M0 block scales per 32 K-elements (fed to the MFMA lane by lane), and the fp8 + block-scale OUTPUT
     mode of the epilogue (what fc1 hands to fc2 in the fp8 engine)."""
     from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
     g = torch.Generator().manual_seed(5)
-    for (M, N, K) in ((512, 256, 256), (700, 544, 384)):
+    for (M, N, K) in ((512, 256, 256), (700, 640, 384)):
         a = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K // 32, 1, generator=g)).expand(M, K // 32, 32).reshape(M, K)).cuda()
         b = (torch.randn(N, K, generator=g) * 0.05).cuda()
         qa, ma = _mx_quant(a)
@@ -211,12 +218,14 @@ def test_fp8_gemm_with_mx_block_scales_in_and_out():
         check(lib.natinf_debug_quant_fp8_rows(ptr(b), ptr(qb), ptr(sb), N, K, stream_ptr()), "quant")
         ref = (_mx_dequant(qa, ma).double() @ (qb.view(torch.float8_e4m3fn).float() * sb[:, None]).double().t()).float()
         c = torch.empty(M, N, device="cuda")
-        check(lib.natinf_debug_gemm_fp8(M, N, K, ptr(qa), None, ptr(ma), ptr(qb), ptr(sb), None, ptr(c), None, 1, 1, stream_ptr()), "gemm_fp8")
+        mat = _ktile_major(ma)
+        check(lib.natinf_debug_gemm_fp8(M, N, K, ptr(qa), None, ptr(mat), ptr(qb), ptr(sb), None, ptr(c), None, 1, 1, stream_ptr()), "gemm_fp8")
         assert ((c - ref).abs().max() / ref.abs().max()).item() <= 1e-4
         assert ((_mx_dequant(qa, ma) - a).abs() <= 0.0625 * a.abs() + 1e-6 * a.abs().max()).all()      # the reference quantiser itself
         # output mode: e4m3 bytes + one scale per row and 32 columns, against the fp32 output of the same launch
-        c8, cm = torch.empty(M, N, dtype=torch.uint8, device="cuda"), torch.empty(M, N // 32, dtype=torch.uint8, device="cuda")
-        check(lib.natinf_debug_gemm_fp8(M, N, K, ptr(qa), None, ptr(ma), ptr(qb), ptr(sb), None, ptr(c8), ptr(cm), 3, 1, stream_ptr()), "gemm_fp8")
+        c8, cmt = torch.empty(M, N, dtype=torch.uint8, device="cuda"), torch.empty((N // 128) * M * 4, dtype=torch.uint8, device="cuda")
+        check(lib.natinf_debug_gemm_fp8(M, N, K, ptr(qa), None, ptr(mat), ptr(qb), ptr(sb), None, ptr(c8), ptr(cmt), 3, 1, stream_ptr()), "gemm_fp8")
+        cm = cmt.reshape(N // 128, M, 4).permute(1, 0, 2).reshape(M, N // 32).contiguous()
         want_q, want_m = _mx_quant(c)
         assert torch.equal(cm, want_m)
         dec = _mx_dequant(c8, cm)

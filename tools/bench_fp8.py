@@ -35,3 +35,21 @@ def run(M, N, K, iters=10, chk=False):
 print(run(512, 256, 256, 2, True)); print(run(1000, 520, 384, 2, True)); print(run(4096, 1536, 1536, 2, True))
 for shp in ((32768, 1536, 1536), (32768, 3072, 1536), (32768, 6144, 1536), (32768, 1536, 6144), (8192, 8192, 8192)):
     print(shp, {k: round(v, 1) for k, v in run(*shp).items()})
+
+def run_mx(M, N, K, iters=10):
+    qa = torch.randint(0, 120, (M, K), dtype=torch.uint8, device=dev); ma = torch.randint(120, 130, (M * K // 32 + 1024,), dtype=torch.uint8, device=dev)
+    b = torch.randn(N, K, device=dev) * 0.05; qb, sb = quant(b)
+    c = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    c8 = torch.empty(M, N, dtype=torch.uint8, device=dev); cm = torch.empty(M * N // 32 + 1024, dtype=torch.uint8, device=dev)
+    res = {}
+    for name, args in (("mxa->bf16", lambda it: (M, N, K, ptr(qa), None, ptr(ma), ptr(qb), ptr(sb), None, ptr(c), None, 0, it, stream_ptr())),
+                       ("plain->bf16", lambda it: (M, N, K, ptr(qa), None, None, ptr(qb), ptr(sb), None, ptr(c), None, 0, it, stream_ptr())),
+                       ("plain->fp8mx", lambda it: (M, N, K, ptr(qa), None, None, ptr(qb), ptr(sb), None, ptr(c8), ptr(cm), 3, it, stream_ptr()))):
+        check(lib.natinf_debug_gemm_fp8(*args(2)), "gemm_fp8"); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); check(lib.natinf_debug_gemm_fp8(*args(iters)), "gemm_fp8"); e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        res[name] = round(2.0 * M * N * K / ms / 1e9)
+    return res
+for shp in ((32768, 1536, 1536), (32768, 1536, 6144), (32768, 6144, 1536)):
+    print("mx", shp, run_mx(*shp))
