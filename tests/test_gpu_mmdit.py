@@ -141,14 +141,15 @@ def test_full_sequence_length_narrow_width_matches_oracle():
     assert ((out - ref).abs().max() / ref.abs().max()).item() <= TOL
 
 
-def test_forward_is_deterministic_and_ignores_workspace_contents():
+@pytest.mark.parametrize("fp8", [False, True])
+def test_forward_is_deterministic_and_ignores_workspace_contents(fp8):
     """Two forwards over a NaN-poisoned and a zeroed workspace give bit-identical, finite results (guards the LDS-DMA
     completion wait in the attention kernel and every padded / never-written region of the joint buffers)."""
     from oracle import mmdit_oracle as M
     from naturaldiffusion_amd.mmdit import MMDiTEngine, flatten_state_dict
     cfg = dict(layers=4, heads=4, joint_dim=64, pooled_dim=32)
     P = M.make_params(seed=12, pos_max=192, pos_base=64, **cfg)
-    eng = MMDiTEngine(flatten_state_dict(P, 64, **cfg), max_batch=3, grid=64, ctx_tokens=333, **cfg)
+    eng = MMDiTEngine(flatten_state_dict(P, 64, **cfg), max_batch=3, grid=64, ctx_tokens=333, fp8=fp8, **cfg)
     g = torch.Generator().manual_seed(4)
     x, t = torch.randn(3, 16, 128, 128, generator=g).cuda(), torch.tensor([999.0, 500.0, 1.0]).cuda()
     e, p = torch.randn(3, 333, 64, generator=g).cuda(), torch.randn(3, 32, generator=g).cuda()
