@@ -19,8 +19,11 @@
 // 8-wave blocks sharing a K/V tile (half the DMA requests per wave): +-0; v_permlane16/32_swap instead of ds_bpermute for
 // the 4-lane maxima: +-0; tree instead of chain reductions: slower.  Ablation of the loop: without the softmax block
 // 0.90 ms, without P V 1.13 ms, S^T alone 0.47 ms (1.0 PFLOP/s), without the exp only: unchanged -- the serial
-// S -> softmax -> PV order inside a wave is the cost, not any single instruction class; overlapping tile t's softmax
-// with tile t+1's S^T (two S register sets) is the open step.
+// S -> softmax -> PV order inside a wave is the cost, not any single instruction class.  Also without effect (+-2 %):
+// 64 queries per wave with 64-key tiles (half the LDS fragment bytes per MFMA), 64-key tiles at 3 and 4 waves per SIMD
+// (130 / 128 VGPRs).  What is common to all of them is the instruction count per tile -- ~250 VALU + 66 v_exp beside 64
+// MFMAs per wave -- so the open steps are fewer VALU instructions per score (row sums through an all-ones V^T row on the
+// matrix pipe, max over packed halves) and overlapping tile t's softmax with tile t+1's S^T (two S register sets).
 // Reference: diffusers JointAttnProcessor2_0 as called by pipe.transformer (src/SD3NaturalInference.py:210-213).
 #pragma once
 #include "ncsnpp_kernels.h"
