@@ -17,25 +17,28 @@
 
 namespace ncsn {
 
-template <int NQK, int ND>
+// TWO_PHASE (head_dim 256, the NCSN++ attention): K and V^T do not fit LDS together, so V^T is loaded into K's place after
+// the scores are done -- P waits in registers as packed bf16 meanwhile.
+template <int NQK, int ND, bool TWO_PHASE = false>
 struct AttnCfg {
     static constexpr int T = 256, THREADS = 512;
     static constexpr int KSTR = NQK * 64 + 16;            // bytes per K row (NQK*32 bf16 + pad)
     static constexpr int VSTR = T * 2 + 16;               // bytes per V^T row
-    static constexpr int LDS_BYTES = T * KSTR + ND * 16 * VSTR;
+    static constexpr int KB = T * KSTR, VB = ND * 16 * VSTR;
+    static constexpr int LDS_BYTES = TWO_PHASE ? (KB > VB ? KB : VB) : KB + VB;
     static_assert(LDS_BYTES <= 163840, "LDS budget");
 };
 
 // qk: [B*256][qk_ld] bf16 with q at column 0 and k at column k_off (+ head*hd); vT: [B][H*hd][256]; o: [B*256][o_ld]
-template <int NQK, int ND>
+template <int NQK, int ND, bool TWO_PHASE = false>
 __global__ __launch_bounds__(512) void k_attn_fused(const bf16* __restrict__ qk, int qk_ld, int k_off, const bf16* __restrict__ vT,
                                                     bf16* __restrict__ o, int o_ld, int H, int hd, float scale)
 {
-    using Cfg = AttnCfg<NQK, ND>;
+    using Cfg = AttnCfg<NQK, ND, TWO_PHASE>;
     constexpr int T = Cfg::T, KSTR = Cfg::KSTR, VSTR = Cfg::VSTR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sK = smem;
-    unsigned char* sV = smem + T * KSTR;
+    unsigned char* sV = TWO_PHASE ? smem : smem + T * KSTR;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
@@ -49,14 +52,17 @@ __global__ __launch_bounds__(512) void k_attn_fused(const bf16* __restrict__ qk,
         const uint4 v = ch * 8 < hd ? *reinterpret_cast<const uint4*>(kbase + (int64_t)row * qk_ld + ch * 8) : zero4;
         *reinterpret_cast<uint4*>(sK + row * KSTR + ch * 16) = v;
     }
-    for (int idx = tid; idx < ND * 16 * 32; idx += 512) {                      // V^T rows, keys permuted inside 32-key chunks
-        const int d = idx >> 5, m8 = idx & 31, c = m8 >> 2, m = m8 & 3;
-        const uint4 v = d < hd ? *reinterpret_cast<const uint4*>(vbase + (int64_t)d * T + m8 * 8) : zero4;
-        const int qa = (m & 1) * 2, jo = (m >> 1) * 4;
-        unsigned char* row = sV + d * VSTR + (32 * c + jo) * 2;
-        *reinterpret_cast<uint2*>(row + 8 * qa * 2) = make_uint2(v.x, v.y);
-        *reinterpret_cast<uint2*>(row + 8 * (qa + 1) * 2) = make_uint2(v.z, v.w);
-    }
+    auto load_vT = [&]() __attribute__((always_inline)) {
+        for (int idx = tid; idx < ND * 16 * 32; idx += 512) {                      // V^T rows, keys permuted inside 32-key chunks
+            const int d = idx >> 5, m8 = idx & 31, c = m8 >> 2, m = m8 & 3;
+            const uint4 v = d < hd ? *reinterpret_cast<const uint4*>(vbase + (int64_t)d * T + m8 * 8) : zero4;
+            const int qa = (m & 1) * 2, jo = (m >> 1) * 4;
+            unsigned char* row = sV + d * VSTR + (32 * c + jo) * 2;
+            *reinterpret_cast<uint2*>(row + 8 * qa * 2) = make_uint2(v.x, v.y);
+            *reinterpret_cast<uint2*>(row + 8 * (qa + 1) * 2) = make_uint2(v.z, v.w);
+        }
+    };
+    if (!TWO_PHASE) load_vT();
     bf16x8 qf[2][NQK];
 #pragma unroll
     for (int g = 0; g < 2; ++g)
@@ -100,21 +106,28 @@ __global__ __launch_bounds__(512) void k_attn_fused(const bf16* __restrict__ qk,
         inv[g] = 1.0f / sum;
     }
 
+    bf16x8 pf[2][8];                                 // P as the B operand of O^T = V^T P^T: the score registers are free after this
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { pf[g][c][i] = (bf16)acc[g][2 * c][i]; pf[g][c][4 + i] = (bf16)acc[g][2 * c + 1][i]; }
+    if (TWO_PHASE) {
+        __syncthreads();                             // every wave is done with K
+        load_vT();
+        __syncthreads();
+    }
     f32x4 oacc[2][ND];
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt) { oacc[0][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc[1][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        bf16x8 pf[2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { pf[g][i] = (bf16)acc[g][2 * c][i]; pf[g][4 + i] = (bf16)acc[g][2 * c + 1][i]; }
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(sV + (16 * dt + r) * VSTR + (32 * c + 8 * q) * 2);
-            oacc[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[0], oacc[0][dt], 0, 0, 0);
-            oacc[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[1], oacc[1][dt], 0, 0, 0);
+            oacc[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[0][c], oacc[0][dt], 0, 0, 0);
+            oacc[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[1][c], oacc[1][dt], 0, 0, 0);
         }
     }
 #pragma unroll

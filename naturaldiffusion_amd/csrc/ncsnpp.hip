@@ -189,6 +189,7 @@ bool configure_gemm_kernels() {
          set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>) &&
          set_lds<CfgD256x256>(&k_gemm_fp8<false>) && set_lds<CfgD256x256>(&k_gemm_fp8<true>) &&
          set_lds<Cfg8ph>(&k_gemm_8ph<0>) && set_lds<Cfg8ph>(&k_gemm_8ph<1>) && set_lds<Cfg8ph>(&k_gemm_8ph<2>) && set_lds<Cfg8ph>(&k_gemm_8ph<3>) &&
+         set_lds<AttnCfg<8, 16, true>>(&k_attn_fused<8, 16, true>) &&
          set_lds<AttnCfg<2, 4>>(&k_attn_fused<2, 4>) && set_lds<AttnCfg<3, 6>>(&k_attn_fused<3, 6>) &&
          set_lds<AttnCfg<3, 5>>(&k_attn_fused<3, 5>) &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess;
@@ -467,31 +468,42 @@ struct Builder {
             launch_gemm(g, c.stream);
         });
         arena.release(h.off);
-        const int64_t S = arena.alloc((int64_t)T * T * 4);
-        op(CLS_GEMM, [=](const Ctx& c) {             // S[b] = q[b] k[b]^T / sqrt(C)
-            GemmArgs g = gemm_defaults();
-            g.a0 = c.at<bf16>(qk); g.a0_ld = 2 * C; g.a0_C = C; g.a_bs = (int64_t)T * 2 * C; g.M = T; g.N = T;
-            g.b = c.at<bf16>(qk) + C; g.b_ld = 2 * C; g.b_bs = (int64_t)T * 2 * C;
-            g.scale = 1.0f / sqrtf((float)C);
-            g.c = c.at<float>(S); g.c_ld = T; g.c_bs = (int64_t)T * T; g.c_mode = OUT_F32; g.batch = c.B;
-            launch_gemm(g, c.stream);
-        });
-        const int64_t P = arena.alloc((int64_t)T * T * 2);
-        op(CLS_OTHER, [=](const Ctx& c) {
-            const int64_t rows = (int64_t)c.B * T;
-            hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c.stream,
-                               c.at<float>(S), c.at<bf16>(P), T, rows);
-        });
-        arena.release(S);
         TRef O = new_act(m.res, C);
-        op(CLS_GEMM, [=](const Ctx& c) {             // O[b] = P[b] V[b]
-            GemmArgs g = gemm_defaults();
-            g.a0 = c.at<bf16>(P); g.a0_ld = T; g.a0_C = T; g.a_bs = (int64_t)T * T; g.M = T; g.N = C;
-            g.b = c.at<bf16>(vT); g.b_ld = T; g.b_bs = (int64_t)C * T;
-            g.c = c.act(O); g.c_ld = C; g.c_bs = (int64_t)T * C; g.batch = c.B;
-            launch_gemm(g, c.stream);
-        });
-        arena.release(P); arena.release(vT); arena.release(qk);
+        if (T == 256 && C == 256) {
+            // 16x16 attention: scores, softmax and P V of a sample in one block (attn_fused.h, two-phase: V^T follows K through LDS)
+            op(CLS_GEMM, [=](const Ctx& c) {
+                using Cfg = AttnCfg<8, 16, true>;
+                auto kern = &k_attn_fused<8, 16, true>;
+                hipLaunchKernelGGL(kern, dim3((unsigned)c.B), dim3(Cfg::THREADS), Cfg::LDS_BYTES, c.stream, c.at<bf16>(qk), 2 * C, C,
+                                   c.at<bf16>(vT), c.act(O), C, 1, C, 1.0f / sqrtf((float)C));
+            });
+            arena.release(vT); arena.release(qk);
+        } else {
+        const int64_t S = arena.alloc((int64_t)T * T * 4);
+            op(CLS_GEMM, [=](const Ctx& c) {             // S[b] = q[b] k[b]^T / sqrt(C)
+                GemmArgs g = gemm_defaults();
+                g.a0 = c.at<bf16>(qk); g.a0_ld = 2 * C; g.a0_C = C; g.a_bs = (int64_t)T * 2 * C; g.M = T; g.N = T;
+                g.b = c.at<bf16>(qk) + C; g.b_ld = 2 * C; g.b_bs = (int64_t)T * 2 * C;
+                g.scale = 1.0f / sqrtf((float)C);
+                g.c = c.at<float>(S); g.c_ld = T; g.c_bs = (int64_t)T * T; g.c_mode = OUT_F32; g.batch = c.B;
+                launch_gemm(g, c.stream);
+            });
+            const int64_t P = arena.alloc((int64_t)T * T * 2);
+            op(CLS_OTHER, [=](const Ctx& c) {
+                const int64_t rows = (int64_t)c.B * T;
+                hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c.stream,
+                                   c.at<float>(S), c.at<bf16>(P), T, rows);
+            });
+            arena.release(S);
+            op(CLS_GEMM, [=](const Ctx& c) {             // O[b] = P[b] V[b]
+                GemmArgs g = gemm_defaults();
+                g.a0 = c.at<bf16>(P); g.a0_ld = T; g.a0_C = T; g.a_bs = (int64_t)T * T; g.M = T; g.N = C;
+                g.b = c.at<bf16>(vT); g.b_ld = T; g.b_bs = (int64_t)C * T;
+                g.c = c.act(O); g.c_ld = C; g.c_bs = (int64_t)T * C; g.batch = c.B;
+                launch_gemm(g, c.stream);
+            });
+            arena.release(P); arena.release(vT); arena.release(qk);
+        }
         const Part po = register_output(out);
         op(CLS_GEMM, [=](const Ctx& c) {             // out = (x + O W3 + b3) / sqrt(2)
             GemmArgs g = gemm_defaults();
