@@ -7,8 +7,8 @@ Same public names as the reference (``space_timesteps``, ``create_ddpm_coeff``, 
 ``vae_path``, ``model_path``).  ``natural_inference`` -- the path being accelerated -- runs one fused
 ``natinf_step_f32prod`` launch per step.  The two *original* samplers are the baselines it is compared
 with and stay host-sequenced tensor algebra.  The DiT-XL/2 denoiser is the gfx950 engine of
-``include/natinf_dit.h`` loaded from ``model_path`` (or whatever ``denoiser_factory`` returns); the VAE comes
-from the un-vendored ``diffusers`` (reference requirements.txt:13) and is injected through ``decoder_factory``.
+``include/natinf_dit.h`` loaded from ``model_path`` (or whatever ``denoiser_factory`` returns); the VAE decoder is
+the engine of ``include/natinf_vae.h`` loaded from ``vae_path`` (or ``decoder_factory``), images written with PIL.
 """
 from __future__ import annotations
 
@@ -172,11 +172,48 @@ def _setup(seed):
     return model, labels, len(labels)
 
 
+def load_vae_decoder(path, max_batch=8):
+    """Reference :212-214 (``AutoencoderKL.from_pretrained(vae_path)``) on the gfx950 decoder engine (include/natinf_vae.h):
+    ``path`` is the model directory (``diffusion_pytorch_model.safetensors`` / ``.bin``) or a weights file."""
+    from .vae import VAEDecoder, flatten_state_dict
+    key = ("vae", str(path), max_batch)
+    if key not in _engine_cache:
+        p = Path(path)
+        if p.is_dir():
+            cand = [p / "diffusion_pytorch_model.safetensors", p / "diffusion_pytorch_model.bin"]
+            p = next((c for c in cand if c.exists()), cand[0])
+        if p.suffix == ".safetensors":
+            from safetensors.torch import load_file
+            sd = load_file(str(p))
+        else:
+            sd = torch.load(p, map_location="cpu", weights_only=True)
+        _engine_cache[key] = VAEDecoder(flatten_state_dict(sd, 4, prefix="decoder."), max_batch, latent_ch=4, latent_res=32, device=device)
+    return _engine_cache[key]
+
+
+def save_image_grid(images: torch.Tensor, path, nrow: int = 4) -> None:
+    """``torchvision.utils.save_image(samples, path, nrow=4, normalize=True, value_range=(-1, 1))`` (reference :236) without
+    torchvision: clamp to [-1, 1], map to [0, 255], tile with 2-pixel padding, write with PIL."""
+    from PIL import Image
+    x = ((images.detach().float().cpu().clamp(-1, 1) + 1) * 0.5)
+    n, c, h, w = x.shape
+    ncol = min(nrow, n); nr = (n + ncol - 1) // ncol
+    grid = torch.zeros(c, nr * (h + 2) + 2, ncol * (w + 2) + 2)
+    for i in range(n):
+        r0, c0 = (i // ncol) * (h + 2) + 2, (i % ncol) * (w + 2) + 2
+        grid[:, r0:r0 + h, c0:c0 + w] = x[i]
+    arr = (grid * 255 + 0.5).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).numpy()
+    Image.fromarray(arr).save(str(path))
+
+
 def _finish(input_z, name):
     global last_latents
     last_latents = input_z
     if decoder_factory is not None:
         decoder_factory()(input_z / 0.18215, make_path(root_path / ("results/validation/" + name)))
+    elif vae_path is not None:                               # reference :231-236: decode the latents, write the 2x4 grid
+        images = load_vae_decoder(vae_path)(input_z / 0.18215)
+        save_image_grid(images, make_path(root_path / ("results/validation/" + name)))
     return input_z
 
 

@@ -72,6 +72,14 @@ SIGNATURES = {
     "natinf_mmdit_load": (C.c_int, [_p, _p, _i64, _p, _i64, _p]),
     "natinf_mmdit_forward": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _p, _i64, _p]),
     "natinf_attention_hd64_bf16": (C.c_int, [_p, _p, _i32, _i64, _p, _p, _i32, _i64, _i32, _i32, _i32, _i32, C.c_float, _p]),
+    # include/natinf_vae.h
+    "natinf_vae_create": (C.c_int, [C.POINTER(_p), _i32, _i32]),
+    "natinf_vae_destroy": (C.c_int, [_p]),
+    "natinf_vae_param_count": (C.c_int64, [_p]),
+    "natinf_vae_packed_bytes": (C.c_int64, [_p]),
+    "natinf_vae_workspace_bytes": (C.c_int64, [_p, _i32]),
+    "natinf_vae_load": (C.c_int, [_p, _p, _i64, _p, _i64, _p]),
+    "natinf_vae_decode": (C.c_int, [_p, _p, _p, _i32, _p, _i64, _p]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

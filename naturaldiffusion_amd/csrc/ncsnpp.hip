@@ -977,3 +977,4 @@ int natinf_ncsnpp_debug_tap(natinf_ncsnpp_t h, int module_idx, float* out, int64
 }  // extern "C"
 #include "dit_engine.inc"
 #include "mmdit_engine.inc"
+#include "vae_engine.inc"

@@ -12,7 +12,8 @@ for the NCSN++ denoiser (A4) by the fixtures under ``tests/golden/`` that
 ``tests/golden/make_golden.py`` captured from the reference itself, imported
 on CPU in the build container; ``dit_oracle`` is pinned to the reference's own
 ``DiT`` class for everything DiT-specific.  PARITY UNPINNED: ``mmdit_oracle``
-(the SD3 MMDiT is ``diffusers``' -- un-vendored, un-pinned, absent here; the
-file restates the published architecture) and the three ``timm`` building
-blocks inside DiT.
+and ``vae_oracle`` (the SD3 MMDiT and the AutoencoderKL decoder are
+``diffusers``' -- un-vendored, un-pinned, absent here; the files restate the
+published architectures) and the three ``timm`` building blocks inside DiT
+(see DESIGN.md section 2).
 """

@@ -24,3 +24,15 @@ def test_small_configs_match_reference_class(fx, tag, depth, hid, heads):
 def test_xl2_parameter_count(fx):
     n = sum(int(np.prod(s)) for k, s in D.param_shapes(28, 1152).items())
     assert n == int(fx["xl2_nparam"]) == 675129632                  # DiT-XL/2 (models.py:333-334), incl. the frozen pos_embed
+
+
+def test_vae_and_mmdit_oracles_have_the_published_sizes():
+    """sanity anchors for the two unpinned restatements: parameter counts of the public checkpoints (sd-vae-ft-ema decoder
+    49.5 M; SD3-medium transformer 2.03 B without the position table) and output shapes."""
+    from oracle import vae_oracle as V, mmdit_oracle as M
+    n = sum(int(np.prod(s)) for s in V.param_shapes(4).values())
+    assert n == 49490179
+    y = V.decode(V.make_params(4, 0), torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(0)))
+    assert y.shape == (1, 3, 64, 64) and torch.isfinite(y).all()
+    sh = M.param_shapes(24, 24, 4096, 2048)
+    assert sum(int(np.prod(s)) for k, s in sh.items() if k != "pos_embed.pos_embed") == 2028328000
