@@ -24,7 +24,7 @@ extern "C" {
 
 typedef struct natinf_vae* natinf_vae_t;
 
-int natinf_vae_create(natinf_vae_t* out, int latent_ch, int latent_res);     /* latent_ch 1..64, latent_res 8, 16, 32 or 64 */
+int natinf_vae_create(natinf_vae_t* out, int latent_ch, int latent_res);     /* latent_ch 1..64, latent_res 8, 16, 32, 64 or 128 */
 int natinf_vae_destroy(natinf_vae_t h);
 int64_t natinf_vae_param_count(natinf_vae_t h);
 int64_t natinf_vae_packed_bytes(natinf_vae_t h);

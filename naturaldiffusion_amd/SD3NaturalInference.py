@@ -24,6 +24,7 @@ from .coeff import load_sd3_csv, SparseRows
 from .sampler import SD3NI
 
 root_path = Path(__file__).resolve().parent.parent
+results_path = root_path            # where results/sd3/*.png go (the reference writes below its own root, :241)
 PROMPT = "A cat holding a sign that says hello world"
 
 
@@ -85,6 +86,17 @@ def use_native_transformer(pipe, n: int, latent_side: int = 128, ctx_tokens: Opt
     return pipe
 
 
+def use_native_vae(pipe, n: int, latent_side: int = 128, device="cuda:0"):
+    """Decode with the HIP AutoencoderKL decoder engine (include/natinf_vae.h) built from ``pipe.vae``'s own weights instead of
+    ``pipe.vae.decode`` (reference :238-240); ``pipe.vae`` stays in place for its config (scaling / shift factors)."""
+    from .vae import VAEDecoder, flatten_state_dict
+    if getattr(pipe, "natinf_vae", None) is None:
+        lc = int(pipe.vae.config.latent_channels)
+        pipe.natinf_vae = VAEDecoder(flatten_state_dict(pipe.vae.state_dict(), lc, prefix="decoder."), max_batch=n,
+                                     latent_ch=lc, latent_res=latent_side, device=device)
+    return pipe
+
+
 def _load_pipe(pipe, device, dtype, n=4):
     if pipe is not None:
         return pipe
@@ -95,7 +107,7 @@ def _load_pipe(pipe, device, dtype, n=4):
                           "weights (un-vendored in the reference); pass pipe=... to use another denoiser") from e
     pipe = StableDiffusion3Pipeline.from_pretrained("stabilityai/stable-diffusion-3-medium-diffusers",
                                                     torch_dtype=dtype, local_files_only=True).to(device)
-    return use_native_transformer(pipe, n, device=device)
+    return use_native_vae(use_native_transformer(pipe, n, device=device), n, device=device)
 
 
 def _prepare(pipe, device, dtype, n, seed, num_step, noises):
@@ -110,9 +122,22 @@ def _prepare(pipe, device, dtype, n, seed, num_step, noises):
 
 
 def _decode(pipe, latents):
+    """Reference :238-240 -> list of uint8 HWC RGB arrays (the pixels ``image_processor.postprocess(output_type="pil")`` holds:
+    ``(x / 2 + 0.5).clamp(0, 1) * 255`` rounded)."""
     z = (latents / pipe.vae.config.scaling_factor) + pipe.vae.config.shift_factor
+    dec = getattr(pipe, "natinf_vae", None)
+    if dec is not None:
+        images = dec(z.float())
+        return list(((images * 0.5 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy())
     images = pipe.vae.decode(z, return_dict=False)[0]
-    return pipe.image_processor.postprocess(images, output_type="pil")
+    return [np.array(im) for im in pipe.image_processor.postprocess(images, output_type="pil")]
+
+
+def _write_row(path, images):
+    """Reference :241-243 (``cv2.imwrite`` of the BGR-flipped row of images) without cv2: the same RGB file through PIL."""
+    from PIL import Image
+    os.makedirs(os.path.dirname(str(path)), exist_ok=True)
+    Image.fromarray(np.hstack(images)).save(str(path))
 
 
 def _velocities(pipe, x, ts, emb):
@@ -149,12 +174,7 @@ def sd_natural_inference_tx(pipe=None, device="cuda", noises: Optional[torch.Ten
         out = mean.view(shape).clone()
         finals.append(out)
         if decode:
-            import cv2
-            images = _decode(pipe, out)
-            img_all = np.hstack([np.array(image)[:, :, ::-1] for image in images])
-            path = root_path / ("results/sd3/sgl_%s.png" % (weight_name[:-4]))
-            os.makedirs(path.parent, exist_ok=True)
-            cv2.imwrite(str(path), img_all)
+            _write_row(results_path / ("results/sd3/sgl_%s.png" % (weight_name[:-4])), _decode(pipe, out))
     return finals
 
 
@@ -175,11 +195,7 @@ def sd_euler_natural_inference_tx(pipe=None, device="cuda", noises: Optional[tor
         mean, x = ni.step(i, x, vt.reshape(-1), vn.reshape(-1), flat_noise, want_next=i + 1 < num_step)
     out = mean.view(shape).clone()
     if decode:
-        import cv2
-        images = _decode(pipe, out)
-        path = root_path / "results/sd3/euler_sgl_clip0.png"
-        os.makedirs(path.parent, exist_ok=True)
-        cv2.imwrite(str(path), np.hstack([np.array(image)[:, :, ::-1] for image in images]))
+        _write_row(results_path / "results/sd3/euler_sgl_clip0.png", _decode(pipe, out))
     return out
 
 

@@ -66,8 +66,8 @@ def flatten_state_dict(sd: Dict[str, torch.Tensor], latent_ch: int = 4, prefix: 
 class VAEDecoder:
     def __init__(self, flat_params: torch.Tensor, max_batch: int, latent_ch: int = 4, latent_res: int = 32, device="cuda:0"):
         _lib.require_gpu()
-        if not (1 <= latent_ch <= 64) or latent_res not in (8, 16, 32, 64):
-            raise ValueError("latent_ch in 1..64, latent_res one of 8, 16, 32, 64")
+        if not (1 <= latent_ch <= 64) or latent_res not in (8, 16, 32, 64, 128):
+            raise ValueError("latent_ch in 1..64, latent_res one of 8, 16, 32, 64, 128")
         self.device = torch.device(device)
         self.max_batch, self.latent_ch, self.latent_res = int(max_batch), latent_ch, latent_res
         self._h = C.c_void_p()
