@@ -83,6 +83,12 @@ int natinf_debug_quant_fp8_rows(const float* w, void* q, float* row_scale, int r
 int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_scale, const void* a_mx, const void* b8, const float* b_scale,
                           const float* bias_n, void* c, void* c_mx, int c_mode, int iters, natinf_stream_t stream);
 int natinf_set_gemm_variant(int variant);
+/* A/B switch for tuning: 1 = every GEMM takes the fp32-slab epilogue, 0 (default) = the packed bf16 epilogue where it applies. */
+int natinf_set_gemm_epilogue(int fp32_slab);
+/* Timing experiments (tools/tile_timeline.py): device buffer of 16 uint64 shader-clock stamps that block 0 / thread 0 of
+ * every natinf_debug_gemm launch writes (kernel start, first tile landed, main loop done, per epilogue pass: slab written,
+ * sweeps done, stores issued).  NULL switches it off. */
+int natinf_debug_timestamps(void* dev_buf16);
 
 /* Measurement hooks (bench.py): while enabled, every launch group of a forward is bracketed by a HIP event
  * pair on `stream`.  natinf_ncsnpp_profile_read waits for the recorded events and returns, per class

@@ -43,6 +43,11 @@ struct EpiCfg {
     static constexpr int SLAB_ROWS = WM * RB * 16;
     static constexpr int SLAB_BYTES = bytes(RB);
     static_assert(TM % RB == 0 && SLAB_BYTES <= AVAIL, "epilogue staging does not fit");
+    // packed (bf16) whole-tile slab of the column-terms-only epilogue: rows of BN bf16 + 16 B (a 4-bank shift per row)
+    static constexpr int PROW = WN * TN * 16 * 2 + 16;
+    static constexpr int PACK_BYTES = WM * TM * 16 * PROW;
+    static constexpr bool PACK_OK = PACK_BYTES <= AVAIL;
+    static constexpr int NEED = PACK_OK && PACK_BYTES > SLAB_BYTES ? PACK_BYTES : SLAB_BYTES;
 };
 
 template <int WM, int WN, int TM, int TN>
@@ -52,7 +57,7 @@ struct DmaCfg {
     static constexpr int STAGE_BYTES = (BM_ + BN_) * BK * 2;
     static constexpr int PA = BM_ / 8 / NW, PB = BN_ / 8 / NW;            // 1-KiB DMA pieces per wave per K-tile
     using Epi = EpiCfg<WM, WN, TM, TN, 2 * STAGE_BYTES + 4096>;
-    static constexpr int LDS_BYTES = Epi::SLAB_BYTES > 2 * STAGE_BYTES ? Epi::SLAB_BYTES : 2 * STAGE_BYTES;
+    static constexpr int LDS_BYTES = Epi::NEED > 2 * STAGE_BYTES ? Epi::NEED : 2 * STAGE_BYTES;
     static_assert(BM_ % (8 * NW) == 0 && BN_ % (8 * NW) == 0, "DMA pieces must divide evenly over the waves");
 };
 
@@ -64,12 +69,125 @@ struct DmaCfg {
 // every run-time branch that touches it.  Not kept.)
 // Epilogue shared by the DMA kernels: in TM/RB passes, RB row-tiles of every wave -> LDS (fp32) -> fused adds
 // (bias, per-sample row vector, residual, scale, SiLU) in fp32 -> 16-byte coalesced stores.
+#define NATINF_TS(i) do { if (g.dbg_ts && tid == 0 && blockIdx.x == 0) g.dbg_ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+// Column-terms-only epilogue (bias, per-sample row vector of a tile that lies inside one sample, scale, activation,
+// GroupNorm partials; bf16 output): everything is applied in the accumulator registers, the tile is rounded to bf16 THERE
+// and crosses LDS once as 2-byte values -- a quarter of the fp32 slab's LDS traffic, one barrier, and sweeps that are pure
+// 16-byte LDS -> global copies.  (Tile timeline of the fp32-slab path at 256x256, shader clocks: slab writes 5.0k +
+// sweeps 11.6k + stores 2.8k = 19.5k per tile against 3.7k per 64-wide K-tile of main loop; tools/tile_timeline.py.)
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+// slab -> global copy of sweeps SW .. NSW-1: all LDS reads first, then the stores (template recursion instead of an array of
+// kept values: hipcc left a 16-entry uint4 array in scratch memory here)
+template <int SW, int NSW, int RPS, int PROW, bool EDGE>
+struct SlabCopy {
+    static __device__ __forceinline__ void run(const unsigned char* src, bf16* dst, int64_t ld, int m, int M) {
+        const uint4 v = *reinterpret_cast<const uint4*>(src + SW * RPS * PROW);
+        SlabCopy<SW + 1, NSW, RPS, PROW, EDGE>::run(src, dst, ld, m, M);
+        if (!EDGE || m + SW * RPS < M) *reinterpret_cast<uint4*>(dst + (int64_t)(SW * RPS) * ld) = v;
+    }
+};
+template <int NSW, int RPS, int PROW, bool EDGE>
+struct SlabCopy<NSW, NSW, RPS, PROW, EDGE> {
+    static __device__ __forceinline__ void run(const unsigned char*, bf16*, int64_t, int, int) {}
+};
+template <int WM, int WN, int TM, int TN, class Cfg, int ACT, bool GN, bool RES>
+__device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned char* smem, f32x4 (&acc)[TM][TN],
+                                                     int m0, int n0, int z, int tid, int lane, int wm, int wn)
+{
+    constexpr int BN_ = WN * TN * 16, BM_ = WM * TM * 16, THREADS = WM * WN * 64, PROW = Cfg::PROW;
+    const int r = lane & 15, q = lane >> 4;
+    float ct[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 16 + j * 16 + q * 4;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f), rv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < g.N) {
+            if (g.bias_n) b = *reinterpret_cast<const float4*>(g.bias_n + n);
+            if (g.rowvec) rv = *reinterpret_cast<const float4*>(g.rowvec + (int64_t)((m0 >> g.log_rows_per_sample) + z * g.z_samples) * g.rowvec_ld + n);
+        }
+        ct[j][0] = b.x + rv.x; ct[j][1] = b.y + rv.y; ct[j][2] = b.z + rv.z; ct[j][3] = b.w + rv.w;
+    }
+    // bf16 residual, fetched in the accumulator layout (8 bytes per lane: 4 columns of one row), all requests in flight at once
+    uint2 rs[RES ? TM : 1][RES ? TN : 1];
+    if constexpr (RES) {
+        const bf16* rb = g.resid + (int64_t)z * g.c_bs + n0 + wn * TN * 16 + q * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = min(m0 + wm * TM * 16 + i * 16 + r, g.M - 1);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                rs[i][j] = n0 + wn * TN * 16 + j * 16 + q * 4 < g.N ? *reinterpret_cast<const uint2*>(rb + (int64_t)m * g.resid_ld + j * 16) : make_uint2(0u, 0u);
+        }
+    }
+    float gs[TN], gq[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
+    const float scale = g.scale;
+    unsigned char* wbase = smem + (wm * TM * 16 + r) * PROW + (wn * TN * 16 + q * 4) * 2;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + ct[j][e];
+            if constexpr (RES) {
+                const bf16x4_t x = __builtin_bit_cast(bf16x4_t, rs[i][j]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)x[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= scale;
+            if constexpr (ACT != ACT_NONE) apply_act4(v, ACT);
+            if constexpr (GN) {
+                gs[j] += (v[0] + v[1]) + (v[2] + v[3]);
+                gq[j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            }
+            bf16x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+            *reinterpret_cast<uint2*>(wbase + i * 16 * PROW + j * 32) = __builtin_bit_cast(uint2, o);
+        }
+    __syncthreads();
+    NATINF_TS(3);
+    constexpr int CPR = BN_ / 8, RPS = THREADS / CPR, NSW = BM_ / RPS;
+    const int cchunk = tid % CPR, rsub = tid / CPR, n = n0 + cchunk * 8;
+    if (n < g.N) {
+        const unsigned char* src = smem + rsub * PROW + cchunk * 16;
+        bf16* dst = reinterpret_cast<bf16*>(g.c) + (int64_t)z * g.c_bs + (int64_t)(m0 + rsub) * g.c_ld + n;
+        if (m0 + BM_ <= g.M) SlabCopy<0, NSW, RPS, PROW, false>::run(src, dst, g.c_ld, m0 + rsub, g.M);
+        else SlabCopy<0, NSW, RPS, PROW, true>::run(src, dst, g.c_ld, m0 + rsub, g.M);
+    }
+    NATINF_TS(4);
+    if constexpr (GN) {
+        // fixed-order reduction: the 16 row-lanes of a lane group (xor butterflies), then the WM waves of a column through LDS
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { gs[j] += __shfl_xor(gs[j], o); gq[j] += __shfl_xor(gq[j], o); }
+        __syncthreads();                               // every sweep has read the slab
+        float2* sred = reinterpret_cast<float2*>(smem);
+        if (r == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) sred[wm * (BN_ / 4) + wn * TN * 4 + j * 4 + q] = make_float2(gs[j], gq[j]);
+        }
+        __syncthreads();
+        if (tid < BN_ / 4 && n0 + tid * 4 < g.N) {
+            float s = 0.f, qq = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { s += sred[w * (BN_ / 4) + tid].x; qq += sred[w * (BN_ / 4) + tid].y; }
+            reinterpret_cast<float2*>(g.gn_part)[(int64_t)(m0 / BM_) * g.gn_quads + (n0 >> 2) + tid] = make_float2(s, qq);
+        }
+    }
+}
+
 template <int WM, int WN, int TM, int TN, class Cfg>
 __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned char* smem, f32x4 (&acc)[TM][TN],
                                                   int m0, int n0, int z, int tid, int lane, int wm, int wn)
 {
     constexpr int BN_ = WN * TN * 16, BM_ = WM * TM * 16, THREADS = WM * WN * 64;
     float* sC = reinterpret_cast<float*>(smem);
+    NATINF_TS(2);
     if (g.c_mode == 102) {                          // timing experiment: no epilogue at all (one store keeps the accumulators live)
         float t = 0.f;
 #pragma unroll
@@ -114,6 +232,7 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
             for (int j = 0; j < TN; ++j)       // swapped-operand accumulators: a lane holds 4 consecutive columns of row (lane & 15)
                 *reinterpret_cast<f32x4*>(sC + (wm * RB * 16 + ii * 16 + (lane & 15)) * CROW + wn * TN * 16 + j * 16 + (lane >> 4) * 4) = acc[pass * RB + ii][j];
         __syncthreads();
+        NATINF_TS(3 + 3 * pass);
         // slab row s  <->  tile row  (s / (RB*16)) * TM*16 + pass*RB*16 + s % (RB*16)
         if (g.c_mode == OUT_F32_NCHW) {
             float* out = reinterpret_cast<float*>(g.c);
@@ -199,6 +318,7 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
                 keep[sw][1] = __builtin_bit_cast(uint4, make_float4(v[4], v[5], v[6], v[7]));
             }
         }
+        NATINF_TS(4 + 3 * pass);
         // ---- this pass's stores, after all of its loads.  vmcnt counts stores as well as loads, and hipcc waits
         // ---- vmcnt(0) for a loaded value whenever stores are outstanding too (mixed event types retire out of order):
         // ---- with the store inside the sweep, every sweep's bias / row-vector / gate / residual use waited for the
@@ -221,6 +341,7 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
                 *reinterpret_cast<uint4*>(o + 4) = keep[sw][1];
             }
         }
+        NATINF_TS(5 + 3 * pass);
     }
     if (g.gn_part) {
         // block reduction in a fixed order: [row-thread][chunk][4] through LDS, then one thread per quad
@@ -235,6 +356,23 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
             for (int r = 0; r < ROWS_PER_SWEEP; ++r) { s += sred[(r * CPR + ch) * 4 + hf]; q += sred[(r * CPR + ch) * 4 + hf + 1]; }
             reinterpret_cast<float2*>(g.gn_part)[(int64_t)(m0 / BM_) * g.gn_quads + (n0 >> 2) + tid] = make_float2(s, q);
         }
+    }
+}
+
+// EPI (kernel template parameter, chosen on the host by packed_epi()): 0 = fp32-slab epilogue with every fused term as a run-time
+// flag; 1..6 = packed epilogue: plain / + GroupNorm partials / + SiLU / + tanh-GELU / + bf16 residual / + residual and partials.  One epilogue per kernel: with both in one
+// kernel behind a run-time branch hipcc spilled inside the packed register phase (measured: isolated GEMMs +15..23 %, the
+// network 8 % SLOWER).
+template <int WM, int WN, int TM, int TN, class Cfg, int EPI>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& g, unsigned char* smem, f32x4 (&acc)[TM][TN],
+                                              int m0, int n0, int z, int tid, int lane, int wm, int wn)
+{
+    if constexpr (EPI == 0) dma_tile_epilogue<WM, WN, TM, TN, Cfg>(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
+    else {
+        static_assert(Cfg::PACK_OK, "packed epilogue needs the whole bf16 tile in LDS");
+        NATINF_TS(2);
+        packed_tile_epilogue<WM, WN, TM, TN, Cfg, EPI == 3 ? ACT_SILU : (EPI == 4 ? ACT_GELU_TANH : ACT_NONE), EPI == 2 || EPI == 6, EPI == 5 || EPI == 6>(
+            g, smem, acc, m0, n0, z, tid, lane, wm, wn);
     }
 }
 
@@ -287,7 +425,7 @@ struct PipeStep {
 // SPREAD = 1: the DMA requests of tile k+1 are not issued in one burst after the barrier (every wave of the block
 // would then be issuing ~100-cycle LDS-DMA instructions at the same moment, with the matrix pipe idle) but one at
 // a time between the MFMA groups of tile k.
-template <int WM, int WN, int TM, int TN, int SPREAD = 0>
+template <int WM, int WN, int TM, int TN, int SPREAD = 0, int EPI = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
 {
     using Cfg = DmaCfg<WM, WN, TM, TN>;
@@ -298,6 +436,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
     const int wm = wave / WN, wn = wave % WN;
     const int nN = (g.N + BN_ - 1) / BN_, nM = (g.M + BM_ - 1) / BM_;
     const int tile = xcd_remap(blockIdx.x, nM * nN);
+    NATINF_TS(0);
     const int m0 = (tile / nN) * BM_, n0 = (tile % nN) * BN_;
     const int z = blockIdx.z;
 
@@ -368,6 +507,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
     issue_tile(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    NATINF_TS(1);
 
     const int frow = lane & 15, fq = lane >> 4, fswz = (frow >> 1) & 7;
     constexpr int NP = Cfg::PA + Cfg::PB, SLOTS = 2 * TM, STEP = SLOTS / NP > 0 ? SLOTS / NP : 1;
@@ -437,7 +577,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's LDS-DMA has landed (explicit: not left to the compiler's tracking)
         __syncthreads();
     }
-    dma_tile_epilogue<WM, WN, TM, TN, typename Cfg::Epi>(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
+    tile_epilogue<WM, WN, TM, TN, typename Cfg::Epi, EPI>(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
 }
 
 
@@ -464,7 +604,7 @@ struct RingCfg {
     static constexpr int PA = BM_ / 16 / NW, PB = BN_ / 16 / NW;          // 1-KiB pieces (16 rows x 64 B) per wave per tile
     static constexpr int DPT = PA + PB;                                    // DMA instructions per wave per tile
     using Epi = EpiCfg<WM, WN, TM, TN, NS * STAGE_BYTES + 4096>;
-    static constexpr int LDS_BYTES = Epi::SLAB_BYTES > NS * STAGE_BYTES ? Epi::SLAB_BYTES : NS * STAGE_BYTES;
+    static constexpr int LDS_BYTES = Epi::NEED > NS * STAGE_BYTES ? Epi::NEED : NS * STAGE_BYTES;
     static_assert(BM_ % (16 * NW) == 0 && BN_ % (16 * NW) == 0, "DMA pieces must divide evenly over the waves");
     static_assert((NS - 2) * DPT <= 63 && NS >= 3, "vmcnt immediate is 6 bits");
 };
@@ -473,7 +613,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(N) : "memory");
 }
 
-template <int WM, int WN, int TM, int TN, int NS>
+template <int WM, int WN, int TM, int TN, int NS, int EPI = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_ring(const GemmArgs g)
 {
     using Cfg = RingCfg<WM, WN, TM, TN, NS>;
@@ -583,7 +723,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_ring(const GemmArgs g)
 #endif
     }
     __syncthreads();               // every wave is done with the ring before the epilogue reuses it
-    dma_tile_epilogue<WM, WN, TM, TN, typename Cfg::Epi>(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
+    tile_epilogue<WM, WN, TM, TN, typename Cfg::Epi, EPI>(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
 }
 
 }  // namespace ncsn

@@ -128,9 +128,11 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
+int g_epi_fp32_slab = 0;           // natinf_set_gemm_epilogue(1): every launch takes the fp32-slab epilogue (A/B runs)
 GemmArgs gemm_defaults() {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
+    g.epi_fp32_slab = g_epi_fp32_slab;
     g.taps = 1; g.batch = 1; g.scale = 1.0f; g.act = ACT_NONE; g.c_mode = OUT_BF16;
     return g;
 }
@@ -156,6 +158,7 @@ const char* variant_name(int v) {
                               "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s", "dma512x128", "patch256x256", "patch256x128", "dma256x256p", "dma128x128p", "dma256x128w4p", "gemm8ph", "gemm8ph_np", "gemm8ph_rf", "gemm8ph_nprf", "fp8_256x256"};
     return v >= 0 && v < V_COUNT ? n[v] : "?";
 }
+unsigned long long* g_dbg_ts = nullptr;
 int g_force_variant = V_AUTO;      // tuning / tests: force one variant for every DMA-eligible launch
 std::string* g_record = nullptr;   // when set, launch_gemm describes the launch instead of issuing it
 
@@ -175,6 +178,14 @@ using CfgR256x128W4 = RingCfg<2, 2, 8, 4, 3>; using CfgD256x128W4 = DmaCfg<2, 2,
 using CfgD512x128 = DmaCfg<4, 2, 8, 4>;
 using CfgP256x256 = PatchCfg<2, 4, 8, 4, 344>; using CfgP256x128 = PatchCfg<4, 2, 4, 4, 400>;
 
+// the packed-epilogue instantiations (EPI 1..4) of the four automatically chosen variants
+template <int EPI>
+bool set_lds_epi() {
+    return set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2, EPI>) && set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2, EPI>) &&
+           set_lds<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3, EPI>) && set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4, EPI>);
+}
+bool set_lds_epi_all() { return set_lds_epi<1>() && set_lds_epi<2>() && set_lds_epi<3>() && set_lds_epi<4>() && set_lds_epi<5>() && set_lds_epi<6>(); }
+
 bool configure_gemm_kernels() {
     bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   GEMM_LDS_BYTES) == hipSuccess;
@@ -187,6 +198,7 @@ bool configure_gemm_kernels() {
          set_lds<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>) && set_lds<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>) &&
          set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2>) && set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2>) &&
          set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>) &&
+         set_lds_epi_all() &&
          set_lds<CfgD256x256>(&k_gemm_fp8<false>) && set_lds<CfgD256x256>(&k_gemm_fp8<true>) &&
          set_lds<Cfg8ph>(&k_gemm_8ph<0>) && set_lds<Cfg8ph>(&k_gemm_8ph<1>) && set_lds<Cfg8ph>(&k_gemm_8ph<2>) && set_lds<Cfg8ph>(&k_gemm_8ph<3>) &&
          set_lds<AttnCfg<8, 16, true>>(&k_attn_fused<8, 16, true>) &&
@@ -239,12 +251,36 @@ void launch_gemm_fp8(const GemmArgs& g, hipStream_t s) {
     if (g.a_mx) launch_tiles<CfgD256x256>(&k_gemm_fp8<true>, g, s); else launch_tiles<CfgD256x256>(&k_gemm_fp8<false>, g, s);
 }
 
+// Which epilogue a launch can take (see tile_epilogue in gemm_dma.h): 0 = the general fp32-slab one; 1..6 = packed, when only
+// column terms (bias, a per-sample row vector with every block tile inside one sample) and a bf16 residual are fused, the output is bf16, and
+// GroupNorm partials (no activation, whole tiles) or an activation -- not both -- are asked for.
+int packed_epi(const GemmArgs& g, int bm) {      // resid must be 8-byte aligned per 4-column group: ld % 4, base from the arena
+    if (g.epi_fp32_slab || g.c_mode != OUT_BF16 || g.resid_f32 || g.gate || g.bias_m || g.deq_m || g.deq_n) return 0;
+    if (g.rowvec && ((1 << g.log_rows_per_sample) % bm != 0)) return 0;
+    if (g.resid && (g.act != ACT_NONE || g.resid_ld % 4 != 0)) return 0;
+    if (g.gn_part) return (g.act == ACT_NONE && g.M % bm == 0) ? (g.resid ? 6 : 2) : 0;
+    if (g.resid) return 5;
+    return g.act == ACT_NONE ? 1 : (g.act == ACT_SILU ? 3 : 4);
+}
+#define NATINF_LAUNCH_EPI(CFG, KERN, ...)                                                   \
+    switch (packed_epi(g, CFG::BM_)) {                                                      \
+        case 1: launch_tiles<CFG>(&KERN<__VA_ARGS__, 1>, g, s); break;                      \
+        case 2: launch_tiles<CFG>(&KERN<__VA_ARGS__, 2>, g, s); break;                      \
+        case 3: launch_tiles<CFG>(&KERN<__VA_ARGS__, 3>, g, s); break;                      \
+        case 4: launch_tiles<CFG>(&KERN<__VA_ARGS__, 4>, g, s); break;                      \
+        case 5: launch_tiles<CFG>(&KERN<__VA_ARGS__, 5>, g, s); break;                      \
+        case 6: launch_tiles<CFG>(&KERN<__VA_ARGS__, 6>, g, s); break;                      \
+        default: launch_tiles<CFG>(&KERN<__VA_ARGS__, 0>, g, s); break;                     \
+    }
+
 // returns the block-tile row count of the variant used
 int launch_gemm(const GemmArgs& g, hipStream_t s) {
     const int v = choose_variant(g);
     if (g_record) {
         char line[160];
-        snprintf(line, sizeof(line), "%d %d %d %d %d %d %s\n", g.M, g.N, g.taps * g.a0_C, g.a1 ? g.a1_C : 0, g.taps, g.batch, variant_name(v));
+        const bool has_packed = v == V_DMA_256x256_P || v == V_DMA_128x128_P || v == V_RING_256x128_W4 || v == V_RING_64x128;
+        snprintf(line, sizeof(line), "%d %d %d %d %d %d %s/e%d\n", g.M, g.N, g.taps * g.a0_C, g.a1 ? g.a1_C : 0, g.taps, g.batch, variant_name(v),
+                 has_packed ? packed_epi(g, variant_bm(v)) : 0);
         *g_record += line;
         return variant_bm(v);
     }
@@ -260,16 +296,16 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
         case V_RING_256x256: launch_tiles<CfgR256x256>(&k_gemm_ring<2, 4, 8, 4, 4>, g, s); break;
         case V_RING_256x128: launch_tiles<CfgR256x128>(&k_gemm_ring<4, 2, 4, 4, 6>, g, s); break;
         case V_RING_128x128: launch_tiles<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4>, g, s); break;
-        case V_RING_64x128: launch_tiles<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4>, g, s); break;
-        case V_RING_256x128_W4: launch_tiles<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3>, g, s); break;
+        case V_RING_64x128: NATINF_LAUNCH_EPI(CfgR64x128, k_gemm_ring, 2, 2, 2, 4, 4) break;
+        case V_RING_256x128_W4: NATINF_LAUNCH_EPI(CfgR256x128W4, k_gemm_ring, 2, 2, 8, 4, 3) break;
         case V_DMA_256x128_W4: launch_tiles<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4>, g, s); break;
         case V_DMA_256x256_S: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 1>, g, s); break;
         case V_DMA_128x128_S: launch_tiles<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 1>, g, s); break;
         case V_DMA_512x128: launch_tiles<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4>, g, s); break;
         case V_PATCH_256x256: launch_tiles<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>, g, s); break;
         case V_PATCH_256x128: launch_tiles<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>, g, s); break;
-        case V_DMA_256x256_P: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2>, g, s); break;
-        case V_DMA_128x128_P: launch_tiles<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2>, g, s); break;
+        case V_DMA_256x256_P: NATINF_LAUNCH_EPI(CfgD256x256, k_gemm_dma, 2, 4, 8, 4, 2) break;
+        case V_DMA_128x128_P: NATINF_LAUNCH_EPI(CfgD128x128, k_gemm_dma, 2, 2, 4, 4, 2) break;
         case V_DMA_256x128W4_P: launch_tiles<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>, g, s); break;
         case V_8PH_256x256: launch_tiles<Cfg8ph>(&k_gemm_8ph<0>, g, s); break;
         case V_FP8_256x256: launch_tiles<CfgD256x256>(&k_gemm_fp8<false>, g, s); break;
@@ -474,6 +510,7 @@ struct Builder {
             op(CLS_GEMM, [=](const Ctx& c) {
                 using Cfg = AttnCfg<8, 16, true>;
                 auto kern = &k_attn_fused<8, 16, true>;
+                if (g_record) return;                    // natinf_ncsnpp_describe_gemms: GEMM launches only, nothing touches memory
                 hipLaunchKernelGGL(kern, dim3((unsigned)c.B), dim3(Cfg::THREADS), Cfg::LDS_BYTES, c.stream, c.at<bf16>(qk), 2 * C, C,
                                    c.at<bf16>(vT), c.act(O), C, 1, C, 1.0f / sqrtf((float)C));
             });
@@ -905,6 +942,7 @@ int natinf_debug_gemm(int variant, int M, int N, int K0, int K1, int taps, int l
     g.M = M; g.N = N; g.b = (const bf16*)b; g.b_ld = K0 + (a1 ? K1 : 0); g.batch = batch;
     if (batch > 1) { g.a_bs = (int64_t)M * g.a0_ld; g.b_bs = (int64_t)N * g.b_ld; g.c_bs = (int64_t)M * N; }
     g.bias_n = bias_n; g.scale = scale; g.c = c; g.c_ld = N; g.c_mode = c_f32 == 1 ? OUT_F32 : (c_f32 >= 2 ? 100 + c_f32 : OUT_BF16);      // >= 2: timing experiments (tools/bench_gemm.py)
+    g.dbg_ts = g_dbg_ts;
     const int saved = g_force_variant;
     g_force_variant = variant;
     for (int i = 0; i < iters; ++i) launch_gemm(g, (hipStream_t)stream);
@@ -931,6 +969,11 @@ int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_sc
     for (int i = 0; i < iters; ++i) launch_gemm_fp8(g, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
 }
+
+// timing experiments: device buffer of 16 uint64 s_memtime stamps written by block 0 / thread 0 of natinf_debug_gemm launches
+int natinf_debug_timestamps(void* dev_buf16) { g_dbg_ts = reinterpret_cast<unsigned long long*>(dev_buf16); return NATINF_OK; }
+
+int natinf_set_gemm_epilogue(int fp32_slab) { g_epi_fp32_slab = fp32_slab != 0; return NATINF_OK; }
 
 int natinf_set_gemm_variant(int variant) {
     if (variant < 0 || variant >= V_COUNT) return NATINF_EINVAL;

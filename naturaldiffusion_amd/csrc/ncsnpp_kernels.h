@@ -58,6 +58,8 @@ struct GemmArgs {
     // (k_gemm_fp8<true>; the plane must be readable up to row m0 + 255); c_mx: of the OUTPUT when c_mode == OUT_FP8_MX.
     const uint8_t* a_mx; int a_mx_ld; int64_t a_mx_bs;
     uint8_t* c_mx; int c_mx_ld; int64_t c_mx_bs;
+    int epi_fp32_slab;                  // A/B switch: 1 = always the fp32-slab epilogue (g_epi_fp32_slab)
+    unsigned long long* dbg_ts;         // timing experiments: s_memtime stamps of block 0 / thread 0 (null in production)
     void* c; int c_ld; int c_mode;
     // fused GroupNorm statistics of the OUTPUT (DMA kernels, block tile inside one sample): per block tile and per
     // 4-channel quad, (sum, sum of squares) of the fp32 results -> gn_part[(m0/BM)*gn_quads + n/4] (float2)
@@ -103,6 +105,19 @@ __device__ __forceinline__ void apply_act8(float (&v)[8], int act) {
         for (int q = 0; q < 8; ++q) {
             const float u = 0.7978845608028654f * (v[q] + 0.044715f * v[q] * v[q] * v[q]);
             v[q] = v[q] * (1.0f - __builtin_amdgcn_rcpf(__expf(2.0f * u) + 1.0f));          // 0.5 v (1 + tanh u)
+        }
+    }
+}
+
+__device__ __forceinline__ void apply_act4(float (&v)[4], int act) {
+    if (act == ACT_SILU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[q]));
+    } else if (act == ACT_GELU_TANH) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float u = 0.7978845608028654f * (v[q] + 0.044715f * v[q] * v[q] * v[q]);
+            v[q] = v[q] * (1.0f - __builtin_amdgcn_rcpf(__expf(2.0f * u) + 1.0f));
         }
     }
 }
