@@ -359,8 +359,61 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
     }
 }
 
+// Residual-stream epilogue of the transformer engines: out_f32 = (resid_f32 + gate * (acc + bias [+ row vector])) * scale with the
+// gate / row vector constant over the block tile (one sample per tile), straight from the accumulator registers -- a lane holds
+// four consecutive columns of a row, so the fp32 residual is read and the result written as 16-byte accesses (64 B per row and
+// instruction), no LDS, no barrier.  The residual rows are fetched half a tile at a time (64 VGPRs in flight).
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void direct_f32_epilogue(const GemmArgs& g, f32x4 (&acc)[TM][TN], int m0, int n0, int z, int lane, int wm, int wn)
+{
+    const int r = lane & 15, q = lane >> 4;
+    const int64_t sample = (int64_t)((m0 >> g.log_rows_per_sample) + z * g.z_samples);
+    float ct[TN][4], gt[TN][4];
+    bool n_ok[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 16 + j * 16 + q * 4;
+        n_ok[j] = n < g.N;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f), rv = make_float4(0.f, 0.f, 0.f, 0.f), gv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (n_ok[j]) {
+            if (g.bias_n) b = *reinterpret_cast<const float4*>(g.bias_n + n);
+            if (g.rowvec) rv = *reinterpret_cast<const float4*>(g.rowvec + sample * g.rowvec_ld + n);
+            if (g.gate) gv = *reinterpret_cast<const float4*>(g.gate + sample * g.gate_ld + n);
+        }
+        ct[j][0] = b.x + rv.x; ct[j][1] = b.y + rv.y; ct[j][2] = b.z + rv.z; ct[j][3] = b.w + rv.w;
+        gt[j][0] = gv.x; gt[j][1] = gv.y; gt[j][2] = gv.z; gt[j][3] = gv.w;
+    }
+    const float scale = g.scale;
+    const float* rb = g.resid_f32 + (int64_t)z * g.c_bs + n0 + wn * TN * 16 + q * 4;
+    float* cb = reinterpret_cast<float*>(g.c) + (int64_t)z * g.c_bs + n0 + wn * TN * 16 + q * 4;
+    constexpr int HI = TM > 4 ? TM / 2 : TM;
+#pragma unroll
+    for (int h = 0; h < TM / HI; ++h) {
+        f32x4 rs[HI][TN];
+#pragma unroll
+        for (int i = 0; i < HI; ++i) {
+            const int m = min(m0 + wm * TM * 16 + (h * HI + i) * 16 + r, g.M - 1);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                rs[i][j] = n_ok[j] ? *reinterpret_cast<const f32x4*>(rb + (int64_t)m * g.resid_f32_ld + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < HI; ++i) {
+            const int m = m0 + wm * TM * 16 + (h * HI + i) * 16 + r;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ((acc[h * HI + i][j][e] + ct[j][e]) * gt[j][e] + rs[i][j][e]) * scale;
+                if (m < g.M && n_ok[j]) *reinterpret_cast<f32x4*>(cb + (int64_t)m * g.c_ld + j * 16) = v;
+            }
+        }
+    }
+}
+
 // EPI (kernel template parameter, chosen on the host by packed_epi()): 0 = fp32-slab epilogue with every fused term as a run-time
-// flag; 1..6 = packed epilogue: plain / + GroupNorm partials / + SiLU / + tanh-GELU / + bf16 residual / + residual and partials.  One epilogue per kernel: with both in one
+// flag; 1..6 = packed epilogue: plain / + GroupNorm partials / + SiLU / + tanh-GELU / + bf16 residual / + residual and partials;
+// 7 = the direct fp32 residual-stream epilogue.  One epilogue per kernel: with both in one
 // kernel behind a run-time branch hipcc spilled inside the packed register phase (measured: isolated GEMMs +15..23 %, the
 // network 8 % SLOWER).
 template <int WM, int WN, int TM, int TN, class Cfg, int EPI>
@@ -368,6 +421,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, unsigned char* 
                                               int m0, int n0, int z, int tid, int lane, int wm, int wn)
 {
     if constexpr (EPI == 0) dma_tile_epilogue<WM, WN, TM, TN, Cfg>(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
+    else if constexpr (EPI == 7) direct_f32_epilogue<WM, WN, TM, TN>(g, acc, m0, n0, z, lane, wm, wn);
     else {
         static_assert(Cfg::PACK_OK, "packed epilogue needs the whole bf16 tile in LDS");
         NATINF_TS(2);
