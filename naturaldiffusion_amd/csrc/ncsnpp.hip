@@ -159,7 +159,8 @@ const char* variant_name(int v) {
     return v >= 0 && v < V_COUNT ? n[v] : "?";
 }
 unsigned long long* g_dbg_ts = nullptr;
-int g_force_variant = V_AUTO;      // tuning / tests: force one variant for every DMA-eligible launch
+int g_force_variant = V_AUTO;
+int g_pref_512 = 1;                // N <= 128 layers with >= 2 tiles per CU: the 512x128 hand-pipelined tile (natinf_set_gemm_pref512: A/B runs)      // tuning / tests: force one variant for every DMA-eligible launch
 std::string* g_record = nullptr;   // when set, launch_gemm describes the launch instead of issuing it
 
 template <class Cfg, class K>
@@ -182,9 +183,10 @@ using CfgP256x256 = PatchCfg<2, 4, 8, 4, 344>; using CfgP256x128 = PatchCfg<4, 2
 template <int EPI>
 bool set_lds_epi() {
     return set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2, EPI>) && set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2, EPI>) &&
-           set_lds<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3, EPI>) && set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4, EPI>);
+           set_lds<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3, EPI>) && set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4, EPI>) &&
+           set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4, 2, EPI>);
 }
-bool set_lds_epi_all() { return set_lds_epi<1>() && set_lds_epi<2>() && set_lds_epi<3>() && set_lds_epi<4>() && set_lds_epi<5>() && set_lds_epi<6>() && set_lds_epi<7>(); }
+bool set_lds_epi_all() { return set_lds_epi<0>() && set_lds_epi<1>() && set_lds_epi<2>() && set_lds_epi<3>() && set_lds_epi<4>() && set_lds_epi<5>() && set_lds_epi<6>() && set_lds_epi<7>(); }
 
 bool configure_gemm_kernels() {
     bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -231,6 +233,7 @@ int choose_variant(const GemmArgs& g) {
     const int64_t mt256 = (g.M + 255) / 256, mt128 = (g.M + 127) / 128;
     const int64_t nt128 = (g.N + 127) / 128;
     if (g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) * g.batch >= NUM_CU) return V_DMA_256x256_P;
+    if (g_pref_512 && g.N <= 128 && K0 + K1 >= 1024 && ((g.M + 511) / 512) * g.batch >= 2 * NUM_CU) return V_DMA_512x128;
     if (mt256 * nt128 * g.batch >= 2 * NUM_CU) return V_RING_256x128_W4;        // it runs two blocks per CU
     if (mt128 * nt128 * g.batch >= NUM_CU) return V_DMA_128x128_P;
     return V_RING_64x128;
@@ -304,7 +307,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
         case V_DMA_256x128_W4: launch_tiles<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4>, g, s); break;
         case V_DMA_256x256_S: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 1>, g, s); break;
         case V_DMA_128x128_S: launch_tiles<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 1>, g, s); break;
-        case V_DMA_512x128: launch_tiles<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4>, g, s); break;
+        case V_DMA_512x128: NATINF_LAUNCH_EPI(CfgD512x128, k_gemm_dma, 4, 2, 8, 4, 2) break;
         case V_PATCH_256x256: launch_tiles<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>, g, s); break;
         case V_PATCH_256x128: launch_tiles<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>, g, s); break;
         case V_DMA_256x256_P: NATINF_LAUNCH_EPI(CfgD256x256, k_gemm_dma, 2, 4, 8, 4, 2) break;
@@ -976,6 +979,7 @@ int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_sc
 // timing experiments: device buffer of 16 uint64 s_memtime stamps written by block 0 / thread 0 of natinf_debug_gemm launches
 int natinf_debug_timestamps(void* dev_buf16) { g_dbg_ts = reinterpret_cast<unsigned long long*>(dev_buf16); return NATINF_OK; }
 
+int natinf_set_gemm_pref512(int on) { g_pref_512 = on != 0; return NATINF_OK; }
 int natinf_set_gemm_epilogue(int fp32_slab) { g_epi_fp32_slab = fp32_slab != 0; return NATINF_OK; }
 
 int natinf_set_gemm_variant(int variant) {
