@@ -284,7 +284,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
     const int v = choose_variant(g);
     if (g_record) {
         char line[160];
-        const bool has_packed = v == V_DMA_256x256_P || v == V_DMA_128x128_P || v == V_RING_256x128_W4 || v == V_RING_64x128;
+        const bool has_packed = v == V_DMA_256x256_P || v == V_DMA_128x128_P || v == V_RING_256x128_W4 || v == V_RING_64x128 || v == V_DMA_512x128;
         snprintf(line, sizeof(line), "%d %d %d %d %d %d %s/e%d\n", g.M, g.N, g.taps * g.a0_C, g.a1 ? g.a1_C : 0, g.taps, g.batch, variant_name(v),
                  has_packed ? packed_epi(g, variant_bm(v)) : 0);
         *g_record += line;
