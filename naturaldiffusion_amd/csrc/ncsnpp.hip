@@ -233,7 +233,9 @@ int choose_variant(const GemmArgs& g) {
     const int64_t mt256 = (g.M + 255) / 256, mt128 = (g.M + 127) / 128;
     const int64_t nt128 = (g.N + 127) / 128;
     if (g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) * g.batch >= NUM_CU) return V_DMA_256x256_P;
-    if (g_pref_512 && g.N <= 128 && K0 + K1 >= 1024 && ((g.M + 511) / 512) * g.batch >= 2 * NUM_CU) return V_DMA_512x128;
+    if (g_pref_512 && g.N <= 128 && K0 + K1 >= 1024 && ((g.M + 511) / 512) * g.batch >= 2 * NUM_CU &&
+        (!g.gn_part || (g.taps == 9 && (1 << g.logHW) % 512 == 0)))           // GroupNorm partials: a tile inside one sample
+        return V_DMA_512x128;
     if (mt256 * nt128 * g.batch >= 2 * NUM_CU) return V_RING_256x128_W4;        // it runs two blocks per CU
     if (mt128 * nt128 * g.batch >= NUM_CU) return V_DMA_128x128_P;
     return V_RING_64x128;
@@ -581,7 +583,9 @@ struct Builder {
         parts[{out.off, out.coff}] = p;
         return p;
     }
-    // statistics of x from partial tables if every channel slice of x has a valid one; otherwise the streaming kernel
+    // statistics of x from partial tables if every channel slice of x has a valid one; otherwise the streaming kernel.
+    // (Folding the tables inside k_gn_apply instead of this one-block-per-sample launch was built and measured: bit-identical,
+    // 1.6 % SLOWER per forward in a same-box A/B -- every 4-row apply block then starts with two dependent load round trips.)
     bool emit_gn_from_parts(const TRef& x, GN gn, int64_t sc, int64_t sh) {
         std::vector<Part> src;
         int ch = 0;
