@@ -24,6 +24,13 @@
 // (130 / 128 VGPRs).  What is common to all of them is the instruction count per tile -- ~250 VALU + 66 v_exp beside 64
 // MFMAs per wave -- so the open steps are fewer VALU instructions per score (row sums through an all-ones V^T row on the
 // matrix pipe, max over packed halves) and overlapping tile t's softmax with tile t+1's S^T (two S register sets).
+// Built and measured after that (same-box A/B, bit-identical output): the loop software-pipelined INSIDE a wave -- S^T(kt+1)
+// issued in eight groups of four MFMAs in front of the slices of softmax(kt), two S register sets, 253 VGPRs, no spills -- is
+// 3-5 % SLOWER (1,228 vs 1,190 us).  The SIMD's vector issue port is the resource, not the overlap: per key tile and wave
+// 64 MFMAs x 8 issue cycles + 66 v_exp x 8 + ~250 VALU x 4 = ~2.0k cycles of issue against the measured 2.6k, shared by the
+// two waves of a SIMD, so moving work between the pipes buys nothing.  `-fno-slp-vectorize` (the compiler packs the row sums
+// and the rescale into v_pk_add/mul_f32) is +-1 %.  What is left is fewer issue cycles per score: 32x32x16 MFMAs (half the
+// MFMA issue cost), row sums on the matrix pipe.
 // Reference: diffusers JointAttnProcessor2_0 as called by pipe.transformer (src/SD3NaturalInference.py:210-213).
 #pragma once
 #include "ncsnpp_kernels.h"
