@@ -80,7 +80,8 @@ typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 // kept values: hipcc left a 16-entry uint4 array in scratch memory here)
 template <int SW, int NSW, int RPS, int PROW, bool EDGE>
 struct SlabCopy {
-    static __device__ __forceinline__ void run(const unsigned char* src, bf16* dst, int64_t ld, int m, int M) {
+    template <class T>
+    static __device__ __forceinline__ void run(const unsigned char* src, T* dst, int64_t ld, int m, int M) {
         const uint4 v = *reinterpret_cast<const uint4*>(src + SW * RPS * PROW);
         SlabCopy<SW + 1, NSW, RPS, PROW, EDGE>::run(src, dst, ld, m, M);
         if (!EDGE || m + SW * RPS < M) *reinterpret_cast<uint4*>(dst + (int64_t)(SW * RPS) * ld) = v;
@@ -88,14 +89,34 @@ struct SlabCopy {
 };
 template <int NSW, int RPS, int PROW, bool EDGE>
 struct SlabCopy<NSW, NSW, RPS, PROW, EDGE> {
-    static __device__ __forceinline__ void run(const unsigned char*, bf16*, int64_t, int, int) {}
+    template <class T> static __device__ __forceinline__ void run(const unsigned char*, T*, int64_t, int, int) {}
 };
-template <int WM, int WN, int TM, int TN, class Cfg, int ACT, bool GN, bool RES>
+// DEQ (fp8 operands): acc * (deq_m[row] * deq_n[col]) first, and a row bias (bias_m) next to the column terms.
+// OUT8: the tile leaves as e4m3 bytes with one E8M0 scale per 32 columns (OUT_FP8_MX; a block = two 16-column MFMA tiles x the
+// four lanes of a row) -- the bytes cross LDS like the bf16 values do, the scale bytes are stored from the registers.
+template <int WM, int WN, int TM, int TN, class Cfg, int ACT, bool GN, bool RES, bool DEQ = false, bool OUT8 = false>
 __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned char* smem, f32x4 (&acc)[TM][TN],
                                                      int m0, int n0, int z, int tid, int lane, int wm, int wn)
 {
-    constexpr int BN_ = WN * TN * 16, BM_ = WM * TM * 16, THREADS = WM * WN * 64, PROW = Cfg::PROW;
+    constexpr int BN_ = WN * TN * 16, BM_ = WM * TM * 16, THREADS = WM * WN * 64, PROW = OUT8 ? BN_ + 16 : Cfg::PROW;
+    static_assert(!OUT8 || (!GN && !RES && TN % 2 == 0), "fp8 output: plain column terms only");
     const int r = lane & 15, q = lane >> 4;
+    float dn[DEQ ? TN : 1][4], rsc[DEQ ? TM : 1], rbm[DEQ ? TM : 1];
+    if constexpr (DEQ) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * TN * 16 + j * 16 + q * 4;
+            float4 d = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (g.deq_n && n < g.N) d = *reinterpret_cast<const float4*>(g.deq_n + (int64_t)z * g.deq_n_bs + n);
+            dn[j][0] = d.x; dn[j][1] = d.y; dn[j][2] = d.z; dn[j][3] = d.w;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = min(m0 + wm * TM * 16 + i * 16 + r, g.M - 1);
+            rsc[i] = g.deq_m ? g.deq_m[(int64_t)z * g.deq_m_bs + m] : 1.f;
+            rbm[i] = g.bias_m ? g.bias_m[m] : 0.f;
+        }
+    }
     float ct[TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -123,40 +144,82 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
 #pragma unroll
     for (int j = 0; j < TN; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
     const float scale = g.scale;
-    unsigned char* wbase = smem + (wm * TM * 16 + r) * PROW + (wn * TN * 16 + q * 4) * 2;
+    // the finished fp32 values of accumulator tile (i, j)
+    auto value = [&](int i, int j, float (&v)[4]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + ct[j][e];
-            if constexpr (RES) {
-                const bf16x4_t x = __builtin_bit_cast(bf16x4_t, rs[i][j]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)x[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= scale;
-            if constexpr (ACT != ACT_NONE) apply_act4(v, ACT);
-            if constexpr (GN) {
-                gs[j] += (v[0] + v[1]) + (v[2] + v[3]);
-                gq[j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-            }
-            bf16x4_t o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-            *reinterpret_cast<uint2*>(wbase + i * 16 * PROW + j * 32) = __builtin_bit_cast(uint2, o);
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (DEQ) v[e] = (acc[i][j][e] * (rsc[i] * dn[j][e]) + ct[j][e]) + rbm[i];
+            else v[e] = acc[i][j][e] + ct[j][e];
         }
+        if constexpr (RES) {
+            const bf16x4_t x = __builtin_bit_cast(bf16x4_t, rs[i][j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)x[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= scale;
+        if constexpr (ACT != ACT_NONE) apply_act4(v, ACT);
+        if constexpr (GN) {
+            gs[j] += (v[0] + v[1]) + (v[2] + v[3]);
+            gq[j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+    };
+    constexpr int EB = OUT8 ? 1 : 2;                   // bytes per output element
+    unsigned char* wbase = smem + (wm * TM * 16 + r) * PROW + (wn * TN * 16 + q * 4) * EB;
+    if constexpr (!OUT8) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v[4];
+                value(i, j, v);
+                bf16x4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+                *reinterpret_cast<uint2*>(wbase + i * 16 * PROW + j * 32) = __builtin_bit_cast(uint2, o);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * TM * 16 + i * 16 + r;
+            unsigned e8pair = 0;
+#pragma unroll
+            for (int b = 0; b < TN / 2; ++b) {
+                float v0[4], v1[4];
+                value(i, 2 * b, v0);
+                value(i, 2 * b + 1, v1);
+                float amax = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
+                                   fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
+                amax = fmaxf(amax, __shfl_xor(amax, 16));
+                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                float inv;
+                const unsigned e8 = mx_scale_of(amax, inv);
+                *reinterpret_cast<unsigned*>(wbase + i * 16 * PROW + (2 * b) * 16) = pack_fp8x4(v0[0] * inv, v0[1] * inv, v0[2] * inv, v0[3] * inv);
+                *reinterpret_cast<unsigned*>(wbase + i * 16 * PROW + (2 * b + 1) * 16) = pack_fp8x4(v1[0] * inv, v1[1] * inv, v1[2] * inv, v1[3] * inv);
+                e8pair |= e8 << (8 * b);
+            }
+            // the wave's 64 columns are blocks (wn & 1) * 2 + {0, 1} of their 128-column group: two adjacent scale bytes
+            static_assert(TN == 4, "scale bytes are stored as one 16-bit pair per row and wave");
+            const int nb = n0 + wn * 64;
+            if (q == 0 && m < g.M && nb < g.N)
+                *reinterpret_cast<unsigned short*>(g.c_mx + (int64_t)z * g.c_mx_bs + ((int64_t)(nb >> 7) * g.c_mx_ld + m) * 4 + ((nb >> 5) & 3)) = (unsigned short)e8pair;
+        }
+    }
     __syncthreads();
     NATINF_TS(3);
-    constexpr int CPR = BN_ / 8, RPS = THREADS / CPR, NSW = BM_ / RPS;
-    const int cchunk = tid % CPR, rsub = tid / CPR, n = n0 + cchunk * 8;
+    constexpr int CPR = BN_ * EB / 16, RPS = THREADS / CPR, NSW = BM_ / RPS;
+    const int cchunk = tid % CPR, rsub = tid / CPR, n = n0 + cchunk * (16 / EB);
     if (n < g.N) {
         const unsigned char* src = smem + rsub * PROW + cchunk * 16;
-        bf16* dst = reinterpret_cast<bf16*>(g.c) + (int64_t)z * g.c_bs + (int64_t)(m0 + rsub) * g.c_ld + n;
-        if (m0 + BM_ <= g.M) SlabCopy<0, NSW, RPS, PROW, false>::run(src, dst, g.c_ld, m0 + rsub, g.M);
-        else SlabCopy<0, NSW, RPS, PROW, true>::run(src, dst, g.c_ld, m0 + rsub, g.M);
+        if constexpr (OUT8) {
+            uint8_t* dst = reinterpret_cast<uint8_t*>(g.c) + (int64_t)z * g.c_bs + (int64_t)(m0 + rsub) * g.c_ld + n;
+            if (m0 + BM_ <= g.M) SlabCopy<0, NSW, RPS, PROW, false>::run(src, dst, g.c_ld, m0 + rsub, g.M);
+            else SlabCopy<0, NSW, RPS, PROW, true>::run(src, dst, g.c_ld, m0 + rsub, g.M);
+        } else {
+            bf16* dst = reinterpret_cast<bf16*>(g.c) + (int64_t)z * g.c_bs + (int64_t)(m0 + rsub) * g.c_ld + n;
+            if (m0 + BM_ <= g.M) SlabCopy<0, NSW, RPS, PROW, false>::run(src, dst, g.c_ld, m0 + rsub, g.M);
+            else SlabCopy<0, NSW, RPS, PROW, true>::run(src, dst, g.c_ld, m0 + rsub, g.M);
+        }
     }
     NATINF_TS(4);
     if constexpr (GN) {
@@ -363,12 +426,25 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
 // gate / row vector constant over the block tile (one sample per tile), straight from the accumulator registers -- a lane holds
 // four consecutive columns of a row, so the fp32 residual is read and the result written as 16-byte accesses (64 B per row and
 // instruction), no LDS, no barrier.  The residual rows are fetched half a tile at a time (64 VGPRs in flight).
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool DEQ = false>
 __device__ __forceinline__ void direct_f32_epilogue(const GemmArgs& g, f32x4 (&acc)[TM][TN], int m0, int n0, int z, int lane, int wm, int wn)
 {
     const int r = lane & 15, q = lane >> 4;
     const int64_t sample = (int64_t)((m0 >> g.log_rows_per_sample) + z * g.z_samples);
     float ct[TN][4], gt[TN][4];
+    float dn[DEQ ? TN : 1][4], rsc[DEQ ? TM : 1];          // fp8 operands: column / row dequantization scales
+    if constexpr (DEQ) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * TN * 16 + j * 16 + q * 4;
+            float4 d = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (g.deq_n && n < g.N) d = *reinterpret_cast<const float4*>(g.deq_n + (int64_t)z * g.deq_n_bs + n);
+            dn[j][0] = d.x; dn[j][1] = d.y; dn[j][2] = d.z; dn[j][3] = d.w;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            rsc[i] = g.deq_m ? g.deq_m[(int64_t)z * g.deq_m_bs + min(m0 + wm * TM * 16 + i * 16 + r, g.M - 1)] : 1.f;
+    }
     bool n_ok[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -386,7 +462,7 @@ __device__ __forceinline__ void direct_f32_epilogue(const GemmArgs& g, f32x4 (&a
     const float scale = g.scale;
     const float* rb = g.resid_f32 + (int64_t)z * g.c_bs + n0 + wn * TN * 16 + q * 4;
     float* cb = reinterpret_cast<float*>(g.c) + (int64_t)z * g.c_bs + n0 + wn * TN * 16 + q * 4;
-    constexpr int HI = TM > 4 ? TM / 2 : TM;
+    constexpr int HI = DEQ ? (TM > 2 ? 2 : TM) : (TM > 4 ? TM / 2 : TM);      // residual row-tiles in flight (register budget)
 #pragma unroll
     for (int h = 0; h < TM / HI; ++h) {
         f32x4 rs[HI][TN];
@@ -404,7 +480,10 @@ __device__ __forceinline__ void direct_f32_epilogue(const GemmArgs& g, f32x4 (&a
             for (int j = 0; j < TN; ++j) {
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = ((acc[h * HI + i][j][e] + ct[j][e]) * gt[j][e] + rs[i][j][e]) * scale;
+                for (int e = 0; e < 4; ++e) {
+                    const float a0 = DEQ ? acc[h * HI + i][j][e] * (rsc[h * HI + i] * dn[j][e]) : acc[h * HI + i][j][e];
+                    v[e] = ((a0 + ct[j][e]) * gt[j][e] + rs[i][j][e]) * scale;
+                }
                 if (m < g.M && n_ok[j]) *reinterpret_cast<f32x4*>(cb + (int64_t)m * g.c_ld + j * 16) = v;
             }
         }

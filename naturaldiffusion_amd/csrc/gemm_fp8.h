@@ -15,7 +15,9 @@ namespace ncsn {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-template <bool MXA>     // MXA: the A operand carries E8M0 block scales (GemmArgs::a_mx), fed to the MFMA lane by lane
+// EPI (chosen on the host, launch_gemm_fp8): 0 = fp32-slab epilogue; 1 = packed bf16 output (row / column scales, biases);
+// 2 = packed e4m3 + E8M0 output with tanh-GELU (fc1 -> fc2's operand); 3 = direct fp32 residual-stream epilogue.
+template <bool MXA, int EPI = 0>     // MXA: the A operand carries E8M0 block scales (GemmArgs::a_mx), fed to the MFMA lane by lane
 __global__ __launch_bounds__(512, 2) void k_gemm_fp8(const GemmArgs g)
 {
     using Cfg = DmaCfg<2, 4, 8, 4>;
@@ -110,7 +112,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_fp8(const GemmArgs g)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    dma_tile_epilogue<2, 4, 8, 4, typename Cfg::Epi>(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
+    if constexpr (EPI == 1) packed_tile_epilogue<2, 4, 8, 4, typename Cfg::Epi, ACT_NONE, false, false, true, false>(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
+    else if constexpr (EPI == 2) packed_tile_epilogue<2, 4, 8, 4, typename Cfg::Epi, ACT_GELU_TANH, false, false, true, true>(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
+    else if constexpr (EPI == 3) direct_f32_epilogue<2, 4, 8, 4, true>(g, acc, m0, n0, z, lane, wm, wn);
+    else dma_tile_epilogue<2, 4, 8, 4, typename Cfg::Epi>(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
 }
 
 // x fp32 [rows][D] -> LayerNorm (no affine, eps 1e-6), (1 + scale) / shift modulation, then fp8 e4m3 with one scale per row:

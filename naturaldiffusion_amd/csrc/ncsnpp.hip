@@ -201,7 +201,10 @@ bool configure_gemm_kernels() {
          set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2>) && set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2>) &&
          set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>) &&
          set_lds_epi_all() &&
-         set_lds<CfgD256x256>(&k_gemm_fp8<false>) && set_lds<CfgD256x256>(&k_gemm_fp8<true>) &&
+         set_lds<CfgD256x256>(&k_gemm_fp8<false, 0>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 0>) &&
+         set_lds<CfgD256x256>(&k_gemm_fp8<false, 1>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 1>) &&
+         set_lds<CfgD256x256>(&k_gemm_fp8<false, 2>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 2>) &&
+         set_lds<CfgD256x256>(&k_gemm_fp8<false, 3>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 3>) &&
          set_lds<Cfg8ph>(&k_gemm_8ph<0>) && set_lds<Cfg8ph>(&k_gemm_8ph<1>) && set_lds<Cfg8ph>(&k_gemm_8ph<2>) && set_lds<Cfg8ph>(&k_gemm_8ph<3>) &&
          set_lds<AttnCfg<8, 16, true>>(&k_attn_fused<8, 16, true>) &&
          set_lds<AttnCfg<2, 4>>(&k_attn_fused<2, 4>) && set_lds<AttnCfg<3, 6>>(&k_attn_fused<3, 6>) &&
@@ -252,8 +255,26 @@ int variant_bm(int v) {
 }
 
 // fp8 operands (a0 / b point at e4m3 bytes, a0_ld / b_ld / a_bs / b_bs in bytes, a0_C = K % 128 == 0, deq_m / deq_n set)
+int fp8_epi(const GemmArgs& g) {
+    if (g.epi_fp32_slab || g.resid || g.gn_part) return 0;
+    if ((g.rowvec || g.gate) && g.log_rows_per_sample < 30 && ((1 << g.log_rows_per_sample) % 256 != 0)) return 0;
+    if (g.c_mode == OUT_F32 && g.resid_f32 && !g.bias_m && g.act == ACT_NONE && g.resid_f32_ld % 4 == 0 && g.c_ld % 4 == 0) return 3;
+    if (g.resid_f32 || g.gate) return 0;
+    if (g.c_mode == OUT_BF16 && g.act == ACT_NONE) return 1;
+    if (g.c_mode == OUT_FP8_MX && g.act == ACT_GELU_TANH && g.c_mx && g.N % 32 == 0) return 2;
+    return 0;
+}
+template <bool MXA>
+void launch_gemm_fp8_t(const GemmArgs& g, hipStream_t s) {
+    switch (fp8_epi(g)) {
+        case 1: launch_tiles<CfgD256x256>(&k_gemm_fp8<MXA, 1>, g, s); break;
+        case 2: launch_tiles<CfgD256x256>(&k_gemm_fp8<MXA, 2>, g, s); break;
+        case 3: launch_tiles<CfgD256x256>(&k_gemm_fp8<MXA, 3>, g, s); break;
+        default: launch_tiles<CfgD256x256>(&k_gemm_fp8<MXA, 0>, g, s); break;
+    }
+}
 void launch_gemm_fp8(const GemmArgs& g, hipStream_t s) {
-    if (g.a_mx) launch_tiles<CfgD256x256>(&k_gemm_fp8<true>, g, s); else launch_tiles<CfgD256x256>(&k_gemm_fp8<false>, g, s);
+    if (g.a_mx) launch_gemm_fp8_t<true>(g, s); else launch_gemm_fp8_t<false>(g, s);
 }
 
 // Which epilogue a launch can take (see tile_epilogue in gemm_dma.h): 0 = the general fp32-slab one; 1..6 = packed, when only
@@ -316,7 +337,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
         case V_DMA_128x128_P: NATINF_LAUNCH_EPI(CfgD128x128, k_gemm_dma, 2, 2, 4, 4, 2) break;
         case V_DMA_256x128W4_P: launch_tiles<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>, g, s); break;
         case V_8PH_256x256: launch_tiles<Cfg8ph>(&k_gemm_8ph<0>, g, s); break;
-        case V_FP8_256x256: launch_tiles<CfgD256x256>(&k_gemm_fp8<false>, g, s); break;
+        case V_FP8_256x256: launch_tiles<CfgD256x256>(&k_gemm_fp8<false, 0>, g, s); break;
         case V_8PH_NOPRIO: launch_tiles<Cfg8ph>(&k_gemm_8ph<1>, g, s); break;
         case V_8PH_READFIRST: launch_tiles<Cfg8ph>(&k_gemm_8ph<2>, g, s); break;
         case V_8PH_BOTH: launch_tiles<Cfg8ph>(&k_gemm_8ph<3>, g, s); break;
