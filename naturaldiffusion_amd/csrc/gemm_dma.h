@@ -492,7 +492,7 @@ __device__ __forceinline__ void direct_f32_epilogue(const GemmArgs& g, f32x4 (&a
 
 // EPI (kernel template parameter, chosen on the host by packed_epi()): 0 = fp32-slab epilogue with every fused term as a run-time
 // flag; 1..6 = packed epilogue: plain / + GroupNorm partials / + SiLU / + tanh-GELU / + bf16 residual / + residual and partials;
-// 7 = the direct fp32 residual-stream epilogue.  One epilogue per kernel: with both in one
+// 7 = the direct fp32 residual-stream epilogue; 8 = packed with row terms (a row bias: the V^T = W h^T + b GEMMs).  One epilogue per kernel: with both in one
 // kernel behind a run-time branch hipcc spilled inside the packed register phase (measured: isolated GEMMs +15..23 %, the
 // network 8 % SLOWER).
 template <int WM, int WN, int TM, int TN, class Cfg, int EPI>
@@ -504,7 +504,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, unsigned char* 
     else {
         static_assert(Cfg::PACK_OK, "packed epilogue needs the whole bf16 tile in LDS");
         NATINF_TS(2);
-        packed_tile_epilogue<WM, WN, TM, TN, Cfg, EPI == 3 ? ACT_SILU : (EPI == 4 ? ACT_GELU_TANH : ACT_NONE), EPI == 2 || EPI == 6, EPI == 5 || EPI == 6>(
+        packed_tile_epilogue<WM, WN, TM, TN, Cfg, EPI == 3 ? ACT_SILU : (EPI == 4 ? ACT_GELU_TANH : ACT_NONE), EPI == 2 || EPI == 6, EPI == 5 || EPI == 6, EPI == 8>(
             g, smem, acc, m0, n0, z, tid, lane, wm, wn);
     }
 }

@@ -186,7 +186,7 @@ bool set_lds_epi() {
            set_lds<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3, EPI>) && set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4, EPI>) &&
            set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4, 2, EPI>);
 }
-bool set_lds_epi_all() { return set_lds_epi<0>() && set_lds_epi<1>() && set_lds_epi<2>() && set_lds_epi<3>() && set_lds_epi<4>() && set_lds_epi<5>() && set_lds_epi<6>() && set_lds_epi<7>(); }
+bool set_lds_epi_all() { return set_lds_epi<0>() && set_lds_epi<1>() && set_lds_epi<2>() && set_lds_epi<3>() && set_lds_epi<4>() && set_lds_epi<5>() && set_lds_epi<6>() && set_lds_epi<7>() && set_lds_epi<8>(); }
 
 bool configure_gemm_kernels() {
     bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -281,7 +281,8 @@ void launch_gemm_fp8(const GemmArgs& g, hipStream_t s) {
 // column terms (bias, a per-sample row vector with every block tile inside one sample) and a bf16 residual are fused, the output is bf16, and
 // GroupNorm partials (no activation, whole tiles) or an activation -- not both -- are asked for.
 int packed_epi(const GemmArgs& g, int bm) {      // resid must be 8-byte aligned per 4-column group: ld % 4, base from the arena
-    if (g.epi_fp32_slab || g.bias_m || g.deq_m || g.deq_n) return 0;
+    if (g.epi_fp32_slab || g.deq_m || g.deq_n) return 0;
+    if (g.bias_m) return (g.c_mode == OUT_BF16 && !g.resid && !g.resid_f32 && !g.gate && !g.rowvec && !g.gn_part && g.act == ACT_NONE) ? 8 : 0;
     if ((g.rowvec || g.gate) && g.log_rows_per_sample < 30 && ((1 << g.log_rows_per_sample) % bm != 0)) return 0;    // per-sample terms: one sample per tile
     if (g.c_mode == OUT_F32 && g.resid_f32 && !g.resid && !g.gn_part && g.act == ACT_NONE && g.resid_f32_ld % 4 == 0 && g.c_ld % 4 == 0) return 7;
     if (g.c_mode != OUT_BF16 || g.resid_f32 || g.gate) return 0;
@@ -299,6 +300,7 @@ int packed_epi(const GemmArgs& g, int bm) {      // resid must be 8-byte aligned
         case 5: launch_tiles<CFG>(&KERN<__VA_ARGS__, 5>, g, s); break;                      \
         case 6: launch_tiles<CFG>(&KERN<__VA_ARGS__, 6>, g, s); break;                      \
         case 7: launch_tiles<CFG>(&KERN<__VA_ARGS__, 7>, g, s); break;                      \
+        case 8: launch_tiles<CFG>(&KERN<__VA_ARGS__, 8>, g, s); break;                      \
         default: launch_tiles<CFG>(&KERN<__VA_ARGS__, 0>, g, s); break;                     \
     }
 
