@@ -80,6 +80,13 @@ int natinf_debug_quant_fp8_rows(const float* w, void* q, float* row_scale, int r
 /* a_mx (optional): E8M0 block scales of a8 (then a_scale is normally NULL), stored K-tile major: the byte of (row r, 32-block
  * kb) at [(kb / 4) * M * 4 + r * 4 + kb % 4], readable up to 256-row granularity (allocate ceil(M / 256) * 256 rows per
  * plane).  c_mode 0 bf16, 1 fp32, 3 = fp8 e4m3 bytes [M][N] + block scales c_mx in the same layout (N % 128 == 0). */
+/* One plain GEMM C[M][N] = A[M][K] B[N][K]^T (bf16 operands) with the fused epilogue terms, any of which may be NULL: column bias,
+ * row bias, per-sample row vector and gate ([samples][N], sample = row >> log_rows_per_sample), bf16 / fp32 residual [M][N], scale,
+ * activation (0 none, 1 SiLU, 2 tanh-GELU); output bf16 or fp32 [M][N]; gn_part (optional) receives (sum, sum of squares) per
+ * block tile of *bm_out rows and 4-column quad.  fp32_slab = 1 forces the general fp32-slab epilogue.  N % 8 == 0. */
+int natinf_debug_gemm_fused(int variant, int M, int N, int K, const void* a, const void* b, const float* bias_n, const float* bias_m,
+                            const float* rowvec, const float* gate, int log_rows_per_sample, const void* resid_bf16, const float* resid_f32,
+                            float scale, int act, void* c, int c_f32, float* gn_part, int* bm_out, int fp32_slab, natinf_stream_t stream);
 int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_scale, const void* a_mx, const void* b8, const float* b_scale,
                           const float* bias_n, void* c, void* c_mx, int c_mode, int iters, natinf_stream_t stream);
 int natinf_set_gemm_variant(int variant);

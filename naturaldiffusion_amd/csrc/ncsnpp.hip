@@ -983,6 +983,28 @@ int natinf_debug_gemm(int variant, int M, int N, int K0, int K1, int taps, int l
     return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
 }
 
+// One plain GEMM C = A B^T with the fused epilogue terms of GemmArgs (tests/test_gpu_gemm_epilogue.py): every pointer but a / b / c
+// may be NULL.  rowvec / gate are [samples][N] tables indexed by row >> log_rows_per_sample; gn_part receives (sum, sum of
+// squares) per block tile and 4-column quad ([ceil(M / *bm_out)][N / 4] float2).  fp32_slab forces the general epilogue.
+int natinf_debug_gemm_fused(int variant, int M, int N, int K, const void* a, const void* b, const float* bias_n, const float* bias_m,
+                            const float* rowvec, const float* gate, int log_rows_per_sample, const void* resid_bf16, const float* resid_f32,
+                            float scale, int act, void* c, int c_f32, float* gn_part, int* bm_out, int fp32_slab, natinf_stream_t stream) {
+    if (variant < 0 || variant >= V_COUNT || !a || !b || !c || M <= 0 || N <= 0 || K <= 0 || N % 8) return NATINF_EINVAL;
+    if (!configure_gemm_kernels()) return NATINF_ENODEV;
+    GemmArgs g = gemm_defaults();
+    g.a0 = (const bf16*)a; g.a0_C = K; g.a0_ld = K; g.M = M; g.N = N; g.b = (const bf16*)b; g.b_ld = K;
+    g.bias_n = bias_n; g.bias_m = bias_m; g.rowvec = rowvec; g.rowvec_ld = N; g.gate = gate; g.gate_ld = N; g.log_rows_per_sample = log_rows_per_sample;
+    g.resid = (const bf16*)resid_bf16; g.resid_ld = N; g.resid_f32 = resid_f32; g.resid_f32_ld = N;
+    g.scale = scale; g.act = act; g.c = c; g.c_ld = N; g.c_mode = c_f32 ? OUT_F32 : OUT_BF16;
+    g.gn_part = gn_part; g.gn_quads = N / 4; g.epi_fp32_slab = fp32_slab != 0;
+    const int saved = g_force_variant;
+    g_force_variant = variant;
+    const int bm = launch_gemm(g, (hipStream_t)stream);
+    g_force_variant = saved;
+    if (bm_out) *bm_out = bm;
+    return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
+}
+
 int natinf_debug_quant_fp8_rows(const float* w, void* q, float* row_scale, int rows, int cols, natinf_stream_t stream) {
     if (!w || !q || !row_scale || rows <= 0 || cols <= 0 || cols % 2) return NATINF_EINVAL;
     hipLaunchKernelGGL(k_pack_fp8_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, w, (uint8_t*)q, row_scale, rows, cols);

@@ -1,0 +1,81 @@
+"""The GEMM epilogue specializations (csrc/gemm_dma.h: packed bf16 / direct fp32 / fp32 slab) one by one, on plain GEMMs with
+ragged M and N, against an fp32 torch reference of the same fused terms -- and the packed path against the general one."""
+import ctypes as C
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+V_DMA256P, V_DMA128P, V_RING256W4, V_RING64, V_DMA512 = 16, 17, 9, 8, 13
+
+
+def _run(variant, M, N, K, lrs, terms, act=0, c_f32=False, fp32_slab=False, scale=1.0, seed=0):
+    from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    a = torch.randn(M, K, device="cuda", generator=g).bfloat16(); b = (torch.randn(N, K, device="cuda", generator=g) * 0.1).bfloat16()
+    ns = (M + (1 << lrs) - 1) >> lrs
+    t = {"bias_n": torch.randn(N, device="cuda", generator=g), "bias_m": torch.randn(M, device="cuda", generator=g),
+         "rowvec": torch.randn(ns, N, device="cuda", generator=g), "gate": torch.randn(ns, N, device="cuda", generator=g),
+         "resid": torch.randn(M, N, device="cuda", generator=g).bfloat16(), "resid_f32": torch.randn(M, N, device="cuda", generator=g)}
+    has = lambda k: k in terms
+    c = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32 if c_f32 else torch.bfloat16)
+    part = torch.zeros(((M + 63) // 64) * (N // 4) * 2, device="cuda") if has("gn") else None
+    bm = C.c_int(0)
+    check(lib.natinf_debug_gemm_fused(variant, M, N, K, ptr(a), ptr(b), ptr(t["bias_n"]) if has("bias_n") else None,
+                                      ptr(t["bias_m"]) if has("bias_m") else None, ptr(t["rowvec"]) if has("rowvec") else None,
+                                      ptr(t["gate"]) if has("gate") else None, lrs, ptr(t["resid"]) if has("resid") else None,
+                                      ptr(t["resid_f32"]) if has("resid_f32") else None, scale, act, ptr(c), int(c_f32),
+                                      ptr(part) if part is not None else None, C.byref(bm), int(fp32_slab), stream_ptr()), "debug_gemm_fused")
+    torch.cuda.synchronize()
+    v = a.float() @ b.float().t()
+    rows = torch.arange(M, device="cuda") >> lrs
+    if has("bias_n"): v = v + t["bias_n"]
+    if has("bias_m"): v = v + t["bias_m"][:, None]
+    if has("rowvec"): v = v + t["rowvec"][rows]
+    if has("gate"): v = v * t["gate"][rows]
+    if has("resid"): v = v + t["resid"].float()
+    if has("resid_f32"): v = v + t["resid_f32"]
+    v = v * scale
+    if act == 1: v = torch.nn.functional.silu(v)
+    if act == 2: v = torch.nn.functional.gelu(v, approximate="tanh")
+    return c.float(), v, part, bm.value
+
+
+CASES = [   # (variant, M, N, K, log2 rows per sample, fused terms, activation, fp32 output)
+    (V_DMA256P, 1000, 392, 192, 8, ("bias_n",), 0, False),                       # EPI 1, ragged M and N
+    (V_DMA256P, 1024, 512, 128, 8, ("bias_n", "rowvec", "gn"), 0, False),        # EPI 2
+    (V_DMA128P, 900, 264, 64, 7, ("bias_n",), 1, False),                         # EPI 3 (SiLU)
+    (V_DMA256P, 777, 1160, 256, 8, ("bias_n",), 2, False),                       # EPI 4 (tanh-GELU)
+    (V_RING256W4, 1000, 136, 128, 8, ("bias_n", "resid"), 0, False),             # EPI 5
+    (V_DMA512, 2048, 128, 1152, 9, ("bias_n", "rowvec", "resid", "gn"), 0, False),   # EPI 6 on the 512x128 tile
+    (V_DMA256P, 1000, 392, 192, 30, ("bias_n", "gate", "resid_f32"), 0, True),   # EPI 7 (direct fp32 residual stream)
+    (V_RING64, 333, 1536, 128, 30, ("bias_n", "gate", "resid_f32"), 0, True),    # EPI 7, context-stream shape
+    (V_DMA128P, 520, 328, 128, 8, ("bias_m",), 0, False),                        # EPI 8 (row bias)
+    (V_DMA128P, 512, 256, 128, 6, ("bias_n", "rowvec"), 0, False),               # two samples per tile -> general epilogue
+]
+
+
+@pytest.mark.parametrize("variant,M,N,K,lrs,terms,act,c_f32", CASES)
+def test_epilogue_matches_fp32_reference(variant, M, N, K, lrs, terms, act, c_f32):
+    out, ref, part, bm = _run(variant, M, N, K, lrs, terms, act, c_f32)
+    assert torch.isfinite(out).all()
+    tol = (2e-6 if c_f32 else 2 ** -8) * ref.abs().max().item() + 1e-5
+    assert (out - ref).abs().max().item() <= tol
+    # the general epilogue computes the same thing (not bit-identical: fma contraction differs)
+    out0, _, part0, bm0 = _run(variant, M, N, K, lrs, terms, act, c_f32, fp32_slab=True)
+    assert (out0 - ref).abs().max().item() <= tol
+    if part is not None:
+        assert bm == bm0 and M % bm == 0
+        want = ref.reshape(M // bm, bm, N // 4, 4)
+        s, q = want.sum(dim=(1, 3)), (want * want).sum(dim=(1, 3))
+        got = part[: (M // bm) * (N // 4) * 2].reshape(M // bm, N // 4, 2)
+        got0 = part0[: (M // bm) * (N // 4) * 2].reshape(M // bm, N // 4, 2)
+        for g_ in (got, got0):
+            assert (g_[..., 0] - s).abs().max().item() <= 2e-3 * q.sqrt().max().item() + 1e-3
+            assert (g_[..., 1] - q).abs().max().item() <= 2e-3 * q.max().item()
+
+
+def test_packed_epilogue_is_deterministic():
+    a = _run(V_DMA256P, 1024, 512, 128, 8, ("bias_n", "rowvec", "gn"))
+    b = _run(V_DMA256P, 1024, 512, 128, 8, ("bias_n", "rowvec", "gn"))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
