@@ -14,6 +14,9 @@
 //   per tap t:    weight tile (c, t+1) requested, MFMAs on (patch c, weights (c, t)), vmcnt(0) + barrier
 //   the 1x1 shortcut segment (a1) runs after the chunks as plain 64-wide K-tiles through the same buffers.
 // LDS rows are 128 B with the 16-byte chunk XOR-ed by (row>>1)&7 on the DMA source side and on the fragment read.
+// Re-measured at the end of round 1 with the packed epilogue switched in (tools/scan_patch.py): 2-6 % BEHIND the tap-by-tap
+// hand-pipelined kernels on every 3x3 shape (e.g. 133 vs 126 us at (131072, 256, 2304)) -- fewer DMA pieces do not shorten
+// the K loop, so this stays a non-selected variant with the general epilogue.
 #pragma once
 #include "gemm_dma.h"
 
