@@ -536,7 +536,7 @@ constexpr int pipe_lgkm_after(int TM, int st) {
     if (st >= TM && pos_fb1_last > need) need = pos_fb1_last;
     return n - 1 - need;
 }
-template <int TM, int ST>
+template <int TM, int ST, bool NOMFMA = false>       // NOMFMA: ablation (k_gemm_dma<..., 4>): the fragment reads and waits without the MFMAs
 struct PipeStep {
     static __device__ __forceinline__ void run(u32x4 (&fa)[3], u32x4 (&fb)[2][4], f32x4 (&acc)[TM][4],
                                                unsigned a0, unsigned a1, unsigned b1) {
@@ -547,11 +547,15 @@ struct PipeStep {
         }
         if constexpr (ks == 0 && i >= TM - 4) fb[1][i - (TM - 4)] = lds_read16<(i - (TM - 4)) * 2048>(b1);
         wait_lgkmcnt<pipe_lgkm_after(TM, ST)>();
+        if constexpr (!NOMFMA) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[ks][j]),
-                                                                __builtin_bit_cast(bf16x8, fa[ST % 3]), acc[i][j], 0, 0, 0);
-        if constexpr (ST + 1 < S) PipeStep<TM, ST + 1>::run(fa, fb, acc, a0, a1, b1);
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[ks][j]),
+                                                                    __builtin_bit_cast(bf16x8, fa[ST % 3]), acc[i][j], 0, 0, 0);
+        } else {
+            asm volatile("" :: "v"(fa[ST % 3]), "v"(fb[ks][0]), "v"(fb[ks][1]), "v"(fb[ks][2]), "v"(fb[ks][3]));     // keep the reads alive
+        }
+        if constexpr (ST + 1 < S) PipeStep<TM, ST + 1, NOMFMA>::run(fa, fb, acc, a0, a1, b1);
     }
 };
 
@@ -670,13 +674,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pb), (lds_void*)(dBn + (p - Cfg::PA) * 1024), 16, 0, 0);
             }
         };
-        if (SPREAD != 1 && more) {
+        if (SPREAD != 1 && SPREAD != 3 && more) {          // SPREAD 3 / 4: ablations of the hand-pipelined loop (no DMA after tile 0 / no MFMAs)
 #pragma unroll
             for (int p = 0; p < NP; ++p) issue_piece(p);
         }
         const bf16* ta = reinterpret_cast<const bf16*>(smem + cur * Cfg::STAGE_BYTES) + (wm * TM * 16 + frow) * LDS_ROW;
         const bf16* tb = reinterpret_cast<const bf16*>(smem + cur * Cfg::STAGE_BYTES + BM_ * BK * 2) + (wn * TN * 16 + frow) * LDS_ROW;
-        if constexpr (SPREAD != 2) {
+        if constexpr (SPREAD < 2) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int ko = (((ks << 2) | fq) ^ fswz) << 3;
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
                 }
             }
         } else {
-            static_assert(SPREAD != 2 || TN == 4, "the hand-counted pipeline is written for TN = 4");
+            static_assert(SPREAD < 2 || TN == 4, "the hand-counted pipeline is written for TN = 4");
             typedef __attribute__((address_space(3))) unsigned char lds_u8;
             const unsigned a_lds = (unsigned)(uintptr_t)((lds_u8*)(unsigned char*)const_cast<bf16*>(ta));
             const unsigned b_lds = (unsigned)(uintptr_t)((lds_u8*)(unsigned char*)const_cast<bf16*>(tb));
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
             fb[0][0] = lds_read16<0>(b_lds + ko0); fb[0][1] = lds_read16<2048>(b_lds + ko0);
             fb[0][2] = lds_read16<4096>(b_lds + ko0); fb[0][3] = lds_read16<6144>(b_lds + ko0);
             fa[0] = lds_read16<0>(a_lds + ko0); fa[1] = lds_read16<2048>(a_lds + ko0);
-            PipeStep<TM, 0>::run(fa, fb, acc, a_lds + ko0, a_lds + ko1, b_lds + ko1);
+            PipeStep<TM, 0, SPREAD == 4>::run(fa, fb, acc, a_lds + ko0, a_lds + ko1, b_lds + ko1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's LDS-DMA has landed (explicit: not left to the compiler's tracking)
         __syncthreads();

@@ -151,11 +151,12 @@ enum GemmVariant {
     V_DMA_256x256_P = 16, V_DMA_128x128_P = 17, V_DMA_256x128W4_P = 18,  // two-stage + hand-counted LDS fragment pipeline
     V_8PH_256x256 = 19, V_8PH_NOPRIO = 20, V_8PH_READFIRST = 21, V_8PH_BOTH = 22,   // phase-interleaved schedule, counted vmcnt (gemm_8phase.h)
     V_FP8_256x256 = 23,                                                 // fp8 e4m3 operands (gemm_fp8.h); selected by GemmArgs::deq_m/deq_n callers only
+    V_ABL_NODMA = 24, V_ABL_NOMFMA = 25,                                // ablations of dma256x256p's K loop (wrong results by design; tools/ablate_loop.py)
     V_COUNT
 };
 const char* variant_name(int v) {
     static const char* n[] = {"auto", "generic128", "dma256x256", "dma256x128", "dma128x128", "ring256x256", "ring256x128",
-                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s", "dma512x128", "patch256x256", "patch256x128", "dma256x256p", "dma128x128p", "dma256x128w4p", "gemm8ph", "gemm8ph_np", "gemm8ph_rf", "gemm8ph_nprf", "fp8_256x256"};
+                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s", "dma512x128", "patch256x256", "patch256x128", "dma256x256p", "dma128x128p", "dma256x128w4p", "gemm8ph", "gemm8ph_np", "gemm8ph_rf", "gemm8ph_nprf", "fp8_256x256", "abl_nodma", "abl_nomfma"};
     return v >= 0 && v < V_COUNT ? n[v] : "?";
 }
 unsigned long long* g_dbg_ts = nullptr;
@@ -200,7 +201,7 @@ bool configure_gemm_kernels() {
          set_lds<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>) && set_lds<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>) &&
          set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2>) && set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2>) &&
          set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>) &&
-         set_lds_epi_all() &&
+         set_lds_epi_all() && set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 3, 1>) && set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 4, 1>) &&
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 0>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 0>) &&
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 1>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 1>) &&
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 2>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 2>) &&
@@ -220,6 +221,7 @@ bool configure_gemm_kernels() {
 // k_gemm_8ph has no edge clamping and addresses the 1x1 segment row-linearly
 inline bool eligible_8ph(const GemmArgs& g) { return g.M % 256 == 0 && g.N % 256 == 0; }
 
+int variant_bm(int v);
 int choose_variant(const GemmArgs& g) {
     const int K0 = g.taps * g.a0_C, K1 = g.a1 ? g.a1_C : 0;
     const bool dma = K0 % BK == 0 && K1 % BK == 0 && (g.taps == 1 || (g.a0_padded && g.a0_C % BK == 0));
@@ -229,7 +231,10 @@ int choose_variant(const GemmArgs& g) {
         if (patch_ok && (g_force_variant == V_PATCH_256x128 || g.logW >= 4)) return g_force_variant;
     } else if (g_force_variant >= V_8PH_256x256 && g_force_variant <= V_8PH_BOTH) {
         if (eligible_8ph(g)) return g_force_variant;
-    } else if (g_force_variant > V_GENERIC) return g_force_variant;
+    } else if (g_force_variant > V_GENERIC) {
+        // a forced tile must keep GroupNorm partial tiles inside one sample (e.g. 512-row tiles on the 16x16 level do not)
+        if (!g.gn_part || (g.taps == 9 && (1 << g.logHW) % variant_bm(g_force_variant) == 0)) return g_force_variant;
+    }
     // measured on the engine's layer shapes (tools/bench_gemm.py, profiles/r01): 256x256 two-stage for wide-N,
     // long-K layers; the 4-wave 256x128 ring (wave tile 128x64, 2 blocks/CU) for N = 128 and short-K layers;
     // 128x128 when 256-row tiles would leave CUs idle; 64x128 for the 4x4 level
@@ -247,7 +252,7 @@ int choose_variant(const GemmArgs& g) {
 int variant_bm(int v) {
     switch (v) {
         case V_DMA_256x256: case V_DMA_256x128: case V_RING_256x256: case V_RING_256x128: case V_RING_256x128_W4: case V_DMA_256x128_W4:
-        case V_DMA_256x256_S: case V_PATCH_256x256: case V_PATCH_256x128: case V_DMA_256x256_P: case V_DMA_256x128W4_P: case V_8PH_256x256: case V_8PH_NOPRIO: case V_8PH_READFIRST: case V_8PH_BOTH: case V_FP8_256x256: return 256;
+        case V_ABL_NODMA: case V_ABL_NOMFMA: case V_DMA_256x256_S: case V_PATCH_256x256: case V_PATCH_256x128: case V_DMA_256x256_P: case V_DMA_256x128W4_P: case V_8PH_256x256: case V_8PH_NOPRIO: case V_8PH_READFIRST: case V_8PH_BOTH: case V_FP8_256x256: return 256;
         case V_DMA_512x128: return 512;
         case V_RING_64x128: return 64;
         default: return 128;
@@ -340,6 +345,8 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
         case V_DMA_256x128W4_P: launch_tiles<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>, g, s); break;
         case V_8PH_256x256: launch_tiles<Cfg8ph>(&k_gemm_8ph<0>, g, s); break;
         case V_FP8_256x256: launch_tiles<CfgD256x256>(&k_gemm_fp8<false, 0>, g, s); break;
+        case V_ABL_NODMA: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 3, 1>, g, s); break;
+        case V_ABL_NOMFMA: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 4, 1>, g, s); break;
         case V_8PH_NOPRIO: launch_tiles<Cfg8ph>(&k_gemm_8ph<1>, g, s); break;
         case V_8PH_READFIRST: launch_tiles<Cfg8ph>(&k_gemm_8ph<2>, g, s); break;
         case V_8PH_BOTH: launch_tiles<Cfg8ph>(&k_gemm_8ph<3>, g, s); break;
