@@ -94,6 +94,8 @@ int natinf_set_gemm_variant(int variant);
 int natinf_set_gemm_epilogue(int fp32_slab);
 /* A/B switch for tuning: 0 = N <= 128 layers on the 4-wave 256x128 ring tile, 1 (default) = on the 512x128 hand-pipelined tile. */
 int natinf_set_gemm_pref512(int on);
+/* Tuning: row-tiles per raster group of launches with >= 8 column tiles (default 8; 0 = plain row-major tile order). */
+int natinf_set_gemm_raster(int rows);
 /* Timing experiments (tools/tile_timeline.py): device buffer of 16 uint64 shader-clock stamps that block 0 / thread 0 of
  * every natinf_debug_gemm launch writes (kernel start, first tile landed, main loop done, per epilogue pass: slab written,
  * sweeps done, stores issued).  NULL switches it off. */

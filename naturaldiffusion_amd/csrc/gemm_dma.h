@@ -574,7 +574,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
     const int nN = (g.N + BN_ - 1) / BN_, nM = (g.M + BM_ - 1) / BM_;
     const int tile = xcd_remap(blockIdx.x, nM * nN);
     NATINF_TS(0);
-    const int m0 = (tile / nN) * BM_, n0 = (tile % nN) * BN_;
+    int mt_, nt_;
+    tile_coords(tile, nM, nN, g.raster_g, mt_, nt_);
+    const int m0 = mt_ * BM_, n0 = nt_ * BN_;
     const int z = blockIdx.z;
 
     const bf16* a0 = g.a0 + (int64_t)z * g.a_bs;
@@ -761,7 +763,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_ring(const GemmArgs g)
     const int wm = wave / WN, wn = wave % WN;
     const int nN = (g.N + BN_ - 1) / BN_, nM = (g.M + BM_ - 1) / BM_;
     const int tile = xcd_remap(blockIdx.x, nM * nN);
-    const int m0 = (tile / nN) * BM_, n0 = (tile % nN) * BN_;
+    int mt_, nt_;
+    tile_coords(tile, nM, nN, g.raster_g, mt_, nt_);
+    const int m0 = mt_ * BM_, n0 = nt_ * BN_;
     const int z = blockIdx.z;
 
     const bf16* a0 = g.a0 + (int64_t)z * g.a_bs;

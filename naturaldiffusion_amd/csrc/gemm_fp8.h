@@ -29,7 +29,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_fp8(const GemmArgs g)
     const int wm = wave / WN, wn = wave % WN;
     const int nN = (g.N + BN_ - 1) / BN_, nM = (g.M + BM_ - 1) / BM_;
     const int tile = xcd_remap(blockIdx.x, nM * nN);
-    const int m0 = (tile / nN) * BM_, n0 = (tile % nN) * BN_;
+    int mt_, nt_;
+    tile_coords(tile, nM, nN, g.raster_g, mt_, nt_);
+    const int m0 = mt_ * BM_, n0 = nt_ * BN_;
     const int z = blockIdx.z;
     const uint8_t* a0 = reinterpret_cast<const uint8_t*>(g.a0) + (int64_t)z * g.a_bs;     // strides in bytes = elements
     const uint8_t* bp = reinterpret_cast<const uint8_t*>(g.b) + (int64_t)z * g.b_bs;

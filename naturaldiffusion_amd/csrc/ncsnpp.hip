@@ -164,9 +164,12 @@ int g_force_variant = V_AUTO;
 int g_pref_512 = 1;                // N <= 128 layers with >= 2 tiles per CU: the 512x128 hand-pipelined tile (natinf_set_gemm_pref512: A/B runs)      // tuning / tests: force one variant for every DMA-eligible launch
 std::string* g_record = nullptr;   // when set, launch_gemm describes the launch instead of issuing it
 
+int g_raster_g = 8;                 // natinf_set_gemm_raster: row-tiles per raster group of wide-N launches (0 / 1 = plain row-major)
 template <class Cfg, class K>
-inline void launch_tiles(K kernel, const GemmArgs& g, hipStream_t s) {
-    const int nM = (g.M + Cfg::BM_ - 1) / Cfg::BM_, nN = (g.N + Cfg::BN_ - 1) / Cfg::BN_;
+inline void launch_tiles(K kernel, const GemmArgs& g0, hipStream_t s) {
+    const int nM = (g0.M + Cfg::BM_ - 1) / Cfg::BM_, nN = (g0.N + Cfg::BN_ - 1) / Cfg::BN_;
+    GemmArgs g = g0;
+    g.raster_g = (g_raster_g > 1 && nN >= 8 && nM >= g_raster_g) ? g_raster_g : 0;
     hipLaunchKernelGGL(kernel, dim3(nM * nN, 1, g.batch), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, g);
 }
 template <class Cfg, class K>
@@ -1035,6 +1038,7 @@ int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_sc
 // timing experiments: device buffer of 16 uint64 s_memtime stamps written by block 0 / thread 0 of natinf_debug_gemm launches
 int natinf_debug_timestamps(void* dev_buf16) { g_dbg_ts = reinterpret_cast<unsigned long long*>(dev_buf16); return NATINF_OK; }
 
+int natinf_set_gemm_raster(int rows) { g_raster_g = rows; return NATINF_OK; }
 int natinf_set_gemm_pref512(int on) { g_pref_512 = on != 0; return NATINF_OK; }
 int natinf_set_gemm_epilogue(int fp32_slab) { g_epi_fp32_slab = fp32_slab != 0; return NATINF_OK; }
 

@@ -58,6 +58,7 @@ struct GemmArgs {
     // (k_gemm_fp8<true>; the plane must be readable up to row m0 + 255); c_mx: of the OUTPUT when c_mode == OUT_FP8_MX.
     const uint8_t* a_mx; int a_mx_ld; int64_t a_mx_bs;
     uint8_t* c_mx; int c_mx_ld; int64_t c_mx_bs;
+    int raster_g;                       // > 1: tiles walk groups of raster_g row-tiles, columns outer inside a group (wide-N GEMMs; tile_coords)
     int epi_fp32_slab;                  // A/B switch: 1 = always the fp32-slab epilogue (g_epi_fp32_slab)
     unsigned long long* dbg_ts;         // timing experiments: s_memtime stamps of block 0 / thread 0 (null in production)
     void* c; int c_ld; int c_mode;
@@ -120,6 +121,16 @@ __device__ __forceinline__ void apply_act4(float (&v)[4], int act) {
             v[q] = v[q] * (1.0f - __builtin_amdgcn_rcpf(__expf(2.0f * u) + 1.0f));
         }
     }
+}
+
+// Linear tile index -> (row-tile, column-tile).  Row-major by default; with g (= GemmArgs::raster_g) > 1 the tiles of a group of
+// g row-tiles are visited column by column, so that the ~32 tiles an XCD works on at one time form a g x (32/g) patch: they
+// share g + 32/g operand panels instead of 1 + 32 when the matrix is wide (nN >> 32/g) -- L2 hits for the LDS fill.
+__device__ __forceinline__ void tile_coords(int tile, int nM, int nN, int g, int& mt, int& nt) {
+    if (g > 1) {
+        const int per = g * nN, grp = tile / per, r = tile - grp * per, rows = min(g, nM - grp * g);
+        nt = r / rows; mt = grp * g + (r - nt * rows);
+    } else { mt = tile / nN; nt = tile - mt * nN; }
 }
 
 // XCD-aware bijective remap of a linear block id: consecutive ids land on different XCDs (round-robin
