@@ -94,6 +94,8 @@ int natinf_set_gemm_variant(int variant);
 int natinf_set_gemm_epilogue(int fp32_slab);
 /* A/B switch for tuning: 0 = N <= 128 layers on the 4-wave 256x128 ring tile, 1 (default) = on the 512x128 hand-pipelined tile. */
 int natinf_set_gemm_pref512(int on);
+/* A/B switch for tuning: 1 (default) = in the 256x256 / 512x128 kernels one wave per SIMD issues all LDS-DMA pieces, 0 = every wave its own. */
+int natinf_set_gemm_half_issue(int on);
 /* Tuning: row-tiles per raster group of launches with >= 8 column tiles (default 8; 0 = plain row-major tile order). */
 int natinf_set_gemm_raster(int rows);
 /* Timing experiments (tools/tile_timeline.py): device buffer of 16 uint64 shader-clock stamps that block 0 / thread 0 of

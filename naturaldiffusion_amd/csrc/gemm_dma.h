@@ -586,10 +586,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
     const int nk0 = K0 / BK, nk = nk0 + K1 / BK;
     const int Wp = (1 << g.logW) + 2, Hp = (1 << (g.logHW - g.logW)) + 2;
 
-    uint64_t a_row[Cfg::PA], a_delta[Cfg::PA], b_row[Cfg::PB];
+    // SPREAD 6: only the first half of the waves (one per SIMD) issue LDS-DMA, two waves' worth each; the other wave of every
+    // SIMD goes straight to its MFMAs, so the matrix pipe is not idle while the DMA burst is being issued.
+    constexpr bool HALF = SPREAD == 6;
+    constexpr int PAI = HALF ? 2 * Cfg::PA : Cfg::PA, PBI = HALF ? 2 * Cfg::PB : Cfg::PB;
+    const bool issuer = !HALF || wave < Cfg::NW / 2;
+    uint64_t a_row[PAI], a_delta[PAI], b_row[PBI];
 #pragma unroll
-    for (int j = 0; j < Cfg::PA; ++j) {
-        const int r = (wave * Cfg::PA + j) * 8 + (lane >> 3);
+    for (int j = 0; j < PAI; ++j) {
+        const int r = (wave * PAI + j) * 8 + (lane >> 3);
         const int lchunk = ((lane & 7) ^ ((r >> 1) & 7)) << 3;
         const int m = min(m0 + r, g.M - 1);
         int64_t off0;
@@ -603,16 +608,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
         a_delta[j] = a1 ? reinterpret_cast<uint64_t>(a1 + (int64_t)m * g.a1_ld + lchunk) - a_row[j] : 0;
     }
 #pragma unroll
-    for (int j = 0; j < Cfg::PB; ++j) {
-        const int r = (wave * Cfg::PB + j) * 8 + (lane >> 3);
+    for (int j = 0; j < PBI; ++j) {
+        const int r = (wave * PBI + j) * 8 + (lane >> 3);
         const int lchunk = ((lane & 7) ^ ((r >> 1) & 7)) << 3;
         b_row[j] = reinterpret_cast<uint64_t>(bp + (int64_t)min(n0 + r, g.N - 1) * g.b_ld + lchunk);
     }
 
     typedef __attribute__((address_space(3))) void lds_void;
     auto issue_tile = [&](int kt, int buf) __attribute__((always_inline)) {
-        unsigned char* dA = smem + buf * Cfg::STAGE_BYTES + wave * (Cfg::PA * 1024);
-        unsigned char* dB = smem + buf * Cfg::STAGE_BYTES + BM_ * BK * 2 + wave * (Cfg::PB * 1024);
+        if (!issuer) return;
+        unsigned char* dA = smem + buf * Cfg::STAGE_BYTES + wave * (PAI * 1024);
+        unsigned char* dB = smem + buf * Cfg::STAGE_BYTES + BM_ * BK * 2 + wave * (PBI * 1024);
         const bool seg0 = kt < nk0;
         int64_t ashift;
         int kk;
@@ -626,12 +632,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
             ashift = (int64_t)(kt - nk0) * BK * 2; kk = K0 + (kt - nk0) * BK;
         }
 #pragma unroll
-        for (int j = 0; j < Cfg::PA; ++j) {
+        for (int j = 0; j < PAI; ++j) {
             const uint64_t pa = a_row[j] + (seg0 ? 0 : a_delta[j]) + (uint64_t)ashift;
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pa), (lds_void*)(dA + j * 1024), 16, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < Cfg::PB; ++j) {
+        for (int j = 0; j < PBI; ++j) {
             const uint64_t pb = b_row[j] + (uint64_t)kk * 2;
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pb), (lds_void*)(dB + j * 1024), 16, 0, 0);
         }
@@ -649,7 +655,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
     NATINF_TS(1);
 
     const int frow = lane & 15, fq = lane >> 4, fswz = (frow >> 1) & 7;
-    constexpr int NP = Cfg::PA + Cfg::PB, SLOTS = 2 * TM, STEP = SLOTS / NP > 0 ? SLOTS / NP : 1;
+    constexpr int NP = PAI + PBI, SLOTS = 2 * TM, STEP = SLOTS / NP > 0 ? SLOTS / NP : 1;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
@@ -665,18 +671,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
         } else {
             ashiftn = (int64_t)(kn - nk0) * BK * 2; kkn = K0 + (kn - nk0) * BK;
         }
-        unsigned char* dAn = smem + (cur ^ 1) * Cfg::STAGE_BYTES + wave * (Cfg::PA * 1024);
-        unsigned char* dBn = smem + (cur ^ 1) * Cfg::STAGE_BYTES + BM_ * BK * 2 + wave * (Cfg::PB * 1024);
+        unsigned char* dAn = smem + (cur ^ 1) * Cfg::STAGE_BYTES + wave * (PAI * 1024);
+        unsigned char* dBn = smem + (cur ^ 1) * Cfg::STAGE_BYTES + BM_ * BK * 2 + wave * (PBI * 1024);
         auto issue_piece = [&](int p) __attribute__((always_inline)) {
-            if (p < Cfg::PA) {
+            if (p < PAI) {
                 const uint64_t pa = a_row[p] + (seg0n ? 0 : a_delta[p]) + (uint64_t)ashiftn;
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pa), (lds_void*)(dAn + p * 1024), 16, 0, 0);
             } else {
-                const uint64_t pb = b_row[p - Cfg::PA] + (uint64_t)kkn * 2;
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pb), (lds_void*)(dBn + (p - Cfg::PA) * 1024), 16, 0, 0);
+                const uint64_t pb = b_row[p - PAI] + (uint64_t)kkn * 2;
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pb), (lds_void*)(dBn + (p - PAI) * 1024), 16, 0, 0);
             }
         };
-        if (SPREAD != 1 && SPREAD != 3 && more) {          // SPREAD 3 / 4: ablations of the hand-pipelined loop (no DMA after tile 0 / no MFMAs)
+        if (SPREAD != 1 && SPREAD != 3 && more && issuer) {          // SPREAD 3 / 4: ablations of the hand-pipelined loop (no DMA after tile 0 / no MFMAs)
 #pragma unroll
             for (int p = 0; p < NP; ++p) issue_piece(p);
         }

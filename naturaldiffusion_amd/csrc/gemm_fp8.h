@@ -37,25 +37,29 @@ __global__ __launch_bounds__(512, 2) void k_gemm_fp8(const GemmArgs g)
     const uint8_t* bp = reinterpret_cast<const uint8_t*>(g.b) + (int64_t)z * g.b_bs;
     const int nk = g.a0_C / BKB;
 
-    uint64_t a_row[Cfg::PA], b_row[Cfg::PB];
+    // one wave per SIMD (waves 0..3) issues all LDS-DMA pieces, two waves' worth each (see k_gemm_dma SPREAD 6)
+    constexpr int PAI = 2 * Cfg::PA, PBI = 2 * Cfg::PB;
+    const bool issuer = wave < Cfg::NW / 2;
+    uint64_t a_row[PAI], b_row[PBI];
 #pragma unroll
-    for (int j = 0; j < Cfg::PA; ++j) {
-        const int r = (wave * Cfg::PA + j) * 8 + (lane >> 3);
+    for (int j = 0; j < PAI; ++j) {
+        const int r = (wave * PAI + j) * 8 + (lane >> 3);
         a_row[j] = reinterpret_cast<uint64_t>(a0 + (int64_t)min(m0 + r, g.M - 1) * g.a0_ld + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
     }
 #pragma unroll
-    for (int j = 0; j < Cfg::PB; ++j) {
-        const int r = (wave * Cfg::PB + j) * 8 + (lane >> 3);
+    for (int j = 0; j < PBI; ++j) {
+        const int r = (wave * PBI + j) * 8 + (lane >> 3);
         b_row[j] = reinterpret_cast<uint64_t>(bp + (int64_t)min(n0 + r, g.N - 1) * g.b_ld + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
     }
     auto issue_tile = [&](int kt, int buf) __attribute__((always_inline)) {
-        unsigned char* dA = smem + buf * Cfg::STAGE_BYTES + wave * (Cfg::PA * 1024);
-        unsigned char* dB = smem + buf * Cfg::STAGE_BYTES + BM_ * 128 + wave * (Cfg::PB * 1024);
+        if (!issuer) return;
+        unsigned char* dA = smem + buf * Cfg::STAGE_BYTES + wave * (PAI * 1024);
+        unsigned char* dB = smem + buf * Cfg::STAGE_BYTES + BM_ * 128 + wave * (PBI * 1024);
 #pragma unroll
-        for (int j = 0; j < Cfg::PA; ++j)
+        for (int j = 0; j < PAI; ++j)
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(a_row[j] + (uint64_t)kt * BKB), (lds_void*)(dA + j * 1024), 16, 0, 0);
 #pragma unroll
-        for (int j = 0; j < Cfg::PB; ++j)
+        for (int j = 0; j < PBI; ++j)
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(b_row[j] + (uint64_t)kt * BKB), (lds_void*)(dB + j * 1024), 16, 0, 0);
     };
 

@@ -151,16 +151,18 @@ enum GemmVariant {
     V_DMA_256x256_P = 16, V_DMA_128x128_P = 17, V_DMA_256x128W4_P = 18,  // two-stage + hand-counted LDS fragment pipeline
     V_8PH_256x256 = 19, V_8PH_NOPRIO = 20, V_8PH_READFIRST = 21, V_8PH_BOTH = 22,   // phase-interleaved schedule, counted vmcnt (gemm_8phase.h)
     V_FP8_256x256 = 23,                                                 // fp8 e4m3 operands (gemm_fp8.h); selected by GemmArgs::deq_m/deq_n callers only
-    V_ABL_NODMA = 24, V_ABL_NOMFMA = 25,                                // ablations of dma256x256p's K loop (wrong results by design; tools/ablate_loop.py)
+    V_ABL_NODMA = 24, V_ABL_NOMFMA = 25,
+    V_DMA_256x256_H = 26, V_DMA_512x128_H = 27,                         // hand pipeline, DMA issued by one wave per SIMD only                                // ablations of dma256x256p's K loop (wrong results by design; tools/ablate_loop.py)
     V_COUNT
 };
 const char* variant_name(int v) {
     static const char* n[] = {"auto", "generic128", "dma256x256", "dma256x128", "dma128x128", "ring256x256", "ring256x128",
-                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s", "dma512x128", "patch256x256", "patch256x128", "dma256x256p", "dma128x128p", "dma256x128w4p", "gemm8ph", "gemm8ph_np", "gemm8ph_rf", "gemm8ph_nprf", "fp8_256x256", "abl_nodma", "abl_nomfma"};
+                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s", "dma512x128", "patch256x256", "patch256x128", "dma256x256p", "dma128x128p", "dma256x128w4p", "gemm8ph", "gemm8ph_np", "gemm8ph_rf", "gemm8ph_nprf", "fp8_256x256", "abl_nodma", "abl_nomfma", "dma256x256h", "dma512x128h"};
     return v >= 0 && v < V_COUNT ? n[v] : "?";
 }
 unsigned long long* g_dbg_ts = nullptr;
 int g_force_variant = V_AUTO;
+int g_half_issue = 1;              // natinf_set_gemm_half_issue(0): every wave issues its own LDS-DMA pieces (A/B runs)
 int g_pref_512 = 1;                // N <= 128 layers with >= 2 tiles per CU: the 512x128 hand-pipelined tile (natinf_set_gemm_pref512: A/B runs)      // tuning / tests: force one variant for every DMA-eligible launch
 std::string* g_record = nullptr;   // when set, launch_gemm describes the launch instead of issuing it
 
@@ -188,7 +190,8 @@ template <int EPI>
 bool set_lds_epi() {
     return set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2, EPI>) && set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2, EPI>) &&
            set_lds<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3, EPI>) && set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4, EPI>) &&
-           set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4, 2, EPI>);
+           set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4, 2, EPI>) &&
+           set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 6, EPI>) && set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4, 6, EPI>);
 }
 bool set_lds_epi_all() { return set_lds_epi<0>() && set_lds_epi<1>() && set_lds_epi<2>() && set_lds_epi<3>() && set_lds_epi<4>() && set_lds_epi<5>() && set_lds_epi<6>() && set_lds_epi<7>() && set_lds_epi<8>(); }
 
@@ -243,10 +246,10 @@ int choose_variant(const GemmArgs& g) {
     // 128x128 when 256-row tiles would leave CUs idle; 64x128 for the 4x4 level
     const int64_t mt256 = (g.M + 255) / 256, mt128 = (g.M + 127) / 128;
     const int64_t nt128 = (g.N + 127) / 128;
-    if (g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) * g.batch >= NUM_CU) return V_DMA_256x256_P;
+    if (g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) * g.batch >= NUM_CU) return g_half_issue ? V_DMA_256x256_H : V_DMA_256x256_P;
     if (g_pref_512 && g.N <= 128 && K0 + K1 >= 1024 && ((g.M + 511) / 512) * g.batch >= 2 * NUM_CU &&
         (!g.gn_part || (g.taps == 9 && (1 << g.logHW) % 512 == 0)))           // GroupNorm partials: a tile inside one sample
-        return V_DMA_512x128;
+        return g_half_issue ? V_DMA_512x128_H : V_DMA_512x128;
     if (mt256 * nt128 * g.batch >= 2 * NUM_CU) return V_RING_256x128_W4;        // it runs two blocks per CU
     if (mt128 * nt128 * g.batch >= NUM_CU) return V_DMA_128x128_P;
     return V_RING_64x128;
@@ -255,8 +258,8 @@ int choose_variant(const GemmArgs& g) {
 int variant_bm(int v) {
     switch (v) {
         case V_DMA_256x256: case V_DMA_256x128: case V_RING_256x256: case V_RING_256x128: case V_RING_256x128_W4: case V_DMA_256x128_W4:
-        case V_ABL_NODMA: case V_ABL_NOMFMA: case V_DMA_256x256_S: case V_PATCH_256x256: case V_PATCH_256x128: case V_DMA_256x256_P: case V_DMA_256x128W4_P: case V_8PH_256x256: case V_8PH_NOPRIO: case V_8PH_READFIRST: case V_8PH_BOTH: case V_FP8_256x256: return 256;
-        case V_DMA_512x128: return 512;
+        case V_ABL_NODMA: case V_ABL_NOMFMA: case V_DMA_256x256_H: case V_DMA_256x256_S: case V_PATCH_256x256: case V_PATCH_256x128: case V_DMA_256x256_P: case V_DMA_256x128W4_P: case V_8PH_256x256: case V_8PH_NOPRIO: case V_8PH_READFIRST: case V_8PH_BOTH: case V_FP8_256x256: return 256;
+        case V_DMA_512x128: case V_DMA_512x128_H: return 512;
         case V_RING_64x128: return 64;
         default: return 128;
     }
@@ -317,7 +320,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
     const int v = choose_variant(g);
     if (g_record) {
         char line[160];
-        const bool has_packed = v == V_DMA_256x256_P || v == V_DMA_128x128_P || v == V_RING_256x128_W4 || v == V_RING_64x128 || v == V_DMA_512x128;
+        const bool has_packed = v == V_DMA_256x256_P || v == V_DMA_128x128_P || v == V_RING_256x128_W4 || v == V_RING_64x128 || v == V_DMA_512x128 || v == V_DMA_256x256_H || v == V_DMA_512x128_H;
         snprintf(line, sizeof(line), "%d %d %d %d %d %d %s/e%d\n", g.M, g.N, g.taps * g.a0_C, g.a1 ? g.a1_C : 0, g.taps, g.batch, variant_name(v),
                  has_packed ? packed_epi(g, variant_bm(v)) : 0);
         *g_record += line;
@@ -348,6 +351,8 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
         case V_DMA_256x128W4_P: launch_tiles<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>, g, s); break;
         case V_8PH_256x256: launch_tiles<Cfg8ph>(&k_gemm_8ph<0>, g, s); break;
         case V_FP8_256x256: launch_tiles<CfgD256x256>(&k_gemm_fp8<false, 0>, g, s); break;
+        case V_DMA_256x256_H: NATINF_LAUNCH_EPI(CfgD256x256, k_gemm_dma, 2, 4, 8, 4, 6) break;
+        case V_DMA_512x128_H: NATINF_LAUNCH_EPI(CfgD512x128, k_gemm_dma, 4, 2, 8, 4, 6) break;
         case V_ABL_NODMA: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 3, 1>, g, s); break;
         case V_ABL_NOMFMA: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 4, 1>, g, s); break;
         case V_8PH_NOPRIO: launch_tiles<Cfg8ph>(&k_gemm_8ph<1>, g, s); break;
@@ -1039,6 +1044,7 @@ int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_sc
 int natinf_debug_timestamps(void* dev_buf16) { g_dbg_ts = reinterpret_cast<unsigned long long*>(dev_buf16); return NATINF_OK; }
 
 int natinf_set_gemm_raster(int rows) { g_raster_g = rows; return NATINF_OK; }
+int natinf_set_gemm_half_issue(int on) { g_half_issue = on != 0; return NATINF_OK; }
 int natinf_set_gemm_pref512(int on) { g_pref_512 = on != 0; return NATINF_OK; }
 int natinf_set_gemm_epilogue(int fp32_slab) { g_epi_fp32_slab = fp32_slab != 0; return NATINF_OK; }
 
