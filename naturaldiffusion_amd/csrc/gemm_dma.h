@@ -592,6 +592,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
     constexpr int PAI = HALF ? 2 * Cfg::PA : Cfg::PA, PBI = HALF ? 2 * Cfg::PB : Cfg::PB;
     const bool issuer = !HALF || wave < Cfg::NW / 2;
     uint64_t a_row[PAI], a_delta[PAI], b_row[PBI];
+    // the first K-tile's pieces are requested as soon as each address exists (kt = 0: tap (-1, -1) of chunk 0, or column 0)
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int64_t ashift0 = g.taps == 9 ? (int64_t)(-Wp - 1) * g.a0_ld * 2 : 0;
 #pragma unroll
     for (int j = 0; j < PAI; ++j) {
         const int r = (wave * PAI + j) * 8 + (lane >> 3);
@@ -606,42 +609,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
         }
         a_row[j] = reinterpret_cast<uint64_t>(a0 + off0 + lchunk);
         a_delta[j] = a1 ? reinterpret_cast<uint64_t>(a1 + (int64_t)m * g.a1_ld + lchunk) - a_row[j] : 0;
+        if (issuer)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(a_row[j] + (uint64_t)ashift0),
+                                             (lds_void*)(smem + wave * (PAI * 1024) + j * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < PBI; ++j) {
         const int r = (wave * PBI + j) * 8 + (lane >> 3);
         const int lchunk = ((lane & 7) ^ ((r >> 1) & 7)) << 3;
         b_row[j] = reinterpret_cast<uint64_t>(bp + (int64_t)min(n0 + r, g.N - 1) * g.b_ld + lchunk);
+        if (issuer)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(b_row[j]), (lds_void*)(smem + BM_ * BK * 2 + wave * (PBI * 1024) + j * 1024), 16, 0, 0);
     }
-
-    typedef __attribute__((address_space(3))) void lds_void;
-    auto issue_tile = [&](int kt, int buf) __attribute__((always_inline)) {
-        if (!issuer) return;
-        unsigned char* dA = smem + buf * Cfg::STAGE_BYTES + wave * (PAI * 1024);
-        unsigned char* dB = smem + buf * Cfg::STAGE_BYTES + BM_ * BK * 2 + wave * (PBI * 1024);
-        const bool seg0 = kt < nk0;
-        int64_t ashift;
-        int kk;
-        if (seg0) {
-            const int kbase = kt * BK;
-            int tap = 0, c0 = kbase;
-            if (g.taps == 9) { const int cch = kt / 9; tap = kt - 9 * cch; c0 = cch * BK; }   // chunk outer, tap inner
-            const int dy = g.taps == 9 ? tap / 3 - 1 : 0, dx = g.taps == 9 ? tap % 3 - 1 : 0;
-            ashift = ((int64_t)(dy * Wp + dx) * g.a0_ld + c0) * 2; kk = kbase;
-        } else {
-            ashift = (int64_t)(kt - nk0) * BK * 2; kk = K0 + (kt - nk0) * BK;
-        }
-#pragma unroll
-        for (int j = 0; j < PAI; ++j) {
-            const uint64_t pa = a_row[j] + (seg0 ? 0 : a_delta[j]) + (uint64_t)ashift;
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pa), (lds_void*)(dA + j * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < PBI; ++j) {
-            const uint64_t pb = b_row[j] + (uint64_t)kk * 2;
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pb), (lds_void*)(dB + j * 1024), 16, 0, 0);
-        }
-    };
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -649,8 +628,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    issue_tile(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // K-tile 0 (requested in the address loops above)
     __syncthreads();
     NATINF_TS(1);
 
