@@ -52,6 +52,8 @@ CASES = [   # (variant, M, N, K, log2 rows per sample, fused terms, activation, 
     (V_RING64, 333, 1536, 128, 30, ("bias_n", "gate", "resid_f32"), 0, True),    # EPI 7, context-stream shape
     (V_DMA128P, 520, 328, 128, 8, ("bias_m",), 0, False),                        # EPI 8 (row bias)
     (V_DMA128P, 512, 256, 128, 6, ("bias_n", "rowvec"), 0, False),               # two samples per tile -> general epilogue
+    (V_DMA256P, 2200, 2568, 128, 30, ("bias_n",), 0, False),                     # 9 x 11 tiles: grouped rasterisation, partial last group
+    (V_DMA128P, 2100, 1160, 64, 30, ("bias_n", "gate", "resid_f32"), 0, True),   # 17 x 10 tiles of 128: grouped rasterisation
 ]
 
 
