@@ -31,7 +31,8 @@
 // two waves of a SIMD, so moving work between the pipes buys nothing.  `-fno-slp-vectorize` (the compiler packs the row sums
 // and the rescale into v_pk_add/mul_f32) is +-1 %.  What is left is fewer issue cycles per score: 32x32x16 MFMAs (half the
 // MFMA issue cost).  Row sums on the matrix pipe (an all-ones A operand in front of P^T: 8 MFMAs instead of 64 adds per tile and
-// lane, no final cross-lane reduction) were built too: +-1 %, not kept.
+// lane, no final cross-lane reduction) were built too: +-1 %, not kept.  The next tile's DMA requests issued behind the S^T MFMAs
+// instead of in front of them: 3 % slower.
 // Reference: diffusers JointAttnProcessor2_0 as called by pipe.transformer (src/SD3NaturalInference.py:210-213).
 #pragma once
 #include "ncsnpp_kernels.h"
