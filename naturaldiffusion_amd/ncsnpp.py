@@ -16,7 +16,6 @@ from . import _lib
 from ._lib import lib, check, ptr, stream_ptr
 
 KEEP_ACTIVATIONS = 1
-TEMB = 512
 
 
 def module_table(handle=None) -> List[Tuple[int, str, int, int, int, int, int, int]]:
@@ -39,11 +38,16 @@ def module_table(handle=None) -> List[Tuple[int, str, int, int, int, int, int, i
     return rows
 
 
-def param_layout() -> List[Tuple[str, Tuple[int, ...]]]:
+def param_layout(nf: int = 128) -> List[Tuple[str, Tuple[int, ...]]]:
     """Flat parameter order the engine expects: ``all_modules`` order, leaves in registration order
-    (= ``model.parameters()`` order = EMA ``shadow_params`` order, ema.py:28-29)."""
+    (= ``model.parameters()`` order = EMA ``shadow_params`` order, ema.py:28-29).  ``nf`` is ``config.model.nf``
+    (configs/vp/cifar10_ddpmpp_continuous.py:47): the engine is built for 128; other widths only serve the host-side
+    loaders (checkpoint-format tests on a small reference-written pickle)."""
     out: List[Tuple[str, Tuple[int, ...]]] = []
+    sc = lambda c: c if c == 3 else c * nf // 128           # image channels stay 3; every feature width is a multiple of nf
+    TEMB = 4 * nf
     for idx, kind, cin, cout, up, down, res, _ in module_table():
+        cin, cout = sc(cin), sc(cout)
         p = f"all_modules.{idx}."
         if kind == "lin":
             out += [(p + "weight", (cout, cin)), (p + "bias", (cout,))]
@@ -83,9 +87,9 @@ def flatten_state_dict(sd: Dict[str, torch.Tensor]) -> torch.Tensor:
     return torch.cat(parts)
 
 
-def flatten_ema(shadow_params: List[torch.Tensor]) -> torch.Tensor:
+def flatten_ema(shadow_params: List[torch.Tensor], nf: int = 128) -> torch.Tensor:
     """EMA list of the score_sde checkpoint (``state['ema']['shadow_params']``, ema.py:91-97)."""
-    layout = param_layout()
+    layout = param_layout(nf)
     if len(shadow_params) != len(layout):
         raise ValueError(f"EMA list has {len(shadow_params)} tensors, the model has {len(layout)} parameters")
     parts = []
@@ -96,11 +100,20 @@ def flatten_ema(shadow_params: List[torch.Tensor]) -> torch.Tensor:
     return torch.cat(parts)
 
 
-def load_score_sde_checkpoint(path: str) -> torch.Tensor:
+def load_score_sde_checkpoint(path: str, nf: int = 128) -> torch.Tensor:
     """``restore_checkpoint`` + ``ema.copy_to`` (deps/score_sde_pytorch/utils.py:7-19, ema.py:53-64):
-    the weights the reference samples with are the EMA shadow parameters."""
+    the weights the reference samples with are the EMA shadow parameters.  The pickle's ``model`` entry (DataParallel
+    ``module.`` keys plus the ``sigmas`` buffer) is only used to cross-check the names and shapes of the EMA list."""
     state = torch.load(path, map_location="cpu", weights_only=False)
-    return flatten_ema(list(state["ema"]["shadow_params"]))
+    for key in ("model", "ema", "step"):
+        if key not in state:
+            raise KeyError(f"{path}: not a score_sde checkpoint (no '{key}' entry; utils.py:22-29)")
+    shadow = list(state["ema"]["shadow_params"])
+    model_sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state["model"].items()}
+    for (name, shape), t in zip(param_layout(nf), shadow):
+        if name in model_sd and tuple(model_sd[name].shape) != tuple(t.shape):
+            raise ValueError(f"{path}: EMA entry for {name} has shape {tuple(t.shape)}, the model's is {tuple(model_sd[name].shape)}")
+    return flatten_ema(shadow, nf)
 
 
 class NCSNppEngine:

@@ -15,6 +15,10 @@ Groups
   validate  K3/K5  weighted_sum, ddpm/ddim originals vs natural_inference (ValidateNaturalInference.py)
   sd3       K3/K6  weighted_sum, sd_natural_inference_tx, sd_euler (SD3NaturalInference.py)
   ncsnpp    K7  NCSNpp forward (reference nn.Module) on the oracle's synthetic weights
+  k5        K5  the vendored classical solver itself (deps/dpm_solver_pytorch.py:906 singlestep updates) next to NI with
+                the shipped dpmsolverpp2s_018 / dpmsolver2s_018 / dpmsolver3s_018 matrices, same noise, same denoiser
+  ckpt      B-iii  a score_sde checkpoint written through the reference's own ExponentialMovingAverage.state_dict()
+                and DataParallel state_dict() (utils.py:22-29, ema.py:91-97): the file and what restore + ema.copy_to give
 """
 import hashlib
 import json
@@ -32,9 +36,11 @@ sys.path.insert(0, str(REPO))
 
 # --------------------------------------------------------------------------- #
 def _stub(name, **attrs):
+    import importlib.machinery
     m = types.ModuleType(name)
     m.__dict__.update(attrs)
     m.__path__ = []
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)      # torch._dynamo walks sys.modules with find_spec
     sys.modules[name] = m
     return m
 
@@ -434,7 +440,108 @@ def group_dit():
     print("dit:", {k: getattr(v, "shape", v) for k, v in out.items() if k.endswith(("out", "stats", "nparam"))})
 
 
-GROUPS = dict(dit=group_dit, loaders=group_loaders, cifar=group_cifar, validate=group_validate, sd3=group_sd3, ncsnpp=group_ncsnpp)
+def group_k5():
+    """DPM_Solver.singlestep_dpm_solver_update over linspace(1, 1e-3, K+1) == CIFAR10-form NI with the shipped
+    matrix of the same sampler.  ``orig`` = the reference's solver class, ``ni`` = the reference's data_fn / weighted_sum
+    loop (src/CIFAR10NaturalInference.py:292-304); both on the analytic denoiser, fp32 model I/O."""
+    import numpy as np
+    import torch
+    _stub_cifar_env()
+    import CIFAR10NaturalInference as R
+    from oracle import ni_oracle as O
+    model_fn = O.analytic_vp_model()
+    sde = R.VPSDE(beta_min=0.1, beta_max=20.0, N=1000)
+    score_fn = R.mutils.get_score_fn(sde, model_fn_module(model_fn), train=False, continuous=True)
+    noise_fn = lambda x, t: model_fn(x, t * 999)               # the reference's get_noise_fn contract: eps-hat at continuous t
+    ns = R.NoiseScheduleVP('linear', continuous_beta_0=sde.beta_0, continuous_beta_1=sde.beta_1)
+    out = {}
+    g = torch.Generator().manual_seed(4242)
+    cases = (("dpmsolverpp/dpmsolverpp2s_018", "dpmsolver++", 2, 9), ("dpmsolver/dpmsolver2s_018", "dpmsolver", 2, 9),
+             ("dpmsolver/dpmsolver3s_018", "dpmsolver", 3, 6))
+    for rel, alg, order, K in cases:
+        key = rel.split("/")[1]
+        C, B, node = np.load(REF / f"results/{rel}.npz").values()
+        noise = torch.randn(2, 3, 32, 32, generator=g)
+        solver = R.DPM_Solver(noise_fn, ns, algorithm_type=alg)
+        grid = torch.linspace(1.0, 1e-3, K + 1)
+        x = noise
+        with torch.no_grad():
+            for i in range(K):
+                kw = dict(r1=0.5) if order == 2 else dict(r1=1.0 / 3.0, r2=2.0 / 3.0)
+                x = solver.singlestep_dpm_solver_update(x, grid[i:i + 1], grid[i + 1:i + 2], order, solver_type='dpmsolver', **kw)
+        ts = node[:, 0]
+        seq_x0, y = [], noise
+        for kk in range(ts.shape[0] - 1):
+            seq_x0.append(R.data_fn(score_fn, y, ts[kk], node[kk, 1], node[kk, 2], "cpu"))
+            y = R.weighted_sum(C[kk], seq_x0) + B[kk, 0] * noise
+        out[f"{key}_noise"] = noise.numpy()
+        out[f"{key}_stds"] = np.array([float(sde.marginal_prob(torch.zeros(1), torch.ones(1) * t)[1][0]) for t in node[:-1, 0]], np.float32)
+        out[f"{key}_orig"] = x.numpy()
+        out[f"{key}_ni"] = y.numpy()
+        print(f"k5: {key}: |orig - ni| max {np.abs(x.numpy() - y.numpy()).max():.3e}  (|orig| max {np.abs(x.numpy()).max():.3f})")
+    np.savez_compressed(HERE / "k5_classical.npz", **out)
+
+
+def group_ckpt():
+    """A score_sde checkpoint made the way the reference's training loop makes one (utils.save_checkpoint, utils.py:22-29):
+    {'optimizer', 'model' (DataParallel state_dict, 'module.' keys), 'ema' (ExponentialMovingAverage.state_dict(),
+    ema.py:91-97), 'step'}, at width nf = 8 so that the reference-written pickle is a 2 MB fixture (the full model is
+    61.8 M floats x 2).  The EMA shadow parameters differ from the model's -- they are what sampling uses.  Committed:
+      checkpoint_nf8.pth        the pickle, written by the reference's classes
+      ckpt_nf8_expected.npz     cat(p.flatten() for p in model.parameters()) after the reference's restore_checkpoint
+                                (utils.py:7-19) + ema.copy_to (ema.py:53-64)
+      ckpt_layout.json          names and shapes of net.named_parameters() at the real width nf = 128 (564 tensors)"""
+    import numpy as np
+    import torch
+    _stub_cifar_env()
+    import CIFAR10NaturalInference as R
+    from models.ema import ExponentialMovingAverage
+    torch.manual_seed(31)
+    config = R.configs.get_config()
+    config.device = torch.device("cpu")
+    full = R.mutils.create_model(config).module
+    layout = [(n, list(p.shape)) for n, p in full.named_parameters()]
+    (HERE / "ckpt_layout.json").write_text(json.dumps(dict(names=[n for n, _ in layout], shapes=[s for _, s in layout],
+                                                              n_param=int(sum(int(np.prod(s)) for _, s in layout))), indent=0))
+    del full
+    config.model.nf = 8
+    model = R.mutils.create_model(config)                                    # DataParallel(NCSNpp)
+    ema = ExponentialMovingAverage(model.parameters(), decay=config.model.ema_rate)
+    optimizer = torch.optim.Adam(model.parameters(), lr=2e-4)
+    with torch.no_grad():                                                    # stand-in for optimiser steps + EMA updates
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    ema.update(model.parameters())
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    state = dict(optimizer=optimizer, model=model, ema=ema, step=8)
+    # utils.save_checkpoint's body (utils.py:22-29; the module itself imports tensorflow at the top)
+    saved_state = {'optimizer': state['optimizer'].state_dict(), 'model': state['model'].state_dict(),
+                   'ema': state['ema'].state_dict(), 'step': state['step']}
+    torch.save(saved_state, HERE / "checkpoint_nf8.pth")
+    # restore_checkpoint's body (utils.py:14-19) + ema.copy_to on a fresh model, as src/CIFAR10NaturalInference.py:258-265 does
+    model2 = R.mutils.create_model(config)
+    ema2 = ExponentialMovingAverage(model2.parameters(), decay=config.model.ema_rate)
+    opt2 = torch.optim.Adam(model2.parameters(), lr=2e-4)
+    st = dict(optimizer=opt2, model=model2, ema=ema2, step=0)
+    loaded_state = torch.load(HERE / "checkpoint_nf8.pth", map_location="cpu", weights_only=False)
+    st['optimizer'].load_state_dict(loaded_state['optimizer'])
+    st['model'].load_state_dict(loaded_state['model'], strict=False)
+    st['ema'].load_state_dict(loaded_state['ema'])
+    st['step'] = loaded_state['step']
+    ema2.copy_to(model2.parameters())
+    flat = torch.cat([p.detach().flatten() for p in model2.parameters()]).numpy()
+    raw = torch.cat([p.detach().flatten() for p in model.parameters()]).numpy()
+    assert np.abs(flat - raw).max() > 1e-3                                   # EMA != raw weights: the test can tell them apart
+    np.savez_compressed(HERE / "ckpt_nf8_expected.npz", flat=flat, names=np.array([n for n, _ in model2.module.named_parameters()]))
+    from naturaldiffusion_amd.ncsnpp import load_score_sde_checkpoint       # the product loader must agree, here and now
+    got = load_score_sde_checkpoint(str(HERE / "checkpoint_nf8.pth"), nf=8).numpy()
+    assert np.array_equal(got, flat), "load_score_sde_checkpoint differs from restore_checkpoint + ema.copy_to"
+    print("ckpt:", len(layout), "parameters at nf=128;", flat.size, "floats at nf=8; loader agrees")
+
+
+GROUPS = dict(k5=group_k5, ckpt=group_ckpt, dit=group_dit, loaders=group_loaders, cifar=group_cifar, validate=group_validate, sd3=group_sd3, ncsnpp=group_ncsnpp)
 
 if __name__ == "__main__":
     assert REF.exists(), "the reference is only mounted in the build container"

@@ -164,7 +164,8 @@ def test_fp8_gemm_matches_the_dequantised_product():
     """k_gemm_fp8 on its own: same quantised operands, fp32 reference -> only the bf16 output rounding remains."""
     from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
     g = torch.Generator().manual_seed(3)
-    for (M, N, K) in ((512, 256, 256), (1000, 520, 384), (300, 264, 128)):
+    # K = 1536 / 6144: the SD3-medium projections (q|k|v, fc1 / fc2): 12 and 48 K-tiles through the two-stage DMA pipeline
+    for (M, N, K) in ((512, 256, 256), (1000, 520, 384), (300, 264, 128), (768, 1536, 1536), (520, 1536, 6144)):
         a = (torch.randn(M, K, generator=g) * (torch.rand(M, 1, generator=g) * 3 + 0.1)).cuda()
         b = (torch.randn(N, K, generator=g) * 0.05).cuda()
         bias = torch.randn(N, generator=g).cuda()
@@ -211,7 +212,7 @@ def test_fp8_gemm_with_mx_block_scales_in_and_out():
     mode of the epilogue (what fc1 hands to fc2 in the fp8 engine)."""
     from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
     g = torch.Generator().manual_seed(5)
-    for (M, N, K) in ((512, 256, 256), (700, 640, 384)):
+    for (M, N, K) in ((512, 256, 256), (700, 640, 384), (512, 1536, 6144)):
         a = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K // 32, 1, generator=g)).expand(M, K // 32, 32).reshape(M, K)).cuda()
         b = (torch.randn(N, K, generator=g) * 0.05).cuda()
         qa, ma = _mx_quant(a)
@@ -254,3 +255,34 @@ def test_fp8_engine_close_to_bf16_engine_and_oracle():
     assert e16 <= TOL and e8 <= 8e-2, (e16, e8)
     with pytest.raises(ValueError):
         MMDiTEngine(flat, max_batch=1, grid=8, ctx_tokens=13, fp8=True, layers=3, heads=3, joint_dim=64, pooled_dim=32)
+
+
+import functools
+
+
+@functools.lru_cache(maxsize=1)
+def _sd3_width_case():
+    from oracle import mmdit_oracle as M
+    cfg = dict(layers=2, heads=24, joint_dim=4096, pooled_dim=2048)
+    P = M.make_params(seed=21, pos_max=64, pos_base=64, **cfg)
+    g = torch.Generator().manual_seed(9)
+    x, t = torch.randn(1, 16, 128, 128, generator=g), torch.tensor([640.0])
+    e, p = torch.randn(1, 333, 4096, generator=g), torch.randn(1, 2048, generator=g)
+    return cfg, P, (x, t, e, p), M.forward(P, x, t, e, p)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_sd3_medium_width_joint_block_matches_oracle(fp8):
+    """BASELINE configs 4 / 5 at the width they are benchmarked on: D = 1536, 24 heads x 64, 64x64 image tokens + 333
+    text tokens (4,429 -> padded 4,480 keys), joint_dim 4096, pooled 2048 -- two blocks (one full JointTransformerBlock with
+    both MLPs, one context_pre_only), one sequence, so that the CPU oracle (~0.8 TFLOP, 1.9 GB of scores) finishes in well
+    under a minute.  Exercises what the narrow configurations cannot: 12- and 48-K-tile GEMM loops (bf16 and fp8), the
+    residual-stream / packed / fp8+MX epilogues at N = 1536 / 6144, 24-head flash attention over the joint buffer."""
+    from naturaldiffusion_amd.mmdit import MMDiTEngine, flatten_state_dict
+    cfg, P, (x, t, e, p), ref = _sd3_width_case()
+    eng = MMDiTEngine(flatten_state_dict(P, 64, **cfg), max_batch=1, grid=64, ctx_tokens=333, fp8=fp8, **cfg)
+    out = eng.forward(x.cuda(), t.cuda(), e.cuda(), p.cuda()).cpu()
+    assert torch.isfinite(out).all()
+    err = ((out - ref).abs().max() / ref.abs().max()).item()
+    print(f"SD3-medium-width block, fp8={fp8}: max rel err {err:.3e}")
+    assert err <= (8e-2 if fp8 else TOL), err

@@ -115,7 +115,8 @@ def test_every_gemm_variant_gives_the_same_network(dev, flat, golden_dir):
     eng = NCSNppEngine(flat, max_batch=2, device=dev)
     outs = {}
     try:
-        for v in (0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 16, 17, 18, 19):      # 13 / 16 / 17: the automatic choices at B = 512 (packed epilogues)
+        # 26 / 27 (dma256x256h / dma512x128h) are the automatic choices of the big launches at B = 512, 9 / 17 / 8 of the rest
+        for v in (0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 16, 17, 18, 19, 26, 27):
             assert lib.natinf_set_gemm_variant(v) == 0
             outs[v] = eng(x, labels).clone()
             torch.cuda.synchronize()
@@ -125,6 +126,49 @@ def test_every_gemm_variant_gives_the_same_network(dev, flat, golden_dir):
     for v, y in outs.items():
         assert _rel(y.cpu(), ref) <= TOL, (v, _rel(y.cpu(), ref))
         assert torch.equal(y, outs[0]) or _rel(y.cpu(), outs[0].cpu()) < 2e-2
+
+
+def _describe_gemms(eng, B):
+    import ctypes as C
+    from naturaldiffusion_amd._lib import lib
+    buf = C.create_string_buffer(1 << 16)
+    n = lib.natinf_ncsnpp_describe_gemms(eng._h, B, buf, len(buf))
+    assert n > 0
+    return [ln.split() for ln in buf.value.decode().strip().split("\n")]
+
+
+def test_bench_batch_512_runs_the_benchmarked_kernels_and_matches_golden(dev, flat, golden_dir):
+    """BASELINE config 2's batch: at B = 512 the dispatcher picks the tile variants bench.py is timed on (they are
+    never chosen at B <= 7).  The two golden samples sit in slots 0-1 AND 510-511 of a batch of noise: both pairs must
+    match the reference module's output (fixture y) within TOL and be bit-identical to each other (a sample's result
+    depends neither on its slot nor on its neighbours)."""
+    from naturaldiffusion_amd.ncsnpp import NCSNppEngine
+    fx = np.load(golden_dir / "ncsnpp_forward.npz")
+    gx, gl = torch.from_numpy(fx["x"]), torch.from_numpy(fx["labels"])
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(512, 3, 32, 32, generator=g)
+    labels = torch.rand(512, generator=g) * 999
+    for s in (0, 510):
+        x[s:s + 2] = gx
+        labels[s:s + 2] = gl
+    eng = NCSNppEngine(flat, max_batch=512, device=dev)
+    chosen = {}
+    for f in _describe_gemms(eng, 512):
+        chosen.setdefault(f[6].split("/")[0], []).append((int(f[0]), int(f[1])))
+    # the two families that carry ~half of the bench's device time
+    assert len(chosen.get("dma256x256h", [])) >= 15, chosen.keys()
+    assert len(chosen.get("dma512x128h", [])) >= 15, chosen.keys()
+    y = eng(x.to(dev), labels.to(dev))
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    ref = torch.from_numpy(fx["y"])
+    head, tail = y[0:2].cpu(), y[510:512].cpu()
+    assert _rel(head, ref) <= TOL, _rel(head, ref)
+    assert _rel(tail, ref) <= TOL, _rel(tail, ref)
+    assert torch.equal(head, tail)
+    # and the same samples through the B = 2 plan (other tile variants) agree to bf16 rounding noise
+    y2 = NCSNppEngine(flat, max_batch=2, device=dev)(gx.to(dev), gl.to(dev)).cpu()
+    assert _rel(head, y2) < 2e-2
 
 
 def test_workspace_too_small_is_an_error(dev, flat):
