@@ -60,8 +60,9 @@ int natinf_mmdit_forward(natinf_mmdit_t h, const float* latents, const float* ti
 
 /* The attention kernel on its own: o = softmax(q k^T * scale) v per (sequence, head), head_dim 64, bf16.
  * q, k: [B][Tp][ld_qk] (head h at columns 64h..64h+63; per-sequence stride qk_bs elements); vT: [B][64*H][Tp] (V
- * TRANSPOSED: keys contiguous; must be finite at keys >= T); o: [B][Tp][ld_o].  Tp % 128 == 0, 0 < T <= Tp; keys >= T
- * are ignored, query rows >= T produce unspecified values. */
+ * TRANSPOSED: keys contiguous; must be finite at keys >= T); o: [B][Tp][ld_o].  Tp % 128 == 0, Tp - 128 < T <= Tp (the padding
+ * must fit inside the last 128-key tile, the only one the kernel masks; anything else is NATINF_EINVAL); keys >= T are ignored,
+ * query rows >= T produce unspecified values. */
 int natinf_attention_hd64_bf16(const void* q, const void* k, int ld_qk, int64_t qk_bs, const void* vT, void* o, int ld_o,
                                int64_t o_bs, int B, int H, int Tp, int T, float scale, natinf_stream_t stream);
 

@@ -191,8 +191,9 @@ def load_vae_decoder(path, max_batch=8):
     return _engine_cache[key]
 
 
-def save_image_grid(images: torch.Tensor, path, nrow: int = 4) -> None:
-    """``torchvision.utils.save_image(samples, path, nrow=4, normalize=True, value_range=(-1, 1))`` (reference :236) without
+def save_image_grid(images: torch.Tensor, path, nrow: int = 8) -> None:
+    """``torchvision.utils.save_image(samples, path, nrow=8, normalize=True, value_range=(-1, 1))`` (reference :236; the 8
+    validation images come out as one row of 8) without
     torchvision: clamp to [-1, 1], map to [0, 255], tile with 2-pixel padding, write with PIL."""
     from PIL import Image
     x = ((images.detach().float().cpu().clamp(-1, 1) + 1) * 0.5)
@@ -211,7 +212,7 @@ def _finish(input_z, name):
     last_latents = input_z
     if decoder_factory is not None:
         decoder_factory()(input_z / 0.18215, make_path(root_path / ("results/validation/" + name)))
-    elif vae_path is not None:                               # reference :231-236: decode the latents, write the 2x4 grid
+    elif vae_path is not None:                               # reference :231-236: decode the latents, write the 1x8 image row
         images = load_vae_decoder(vae_path)(input_z / 0.18215)
         save_image_grid(images, make_path(root_path / ("results/validation/" + name)))
     return input_z

@@ -45,17 +45,20 @@ __global__ __launch_bounds__(512) void k_attn_fused(const bf16* __restrict__ qk,
     const bf16* qbase = qk + (int64_t)b * T * qk_ld + hh * hd;
     const bf16* kbase = qbase + k_off;
     const bf16* vbase = vT + ((int64_t)b * H + hh) * hd * T;
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    // (zero fill by assignment, not `cond ? *p : zero4`: hipcc turns that select of two lvalues into a select of ADDRESSES and
+    // parks the zero vector in scratch memory)
 
     for (int idx = tid; idx < T * NQK * 4; idx += 512) {                       // K rows, zero-padded to NQK*32 channels
         const int row = idx / (NQK * 4), ch = idx - row * (NQK * 4);
-        const uint4 v = ch * 8 < hd ? *reinterpret_cast<const uint4*>(kbase + (int64_t)row * qk_ld + ch * 8) : zero4;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (ch * 8 < hd) v = *reinterpret_cast<const uint4*>(kbase + (int64_t)row * qk_ld + ch * 8);
         *reinterpret_cast<uint4*>(sK + row * KSTR + ch * 16) = v;
     }
     auto load_vT = [&]() __attribute__((always_inline)) {
         for (int idx = tid; idx < ND * 16 * 32; idx += 512) {                      // V^T rows, keys permuted inside 32-key chunks
             const int d = idx >> 5, m8 = idx & 31, c = m8 >> 2, m = m8 & 3;
-            const uint4 v = d < hd ? *reinterpret_cast<const uint4*>(vbase + (int64_t)d * T + m8 * 8) : zero4;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (d < hd) v = *reinterpret_cast<const uint4*>(vbase + (int64_t)d * T + m8 * 8);
             const int qa = (m & 1) * 2, jo = (m >> 1) * 4;
             unsigned char* row = sV + d * VSTR + (32 * c + jo) * 2;
             *reinterpret_cast<uint2*>(row + 8 * qa * 2) = make_uint2(v.x, v.y);
@@ -69,7 +72,8 @@ __global__ __launch_bounds__(512) void k_attn_fused(const bf16* __restrict__ qk,
 #pragma unroll
         for (int c = 0; c < NQK; ++c) {
             const int dcol = 32 * c + 8 * q;
-            const uint4 v = dcol < hd ? *reinterpret_cast<const uint4*>(qbase + (int64_t)(wave * 32 + 16 * g + r) * qk_ld + dcol) : zero4;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (dcol < hd) v = *reinterpret_cast<const uint4*>(qbase + (int64_t)(wave * 32 + 16 * g + r) * qk_ld + dcol);
             qf[g][c] = __builtin_bit_cast(bf16x8, v);
         }
     __syncthreads();
@@ -112,7 +116,9 @@ __global__ __launch_bounds__(512) void k_attn_fused(const bf16* __restrict__ qk,
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { pf[g][c][i] = (bf16)acc[g][2 * c][i]; pf[g][c][4 + i] = (bf16)acc[g][2 * c + 1][i]; }
+            for (int i = 0; i < 4; ++i) {      // normalised here: nothing but pf has to survive the second phase (no spills at 256 VGPRs)
+                pf[g][c][i] = (bf16)(acc[g][2 * c][i] * inv[g]); pf[g][c][4 + i] = (bf16)(acc[g][2 * c + 1][i] * inv[g]);
+            }
     if (TWO_PHASE) {
         __syncthreads();                             // every wave is done with K
         load_vT();
@@ -130,17 +136,22 @@ __global__ __launch_bounds__(512) void k_attn_fused(const bf16* __restrict__ qk,
             oacc[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[1][c], oacc[1][dt], 0, 0, 0);
         }
     }
+    // lane coordinates recomputed from the hardware lane id: hipcc otherwise keeps r and q of the prologue alive through both
+    // MFMA phases -- in scratch memory, at 256 VGPRs
+    int lane_e;                                      // (asm: the builtin would be merged with the lane id __shfl_xor computed, and spilled)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int re = lane_e & 15, qe = lane_e >> 4;
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt) {
-            const int d0 = 16 * dt + 4 * q;
+            const int d0 = 16 * dt + 4 * qe;
             if (d0 < hd) {
                 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                 bf16x4 w;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) w[i] = (bf16)(oacc[g][dt][i] * inv[g]);
-                *reinterpret_cast<bf16x4*>(o + ((int64_t)b * T + wave * 32 + 16 * g + r) * o_ld + hh * hd + d0) = w;
+                for (int i = 0; i < 4; ++i) w[i] = (bf16)oacc[g][dt][i];
+                *reinterpret_cast<bf16x4*>(o + ((int64_t)b * T + wave * 32 + 16 * g + re) * o_ld + hh * hd + d0) = w;
             }
         }
 }

@@ -207,7 +207,10 @@ bool configure_gemm_kernels() {
          set_lds<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>) && set_lds<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>) &&
          set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2>) && set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2>) &&
          set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>) &&
-         set_lds_epi_all() && set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 3, 1>) && set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 4, 1>) &&
+         set_lds_epi_all() &&
+#ifdef NATINF_DEV
+         set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 3, 1>) && set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 4, 1>) &&
+#endif
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 0>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 0>) &&
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 1>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 1>) &&
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 2>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 2>) &&
@@ -237,6 +240,9 @@ int choose_variant(const GemmArgs& g) {
         if (patch_ok && (g_force_variant == V_PATCH_256x128 || g.logW >= 4)) return g_force_variant;
     } else if (g_force_variant >= V_8PH_256x256 && g_force_variant <= V_8PH_BOTH) {
         if (eligible_8ph(g)) return g_force_variant;
+#ifndef NATINF_DEV
+    } else if (g_force_variant == V_ABL_NODMA || g_force_variant == V_ABL_NOMFMA) {      // ablation kernels: development builds only
+#endif
     } else if (g_force_variant > V_GENERIC) {
         // a forced tile must keep GroupNorm partial tiles inside one sample (e.g. 512-row tiles on the 16x16 level do not)
         if (!g.gn_part || (g.taps == 9 && (1 << g.logHW) % variant_bm(g_force_variant) == 0)) return g_force_variant;
@@ -353,8 +359,10 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
         case V_FP8_256x256: launch_tiles<CfgD256x256>(&k_gemm_fp8<false, 0>, g, s); break;
         case V_DMA_256x256_H: NATINF_LAUNCH_EPI(CfgD256x256, k_gemm_dma, 2, 4, 8, 4, 6) break;
         case V_DMA_512x128_H: NATINF_LAUNCH_EPI(CfgD512x128, k_gemm_dma, 4, 2, 8, 4, 6) break;
+#ifdef NATINF_DEV
         case V_ABL_NODMA: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 3, 1>, g, s); break;
         case V_ABL_NOMFMA: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 4, 1>, g, s); break;
+#endif
         case V_8PH_NOPRIO: launch_tiles<Cfg8ph>(&k_gemm_8ph<1>, g, s); break;
         case V_8PH_READFIRST: launch_tiles<Cfg8ph>(&k_gemm_8ph<2>, g, s); break;
         case V_8PH_BOTH: launch_tiles<Cfg8ph>(&k_gemm_8ph<3>, g, s); break;
@@ -982,6 +990,9 @@ int natinf_debug_gemm(int variant, int M, int N, int K0, int K1, int taps, int l
                       const void* a0, const void* a1, const void* b, const float* bias_n, void* c, int c_f32, float scale,
                       int iters, natinf_stream_t stream) {
     if (variant < 0 || variant >= V_COUNT || !a0 || !b || !c || M <= 0 || N <= 0 || iters <= 0 || (taps != 1 && taps != 9)) return NATINF_EINVAL;
+#ifndef NATINF_DEV
+    if (c_f32 >= 2 || variant == V_ABL_NODMA || variant == V_ABL_NOMFMA) return NATINF_ESTATE;      // timing experiments: -DNATINF_DEV builds
+#endif
     static bool configured = false;
     if (!configured) { if (!configure_gemm_kernels()) return NATINF_ENODEV; configured = true; }
     GemmArgs g = gemm_defaults();
@@ -1041,7 +1052,13 @@ int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_sc
 }
 
 // timing experiments: device buffer of 16 uint64 s_memtime stamps written by block 0 / thread 0 of natinf_debug_gemm launches
-int natinf_debug_timestamps(void* dev_buf16) { g_dbg_ts = reinterpret_cast<unsigned long long*>(dev_buf16); return NATINF_OK; }
+int natinf_debug_timestamps(void* dev_buf16) {
+#ifdef NATINF_DEV
+    g_dbg_ts = reinterpret_cast<unsigned long long*>(dev_buf16); return NATINF_OK;
+#else
+    (void)dev_buf16; return NATINF_ESTATE;             // the shipped kernels carry no stamps (make EXTRA=-DNATINF_DEV)
+#endif
+}
 
 int natinf_set_gemm_raster(int rows) { g_raster_g = rows; return NATINF_OK; }
 int natinf_set_gemm_half_issue(int on) { g_half_issue = on != 0; return NATINF_OK; }

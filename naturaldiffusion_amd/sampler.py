@@ -139,7 +139,11 @@ class SD3NI:
         if euler:
             # weights w_j = sigma_j - sigma_{j+1} are fp32 0-d tensors: as the FIRST operand of `w * x` eager
             # PyTorch casts them to fp16, but as the SECOND operand of `acc / total` the CPU kernel keeps the
-            # fp32 value (original_scalar_value); the row total is the fp32 running sum (SD3...:61-69)
+            # fp32 value (original_scalar_value); the row total is the fp32 running sum (SD3...:61-69).
+            # This pins eager-CPU semantics (what tests/golden/sd3_form.npz was captured with).  On CUDA the
+            # divisor is a 0-d device tensor and the Half functor rounds it to fp16 first: up to 1 fp16 ulp in
+            # the mean -- a property of the reference's platform, not of the algorithm; the bit-exact contract
+            # of the Euler twin is therefore stated against the CPU run.
             n = sig.numel() - 1
             w32 = [-1 * (sig[i + 1] - sig[i]) for i in range(n)]
             W = np.zeros((n, n))

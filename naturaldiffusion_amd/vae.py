@@ -45,10 +45,30 @@ def param_layout(latent_ch: int = 4) -> List[Tuple[str, Tuple[int, ...]]]:
     return out
 
 
+_OLD_ATTN_KEYS = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+
+def _modernise_attention_keys(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Checkpoints written before diffusers renamed its attention block (e.g. the 2022 ``sd-vae-ft-*`` repos the
+    reference's ``vae_path`` points at) store ``...attentions.0.{query,key,value,proj_attn}`` -- as Linear [C, C] or as 1x1
+    conv [C, C, 1, 1] weights; ``AutoencoderKL.from_pretrained`` maps them to ``to_q / to_k / to_v / to_out.0`` on load.
+    Same mapping here, so the raw weights file is accepted."""
+    out = {}
+    for k, v in sd.items():
+        parts = k.split(".")
+        if len(parts) >= 4 and parts[-4] == "attentions" and parts[-2] in _OLD_ATTN_KEYS:
+            k = ".".join(parts[:-2] + [_OLD_ATTN_KEYS[parts[-2]], parts[-1]])
+        if ".attentions." in k and k.endswith(".weight") and v.dim() == 4 and v.shape[2:] == (1, 1):
+            v = v[:, :, 0, 0]
+        out[k] = v
+    return out
+
+
 def flatten_state_dict(sd: Dict[str, torch.Tensor], latent_ch: int = 4, prefix: str = "") -> torch.Tensor:
     """state dict -> the flat fp32 vector of ``natinf_vae_load``.  ``prefix='decoder.'`` for a whole AutoencoderKL checkpoint,
     whose ``post_quant_conv`` (1x1 on the latents, applied by ``AutoencoderKL.decode``) is picked up too; a bare decoder
     state dict gets the identity there."""
+    sd = _modernise_attention_keys(sd)
     if "post_quant_conv.weight" in sd:
         parts = [sd["post_quant_conv.weight"].detach().to(torch.float32).reshape(-1), sd["post_quant_conv.bias"].detach().to(torch.float32).reshape(-1)]
         if parts[0].numel() != latent_ch * latent_ch:

@@ -166,3 +166,43 @@ def test_synthetic_mmdit_weights_match_the_oracle_recipe():
     a = synthetic_mmdit_flat(grid=8, seed=5, pos_max=24, pos_base=8, **cfg)
     b = flatten_state_dict(M.make_params(seed=5, pos_max=24, pos_base=8, **cfg), 8, **cfg)
     assert torch.equal(a, b)
+
+
+def test_vae_loader_accepts_pre_rename_attention_keys():
+    """The 2022 sd-vae-ft-* weight files keep the mid-block attention under query / key / value / proj_attn (some as 1x1
+    conv weights); AutoencoderKL.from_pretrained renames them on load (reference ValidateNaturalInference.py:212-214 goes
+    through it), so the raw-file loader must as well."""
+    import torch
+    from naturaldiffusion_amd.vae import flatten_state_dict, param_layout
+    g = torch.Generator().manual_seed(2)
+    new = {"decoder." + n: torch.randn(s, generator=g) for n, s in param_layout(4)}
+    new["post_quant_conv.weight"] = torch.randn(4, 4, 1, 1, generator=g)
+    new["post_quant_conv.bias"] = torch.randn(4, generator=g)
+    old = {}
+    for k, v in new.items():
+        for a, b in (("to_q", "query"), ("to_k", "key"), ("to_v", "value"), ("to_out.0", "proj_attn")):
+            if f".attentions.0.{a}." in k:
+                k = k.replace(f".attentions.0.{a}.", f".attentions.0.{b}.")
+                if k.endswith("weight") and b in ("query", "proj_attn"):
+                    v = v[:, :, None, None]                 # conv-style storage of the same matrix
+        old[k] = v
+    assert any(".query." in k for k in old) and not any(".to_q." in k for k in old)
+    assert torch.equal(flatten_state_dict(old, 4, prefix="decoder."), flatten_state_dict(new, 4, prefix="decoder."))
+
+
+def test_attention_abi_rejects_padding_beyond_the_masked_tile():
+    """natinf_attention_hd64_bf16 masks only the last 128-key tile: Tp - T >= 128 must be an argument error, not a wrong
+    softmax (include/natinf_mmdit.h)."""
+    from naturaldiffusion_amd._lib import lib
+    dummy = 4096
+    assert lib.natinf_attention_hd64_bf16(dummy, dummy, 64, 256 * 64, dummy, dummy, 64, 256 * 64, 1, 1, 256, 128, 0.125, None) == -1
+    assert lib.natinf_attention_hd64_bf16(dummy, dummy, 64, 256 * 64, dummy, dummy, 64, 256 * 64, 1, 1, 256, 300, 0.125, None) == -1
+
+
+def test_validation_grid_is_one_row_of_eight(tmp_path):
+    """reference ValidateNaturalInference.py:236: save_image(samples, path, nrow=8, ...): 8 images -> 1 x 8."""
+    import torch
+    from PIL import Image
+    from naturaldiffusion_amd.ValidateNaturalInference import save_image_grid
+    save_image_grid(torch.zeros(8, 3, 16, 16), tmp_path / "g.png")
+    assert Image.open(tmp_path / "g.png").size == (8 * 18 + 2, 18 + 2)

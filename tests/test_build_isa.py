@@ -1,0 +1,98 @@
+"""ISA-level checks of the built code objects (the listings `make` leaves in csrc/build/ via -save-temps=obj).
+
+  * ni_step.hip carries the bit-exact arithmetic contract: no fused multiply-add may appear outside the correctly
+    rounded division expansions (v_div_scale / v_div_fmas / v_div_fixup sequences), i.e. -ffp-contract=off held;
+  * the kernels on the benchmarked hot paths must not spill (scratch traffic inside an MFMA loop is a silent 2-5x);
+  * the shipped library carries no development-only kernels (K-loop ablations that give wrong results by design).
+"""
+import re
+import subprocess
+from pathlib import Path
+
+import pytest
+
+CSRC = Path(__file__).resolve().parent.parent / "naturaldiffusion_amd" / "csrc"
+BUILD = CSRC / "build"
+
+
+@pytest.fixture(scope="module")
+def listings():
+    subprocess.check_call(["make", "-C", str(CSRC), "-j4"], stdout=subprocess.DEVNULL)       # no-op when up to date
+    out = {}
+    for stem in ("ni_step", "ncsnpp"):
+        p = BUILD / f"{stem}-hip-amdgcn-amd-amdhsa-gfx950.s"
+        assert p.exists(), f"{p} missing: the Makefile builds with -save-temps=obj"
+        out[stem] = p.read_text()
+    return out
+
+
+def _kernels(listing):
+    """name (demangled) -> dict(vgpr, spill, scratch) from the amdhsa.kernels metadata"""
+    md = listing[listing.index("amdhsa.kernels:"):]
+    rows = []
+    for blk in re.split(r"\n  - \.", md)[1:]:
+        get = lambda key: re.search(r"\." + key + r":\s*(\S+)", blk).group(1)
+        rows.append((get("name"), int(get("vgpr_count")), int(get("vgpr_spill_count")), int(get("private_segment_fixed_size")),
+                     int(get("sgpr_spill_count"))))
+    names = subprocess.run(["c++filt"] + [r[0] for r in rows], capture_output=True, text=True,
+                           check=True).stdout.strip().split("\n")
+    return {n: dict(vgpr=r[1], spill=r[2], scratch=r[3], sgpr_spill=r[4]) for n, r in zip(names, rows)}
+
+
+EXACT = ("k_step_f64hist", "k_wsum_f64", "k_step_f32prod", "k_wsum_f32prod", "k_flow_input_f16", "k_wmean_f16", "k_step_f16chain",
+         "k_to_pixel")          # not: k_step_f32hist (the opt-in FMA fast mode), k_randn_philox (explicit fmaf polynomials)
+
+
+def test_ni_step_has_no_contracted_fma(listings):
+    """Every kernel that carries the reference's arithmetic contract: the only fused multiply-adds are the Newton steps of
+    the correctly rounded IEEE divisions (5 per v_div_fixup: 3 v_fma + 2 v_fmac) and the float reciprocal seed of 64-bit
+    INTEGER divisions (v_fmac with the 2^32 / -2^32 literals)."""
+    body = listings["ni_step"]
+    code = body[:body.index("amdhsa.kernels:")]
+    parts = re.split(r"^(_Z\w+):\s*; @", code, flags=re.M)
+    seen = set()
+    for i in range(1, len(parts), 2):
+        name, fn = parts[i], parts[i + 1]
+        tag = next((e for e in EXACT if e in name), None)
+        if tag is None:
+            continue
+        seen.add(tag)
+        lines = [ln.strip() for ln in fn.split("\n")]
+        fused = [ln for ln in lines if re.match(r"v_(fma|fmac|mad|mac|pk_fma|fma_mix\w*|dot\w*)_(f|legacy_f|bf)\w*\s", ln)]
+        fused = [ln for ln in fused if not re.match(r"v_fmac_f32_e32 v\d+, 0x[4c]f800000, ", ln)]          # u64 division seed
+        bad = [ln for ln in fused if not re.match(r"v_(fma|fmac)_f(32|64)(_e32|_e64)?\s", ln)]
+        assert not bad, (name, bad[:3])                                      # no mixed-precision / packed / legacy forms
+        n32 = sum(ln.startswith("v_div_fixup_f32") for ln in lines)
+        n64 = sum(ln.startswith("v_div_fixup_f64") for ln in lines)
+        f32 = sum(bool(re.match(r"v_(fma|fmac)_f32", ln)) for ln in fused)
+        f64 = sum(bool(re.match(r"v_(fma|fmac)_f64", ln)) for ln in fused)
+        assert f32 <= 5 * n32 and f64 <= 5 * n64, (name, f32, n32, f64, n64)
+    assert seen == set(EXACT), set(EXACT) - seen
+    assert all(v["spill"] == 0 and v["scratch"] == 0 for v in _kernels(body).values())
+
+
+HOT = [  # substrings of the demangled names of the kernels the bench lines are timed on
+    "k_gemm_dma<2, 4, 8, 4, 6, 2>", "k_gemm_dma<4, 2, 8, 4, 6, 2>", "k_gemm_dma<2, 4, 8, 4, 6, 6>", "k_gemm_dma<4, 2, 8, 4, 6, 6>",
+    "k_gemm_dma<2, 4, 8, 4, 6, 7>", "k_gemm_dma<2, 4, 8, 4, 6, 1>", "k_gemm_dma<2, 4, 8, 4, 6, 4>",
+    "k_gemm_dma<2, 2, 4, 4, 2, 0>", "k_gemm_dma<2, 2, 4, 4, 2, 1>", "k_gemm_ring<2, 2, 2, 4, 4, 0>", "k_gemm_ring<2, 2, 8, 4, 3, 1>",
+    "k_attn_fused<8, 16, true>", "k_flash_attn64", "k_gn_apply", "k_ln_modulate",
+]
+
+
+def test_hot_kernels_do_not_spill(listings):
+    ks = _kernels(listings["ncsnpp"])
+    for pat in HOT:
+        hit = {n: v for n, v in ks.items() if pat in n}
+        assert hit, f"no kernel matching {pat!r} in the code object"
+        for n, v in hit.items():
+            assert v["spill"] == 0 and v["scratch"] == 0, (n, v)
+            assert v["vgpr"] <= 256, (n, v)                                   # 8 waves per CU: two per SIMD
+            assert v["sgpr_spill"] <= 4, (n, v)                               # scalar spills live in VGPR lanes (no memory traffic): a few are tolerated
+
+
+def test_no_development_kernels_in_the_shipped_library(listings):
+    ks = _kernels(listings["ncsnpp"])
+    abl = [n for n in ks if re.search(r"k_gemm_dma<2, 4, 8, 4, [34], 1>", n)]
+    assert not abl, abl
+    code = listings["ncsnpp"]
+    assert "s_memtime" not in code[:code.index("amdhsa.kernels:")]           # tile-timeline stamps: -DNATINF_DEV builds only

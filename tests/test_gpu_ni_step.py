@@ -60,6 +60,20 @@ def test_classical_sampler_matrices(dev, cifar, repo_root, rel):
     assert np.array_equal(out.cpu().numpy(), cifar[f"k5_{key}_final"])
 
 
+@pytest.mark.parametrize("rel", ["dpmsolverpp/dpmsolverpp2s_018", "dpmsolver/dpmsolver2s_018", "dpmsolver/dpmsolver3s_018"])
+def test_ni_equals_the_vendored_classical_solver(dev, golden_dir, repo_root, rel):
+    """SURVEY K5 on the HIP path: natinf_step_f64hist driven by the shipped DPM-Solver / DPM-Solver++ matrices against the
+    output of the reference's own DPM_Solver class (deps/dpm_solver_pytorch.py:906, captured by make_golden.py group k5):
+    bit-exact against the reference's NI loop, within the survey's 2e-5 of the classical solver."""
+    from naturaldiffusion_amd.CIFAR10NaturalInference import natural_inference
+    fx = np.load(golden_dir / "k5_classical.npz")
+    key = rel.split("/")[1]
+    noise = torch.from_numpy(fx[f"{key}_noise"]).to(dev)
+    out = natural_inference(O.analytic_vp_model(), noise, repo_root / f"results/{rel}.npz", stds=fx[f"{key}_stds"]).cpu().numpy()
+    assert np.array_equal(out, fx[f"{key}_ni"])
+    assert np.abs(out - fx[f"{key}_orig"]).max() <= 2e-5
+
+
 def test_data_fn_and_weighted_sum_mirrors(dev, cifar, repo_root):
     from naturaldiffusion_amd import CIFAR10NaturalInference as M
     C, B, node = O.load_coeff_npz(repo_root / "weights/step_15_weight_173.npz")

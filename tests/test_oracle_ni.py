@@ -83,6 +83,22 @@ def test_k5_classical_sampler_matrices(cifar, repo_root, rel):
     assert np.array_equal(xs[-1].numpy(), cifar[f"k5_{key}_final"])
 
 
+K5_CASES = ["dpmsolverpp/dpmsolverpp2s_018", "dpmsolver/dpmsolver2s_018", "dpmsolver/dpmsolver3s_018"]
+
+
+@pytest.mark.parametrize("rel", K5_CASES)
+def test_k5_ni_equals_the_vendored_classical_solver(golden_dir, repo_root, rel):
+    """SURVEY K5 / BASELINE config 3's claim: NI with a shipped sampler matrix IS that sampler.  ``orig`` was produced by the
+    reference's DPM_Solver.singlestep_dpm_solver_update (deps/dpm_solver_pytorch.py:906) over linspace(1, 1e-3, K+1); ``ni`` by
+    the reference's data_fn / weighted_sum loop on the same noise.  Bound: the survey's 2e-5 (fp32 original)."""
+    fx = np.load(golden_dir / "k5_classical.npz")
+    key = rel.split("/")[1]
+    C, B, node = O.load_coeff_npz(repo_root / f"results/{rel}.npz")
+    xs = O.cifar_ni_trajectory(O.analytic_vp_model(), torch.from_numpy(fx[f"{key}_noise"]), C, B, node, stds=fx[f"{key}_stds"])
+    assert np.array_equal(xs[-1].numpy(), fx[f"{key}_ni"])                # the oracle == the reference's NI loop, bit for bit
+    assert np.abs(xs[-1].numpy() - fx[f"{key}_orig"]).max() <= 2e-5      # == the classical solver (absolute; |x| ~ 2)
+
+
 def test_k3_weighted_sum_validate(validate):
     seq = [torch.from_numpy(a) for a in validate["k3_seq"]]
     got = O.validate_weighted_sum(validate["k3_w"], seq)
