@@ -98,6 +98,9 @@ int natinf_set_gemm_pref512(int on);
 int natinf_set_gemm_half_issue(int on);
 /* Tuning: row-tiles per raster group of launches with >= 8 column tiles (default 8; 0 = plain row-major tile order). */
 int natinf_set_gemm_raster(int rows);
+/* 1 (default): plans built from now on run GroupNorm-apply + SiLU inside the consuming 3x3 convolution where a fused kernel
+ * exists (32x32 and 16x16 levels); 0: the separate normalisation pass everywhere (A/B runs, tests).  Read by natinf_ncsnpp_create. */
+int natinf_set_fuse_gn(int on);
 /* Timing experiments (tools/tile_timeline.py): device buffer of 16 uint64 shader-clock stamps that block 0 / thread 0 of
  * every natinf_debug_gemm launch writes (kernel start, first tile landed, main loop done, per epilogue pass: slab written,
  * sweeps done, stores issued).  NULL switches it off. */

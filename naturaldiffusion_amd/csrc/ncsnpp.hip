@@ -28,6 +28,7 @@
 #include "ncsnpp_kernels.h"
 #include "gemm_dma.h"
 #include "conv_patch.h"
+#include "conv_gn.h"
 #include "gemm_8phase.h"
 #include "gemm_fp8.h"
 #include "attn_fused.h"
@@ -152,12 +153,13 @@ enum GemmVariant {
     V_8PH_256x256 = 19, V_8PH_NOPRIO = 20, V_8PH_READFIRST = 21, V_8PH_BOTH = 22,   // phase-interleaved schedule, counted vmcnt (gemm_8phase.h)
     V_FP8_256x256 = 23,                                                 // fp8 e4m3 operands (gemm_fp8.h); selected by GemmArgs::deq_m/deq_n callers only
     V_ABL_NODMA = 24, V_ABL_NOMFMA = 25,
-    V_DMA_256x256_H = 26, V_DMA_512x128_H = 27,                         // hand pipeline, DMA issued by one wave per SIMD only                                // ablations of dma256x256p's K loop (wrong results by design; tools/ablate_loop.py)
+    V_DMA_256x256_H = 26, V_DMA_512x128_H = 27,                         // hand pipeline, DMA issued by one wave per SIMD only
+    V_CONV_GN = 28,                                                     // 3x3 conv with fused GroupNorm-apply + SiLU of its input (conv_gn.h); GemmArgs::gn_scale callers only
     V_COUNT
 };
 const char* variant_name(int v) {
     static const char* n[] = {"auto", "generic128", "dma256x256", "dma256x128", "dma128x128", "ring256x256", "ring256x128",
-                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s", "dma512x128", "patch256x256", "patch256x128", "dma256x256p", "dma128x128p", "dma256x128w4p", "gemm8ph", "gemm8ph_np", "gemm8ph_rf", "gemm8ph_nprf", "fp8_256x256", "abl_nodma", "abl_nomfma", "dma256x256h", "dma512x128h"};
+                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s", "dma512x128", "patch256x256", "patch256x128", "dma256x256p", "dma128x128p", "dma256x128w4p", "gemm8ph", "gemm8ph_np", "gemm8ph_rf", "gemm8ph_nprf", "fp8_256x256", "abl_nodma", "abl_nomfma", "dma256x256h", "dma512x128h", "conv_gn"};
     return v >= 0 && v < V_COUNT ? n[v] : "?";
 }
 unsigned long long* g_dbg_ts = nullptr;
@@ -184,6 +186,8 @@ using CfgR128x128 = RingCfg<2, 2, 4, 4, 4>; using CfgR64x128 = RingCfg<2, 2, 2, 
 using CfgR256x128W4 = RingCfg<2, 2, 8, 4, 3>; using CfgD256x128W4 = DmaCfg<2, 2, 8, 4>;
 using CfgD512x128 = DmaCfg<4, 2, 8, 4>;
 using CfgP256x256 = PatchCfg<2, 4, 8, 4, 344>; using CfgP256x128 = PatchCfg<4, 2, 4, 4, 400>;
+using CfgG32 = ConvGnCfg<32>; using CfgG16 = ConvGnCfg<16>;
+int g_fuse_gn = 1;                 // natinf_set_fuse_gn (read when a plan is BUILT): GroupNorm-apply + SiLU inside the consuming 3x3 conv
 
 // the packed-epilogue instantiations (EPI 1..4) of the four automatically chosen variants
 template <int EPI>
@@ -192,6 +196,10 @@ bool set_lds_epi() {
            set_lds<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3, EPI>) && set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4, EPI>) &&
            set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4, 2, EPI>) &&
            set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 6, EPI>) && set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4, 6, EPI>);
+}
+template <int EPI>
+bool set_lds_conv_gn() {
+    return set_lds<CfgG32>(&k_conv_gn<32, EPI>) && set_lds<CfgG16>(&k_conv_gn<16, EPI>);
 }
 bool set_lds_epi_all() { return set_lds_epi<0>() && set_lds_epi<1>() && set_lds_epi<2>() && set_lds_epi<3>() && set_lds_epi<4>() && set_lds_epi<5>() && set_lds_epi<6>() && set_lds_epi<7>() && set_lds_epi<8>(); }
 
@@ -207,7 +215,7 @@ bool configure_gemm_kernels() {
          set_lds<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>) && set_lds<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>) &&
          set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2>) && set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2>) &&
          set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>) &&
-         set_lds_epi_all() &&
+         set_lds_epi_all() && set_lds_conv_gn<1>() && set_lds_conv_gn<2>() && set_lds_conv_gn<5>() && set_lds_conv_gn<6>() &&
 #ifdef NATINF_DEV
          set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 3, 1>) && set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 4, 1>) &&
 #endif
@@ -231,7 +239,17 @@ bool configure_gemm_kernels() {
 inline bool eligible_8ph(const GemmArgs& g) { return g.M % 256 == 0 && g.N % 256 == 0; }
 
 int variant_bm(int v);
+// k_conv_gn instantiations: 32x32 and 16x16 images, 256 x 128 tiles; packed epilogues 1 / 2 / 5 / 6 only
+int packed_epi(const GemmArgs& g, int bm);
+inline bool conv_gn_ok(const GemmArgs& g) {
+    if (!g.gn_scale || !g.gn_shift || g.taps != 9 || g.batch != 1 || g.a0_C % BK || (g.a1 && g.a1_C % BK) || g.M % 256) return false;
+    const int res = 1 << g.logW;
+    if (g.logHW != 2 * g.logW || (res != 32 && res != 16) || g.N % 8) return false;
+    const int e = packed_epi(g, 256);
+    return e == 1 || e == 2 || e == 5 || e == 6;
+}
 int choose_variant(const GemmArgs& g) {
+    if (g.gn_scale) return V_CONV_GN;               // the operand is raw: no other kernel can read it (launch_gemm checks conv_gn_ok)
     const int K0 = g.taps * g.a0_C, K1 = g.a1 ? g.a1_C : 0;
     const bool dma = K0 % BK == 0 && K1 % BK == 0 && (g.taps == 1 || (g.a0_padded && g.a0_C % BK == 0));
     if (!dma) return V_GENERIC;
@@ -263,7 +281,7 @@ int choose_variant(const GemmArgs& g) {
 
 int variant_bm(int v) {
     switch (v) {
-        case V_DMA_256x256: case V_DMA_256x128: case V_RING_256x256: case V_RING_256x128: case V_RING_256x128_W4: case V_DMA_256x128_W4:
+        case V_CONV_GN: case V_DMA_256x256: case V_DMA_256x128: case V_RING_256x256: case V_RING_256x128: case V_RING_256x128_W4: case V_DMA_256x128_W4:
         case V_ABL_NODMA: case V_ABL_NOMFMA: case V_DMA_256x256_H: case V_DMA_256x256_S: case V_PATCH_256x256: case V_PATCH_256x128: case V_DMA_256x256_P: case V_DMA_256x128W4_P: case V_8PH_256x256: case V_8PH_NOPRIO: case V_8PH_READFIRST: case V_8PH_BOTH: case V_FP8_256x256: return 256;
         case V_DMA_512x128: case V_DMA_512x128_H: return 512;
         case V_RING_64x128: return 64;
@@ -321,12 +339,14 @@ int packed_epi(const GemmArgs& g, int bm) {      // resid must be 8-byte aligned
         default: launch_tiles<CFG>(&KERN<__VA_ARGS__, 0>, g, s); break;                     \
     }
 
+int g_launch_error = 0;            // set when a launch is asked for something no kernel provides (a plan-builder bug); the forward reports it
 // returns the block-tile row count of the variant used
 int launch_gemm(const GemmArgs& g, hipStream_t s) {
     const int v = choose_variant(g);
+    if (v == V_CONV_GN && !conv_gn_ok(g)) { g_launch_error = 1; return 256; }
     if (g_record) {
         char line[160];
-        const bool has_packed = v == V_DMA_256x256_P || v == V_DMA_128x128_P || v == V_RING_256x128_W4 || v == V_RING_64x128 || v == V_DMA_512x128 || v == V_DMA_256x256_H || v == V_DMA_512x128_H;
+        const bool has_packed = v == V_CONV_GN || v == V_DMA_256x256_P || v == V_DMA_128x128_P || v == V_RING_256x128_W4 || v == V_RING_64x128 || v == V_DMA_512x128 || v == V_DMA_256x256_H || v == V_DMA_512x128_H;
         snprintf(line, sizeof(line), "%d %d %d %d %d %d %s/e%d\n", g.M, g.N, g.taps * g.a0_C, g.a1 ? g.a1_C : 0, g.taps, g.batch, variant_name(v),
                  has_packed ? packed_epi(g, variant_bm(v)) : 0);
         *g_record += line;
@@ -363,6 +383,25 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
         case V_ABL_NODMA: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 3, 1>, g, s); break;
         case V_ABL_NOMFMA: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 4, 1>, g, s); break;
 #endif
+        case V_CONV_GN: {
+            const int e = packed_epi(g, 256);
+            if ((1 << g.logW) == 32) {
+                switch (e) {
+                    case 1: launch_tiles<CfgG32>(&k_conv_gn<32, 1>, g, s); break;
+                    case 2: launch_tiles<CfgG32>(&k_conv_gn<32, 2>, g, s); break;
+                    case 5: launch_tiles<CfgG32>(&k_conv_gn<32, 5>, g, s); break;
+                    default: launch_tiles<CfgG32>(&k_conv_gn<32, 6>, g, s); break;
+                }
+            } else {
+                switch (e) {
+                    case 1: launch_tiles<CfgG16>(&k_conv_gn<16, 1>, g, s); break;
+                    case 2: launch_tiles<CfgG16>(&k_conv_gn<16, 2>, g, s); break;
+                    case 5: launch_tiles<CfgG16>(&k_conv_gn<16, 5>, g, s); break;
+                    default: launch_tiles<CfgG16>(&k_conv_gn<16, 6>, g, s); break;
+                }
+            }
+            break;
+        }
         case V_8PH_NOPRIO: launch_tiles<Cfg8ph>(&k_gemm_8ph<1>, g, s); break;
         case V_8PH_READFIRST: launch_tiles<Cfg8ph>(&k_gemm_8ph<2>, g, s); break;
         case V_8PH_BOTH: launch_tiles<Cfg8ph>(&k_gemm_8ph<3>, g, s); break;
@@ -479,9 +518,15 @@ struct Builder {
 
         const int64_t sc = arena.alloc((int64_t)std::max(cin, cout) * 4), sh = arena.alloc((int64_t)std::max(cin, cout) * 4);
         emit_gn_stats(x, gn0, sc, sh);
-        TRef h = new_act(ro, cin, 1), xr;
-        if (m.up || m.down) xr = new_act(ro, cin);
-        emit_gn_apply(x, sc, sh, h, (m.up || m.down) ? &xr : nullptr, ACT_SILU, m.up ? RS_UP : (m.down ? RS_DOWN : RS_NONE));
+        // GroupNorm-apply + SiLU inside the consuming convolution (conv_gn.h) where an instantiation exists: plain blocks at
+        // 32x32 and 16x16.  Resampling blocks and the 8x8 / 4x4 levels keep the k_gn_apply pass.
+        const bool fuse = g_fuse_gn && !m.up && !m.down && cin % BK == 0 && (ro == 32 || ro == 16);
+        TRef h, xr;
+        if (!fuse) {
+            h = new_act(ro, cin, 1);
+            if (m.up || m.down) xr = new_act(ro, cin);
+            emit_gn_apply(x, sc, sh, h, (m.up || m.down) ? &xr : nullptr, ACT_SILU, m.up ? RS_UP : (m.down ? RS_DOWN : RS_NONE));
+        }
 
         TRef t = new_act(ro, cout);
         const Part pt = register_output(t);
@@ -489,7 +534,9 @@ struct Builder {
         const int dtotal = dense_total; const int64_t dout = dense_out;
         op(CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
-            g.a0 = c.act(h); g.a0_ld = h.ld; g.a0_C = cin; g.taps = 9; g.logW = logW; g.logHW = logHW; g.a0_padded = 1;
+            if (fuse) { g.a0 = c.act(x); g.a0_ld = x.ld; g.gn_scale = c.at<float>(sc); g.gn_shift = c.at<float>(sh); g.gn_ld = cin; }
+            else { g.a0 = c.act(h); g.a0_ld = h.ld; g.a0_padded = 1; }
+            g.a0_C = cin; g.taps = 9; g.logW = logW; g.logHW = logHW;
             g.M = c.B * HWo; g.N = cout; g.b = c.w<bf16>(w0); g.b_ld = K0a;
             g.bias_n = c.w<float>(b0);
             g.rowvec = c.at<float>(dout) + drow; g.rowvec_ld = dtotal; g.log_rows_per_sample = logHW;
@@ -498,17 +545,22 @@ struct Builder {
             const int bm = launch_gemm(g, c.stream);
             if (pt.valid) c.part_bm[pt.id] = bm;
         });
-        arena.release(h.off);
+        if (!fuse) arena.release(h.off);
         emit_gn_stats(t, gn1, sc, sh);
-        TRef u = new_act(ro, cout, 1);
-        emit_gn_apply(t, sc, sh, u, nullptr, ACT_SILU, RS_NONE);
-        arena.release(t.off);
+        TRef u;
+        if (!fuse) {
+            u = new_act(ro, cout, 1);
+            emit_gn_apply(t, sc, sh, u, nullptr, ACT_SILU, RS_NONE);
+            arena.release(t.off);
+        }
         if (pt.valid) arena.release(pt.off);
         const TRef xs = (m.up || m.down) ? xr : x;           // shortcut source at the output resolution
         const Part po = register_output(out);
         op(CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
-            g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_C = cout; g.taps = 9; g.logW = logW; g.logHW = logHW; g.a0_padded = 1;
+            if (fuse) { g.a0 = c.act(t); g.a0_ld = t.ld; g.gn_scale = c.at<float>(sc); g.gn_shift = c.at<float>(sh); g.gn_ld = cout; }
+            else { g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_padded = 1; }
+            g.a0_C = cout; g.taps = 9; g.logW = logW; g.logHW = logHW;
             if (shortcut) { g.a1 = c.act(xs); g.a1_ld = xs.ld; g.a1_C = cin; }
             else { g.resid = c.act(xs); g.resid_ld = xs.ld; }
             g.M = c.B * HWo; g.N = cout; g.b = c.w<bf16>(w1); g.b_ld = K1tot;
@@ -518,7 +570,7 @@ struct Builder {
             const int bm = launch_gemm(g, c.stream);
             if (po.valid) c.part_bm[po.id] = bm;
         });
-        arena.release(u.off);
+        if (fuse) arena.release(t.off); else arena.release(u.off);
         if (m.up || m.down) arena.release(xr.off);
         arena.release(sc); arena.release(sh);
         E.taps[m.idx] = out;
@@ -969,6 +1021,7 @@ int natinf_ncsnpp_forward(natinf_ncsnpp_t h, const float* x, const float* labels
         }
     }
     h->last_B = B; h->last_ws = c.ws;
+    if (g_launch_error) { g_launch_error = 0; return NATINF_ESTATE; }
     return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
 }
 
@@ -1061,6 +1114,7 @@ int natinf_debug_timestamps(void* dev_buf16) {
 }
 
 int natinf_set_gemm_raster(int rows) { g_raster_g = rows; return NATINF_OK; }
+int natinf_set_fuse_gn(int on) { g_fuse_gn = on != 0; return NATINF_OK; }
 int natinf_set_gemm_half_issue(int on) { g_half_issue = on != 0; return NATINF_OK; }
 int natinf_set_gemm_pref512(int on) { g_pref_512 = on != 0; return NATINF_OK; }
 int natinf_set_gemm_epilogue(int fp32_slab) { g_epi_fp32_slab = fp32_slab != 0; return NATINF_OK; }

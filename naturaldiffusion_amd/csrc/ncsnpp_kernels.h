@@ -65,6 +65,9 @@ struct GemmArgs {
     // fused GroupNorm statistics of the OUTPUT (DMA kernels, block tile inside one sample): per block tile and per
     // 4-channel quad, (sum, sum of squares) of the fp32 results -> gn_part[(m0/BM)*gn_quads + n/4] (float2)
     float* gn_part; int gn_quads;
+    // fused GroupNorm-apply + SiLU of the INPUT (k_conv_gn, conv_gn.h): a0 is the RAW, unpadded [B][H][W][a0_ld] tensor and every
+    // element is read as silu(a0 * gn_scale[b*gn_ld + c] + gn_shift[b*gn_ld + c]); a1 (1x1 shortcut segment) stays raw
+    const float* gn_scale; const float* gn_shift; int gn_ld;
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }

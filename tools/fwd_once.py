@@ -1,4 +1,4 @@
-"""NCSN++ forwards at B=512 for rocprofv3 traces: fwd_once.py <epilogue mode 0|1> [n]"""
+"""NCSN++ forwards at B=512 for rocprofv3 traces: fwd_once.py <epilogue mode 0|1> [n] [fuse_gn 0|1]"""
 import sys
 from pathlib import Path
 import torch
@@ -8,6 +8,7 @@ from naturaldiffusion_amd._lib import lib, check
 from naturaldiffusion_amd.ncsnpp import NCSNppEngine
 from naturaldiffusion_amd.synth import synthetic_flat_params
 check(lib.natinf_set_gemm_epilogue(int(sys.argv[1])), "set")
+if len(sys.argv) > 3: check(lib.natinf_set_fuse_gn(int(sys.argv[3])), "set")
 eng = NCSNppEngine(synthetic_flat_params(0), max_batch=512)
 x = torch.randn(512, 3, 32, 32, device="cuda"); t = torch.rand(512, device="cuda") * 999
 for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4): eng(x, t)
