@@ -89,6 +89,15 @@ int natinf_debug_gemm_fused(int variant, int M, int N, int K, const void* a, con
                             float scale, int act, void* c, int c_f32, float* gn_part, int* bm_out, int fp32_slab, natinf_stream_t stream);
 int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_scale, const void* a_mx, const void* b8, const float* b_scale,
                           const float* bias_n, void* c, void* c_mx, int c_mode, int iters, natinf_stream_t stream);
+/* The fused GroupNorm-apply + SiLU + 3x3 convolution kernel (csrc/conv_gn.h) on caller-supplied operands:
+ *   out[m, n] = (sum_{tap, c} silu(x[pixel(m) + tap, c] * scale[b, c] + shift[b, c]) * w[n, c, tap] + sum_c a1[m, c] * w1[n, c]
+ *                + bias_n[n] + resid[m, n]) * out_scale,  zero padding applied after the activation (layerspp.py:242-274).
+ * x: bf16 [B][res][res][cin] (res 32 or 16, cin % 64 == 0); w_packed: bf16 [N][9*cin + c1], K order ((c/64)*9 + tap)*64 + c%64
+ * followed by the c1 shortcut columns; a1: bf16 [B*res*res][c1] or NULL; resid: bf16 [M][N] or NULL; out: bf16 [M][N];
+ * gn_part: NULL or [M/256][N/4] (sum, sum of squares) of the fp32 outputs per 256-pixel tile and 4-channel quad. */
+int natinf_debug_conv_gn(int res, int B, int N, int cin, int c1, const void* x, const float* scale, const float* shift, const void* w_packed,
+                         const void* a1, const float* bias_n, const void* resid, float out_scale, void* out, float* gn_part, int iters,
+                         natinf_stream_t stream);
 int natinf_set_gemm_variant(int variant);
 /* A/B switch for tuning: 1 = every GEMM takes the fp32-slab epilogue, 0 (default) = the packed bf16 epilogue where it applies. */
 int natinf_set_gemm_epilogue(int fp32_slab);

@@ -58,6 +58,24 @@ struct ConvGnCfg {
     static_assert(Epi::PACK_OK && LDS_BYTES <= 81920, "two blocks per CU");
 };
 
+#ifndef NATINF_CG_ABL
+#define NATINF_CG_ABL 0            // development: 1 = no normalisation inside the K loop (timing ablation, wrong results)
+#endif
+#ifdef NATINF_DEV
+// development builds: shader-clock stamps at the section boundaries of a K-tile (block 0 / wave 0), summed over the tile's K loop
+__device__ __forceinline__ unsigned long long cg_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define NATINF_CG_STAMP(v) const unsigned long long v = cg_stamp();
+#define NATINF_CG_ADD(acc, a, b) acc += (b) - (a);
+#else
+#define NATINF_CG_STAMP(v)
+#define NATINF_CG_ADD(acc, a, b)
+#endif
 template <int N> __device__ __forceinline__ void wait_vm_lgkm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N) : "memory");
 }
@@ -94,14 +112,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
     // Every LDS access and every LDS-DMA inside the K loop is inline asm.  (i) With a builtin LDS-DMA in flight hipcc puts
     // `s_waitcnt vmcnt(0)` in front of any LDS access IT can see (a pending LDS write to it), which drains the weight ring at every
     // tap.  (ii) The builtin takes a 64-bit per-lane address: a dozen VALU ops per 1-KiB piece, or -- hoisted -- two registers per
-    // piece.  Here a piece is `global_load_lds_dwordx4 voffset, sbase`: a 32-bit per-lane byte offset computed ONCE per tile (9
-    // registers) and a scalar base that carries everything that changes from tap to tap; no vector instruction per request.
+    // piece.  Here a piece is `global_load_lds_dwordx4 voffset, sbase`: a 32-bit per-lane byte offset (the weight rows: computed once per tile, two registers;
+    // the patch rows: recomputed at tap 0 of every half-chunk) and a scalar base that carries everything that changes from tap to tap; no vector instruction per request.
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     auto lds_addr = [](const unsigned char* p) __attribute__((always_inline)) { return (unsigned)(uintptr_t)((lds_u8*)const_cast<unsigned char*>(p)); };
     auto glds16 = [](unsigned voff, const void* sbase, unsigned lds_dst) __attribute__((always_inline)) {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
     };
-    unsigned off_b[PB], off_p[PPW];
+    unsigned off_b[PB];
     {
         const int prow = lane >> 2, pslot = lane & 3;
 #pragma unroll
@@ -109,38 +127,44 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
             const int r = (wave * PB + j) * 16 + prow;
             off_b[j] = (unsigned)(min(n0 + r, g.N - 1) * g.b_ld + ((pslot ^ ((r >> 1) & 2)) << 3)) * 2u;
         }
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            const int q = min(wave * PPW + j, Cfg::NPIECE - 1);           // wave-uniform piece index (the tail repeats the last piece)
-            const int pp = q * 16 + prow;
-            const int yy = pp / WS, xx = pp - yy * WS;
-            const int y = min(max(y0 - 1 + yy, 0), RES - 1), x = min(max(xx - 1, 0), RES - 1);      // halo / pad: any readable pixel
-            off_p[j] = (unsigned)((y * W + x) * g.a0_ld + ((pslot ^ ((pp >> 1) & 2)) << 3)) * 2u;
-        }
     }
     const unsigned lds_patch = lds_addr(sPatch), lds_b = lds_addr(sB), lds_tab = lds_addr(sTab);
-    auto issue_b = [&](int kt) __attribute__((always_inline)) {            // weight K-tile kt -> ring slot kt % NSB
+    // (every request lambda takes a piece range [j0, j1): inside the K loop the pieces are issued one or two at a time behind
+    // MFMA groups -- an LDS-DMA instruction costs its wave 60-185 issue cycles (MI355X_MICROARCH.md), which then pass while the
+    // wave's own MFMAs execute instead of in front of them)
+    auto issue_b = [&](int kt, int j0 = 0, int j1 = Cfg::PB) __attribute__((always_inline)) {            // weight K-tile kt -> ring slot kt % NSB
         int col;
         if (kt < nk) { const int hc = kt / 9, t = kt - 9 * hc; col = ((hc >> 1) * 9 + t) * 64 + (hc & 1) * KT; }
         else col = K0 + (kt - nk) * KT;
         const unsigned dst = lds_b + (kt % NSB) * Cfg::BT_BYTES + wave * (PB * 1024);
         const bf16* base = g.b + col;
 #pragma unroll
-        for (int j = 0; j < PB; ++j) glds16(off_b[j], base, dst + j * 1024);
+        for (int j = 0; j < PB; ++j)
+            if (j >= j0 && j < j1) glds16(off_b[j], base, dst + j * 1024);
     };
-    auto issue_patch = [&](int hc) __attribute__((always_inline)) {        // (scale | shift) table + raw patch of half-chunk hc -> buffers hc & 1
+    // items: 0 = the (scale | shift) table, 1 .. PPW = the raw patch pieces of half-chunk hc; -> buffers hc & 1
+    auto issue_patch = [&](int hc, int j0 = 0, int j1 = 1 + Cfg::PPW) __attribute__((always_inline)) {
         const int buf = hc & 1;
-        {
+        if (j0 == 0) {
             const float* src = (lane < 32 ? gsc : gsh - 32) + (unsigned)(hc * KT + lane);
             const unsigned dst = lds_tab + buf * Cfg::TAB_BYTES;
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(src), "s"(dst) : "memory");
         }
         const bf16* base = img + hc * KT;
+        int l = lane;
+        asm volatile("" : "+v"(l));                                          // offsets recomputed per request (once per nine taps): no registers held
+        const int prow = l >> 2, pslot = l & 3;
 #pragma unroll
-        for (int j = 0; j < PPW; ++j)
-            glds16(off_p[j], base, lds_patch + buf * Cfg::PATCH_BYTES + min(wave * PPW + j, Cfg::NPIECE - 1) * 1024);
+        for (int j = 0; j < PPW; ++j) {
+            if (j + 1 < j0 || j + 1 >= j1) continue;
+            const int q = min(wave * PPW + j, Cfg::NPIECE - 1);           // wave-uniform piece index (the tail repeats the last piece)
+            const int pp = q * 16 + prow;
+            const int yy = pp / WS, xx = pp - yy * WS;
+            const int y = min(max(y0 - 1 + yy, 0), RES - 1), x = min(max(xx - 1, 0), RES - 1);      // halo / pad: any readable pixel
+            glds16((unsigned)((y * W + x) * g.a0_ld + ((pslot ^ ((pp >> 1) & 2)) << 3)) * 2u, base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
+        }
     };
-    auto issue_shortcut = [&](int s) __attribute__((always_inline)) {      // plain [256][32] tile of a1 -> patch buffer (n_half + s) & 1
+    auto issue_shortcut = [&](int s, int j0 = 0, int j1 = Cfg::PSW) __attribute__((always_inline)) {      // plain [256][32] tile of a1 -> patch buffer (n_half + s) & 1
         const unsigned dst = lds_patch + ((n_half + s) & 1) * Cfg::PATCH_BYTES + wave * (PSW * 1024);
         int l = lane;
         asm volatile("" : "+v"(l));                                          // recomputed per call (a few tiles per launch): no registers held
@@ -148,46 +172,62 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
         const bf16* base = g.a1 + (int64_t)m0 * g.a1_ld + s * KT;
 #pragma unroll
         for (int j = 0; j < PSW; ++j) {
+            if (j < j0 || j >= j1) continue;
             const int pp = (wave * PSW + j) * 16 + prow;
             glds16((unsigned)(pp * g.a1_ld + ((pslot ^ ((pp >> 1) & 2)) << 3)) * 2u, base, dst + j * 1024);
         }
     };
     // ---- in-place normalisation of the patch, slice j: thread t owns the 16-byte slots t + 256 j of the REAL pixels (threads
-    // ---- past the end work on a pad pixel nobody reads).  Split in three so that it can ride in the MFMA shadows of a K-tile:
-    // ---- NORM_LOAD (5 LDS reads, before the fragment reads), NORM_EL(i) (one element: ~10 VALU, after MFMA group i), NORM_STORE.
-    u32x4 nv = {0u, 0u, 0u, 0u}, ns0 = nv, ns1 = nv, nh0 = nv, nh1 = nv;
-    unsigned npa = 0; bool nin = false; float nf[8];
-    auto norm_load = [&](int j, int buf) __attribute__((always_inline)) {
-        int e = tid + THREADS * j;
-        asm volatile("" : "+v"(e));                                          // (no hoisting of six slices' index arithmetic)
+    // ---- past the end work on a pad pixel nobody reads).  Kept as ONE block in front of the K-tile's MFMAs: spreading it one
+    // ---- element per MFMA group was measured (same speed: the vector work competes with the co-resident block's MFMAs for the
+    // ---- SIMD's issue slots wherever it sits) and costs 30 registers held across the tile.
+    // Per slice the thread needs its slot's LDS address and whether the pixel lies inside the image: computed once per tile and
+    // packed one slice per register (address in buffer 0 | inside << 31); the table row follows from the address (bit 8 of the
+    // slot address is bit 2 of the patch row: both patch buffers start on multiples of 512 B).
+    static_assert(Cfg::PATCH_BYTES % 512 == 0, "swizzle bit from the slot address");
+    unsigned ninfo[Cfg::NROUND];
+#pragma unroll
+    for (int j = 0; j < Cfg::NROUND; ++j) {
+        const int e = tid + THREADS * j;
         const bool live = e < Cfg::NREAL * 4;
         const int px = live ? e >> 2 : 0, s = e & 3;
         const int yy = px / WP, xx = live ? px - yy * WP : WP;              // dead threads: pad column WP of patch row 0
-        const int pp = yy * WS + xx;
-        nin = live && (unsigned)(y0 - 1 + yy) < (unsigned)RES && (unsigned)(xx - 1) < (unsigned)RES;
-        npa = lds_patch + buf * Cfg::PATCH_BYTES + pp * 64 + s * 16;
-        const unsigned ta = lds_tab + buf * Cfg::TAB_BYTES + ((s ^ ((pp >> 1) & 2)) << 5);
-        nv = lds_read16<0>(npa);
-        ns0 = lds_read16<0>(ta); ns1 = lds_read16<16>(ta); nh0 = lds_read16<128>(ta); nh1 = lds_read16<144>(ta);
-    };
-#define NATINF_CG_NORM_EL(I)                                                                                                \
-        {                                                                                                                    \
-            const unsigned w_ = nv[(I) >> 1];                                                                                \
-            const float x_ = __uint_as_float(((I) & 1) ? (w_ & 0xffff0000u) : (w_ << 16));                                   \
-            const float sc_ = __uint_as_float((I) < 4 ? ns0[(I) & 3] : ns1[(I) & 3]);                                        \
-            const float sh_ = __uint_as_float((I) < 4 ? nh0[(I) & 3] : nh1[(I) & 3]);                                        \
-            nf[I] = silu_fast(x_ * sc_ + sh_);                                                                               \
-        }                                                                                                                    \
-        __builtin_amdgcn_sched_barrier(0);
-#define NATINF_CG_NO_EL(I)
-    auto norm_store = [&]() __attribute__((always_inline)) {
-        bf16x8 o;
+        const bool in = live && (unsigned)(y0 - 1 + yy) < (unsigned)RES && (unsigned)(xx - 1) < (unsigned)RES;
+        ninfo[j] = (unsigned)((yy * WS + xx) * 64 + s * 16) | (in ? 0x80000000u : 0u);
+    }
+    auto norm_round = [&](int j, int buf) __attribute__((always_inline)) {
+        unsigned inf = ninfo[j];
+        asm volatile("" : "+v"(inf));                                        // (or hipcc hoists both addresses of all six slices out of the loop, and spills them)
+        const unsigned pa = lds_patch + buf * Cfg::PATCH_BYTES + (inf & 0x7fffffffu);
+        const unsigned ta = lds_tab + buf * Cfg::TAB_BYTES + (((inf >> 4) ^ ((inf >> 7) & 2)) & 3) * 32;
+        // two halves of four channels each: 14 live registers instead of 28 while the tile's first fragments wait in theirs
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (bf16)nf[i];
-        u32x4 ou = __builtin_bit_cast(u32x4, o);
-        if (!nin) ou = u32x4{0u, 0u, 0u, 0u};
-        asm volatile("ds_write_b128 %0, %1" :: "v"(npa), "v"(ou) : "memory");
+        for (int hf = 0; hf < 2; ++hf) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 vr; u32x4 s4, h4;
+            if (hf == 0) {
+                asm volatile("ds_read_b64 %0, %1" : "=v"(vr) : "v"(pa) : "memory");
+                s4 = lds_read16<0>(ta); h4 = lds_read16<128>(ta);
+            } else {
+                asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(vr) : "v"(pa) : "memory");
+                s4 = lds_read16<16>(ta); h4 = lds_read16<144>(ta);
+            }
+            wait_lgkmcnt<0>();
+            // to hipcc an asm ds_read's result exists at once: without this it hoists the arithmetic (at IR level) above the wait
+            asm volatile("" : "+v"(vr), "+v"(s4), "+v"(h4));
+            const f32x4 sc = __builtin_bit_cast(f32x4, s4), sh = __builtin_bit_cast(f32x4, h4);
+            typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+            const bf16x4_ v = __builtin_bit_cast(bf16x4_, vr);
+            bf16x4_ o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (bf16)silu_fast((float)v[i] * sc[i] + sh[i]);
+            u32x2 ou = __builtin_bit_cast(u32x2, o);
+            if ((int)inf >= 0) ou = u32x2{0u, 0u};
+            if (hf == 0) asm volatile("ds_write_b64 %0, %1" :: "v"(pa), "v"(ou) : "memory");
+            else asm volatile("ds_write_b64 %0, %1 offset:8" :: "v"(pa), "v"(ou) : "memory");
+        }
     };
+#define NATINF_CG_NO_EL(I)
 
     // ---- fragment addresses: three per-lane bases (dx = -1, 0, +1) at dy = -1; everything else is an immediate ------------
     const int frow = lane & 15, fq = lane >> 4;
@@ -223,16 +263,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                       \
             acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[(I) % 3]), acc[I][j], 0, 0, 0); \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
-        EL(I)
-#define NATINF_CG_TILE(a, AOFF, bb, BOFF, EL)                                                                               \
-    {                                                                                                                        \
+        EL(I)                                                                                                                \
+        post(std::integral_constant<int, (I)>{});
+#define NATINF_CG_HEAD(a, AOFF, bb, BOFF)                                                                                   \
         u32x4 fb[TN], fa[3];                                                                                                 \
         fb[0] = lds_read16<(BOFF)>(bb); fb[1] = lds_read16<(BOFF) + 1024>(bb);                                               \
         fb[2] = lds_read16<(BOFF) + 2048>(bb); fb[3] = lds_read16<(BOFF) + 3072>(bb);                                        \
-        fa[0] = lds_read16<AOFF(0)>(a); fa[1] = lds_read16<AOFF(1)>(a);                                                      \
+        fa[0] = lds_read16<AOFF(0)>(a); fa[1] = lds_read16<AOFF(1)>(a);
+#define NATINF_CG_BODY(a, AOFF, EL)                                                                                         \
         NATINF_CG_STEP(a, AOFF, 0, EL) NATINF_CG_STEP(a, AOFF, 1, EL) NATINF_CG_STEP(a, AOFF, 2, EL) NATINF_CG_STEP(a, AOFF, 3, EL) \
-        NATINF_CG_STEP(a, AOFF, 4, EL) NATINF_CG_STEP(a, AOFF, 5, EL) NATINF_CG_STEP(a, AOFF, 6, EL) NATINF_CG_STEP(a, AOFF, 7, EL) \
-    }
+        NATINF_CG_STEP(a, AOFF, 4, EL) NATINF_CG_STEP(a, AOFF, 5, EL) NATINF_CG_STEP(a, AOFF, 6, EL) NATINF_CG_STEP(a, AOFF, 7, EL)
+#define NATINF_CG_TILE(a, AOFF, bb, BOFF, EL) { NATINF_CG_HEAD(a, AOFF, bb, BOFF) NATINF_CG_BODY(a, AOFF, EL) }
 
     // head of a K-tile: wait until weight tile kt (and everything older) has landed, `allowed` younger requests stay in flight
     auto wait_tile = [&](int aux, bool next_b) __attribute__((always_inline)) {
@@ -241,43 +282,51 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
         else { if (next_b) wait_vm_lgkm_barrier<PSW + PB>(); else wait_vm_lgkm_barrier<PSW>(); }
     };
 
+#ifdef NATINF_DEV
+    unsigned long long dbg_wait = 0, dbg_norm = 0, dbg_mfma = 0;
+    const unsigned long long dbg_t0 = cg_stamp();
+#endif
     // ---- prologue: table + patch of half-chunk 0, weight tiles 0 and 1; half-chunk 0 is normalised before the loop -----------
     issue_patch(0);
     issue_b(0);
     if (NT > 1) issue_b(1);
     wait_vm_lgkm_barrier<0>();
 #pragma unroll
-    for (int j = 0; j < Cfg::NROUND; ++j) {
-        norm_load(j, 0);
-        wait_lgkmcnt<0>();
-        NATINF_CG_NORM_EL(0) NATINF_CG_NORM_EL(1) NATINF_CG_NORM_EL(2) NATINF_CG_NORM_EL(3)
-        NATINF_CG_NORM_EL(4) NATINF_CG_NORM_EL(5) NATINF_CG_NORM_EL(6) NATINF_CG_NORM_EL(7)
-        norm_store();
-    }
+    for (int j = 0; j < Cfg::NROUND; ++j) norm_round(j, 0);
 
     // ---- the nine taps of one half-chunk; BUF (its patch buffer) and the tap index are compile-time: all offsets are immediates
 #define NATINF_CG_AOFF(i) (BUF * Cfg::PATCH_BYTES + ((RES == 32 ? ((i) >> 1) * WS + ((i) & 1) * 16 : (i) * WS) + (T / 3) * WS) * 64)
     auto tap = [&](auto buf_tag, auto t_tag, int hc, bool next_half, int aux0) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value, T = decltype(t_tag)::value;
         const int kt = hc * 9 + T;
+        NATINF_CG_STAMP(ts0)
         // requests younger than weight tile kt: those of taps T-2 and T-1 (aux only at tap 0) + weight tile kt+1
         wait_tile((T == 1 || T == 2) ? aux0 : 0, kt + 1 < NT);
-        if (kt + 2 < NT) issue_b(kt + 2);
-        if (T == 0) {
-            if (next_half) issue_patch(hc + 1);
-            else if (n_sc > 0) issue_shortcut(0);
+        NATINF_CG_STAMP(ts1)
+        // the requests of this step, behind MFMA groups 0, 1 (weight tile kt+2) and 2..7 (tap 0: table + patch of the next half-chunk,
+        // or the first shortcut tile): the order weight tile -> aux is what the vmcnt counts above assume
+        auto post = [&](auto i_tag) __attribute__((always_inline)) {
+            constexpr int I = decltype(i_tag)::value;
+            if constexpr (I < PB) { if (kt + 2 < NT) issue_b(kt + 2, I, I + 1); }
+            if constexpr (T == 0 && I >= 2) {
+                constexpr int A0 = I == 2 ? 0 : (I == 3 ? 2 : I);           // 8 patch items over 6 groups: 2, 2, 1, 1, 1, 1
+                constexpr int A1 = I == 2 ? 2 : (I == 3 ? 4 : I + 1);
+                static_assert(1 + PPW <= 8 && PSW <= 6, "tap-0 request schedule");
+                if (next_half) issue_patch(hc + 1, A0, A1 < 1 + PPW ? A1 : 1 + PPW);
+                else if (n_sc > 0) issue_shortcut(0, I - 2, I - 1);
+            }
+        };
+        // ring slot kt % 3 == T % 3 (9 taps per half-chunk).  The first six fragment reads go out before the normalisation slice
+        // that taps 3..8 carry for the next half-chunk (its DMA was waited for by the head of tap 3): their latency passes under
+        // its vector work.  No run-time branch may enclose the MFMAs: hipcc then keeps two copies of the 128 accumulator registers.
+        NATINF_CG_HEAD(a_dx[T % 3], NATINF_CG_AOFF, b_base, (T % 3) * Cfg::BT_BYTES)
+        if constexpr (T >= 3 && T - 3 < Cfg::NROUND && NATINF_CG_ABL != 1) {
+            if (next_half) norm_round(T - 3, BUF ^ 1);
         }
-        // ring slot kt % 3 == T % 3 (9 taps per half-chunk); taps 3..8 carry a slice of the next half-chunk's normalisation.
-        // No run-time branch may enclose the MFMAs (hipcc then keeps two copies of the 128 accumulator registers and spills):
-        // only the slice's LDS reads and its store are conditional, its vector work runs regardless (on stale registers when
-        // there is no next half-chunk -- in the MFMA shadows either way).
-        if constexpr (T >= 3 && T - 3 < Cfg::NROUND) {
-            if (next_half) norm_load(T - 3, BUF ^ 1);
-            NATINF_CG_TILE(a_dx[T % 3], NATINF_CG_AOFF, b_base, (T % 3) * Cfg::BT_BYTES, NATINF_CG_NORM_EL)
-            if (next_half) norm_store();
-        } else {
-            NATINF_CG_TILE(a_dx[T % 3], NATINF_CG_AOFF, b_base, (T % 3) * Cfg::BT_BYTES, NATINF_CG_NO_EL)
-        }
+        NATINF_CG_STAMP(ts2)
+        NATINF_CG_BODY(a_dx[T % 3], NATINF_CG_AOFF, NATINF_CG_NO_EL)
+        NATINF_CG_STAMP(ts3)
+        NATINF_CG_ADD(dbg_wait, ts0, ts1) NATINF_CG_ADD(dbg_norm, ts1, ts2) NATINF_CG_ADD(dbg_mfma, ts2, ts3)
     };
     auto half_chunk = [&](auto buf_tag, int hc) __attribute__((always_inline)) {
         const bool next_half = hc + 1 < n_half;
@@ -289,6 +338,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
         tap(buf_tag, integral_constant<int, 6>{}, hc, next_half, aux0); tap(buf_tag, integral_constant<int, 7>{}, hc, next_half, aux0);
         tap(buf_tag, integral_constant<int, 8>{}, hc, next_half, aux0);
     };
+#ifdef NATINF_DEV
+    const unsigned long long dbg_t1 = cg_stamp();
+#endif
     for (int hc = 0; hc < n_half; hc += 2) {                              // a0_C is a multiple of 64: half-chunks come in pairs
         half_chunk(std::integral_constant<int, 0>{}, hc);
         half_chunk(std::integral_constant<int, 1>{}, hc + 1);
@@ -301,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
         else wait_vm_lgkm_barrier<0>();                                    // A(s) was the last request of the previous step
         if (kt + 2 < NT) issue_b(kt + 2);
         if (s + 1 < n_sc) issue_shortcut(s + 1);
+        auto post = [](auto) __attribute__((always_inline)) {};
         const unsigned pa = a_plain + ((n_half + s) & 1) * Cfg::PATCH_BYTES, pb = b_base + (kt % NSB) * Cfg::BT_BYTES;
         NATINF_CG_TILE(pa, NATINF_CG_POFF, pb, 0, NATINF_CG_NO_EL)
     }
@@ -308,10 +361,37 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
 #undef NATINF_CG_AOFF
 #undef NATINF_CG_STEP
 #undef NATINF_CG_TILE
-#undef NATINF_CG_NORM_EL
+#undef NATINF_CG_HEAD
+#undef NATINF_CG_BODY
 #undef NATINF_CG_NO_EL
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done with the tiles before the epilogue reuses them
-    tile_epilogue<Cfg::WM, Cfg::WN, TM, TN, typename Cfg::Epi, EPI>(g, smem, acc, m0, n0, 0, tid, lane, wm, wn);
+    // The epilogue's arguments (bias, row vector, residual, partial-sum table, ...) are fetched from the kernel-argument segment
+    // HERE, through a pointer hipcc cannot see through: kept in scalar registers across the K loop they cost ~40 SGPRs, the
+    // allocator spilled them into vector-register lanes, and the vector registers it took for that tipped the loop into scratch
+    // spills -- whose loads and stores would corrupt the hand-counted vmcnt waits above.
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const unsigned __attribute__((address_space(4))) *kernarg_u32_t;
+    kernarg_u32_t gp = (kernarg_u32_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(gp));
+    GemmArgs ge;
+    {
+        unsigned* d = reinterpret_cast<unsigned*>(&ge);
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(GemmArgs) / 4; ++i) d[i] = gp[i];
+    }
+#else
+    const GemmArgs ge = g;
+#endif
+#ifdef NATINF_DEV
+    const unsigned long long dbg_t2 = cg_stamp();
+#endif
+    tile_epilogue<Cfg::WM, Cfg::WN, TM, TN, typename Cfg::Epi, EPI>(ge, smem, acc, m0, n0, 0, tid, lane, wm, wn);
+#ifdef NATINF_DEV
+    if (ge.dbg_ts && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 777)) {
+        unsigned long long* o = ge.dbg_ts + (blockIdx.x ? 8 : 0);
+        o[0] = dbg_t1 - dbg_t0; o[1] = dbg_wait; o[2] = dbg_norm; o[3] = dbg_mfma; o[4] = dbg_t2 - dbg_t1; o[5] = cg_stamp() - dbg_t2; o[6] = (unsigned long long)nk;
+    }
+#endif
 }
 
 }  // namespace ncsn

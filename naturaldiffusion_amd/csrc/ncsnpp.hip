@@ -1030,7 +1030,8 @@ int natinf_ncsnpp_describe_gemms(natinf_ncsnpp_t h, int B, char* buf, int cap) {
     std::string out;
     g_record = &out;
     std::vector<int> scratch_bm(h->part_bm.size(), 128);
-    Ctx c{B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, scratch_bm.data()};
+    // (a non-null fake workspace base: launches are only described, but "is this pointer set" decides the kernel variant)
+    Ctx c{B, reinterpret_cast<unsigned char*>(4096), reinterpret_cast<const unsigned char*>(4096), nullptr, nullptr, nullptr, nullptr, scratch_bm.data()};
     for (size_t i = 0; i < h->ops.size(); ++i)
         if (h->op_cls[i] == CLS_GEMM) h->ops[i](c);          // GEMM ops only compute pointers and call launch_gemm
     g_record = nullptr;
@@ -1081,6 +1082,32 @@ int natinf_debug_gemm_fused(int variant, int M, int N, int K, const void* a, con
     const int bm = launch_gemm(g, (hipStream_t)stream);
     g_force_variant = saved;
     if (bm_out) *bm_out = bm;
+    return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
+}
+
+// The fused GroupNorm-apply + SiLU + 3x3 convolution kernel on its own (tests/test_gpu_conv_gn.py, tools/bench_conv_gn.py):
+//   out[m, n] = (sum_{tap, c} silu(x[pixel(m) + tap, c] * scale[b, c] + shift[b, c]) * w[n, c, tap]  +  sum_c a1[m, c] * w1[n, c]
+//                + bias[n] + resid[m, n]) * out_scale,   zero padding outside the image (applied AFTER the activation).
+// x: raw bf16 [B][res][res][cin]; w_packed: bf16 [N][9*cin + c1] in the engine's K order ((c / 64) * 9 + tap) * 64 + c % 64, then
+// the c1 shortcut columns; a1: bf16 [B*res*res][c1] or NULL (c1 = 0); resid: bf16 [M][N] or NULL; gn_part: NULL or
+// [M / 256][N / 4] float2 partial (sum, sum of squares) of the outputs.
+int natinf_debug_conv_gn(int res, int B, int N, int cin, int c1, const void* x, const float* scale, const float* shift, const void* w_packed,
+                         const void* a1, const float* bias_n, const void* resid, float out_scale, void* out, float* gn_part, int iters,
+                         natinf_stream_t stream) {
+    if ((res != 32 && res != 16) || B <= 0 || N <= 0 || N % 8 || cin <= 0 || cin % 64 || c1 < 0 || c1 % 64 || (c1 > 0) != (a1 != nullptr) ||
+        !x || !scale || !shift || !w_packed || !out || iters <= 0) return NATINF_EINVAL;
+    static bool configured = false;
+    if (!configured) { if (!configure_gemm_kernels()) return NATINF_ENODEV; configured = true; }
+    GemmArgs g = gemm_defaults();
+    g.a0 = (const bf16*)x; g.a0_ld = cin; g.a0_C = cin; g.taps = 9; g.logW = ilog2(res); g.logHW = 2 * g.logW;
+    g.gn_scale = scale; g.gn_shift = shift; g.gn_ld = cin;
+    if (a1) { g.a1 = (const bf16*)a1; g.a1_ld = c1; g.a1_C = c1; }
+    g.M = B * res * res; g.N = N; g.b = (const bf16*)w_packed; g.b_ld = 9 * cin + c1; g.bias_n = bias_n;
+    g.resid = (const bf16*)resid; g.resid_ld = N; g.scale = out_scale; g.c = out; g.c_ld = N;
+    g.gn_part = gn_part; g.gn_quads = N / 4;
+    g.dbg_ts = g_dbg_ts;
+    if (!conv_gn_ok(g)) return NATINF_EINVAL;
+    for (int i = 0; i < iters; ++i) launch_gemm(g, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
 }
 

@@ -1,0 +1,79 @@
+"""k_conv_gn (csrc/conv_gn.h) on its own: the 3x3 convolution with GroupNorm-apply + SiLU fused into its operand path, against
+plain PyTorch fp32 of the same op -- conv2d(silu(x * scale + shift), w, padding=1) + 1x1 shortcut + bias + residual, scaled
+(reference arithmetic: ResnetBlockBigGANpp.forward, deps/score_sde_pytorch/models/layerspp.py:242-274).  Inputs are made
+bf16-representable and the activated operand is rounded to bf16 in the reference too, so what remains is fp32 accumulation order
+and the bf16 rounding of the output: tolerance 1e-2 of max |ref| (observed ~4e-3)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _pack(w, w1):
+    """[N][C][3][3] (+ [N][C1]) -> the engine's K order: ((c / 64) * 9 + tap) * 64 + c % 64, then the shortcut columns"""
+    N, C = w.shape[:2]
+    p = w.reshape(N, C // 64, 64, 9).permute(0, 1, 3, 2).reshape(N, 9 * C)
+    return torch.cat([p, w1], dim=1).contiguous() if w1 is not None else p.contiguous()
+
+
+@pytest.mark.parametrize("res,B,cin,N,c1,resid,parts", [
+    (32, 2, 128, 128, 0, False, True),        # Conv_0 of a level-0 block (+ GroupNorm partials of the output)
+    (32, 3, 256, 128, 256, False, True),      # up-path Conv_1 with the 1x1 shortcut segment
+    (32, 1, 128, 128, 0, True, True),         # Conv_1 with the identity residual
+    (16, 4, 256, 256, 0, True, False),        # 16x16 level: two N tiles per pixel tile
+    (16, 2, 512, 256, 512, False, True),      # widest K: 144 + 16 K-tiles
+    (16, 3, 128, 256, 0, False, False),
+    (32, 2, 384, 128, 384, False, False),     # 384 channels: 12 half-chunks
+    (16, 1, 64, 40, 0, False, False),         # ragged N, single chunk
+])
+def test_conv_gn_matches_torch(res, B, cin, N, c1, resid, parts):
+    from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(res * 1000 + cin + N + c1)
+    bf = lambda t: t.bfloat16().float()
+    x = bf(torch.randn(B, res, res, cin, generator=g))
+    scale = torch.rand(B, cin, generator=g) * 1.5 + 0.25
+    shift = torch.randn(B, cin, generator=g) * 0.5
+    w = bf(torch.randn(N, cin, 3, 3, generator=g) / np.sqrt(9 * cin))
+    w1 = bf(torch.randn(N, c1, generator=g) / np.sqrt(c1)) if c1 else None
+    a1 = bf(torch.randn(B, res, res, c1, generator=g)) if c1 else None
+    bias = torch.randn(N, generator=g) * 0.1
+    r = bf(torch.randn(B * res * res, N, generator=g)) if resid else None
+    out_scale = 0.70710678
+    # reference
+    h = bf(F.silu(x * scale[:, None, None, :] + shift[:, None, None, :]))
+    ref = F.conv2d(h.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1).reshape(B * res * res, N)
+    if c1:
+        ref = ref + a1.reshape(-1, c1).double() @ w1.double().t()
+    ref = ref + bias.double()
+    if resid:
+        ref = ref + r.double()
+    ref = (ref * out_scale).float()
+    # kernel
+    dev = "cuda"
+    xd, wd = x.bfloat16().to(dev).contiguous(), _pack(w, w1).bfloat16().to(dev)
+    out = torch.empty(B * res * res, N, dtype=torch.bfloat16, device=dev)
+    M = B * res * res
+    part = torch.zeros(M // 256, N // 4, 2, device=dev) if parts else None
+    scd, shd, bd = scale.to(dev), shift.to(dev), bias.to(dev)           # (named: a temporary could be recycled before the launch runs)
+    a1d = a1.bfloat16().to(dev).contiguous() if c1 else None
+    rd = r.bfloat16().to(dev) if resid else None
+    check(lib.natinf_debug_conv_gn(res, B, N, cin, c1, ptr(xd), ptr(scd), ptr(shd), ptr(wd), ptr(a1d), ptr(bd), ptr(rd), out_scale,
+                                   ptr(out), ptr(part), 1, stream_ptr()), "conv_gn")
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    assert err <= 1e-2, err
+    if parts:                                               # (sum, sum of squares) per 256-pixel tile and 4-channel quad, of the fp32 results
+        want = torch.stack([ref.reshape(M // 256, 256, N // 4, 4).sum(dim=(1, 3)), (ref ** 2).reshape(M // 256, 256, N // 4, 4).sum(dim=(1, 3))], dim=-1)
+        assert ((part.cpu() - want).abs().max() / want.abs().max()).item() <= 5e-3
+
+
+def test_conv_gn_argument_errors():
+    from naturaldiffusion_amd._lib import lib
+    d = 4096
+    assert lib.natinf_debug_conv_gn(8, 1, 128, 128, 0, d, d, d, d, None, None, None, 1.0, d, None, 1, None) == -1      # resolution
+    assert lib.natinf_debug_conv_gn(32, 1, 128, 96, 0, d, d, d, d, None, None, None, 1.0, d, None, 1, None) == -1      # cin % 64
+    assert lib.natinf_debug_conv_gn(32, 1, 128, 128, 64, d, d, d, d, None, None, None, 1.0, d, None, 1, None) == -1    # c1 without a1

@@ -156,8 +156,8 @@ def test_bench_batch_512_runs_the_benchmarked_kernels_and_matches_golden(dev, fl
     for f in _describe_gemms(eng, 512):
         chosen.setdefault(f[6].split("/")[0], []).append((int(f[0]), int(f[1])))
     # the families that carry the bench's device time: the fused GroupNorm+SiLU convolution (every plain res-block conv of the
-    # 32x32 and 16x16 levels: 2 x 27 launches) and, for the resampling blocks / the head, the hand-pipelined LDS-DMA tiles
-    assert len(chosen.get("conv_gn", [])) >= 50, {k: len(v) for k, v in chosen.items()}
+    # 32x32 and 16x16 levels: 2 x 18 launches) and, for the resampling blocks / the head, the hand-pipelined LDS-DMA tiles
+    assert len(chosen.get("conv_gn", [])) >= 30, {k: len(v) for k, v in chosen.items()}
     assert len(chosen.get("dma256x256h", [])) >= 3 and len(chosen.get("dma512x128h", [])) >= 1, {k: len(v) for k, v in chosen.items()}
     y = eng(x.to(dev), labels.to(dev))
     torch.cuda.synchronize()

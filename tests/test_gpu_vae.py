@@ -80,7 +80,7 @@ def test_argument_errors():
 
 
 def test_validate_script_decodes_and_writes_the_image_grid(tmp_path, monkeypatch):
-    """src/ValidateNaturalInference.py:231-236 end of a sampler: latents / 0.18215 -> vae.decode -> 2x4 image grid on disk,
+    """src/ValidateNaturalInference.py:231-236 end of a sampler: latents / 0.18215 -> vae.decode -> 1x8 image row on disk (save_image nrow=8),
     with the decoder engine loaded from an AutoencoderKL-style safetensors file (synthetic weights)."""
     from PIL import Image
     from safetensors.torch import save_file
@@ -108,7 +108,7 @@ def test_validate_script_decodes_and_writes_the_image_grid(tmp_path, monkeypatch
     shutil.copy(V.__file__.rsplit("/", 2)[0] + "/results/ddim/ddim_024.npz", tmp_path / "results" / "ddim" / "ddim_024.npz")
     z = V.natural_inference("ddim", 24)
     img = Image.open(tmp_path / "results" / "validation" / "ddim_024__seed_0__natural.png")
-    assert img.size == (4 * 258 + 2, 2 * 258 + 2)
+    assert img.size == (8 * 258 + 2, 258 + 2)
     # the pixels are the decoder engine's output for those latents
     from naturaldiffusion_amd.vae import VAEDecoder, flatten_state_dict
     ref = V8.decode(P, (z / 0.18215).cpu())

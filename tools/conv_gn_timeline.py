@@ -1,0 +1,21 @@
+"""Where a k_conv_gn tile spends its shader clocks (needs a -DNATINF_DEV build: NATINF_LIB=gpurun_in/libnatinf_dev.so).
+usage: conv_gn_timeline.py res B cin N c1"""
+import sys
+from pathlib import Path
+import torch
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
+res, B, cin, N, c1 = [int(v) for v in sys.argv[1:6]]
+dev = "cuda"; M = B * res * res
+x = torch.randn(B, res, res, cin, device=dev).bfloat16(); sc = torch.rand(B, cin, device=dev) + 0.5; sh = torch.randn(B, cin, device=dev) * 0.3
+w = (torch.randn(N, 9 * cin + c1, device=dev) / (9 * cin) ** 0.5).bfloat16(); a1 = torch.randn(M, c1, device=dev).bfloat16() if c1 else None
+bias = torch.randn(N, device=dev); out = torch.empty(M, N, dtype=torch.bfloat16, device=dev); part = torch.zeros(M // 256, N // 4, 2, device=dev)
+ts = torch.zeros(16, dtype=torch.int64, device=dev)
+check(lib.natinf_debug_timestamps(ptr(ts)), "ts")
+args = (res, B, N, cin, c1, ptr(x), ptr(sc), ptr(sh), ptr(w), ptr(a1), ptr(bias), None, 0.7071, ptr(out), ptr(part))
+for _ in range(3):
+    check(lib.natinf_debug_conv_gn(*args, 1, stream_ptr()), "run"); torch.cuda.synchronize()
+for blk, o in (("block 0", 0), ("block 777", 8)):
+    t = ts[o:o + 8].tolist(); nk = max(t[6], 1)
+    print(f"{blk}: prologue {t[0]}  loop {t[4]} = {t[4] / nk:.0f}/tap over {nk} taps [wait+barrier {t[1] / nk:.0f}  dma+norm {t[2] / nk:.0f}  mfma section {t[3] / nk:.0f}]  epilogue {t[5]}")
