@@ -94,7 +94,10 @@ int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_sc
  *                + bias_n[n] + resid[m, n]) * out_scale,  zero padding applied after the activation (layerspp.py:242-274).
  * x: bf16 [B][res][res][cin] (res 32 or 16, cin % 64 == 0); w_packed: bf16 [N][9*cin + c1], K order ((c/64)*9 + tap)*64 + c%64
  * followed by the c1 shortcut columns; a1: bf16 [B*res*res][c1] or NULL; resid: bf16 [M][N] or NULL; out: bf16 [M][N];
- * gn_part: NULL or [M/256][N/4] (sum, sum of squares) of the fp32 outputs per 256-pixel tile and 4-channel quad. */
+ * gn_part: NULL or [M/256][N/4] (sum, sum of squares) of the fp32 outputs per 256-pixel tile and 4-channel quad.
+ * Operands are taken in the kernel's FOLDED form: `scale` and `shift` must be the GroupNorm scale / shift multiplied by -log2(e)
+ * and the 3x3 columns of w_packed multiplied by -ln 2 (the shortcut columns are plain); the kernel evaluates t / (1 + exp2(t)),
+ * t = x*scale + shift = -log2(e) v, i.e. -log2(e) silu(v) -- the same function with two vector instructions fewer per element. */
 int natinf_debug_conv_gn(int res, int B, int N, int cin, int c1, const void* x, const float* scale, const float* shift, const void* w_packed,
                          const void* a1, const float* bias_n, const void* resid, float out_scale, void* out, float* gn_part, int iters,
                          natinf_stream_t stream);

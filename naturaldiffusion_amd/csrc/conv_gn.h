@@ -195,38 +195,65 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
         const bool in = live && (unsigned)(y0 - 1 + yy) < (unsigned)RES && (unsigned)(xx - 1) < (unsigned)RES;
         ninfo[j] = (unsigned)((yy * WS + xx) * 64 + s * 16) | (in ? 0x80000000u : 0u);
     }
-    auto norm_round = [&](int j, int buf) __attribute__((always_inline)) {
+    // A slice = five LDS reads (norm_load, ahead of the K-tile's fragment reads), eight elements of arithmetic, one LDS write.
+    // ONE wave cannot overlap its own MFMAs with anything unless the other work sits BETWEEN them: an MFMA occupies the matrix pipe
+    // for 16 cycles and the issue port for 8, which leaves two vector-issue slots per MFMA (measured with one block per CU: 1,750
+    // clocks per tap for 512 clocks of MFMAs when the slice ran as a block of its own; stamps in tools/conv_gn_timeline.py).  So
+    // element i of the slice -- unpack, fma, exp2, add, rcp, mul: six instructions in the folded form -- is scheduled INTO MFMA
+    // group i (sched_group_barrier: one MFMA, two vector instructions, four times).  Folded form (GemmArgs::gn_folded, the only one
+    // the kernel implements): scale / shift carry -log2(e), so t = x*scale + shift = -log2(e) v, exp2(t) = exp(-v) and
+    // t / (1 + exp2(t)) = -log2(e) silu(v); the 3x3 weights carry -ln 2.
+    u32x4 nv = {0u, 0u, 0u, 0u}, ns0 = nv, ns1 = nv, nh0 = nv, nh1 = nv;
+    unsigned npa = 0, npk[4] = {0u, 0u, 0u, 0u};
+    float nf_even = 0.f;
+    auto norm_load = [&](int j, int buf) __attribute__((always_inline)) {
         unsigned inf = ninfo[j];
         asm volatile("" : "+v"(inf));                                        // (or hipcc hoists both addresses of all six slices out of the loop, and spills them)
-        const unsigned pa = lds_patch + buf * Cfg::PATCH_BYTES + (inf & 0x7fffffffu);
+        npa = lds_patch + buf * Cfg::PATCH_BYTES + (inf & 0x7fffffffu);
         const unsigned ta = lds_tab + buf * Cfg::TAB_BYTES + (((inf >> 4) ^ ((inf >> 7) & 2)) & 3) * 32;
-        // two halves of four channels each: 14 live registers instead of 28 while the tile's first fragments wait in theirs
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            u32x2 vr; u32x4 s4, h4;
-            if (hf == 0) {
-                asm volatile("ds_read_b64 %0, %1" : "=v"(vr) : "v"(pa) : "memory");
-                s4 = lds_read16<0>(ta); h4 = lds_read16<128>(ta);
-            } else {
-                asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(vr) : "v"(pa) : "memory");
-                s4 = lds_read16<16>(ta); h4 = lds_read16<144>(ta);
-            }
-            wait_lgkmcnt<0>();
-            // to hipcc an asm ds_read's result exists at once: without this it hoists the arithmetic (at IR level) above the wait
-            asm volatile("" : "+v"(vr), "+v"(s4), "+v"(h4));
-            const f32x4 sc = __builtin_bit_cast(f32x4, s4), sh = __builtin_bit_cast(f32x4, h4);
-            typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
-            const bf16x4_ v = __builtin_bit_cast(bf16x4_, vr);
-            bf16x4_ o;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = (bf16)silu_fast((float)v[i] * sc[i] + sh[i]);
-            u32x2 ou = __builtin_bit_cast(u32x2, o);
-            if ((int)inf >= 0) ou = u32x2{0u, 0u};
-            if (hf == 0) asm volatile("ds_write_b64 %0, %1" :: "v"(pa), "v"(ou) : "memory");
-            else asm volatile("ds_write_b64 %0, %1 offset:8" :: "v"(pa), "v"(ou) : "memory");
-        }
+        nv = lds_read16<0>(npa);
+        ns0 = lds_read16<0>(ta); ns1 = lds_read16<16>(ta); nh0 = lds_read16<128>(ta); nh1 = lds_read16<144>(ta);
+        npa |= inf & 0x80000000u;                                           // bit 31: the pixel lies inside the image
     };
+    // element I: after an lgkmcnt wait that covers norm_load's reads.  The first asm makes the slice's registers "new" values (to
+    // hipcc an asm ds_read's result exists at once: it would hoist the arithmetic above the wait at IR level); the last one pins the
+    // result here (it would otherwise sink the arithmetic into norm_store's branch).
+#define NATINF_CG_NORM_PRE(I) asm volatile("" : "+v"(nv), "+v"(ns0), "+v"(ns1), "+v"(nh0), "+v"(nh1));
+#define NATINF_CG_NORM_EL(I)                                                                                                \
+        {                                                                                                                    \
+            const unsigned w_ = nv[(I) >> 1];                                                                                \
+            const float x_ = __uint_as_float(((I) & 1) ? (w_ & 0xffff0000u) : (w_ << 16));                                   \
+            const float t_ = x_ * __uint_as_float((I) < 4 ? ns0[(I) & 3] : ns1[(I) & 3]) + __uint_as_float((I) < 4 ? nh0[(I) & 3] : nh1[(I) & 3]); \
+            const float y_ = t_ * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t_));                                  \
+            if constexpr (((I) & 1) == 0) nf_even = y_;                                                                      \
+            else {                                                                                                           \
+                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));                                                 \
+                const bf16x2_t pr_ = {(bf16)nf_even, (bf16)y_};                                                              \
+                npk[(I) >> 1] = __builtin_bit_cast(unsigned, pr_);                                                           \
+            }                                                                                                                \
+        }                                                                                                                    \
+        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                                   \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       /* one MFMA */                                           \
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);       /* two vector instructions */                            \
+        }
+#define NATINF_CG_NORM_POST(I) if constexpr (((I) & 1) == 0) asm volatile("" : "+v"(nf_even)); else asm volatile("" : "+v"(npk[(I) >> 1]));
+    auto norm_store = [&]() __attribute__((always_inline)) {
+        u32x4 ou = {npk[0], npk[1], npk[2], npk[3]};
+        if ((int)npa >= 0) ou = u32x4{0u, 0u, 0u, 0u};
+        const unsigned pa = npa & 0x7fffffffu;
+        asm volatile("ds_write_b128 %0, %1" :: "v"(pa), "v"(ou) : "memory");
+    };
+    auto norm_round = [&](int j, int buf) __attribute__((always_inline)) {   // a whole slice at once (prologue)
+        norm_load(j, buf);
+        wait_lgkmcnt<0>();
+#define NATINF_CG_NORM_ONE(I) NATINF_CG_NORM_PRE(I) NATINF_CG_NORM_EL(I) NATINF_CG_NORM_POST(I) __builtin_amdgcn_sched_barrier(0);
+        NATINF_CG_NORM_ONE(0) NATINF_CG_NORM_ONE(1) NATINF_CG_NORM_ONE(2) NATINF_CG_NORM_ONE(3)
+        NATINF_CG_NORM_ONE(4) NATINF_CG_NORM_ONE(5) NATINF_CG_NORM_ONE(6) NATINF_CG_NORM_ONE(7)
+#undef NATINF_CG_NORM_ONE
+        norm_store();
+    };
+#define NATINF_CG_NO_PRE(I)
+#define NATINF_CG_NO_POST(I)
 #define NATINF_CG_NO_EL(I)
 
     // ---- fragment addresses: three per-lane bases (dx = -1, 0, +1) at dy = -1; everything else is an immediate ------------
@@ -260,10 +287,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
 #define NATINF_CG_STEP(a, AOFF, I, EL)                                                                                      \
         if constexpr ((I) + 2 < TM) fa[((I) + 2) % 3] = lds_read16<AOFF(((I) + 2) % TM)>(a);                                \
         wait_lgkmcnt<((I) + 2 < TM ? 2 : TM - 1 - (I))>();                                                                   \
+        EL##_PRE(I)                                                                                                          \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                       \
             acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[(I) % 3]), acc[I][j], 0, 0, 0); \
+        EL##_EL(I)                                                                                                           \
+        EL##_POST(I)                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
-        EL(I)                                                                                                                \
         post(std::integral_constant<int, (I)>{});
 #define NATINF_CG_HEAD(a, AOFF, bb, BOFF)                                                                                   \
         u32x4 fb[TN], fa[3];                                                                                                 \
@@ -303,28 +332,27 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
         // requests younger than weight tile kt: those of taps T-2 and T-1 (aux only at tap 0) + weight tile kt+1
         wait_tile((T == 1 || T == 2) ? aux0 : 0, kt + 1 < NT);
         NATINF_CG_STAMP(ts1)
-        // the requests of this step, behind MFMA groups 0, 1 (weight tile kt+2) and 2..7 (tap 0: table + patch of the next half-chunk,
-        // or the first shortcut tile): the order weight tile -> aux is what the vmcnt counts above assume
-        auto post = [&](auto i_tag) __attribute__((always_inline)) {
-            constexpr int I = decltype(i_tag)::value;
-            if constexpr (I < PB) { if (kt + 2 < NT) issue_b(kt + 2, I, I + 1); }
-            if constexpr (T == 0 && I >= 2) {
-                constexpr int A0 = I == 2 ? 0 : (I == 3 ? 2 : I);           // 8 patch items over 6 groups: 2, 2, 1, 1, 1, 1
-                constexpr int A1 = I == 2 ? 2 : (I == 3 ? 4 : I + 1);
-                static_assert(1 + PPW <= 8 && PSW <= 6, "tap-0 request schedule");
-                if (next_half) issue_patch(hc + 1, A0, A1 < 1 + PPW ? A1 : 1 + PPW);
-                else if (n_sc > 0) issue_shortcut(0, I - 2, I - 1);
-            }
-        };
-        // ring slot kt % 3 == T % 3 (9 taps per half-chunk).  The first six fragment reads go out before the normalisation slice
-        // that taps 3..8 carry for the next half-chunk (its DMA was waited for by the head of tap 3): their latency passes under
-        // its vector work.  No run-time branch may enclose the MFMAs: hipcc then keeps two copies of the 128 accumulator registers.
-        NATINF_CG_HEAD(a_dx[T % 3], NATINF_CG_AOFF, b_base, (T % 3) * Cfg::BT_BYTES)
-        if constexpr (T >= 3 && T - 3 < Cfg::NROUND && NATINF_CG_ABL != 1) {
-            if (next_half) norm_round(T - 3, BUF ^ 1);
+        // The requests of this step: weight tile kt+2 first, then the aux request -- the order the vmcnt counts above assume.
+        // (Measured and not kept, all within noise of this form: one piece behind each MFMA group; waves 0, 1 at the head of the
+        // tap and waves 2, 3 at its end -- the co-resident block already covers the issue cost of the LDS-DMA instructions.)
+        if (kt + 2 < NT) issue_b(kt + 2);
+        if constexpr (T == 0) {
+            if (next_half) issue_patch(hc + 1);
+            else if (n_sc > 0) issue_shortcut(0);
         }
+        auto post = [](auto) __attribute__((always_inline)) {};
+        constexpr bool NORM_TAP = T >= 3 && T - 3 < Cfg::NROUND && NATINF_CG_ABL != 1;
+        // the slice's five LDS reads go out FIRST (older than every fragment read: the counted waits of the steps cover them), its
+        // arithmetic comes after the last MFMA group: no LDS round trip is exposed, and nothing is held across the barrier
+        if constexpr (NORM_TAP) { if (next_half) norm_load(T - 3, BUF ^ 1); }
+        NATINF_CG_HEAD(a_dx[T % 3], NATINF_CG_AOFF, b_base, (T % 3) * Cfg::BT_BYTES)
         NATINF_CG_STAMP(ts2)
-        NATINF_CG_BODY(a_dx[T % 3], NATINF_CG_AOFF, NATINF_CG_NO_EL)
+        if constexpr (NORM_TAP) {
+            NATINF_CG_BODY(a_dx[T % 3], NATINF_CG_AOFF, NATINF_CG_NORM)
+            if (next_half) norm_store();
+        } else {
+            NATINF_CG_BODY(a_dx[T % 3], NATINF_CG_AOFF, NATINF_CG_NO)
+        }
         NATINF_CG_STAMP(ts3)
         NATINF_CG_ADD(dbg_wait, ts0, ts1) NATINF_CG_ADD(dbg_norm, ts1, ts2) NATINF_CG_ADD(dbg_mfma, ts2, ts3)
     };
@@ -355,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
         if (s + 1 < n_sc) issue_shortcut(s + 1);
         auto post = [](auto) __attribute__((always_inline)) {};
         const unsigned pa = a_plain + ((n_half + s) & 1) * Cfg::PATCH_BYTES, pb = b_base + (kt % NSB) * Cfg::BT_BYTES;
-        NATINF_CG_TILE(pa, NATINF_CG_POFF, pb, 0, NATINF_CG_NO_EL)
+        NATINF_CG_TILE(pa, NATINF_CG_POFF, pb, 0, NATINF_CG_NO)
     }
 #undef NATINF_CG_POFF
 #undef NATINF_CG_AOFF
@@ -364,6 +392,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
 #undef NATINF_CG_HEAD
 #undef NATINF_CG_BODY
 #undef NATINF_CG_NO_EL
+#undef NATINF_CG_NO_PRE
+#undef NATINF_CG_NO_POST
+#undef NATINF_CG_NORM_PRE
+#undef NATINF_CG_NORM_EL
+#undef NATINF_CG_NORM_POST
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done with the tiles before the epilogue reuses them
     // The epilogue's arguments (bias, row vector, residual, partial-sum table, ...) are fetched from the kernel-argument segment
     // HERE, through a pointer hipcc cannot see through: kept in scalar registers across the K loop they cost ~40 SGPRs, the

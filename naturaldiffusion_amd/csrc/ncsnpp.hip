@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <functional>
 #include <map>
 #include <string>
@@ -174,7 +175,15 @@ inline void launch_tiles(K kernel, const GemmArgs& g0, hipStream_t s) {
     const int nM = (g0.M + Cfg::BM_ - 1) / Cfg::BM_, nN = (g0.N + Cfg::BN_ - 1) / Cfg::BN_;
     GemmArgs g = g0;
     g.raster_g = (g_raster_g > 1 && nN >= 8 && nM >= g_raster_g) ? g_raster_g : 0;
-    hipLaunchKernelGGL(kernel, dim3(nM * nN, 1, g.batch), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, g);
+    int lds = Cfg::LDS_BYTES;
+#ifdef NATINF_DEV
+    static const int one_per_cu = getenv("NATINF_ONE_BLOCK_PER_CU") ? 1 : 0;      // occupancy experiment: ask for > 80 KB of LDS
+    if (one_per_cu && lds < 84000) {
+        lds = 84000;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
+#endif
+    hipLaunchKernelGGL(kernel, dim3(nM * nN, 1, g.batch), dim3(Cfg::THREADS), lds, s, g);
 }
 template <class Cfg, class K>
 inline bool set_lds(K kernel) {
@@ -242,7 +251,7 @@ int variant_bm(int v);
 // k_conv_gn instantiations: 32x32 and 16x16 images, 256 x 128 tiles; packed epilogues 1 / 2 / 5 / 6 only
 int packed_epi(const GemmArgs& g, int bm);
 inline bool conv_gn_ok(const GemmArgs& g) {
-    if (!g.gn_scale || !g.gn_shift || g.taps != 9 || g.batch != 1 || g.a0_C % BK || (g.a1 && g.a1_C % BK) || g.M % 256) return false;
+    if (!g.gn_scale || !g.gn_shift || !g.gn_folded || g.taps != 9 || g.batch != 1 || g.a0_C % BK || (g.a1 && g.a1_C % BK) || g.M % 256) return false;
     const int res = 1 << g.logW;
     if (g.logHW != 2 * g.logW || (res != 32 && res != 16) || g.N % 8) return false;
     const int e = packed_epi(g, 256);
@@ -431,12 +440,12 @@ struct Builder {
     int64_t take(int64_t n) { const int64_t o = poff; poff += n; return o; }
 
     // ---- weight packing recipes -------------------------------------------------------------
-    void pack_conv(int64_t src, int64_t dst, int N, int Cin, int taps, int dst_ld, int koff, int tapstride) {
+    void pack_conv(int64_t src, int64_t dst, int N, int Cin, int taps, int dst_ld, int koff, int tapstride, float wmul = 1.0f) {
         const int chunked = taps == 9 && Cin % BK == 0;      // every 3x3 conv except the 3-channel stem
         E.packs.push_back([=](const PackCtx& p) {
             const int64_t n = (int64_t)N * Cin * taps;
             hipLaunchKernelGGL(k_pack_conv, dim3(grid1d(n, 256, 1 << 30)), dim3(256), 0, p.stream, p.params + src,
-                               reinterpret_cast<bf16*>(p.packed + dst), N, Cin, taps, dst_ld, koff, tapstride, chunked);
+                               reinterpret_cast<bf16*>(p.packed + dst), N, Cin, taps, dst_ld, koff, tapstride, chunked, wmul);
         });
     }
     void pack_transpose(int64_t src, int64_t dst, int K, int N, int dst_ld) {
@@ -468,12 +477,12 @@ struct Builder {
     GN take_gn(int C) { GN g; g.gamma = pack_f32(take(C), C); g.beta = pack_f32(take(C), C); return g; }
 
     // GroupNorm statistics of x -> (scale, shift) per (image, channel); returns their arena offsets
-    void emit_gn_stats(const TRef& x, GN gn, int64_t sc, int64_t sh) {
-        if (emit_gn_from_parts(x, gn, sc, sh)) return;
+    void emit_gn_stats(const TRef& x, GN gn, int64_t sc, int64_t sh, float out_mul = 1.0f) {
+        if (emit_gn_from_parts(x, gn, sc, sh, out_mul)) return;
         const int HW = x.res * x.res;
         op(CLS_OTHER, [=](const Ctx& c) {
             hipLaunchKernelGGL(k_gn_stats, dim3(c.B), dim3(256), 0, c.stream, c.act(x), x.ld, x.C, HW,
-                               c.w<float>(gn.gamma), c.w<float>(gn.beta), c.at<float>(sc), c.at<float>(sh), GN_EPS);
+                               c.w<float>(gn.gamma), c.w<float>(gn.beta), c.at<float>(sc), c.at<float>(sh), GN_EPS, out_mul);
         });
     }
     void emit_gn_apply(const TRef& x, int64_t sc, int64_t sh, const TRef& y, const TRef* xr, int act, int mode) {
@@ -505,9 +514,14 @@ struct Builder {
         const int64_t p_c2w = shortcut ? take((int64_t)cout * cin) : -1, p_c2b = shortcut ? take(cout) : -1;
 
         const int K0a = 9 * cin, K1tot = 9 * cout + (shortcut ? cin : 0);
+        // GroupNorm-apply + SiLU inside the consuming convolution (conv_gn.h) where an instantiation exists: plain blocks at
+        // 32x32 and 16x16.  Resampling blocks and the 8x8 / 4x4 levels keep the k_gn_apply pass.  Folded form: the GroupNorm
+        // scale / shift carry -log2(e), the 3x3 weights -ln 2 (GemmArgs::gn_folded).
+        const bool fuse = g_fuse_gn && !m.up && !m.down && cin % BK == 0 && (ro == 32 || ro == 16);
+        const float gn_mul = fuse ? -1.4426950408889634f : 1.0f, w_mul = fuse ? -0.6931471805599453f : 1.0f;
         const int64_t w0 = wres((int64_t)cout * K0a * 2), w1 = wres((int64_t)cout * K1tot * 2);
-        pack_conv(p_c0w, w0, cout, cin, 9, K0a, 0, cin);
-        pack_conv(p_c1w, w1, cout, cout, 9, K1tot, 0, cout);
+        pack_conv(p_c0w, w0, cout, cin, 9, K0a, 0, cin, w_mul);
+        pack_conv(p_c1w, w1, cout, cout, 9, K1tot, 0, cout, w_mul);
         if (shortcut) pack_conv(p_c2w, w1, cout, cin, 1, K1tot, 9 * cout, cin);
         const int64_t b0 = pack_f32(p_c0b, cout), b1 = pack_f32(p_c1b, cout, shortcut ? p_c2b : -1);
         // time-embedding projection rows of this block inside the shared bank
@@ -517,10 +531,7 @@ struct Builder {
         dense_rows_next += cout;
 
         const int64_t sc = arena.alloc((int64_t)std::max(cin, cout) * 4), sh = arena.alloc((int64_t)std::max(cin, cout) * 4);
-        emit_gn_stats(x, gn0, sc, sh);
-        // GroupNorm-apply + SiLU inside the consuming convolution (conv_gn.h) where an instantiation exists: plain blocks at
-        // 32x32 and 16x16.  Resampling blocks and the 8x8 / 4x4 levels keep the k_gn_apply pass.
-        const bool fuse = g_fuse_gn && !m.up && !m.down && cin % BK == 0 && (ro == 32 || ro == 16);
+        emit_gn_stats(x, gn0, sc, sh, gn_mul);
         TRef h, xr;
         if (!fuse) {
             h = new_act(ro, cin, 1);
@@ -534,7 +545,7 @@ struct Builder {
         const int dtotal = dense_total; const int64_t dout = dense_out;
         op(CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
-            if (fuse) { g.a0 = c.act(x); g.a0_ld = x.ld; g.gn_scale = c.at<float>(sc); g.gn_shift = c.at<float>(sh); g.gn_ld = cin; }
+            if (fuse) { g.a0 = c.act(x); g.a0_ld = x.ld; g.gn_scale = c.at<float>(sc); g.gn_shift = c.at<float>(sh); g.gn_ld = cin; g.gn_folded = 1; }
             else { g.a0 = c.act(h); g.a0_ld = h.ld; g.a0_padded = 1; }
             g.a0_C = cin; g.taps = 9; g.logW = logW; g.logHW = logHW;
             g.M = c.B * HWo; g.N = cout; g.b = c.w<bf16>(w0); g.b_ld = K0a;
@@ -546,7 +557,7 @@ struct Builder {
             if (pt.valid) c.part_bm[pt.id] = bm;
         });
         if (!fuse) arena.release(h.off);
-        emit_gn_stats(t, gn1, sc, sh);
+        emit_gn_stats(t, gn1, sc, sh, gn_mul);
         TRef u;
         if (!fuse) {
             u = new_act(ro, cout, 1);
@@ -558,7 +569,7 @@ struct Builder {
         const Part po = register_output(out);
         op(CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
-            if (fuse) { g.a0 = c.act(t); g.a0_ld = t.ld; g.gn_scale = c.at<float>(sc); g.gn_shift = c.at<float>(sh); g.gn_ld = cout; }
+            if (fuse) { g.a0 = c.act(t); g.a0_ld = t.ld; g.gn_scale = c.at<float>(sc); g.gn_shift = c.at<float>(sh); g.gn_ld = cout; g.gn_folded = 1; }
             else { g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_padded = 1; }
             g.a0_C = cout; g.taps = 9; g.logW = logW; g.logHW = logHW;
             if (shortcut) { g.a1 = c.act(xs); g.a1_ld = xs.ld; g.a1_C = cin; }
@@ -684,7 +695,7 @@ struct Builder {
     // statistics of x from partial tables if every channel slice of x has a valid one; otherwise the streaming kernel.
     // (Folding the tables inside k_gn_apply instead of this one-block-per-sample launch was built and measured: bit-identical,
     // 1.6 % SLOWER per forward in a same-box A/B -- every 4-row apply block then starts with two dependent load round trips.)
-    bool emit_gn_from_parts(const TRef& x, GN gn, int64_t sc, int64_t sh) {
+    bool emit_gn_from_parts(const TRef& x, GN gn, int64_t sc, int64_t sh, float out_mul) {
         std::vector<Part> src;
         int ch = 0;
         while (ch < x.C) {
@@ -700,7 +711,7 @@ struct Builder {
             const int tps0 = HW / c.part_bm[p0.id], tps1 = p1.valid ? HW / c.part_bm[p1.id] : 0;
             hipLaunchKernelGGL(k_gn_finalize, dim3(c.B), dim3(256), 0, c.stream, c.at<float2>(p0.off), tps0, p0.quads,
                                p1.valid ? c.at<float2>(p1.off) : (const float2*)nullptr, tps1, p1.valid ? p1.quads : 0, C, HW,
-                               c.w<float>(gn.gamma), c.w<float>(gn.beta), c.at<float>(sc), c.at<float>(sh), GN_EPS);
+                               c.w<float>(gn.gamma), c.w<float>(gn.beta), c.at<float>(sc), c.at<float>(sh), GN_EPS, out_mul);
         });
         return true;
     }
@@ -1090,7 +1101,8 @@ int natinf_debug_gemm_fused(int variant, int M, int N, int K, const void* a, con
 //                + bias[n] + resid[m, n]) * out_scale,   zero padding outside the image (applied AFTER the activation).
 // x: raw bf16 [B][res][res][cin]; w_packed: bf16 [N][9*cin + c1] in the engine's K order ((c / 64) * 9 + tap) * 64 + c % 64, then
 // the c1 shortcut columns; a1: bf16 [B*res*res][c1] or NULL (c1 = 0); resid: bf16 [M][N] or NULL; gn_part: NULL or
-// [M / 256][N / 4] float2 partial (sum, sum of squares) of the outputs.
+// [M / 256][N / 4] float2 partial (sum, sum of squares) of the outputs.  The kernel takes its operands in FOLDED form
+// (GemmArgs::gn_folded): the caller passes scale * -log2(e), shift * -log2(e) and the 3x3 columns of w_packed * -ln 2.
 int natinf_debug_conv_gn(int res, int B, int N, int cin, int c1, const void* x, const float* scale, const float* shift, const void* w_packed,
                          const void* a1, const float* bias_n, const void* resid, float out_scale, void* out, float* gn_part, int iters,
                          natinf_stream_t stream) {
@@ -1100,7 +1112,7 @@ int natinf_debug_conv_gn(int res, int B, int N, int cin, int c1, const void* x, 
     if (!configured) { if (!configure_gemm_kernels()) return NATINF_ENODEV; configured = true; }
     GemmArgs g = gemm_defaults();
     g.a0 = (const bf16*)x; g.a0_ld = cin; g.a0_C = cin; g.taps = 9; g.logW = ilog2(res); g.logHW = 2 * g.logW;
-    g.gn_scale = scale; g.gn_shift = shift; g.gn_ld = cin;
+    g.gn_scale = scale; g.gn_shift = shift; g.gn_ld = cin; g.gn_folded = 1;
     if (a1) { g.a1 = (const bf16*)a1; g.a1_ld = c1; g.a1_C = c1; }
     g.M = B * res * res; g.N = N; g.b = (const bf16*)w_packed; g.b_ld = 9 * cin + c1; g.bias_n = bias_n;
     g.resid = (const bf16*)resid; g.resid_ld = N; g.scale = out_scale; g.c = out; g.c_ld = N;

@@ -67,7 +67,9 @@ struct GemmArgs {
     float* gn_part; int gn_quads;
     // fused GroupNorm-apply + SiLU of the INPUT (k_conv_gn, conv_gn.h): a0 is the RAW, unpadded [B][H][W][a0_ld] tensor and every
     // element is read as silu(a0 * gn_scale[b*gn_ld + c] + gn_shift[b*gn_ld + c]); a1 (1x1 shortcut segment) stays raw
-    const float* gn_scale; const float* gn_shift; int gn_ld;
+    // gn_folded: scale / shift arrive multiplied by -log2(e) and the 3x3 weights by -ln 2 (the kernel then computes t = x*scale + shift,
+    // t / (1 + exp2(t)) = -log2(e) * silu(v): two vector instructions per element fewer); 0: plain scale / shift / weights
+    const float* gn_scale; const float* gn_shift; int gn_ld; int gn_folded;
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
@@ -368,12 +370,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const GemmArgs g)
 // ------------------------------------------------------------------------------------------------
 // GroupNorm (32 groups, eps 1e-6): statistics pass -> per-(sample, channel) scale / shift
 // ------------------------------------------------------------------------------------------------
-// One 256-thread block per sample.  scale[b][c] = rstd*gamma[c], shift[b][c] = beta[c] - mean*scale.
+// One 256-thread block per sample.  scale[b][c] = rstd*gamma[c]*out_mul, shift[b][c] = (beta[c] - mean*rstd*gamma[c])*out_mul.
 // Deterministic: per-thread partial sums are parked in LDS and reduced in a fixed order (no atomics), so a
 // sample's statistics do not depend on timing, batch size or batch neighbours.
 __global__ __launch_bounds__(256) void k_gn_stats(const bf16* __restrict__ x, int ld, int C, int HW,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                  float* __restrict__ scale, float* __restrict__ shift, float eps)
+                                                  float* __restrict__ scale, float* __restrict__ shift, float eps, float out_mul)
 {
     __shared__ float s_part[2][16 * 128 + 64];     // [sum|sq][lane * C + c]; lanes*C <= 2048 for every C in use
     __shared__ float s_sum[512], s_sq[512], s_mean[32], s_rstd[32];
@@ -416,8 +418,9 @@ __global__ __launch_bounds__(256) void k_gn_stats(const bf16* __restrict__ x, in
     for (int c = tid; c < C; c += 256) {
         const int gi = c / cg;
         const float sc = s_rstd[gi] * gamma[c];
-        scale[(int64_t)b * C + c] = sc;
-        shift[(int64_t)b * C + c] = beta[c] - s_mean[gi] * sc;
+        // out_mul: 1, or -log2(e) when the consumer is k_conv_gn in folded form (it then gets exp(-v) = exp2(x*scale + shift) at once)
+        scale[(int64_t)b * C + c] = sc * out_mul;
+        shift[(int64_t)b * C + c] = (beta[c] - s_mean[gi] * sc) * out_mul;
     }
 }
 
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(const bf16* __restrict__ x, in
 __global__ __launch_bounds__(256) void k_gn_finalize(const float2* __restrict__ P0, int tps0, int quads0,
                                                      const float2* __restrict__ P1, int tps1, int quads1, int C, int HW,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* __restrict__ scale, float* __restrict__ shift, float eps)
+                                                     float* __restrict__ scale, float* __restrict__ shift, float eps, float out_mul)
 {
     __shared__ float s_s[128], s_q[128], s_mean[32], s_rstd[32];
     const int tid = threadIdx.x, b = blockIdx.x, nq = quads0 + quads1;
@@ -456,8 +459,9 @@ __global__ __launch_bounds__(256) void k_gn_finalize(const float2* __restrict__ 
     for (int c = tid; c < C; c += 256) {
         const int gi = c / cg;
         const float sc = s_rstd[gi] * gamma[c];
-        scale[(int64_t)b * C + c] = sc;
-        shift[(int64_t)b * C + c] = beta[c] - s_mean[gi] * sc;
+        // out_mul: 1, or -log2(e) when the consumer is k_conv_gn in folded form (it then gets exp(-v) = exp2(x*scale + shift) at once)
+        scale[(int64_t)b * C + c] = sc * out_mul;
+        shift[(int64_t)b * C + c] = (beta[c] - s_mean[gi] * sc) * out_mul;
     }
 }
 
@@ -647,13 +651,13 @@ __global__ __launch_bounds__(256) void k_stem_im2col(const float* __restrict__ x
 //   chunked = 1: k = ((c/64)*taps + tap)*64 + c%64              (3x3 convs: 64-channel chunk OUTER, tap INNER, so the
 //                nine shifted reads of one chunk are back to back in the K loop and hit L1/L2 instead of thrashing it)
 __global__ void k_pack_conv(const float* __restrict__ src, bf16* __restrict__ dst, int N, int Cin, int taps,
-                            int dst_ld, int koff, int tap_stride_c, int chunked)
+                            int dst_ld, int koff, int tap_stride_c, int chunked, float wmul)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)N * Cin * taps) return;
     const int tap = (int)(i % taps); const int64_t r = i / taps; const int c = (int)(r % Cin); const int n = (int)(r / Cin);
     const int k = chunked ? ((c >> 6) * taps + tap) * 64 + (c & 63) : tap * tap_stride_c + c;
-    dst[(int64_t)n * dst_ld + koff + k] = (bf16)src[i];
+    dst[(int64_t)n * dst_ld + koff + k] = (bf16)(src[i] * wmul);      // wmul: 1, or -ln 2 for the 3x3 weights of a folded k_conv_gn launch
 }
 // src [K][N] (NIN.W) -> dst[n*dst_ld + k]
 __global__ void k_pack_transpose(const float* __restrict__ src, bf16* __restrict__ dst, int K, int N, int dst_ld)

@@ -52,11 +52,14 @@ def test_conv_gn_matches_torch(res, B, cin, N, c1, resid, parts):
     ref = (ref * out_scale).float()
     # kernel
     dev = "cuda"
-    xd, wd = x.bfloat16().to(dev).contiguous(), _pack(w, w1).bfloat16().to(dev)
+    # the kernel's folded operand form: GroupNorm scale / shift times -log2(e), 3x3 weights times -ln 2 (GemmArgs::gn_folded)
+    LOG2E = 1.4426950408889634
+    wp = _pack(w * (-1.0 / LOG2E), w1)
+    xd, wd = x.bfloat16().to(dev).contiguous(), wp.bfloat16().to(dev)
     out = torch.empty(B * res * res, N, dtype=torch.bfloat16, device=dev)
     M = B * res * res
     part = torch.zeros(M // 256, N // 4, 2, device=dev) if parts else None
-    scd, shd, bd = scale.to(dev), shift.to(dev), bias.to(dev)           # (named: a temporary could be recycled before the launch runs)
+    scd, shd, bd = (scale * -LOG2E).to(dev), (shift * -LOG2E).to(dev), bias.to(dev)           # (named: a temporary could be recycled before the launch runs)
     a1d = a1.bfloat16().to(dev).contiguous() if c1 else None
     rd = r.bfloat16().to(dev) if resid else None
     check(lib.natinf_debug_conv_gn(res, B, N, cin, c1, ptr(xd), ptr(scd), ptr(shd), ptr(wd), ptr(a1d), ptr(bd), ptr(rd), out_scale,
