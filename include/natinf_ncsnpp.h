@@ -120,11 +120,12 @@ int natinf_debug_timestamps(void* dev_buf16);
 
 /* Measurement hooks (bench.py): while enabled, every launch group of a forward is bracketed by a HIP event
  * pair on `stream`.  natinf_ncsnpp_profile_read waits for the recorded events and returns, per class
- * (0 = the MFMA GEMM kernel k_gemm_bf16: all convolutions / NIN / linear / attention products;
- * 1 = everything else: GroupNorm statistics + apply, softmax, embedding, stem im2col), the summed
+ * (0 = the implicit-GEMM kernels k_gemm_*: unfused convolutions / NIN / linear / attention products;
+ * 1 = everything else: GroupNorm statistics + apply, softmax, embedding, stem im2col;
+ * 2 = k_conv_gn: the 3x3 convolutions with GroupNorm-apply + SiLU fused into their operand path), the summed
  * device time in milliseconds and the number of launches since the previous read. */
 int natinf_ncsnpp_profile(natinf_ncsnpp_t h, int enable);
-int natinf_ncsnpp_profile_read(natinf_ncsnpp_t h, double* ms_by_class /*[2]*/, int64_t* launches_by_class /*[2]*/);
+int natinf_ncsnpp_profile_read(natinf_ncsnpp_t h, double* ms_by_class /*[3]*/, int64_t* launches_by_class /*[3]*/);
 
 /* After a forward on a KEEP_ACTIVATIONS handle: copy the output of all_modules[module_idx]
  * (module_idx >= 2) as fp32 NCHW into `out` (capacity in elements).  Same B / workspace as the forward. */

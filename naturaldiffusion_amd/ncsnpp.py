@@ -156,11 +156,23 @@ class NCSNppEngine:
         check(lib.natinf_ncsnpp_profile(self._h, 1 if enable else 0), "natinf_ncsnpp_profile")
 
     def profile_read(self):
-        """-> {"gemm": (ms, launches), "other": (ms, launches)} since the last read (synchronises)."""
-        ms = (C.c_double * 2)()
-        n = (C.c_int64 * 2)()
+        """-> {"gemm": (ms, launches), "other": (...), "conv_gn": (...)} since the last read (synchronises)."""
+        ms = (C.c_double * 3)()
+        n = (C.c_int64 * 3)()
         check(lib.natinf_ncsnpp_profile_read(self._h, ms, n), "natinf_ncsnpp_profile_read")
-        return {"gemm": (ms[0], n[0]), "other": (ms[1], n[1])}
+        return {"gemm": (ms[0], n[0]), "other": (ms[1], n[1]), "conv_gn": (ms[2], n[2])}
+
+    def describe_gemms(self, B: int):
+        """[(M, N, K0, K1, taps, batch, "variant/eN")] of every matmul-shaped launch of a forward at batch B, in launch order."""
+        buf = C.create_string_buffer(1 << 16)
+        n = lib.natinf_ncsnpp_describe_gemms(self._h, B, buf, len(buf))
+        if n < 0:
+            check(n, "natinf_ncsnpp_describe_gemms")
+        rows = []
+        for line in buf.value.decode().strip().split("\n"):
+            f = line.split()
+            rows.append((*map(int, f[:6]), f[6]))
+        return rows
 
     def tap(self, module_idx: int, shape) -> torch.Tensor:
         out = torch.empty(shape, dtype=torch.float32, device=self.device)

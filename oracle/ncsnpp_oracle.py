@@ -158,82 +158,93 @@ def _down(x):
     return x.reshape(n, c, h // 2, 2, w // 2, 2).mean(dim=(3, 5))
 
 
-def res_block(x, temb, P, pre, m: Mod):
-    """layerspp.py:242-274."""
-    h = F.silu(_gn(x, P, pre + "GroupNorm_0"))
+def _same(t):
+    return t
+
+
+def bf16_round(t):
+    """operand-rounding model of the gfx950 engine: a value as it sits in a bf16 tensor / MFMA operand"""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def res_block(x, temb, P, pre, m: Mod, rnd=_same):
+    """layerspp.py:242-274.  ``rnd`` (default: identity) is applied to every matmul operand and stored activation: with
+    ``bf16_round`` the function models WHERE the engine rounds to bf16 (fp32 accumulation and statistics everywhere), which
+    separates operand rounding from every other difference between the engine and the fp32 reference."""
+    h = rnd(F.silu(_gn(x, P, pre + "GroupNorm_0")))
     if m.up:
         h, x = _up(h), _up(x)
     elif m.down:
-        h, x = _down(h), _down(x)
-    h = F.conv2d(h, P[pre + "Conv_0.weight"], P[pre + "Conv_0.bias"], padding=1)
-    h = h + F.linear(F.silu(temb), P[pre + "Dense_0.weight"], P[pre + "Dense_0.bias"])[:, :, None, None]
-    h = F.silu(_gn(h, P, pre + "GroupNorm_1"))
-    h = F.conv2d(h, P[pre + "Conv_1.weight"], P[pre + "Conv_1.bias"], padding=1)
+        h, x = rnd(_down(h)), rnd(_down(x))
+    h = F.conv2d(h, rnd(P[pre + "Conv_0.weight"]), P[pre + "Conv_0.bias"], padding=1)
+    h = rnd(h + F.linear(rnd(F.silu(temb)), rnd(P[pre + "Dense_0.weight"]), P[pre + "Dense_0.bias"])[:, :, None, None])
+    h = rnd(F.silu(_gn(h, P, pre + "GroupNorm_1")))
+    h = F.conv2d(h, rnd(P[pre + "Conv_1.weight"]), P[pre + "Conv_1.bias"], padding=1)
     if m.cin != m.cout or m.up or m.down:
-        x = F.conv2d(x, P[pre + "Conv_2.weight"], P[pre + "Conv_2.bias"])
-    return (x + h) / np.sqrt(2.0)
+        x = F.conv2d(x, rnd(P[pre + "Conv_2.weight"]), P[pre + "Conv_2.bias"])
+    return rnd((x + h) / np.sqrt(2.0))
 
 
-def attn_block(x, P, pre):
+def attn_block(x, P, pre, rnd=_same):
     """layerspp.py:75-91."""
     n, c, hh, ww = x.shape
-    h = _gn(x, P, pre + "GroupNorm_0")
+    h = rnd(_gn(x, P, pre + "GroupNorm_0"))
     tok = h.permute(0, 2, 3, 1).reshape(n, hh * ww, c)
-    nin = lambda t, i: t @ P[pre + f"NIN_{i}.W"] + P[pre + f"NIN_{i}.b"]
-    q, k, v = nin(tok, 0), nin(tok, 1), nin(tok, 2)
-    w = torch.softmax(torch.einsum("bqc,bkc->bqk", q, k) * (int(c) ** (-0.5)), dim=-1)
-    o = nin(torch.einsum("bqk,bkc->bqc", w, v), 3)
+    nin = lambda t, i: t @ rnd(P[pre + f"NIN_{i}.W"]) + P[pre + f"NIN_{i}.b"]
+    q, k, v = rnd(nin(tok, 0)), rnd(nin(tok, 1)), rnd(nin(tok, 2))
+    w = rnd(torch.softmax(torch.einsum("bqc,bkc->bqk", q, k) * (int(c) ** (-0.5)), dim=-1))
+    o = nin(rnd(torch.einsum("bqk,bkc->bqc", w, v)), 3)
     o = o.reshape(n, hh, ww, c).permute(0, 3, 1, 2)
-    return (x + o) / np.sqrt(2.0)
+    return rnd((x + o) / np.sqrt(2.0))
 
 
 @torch.no_grad()
 def forward(P: Dict[str, torch.Tensor], x: torch.Tensor, labels: torch.Tensor,
-            taps: Optional[Dict[int, torch.Tensor]] = None) -> torch.Tensor:
+            taps: Optional[Dict[int, torch.Tensor]] = None, rnd=_same) -> torch.Tensor:
     """ncsnpp.py:232-381 under the fixed configuration; ``taps`` (optional) receives the
-    output of every ``all_modules`` entry keyed by its index."""
+    output of every ``all_modules`` entry keyed by its index; ``rnd``: see ``res_block`` (identity = the reference)."""
     mods = plan()
     rec = (lambda i, t: taps.__setitem__(i, t)) if taps is not None else (lambda i, t: None)
     it = iter(mods)
-    m = next(it); temb = F.linear(timestep_embedding(labels), P[f"all_modules.{m.idx}.weight"], P[f"all_modules.{m.idx}.bias"]); rec(m.idx, temb)
-    m = next(it); temb = F.linear(F.silu(temb), P[f"all_modules.{m.idx}.weight"], P[f"all_modules.{m.idx}.bias"]); rec(m.idx, temb)
-    m = next(it); h = F.conv2d(x, P[f"all_modules.{m.idx}.weight"], P[f"all_modules.{m.idx}.bias"], padding=1); rec(m.idx, h)
+    m = next(it); temb = F.linear(rnd(timestep_embedding(labels)), rnd(P[f"all_modules.{m.idx}.weight"]), P[f"all_modules.{m.idx}.bias"]); rec(m.idx, temb)
+    m = next(it); temb = F.linear(rnd(F.silu(temb)), rnd(P[f"all_modules.{m.idx}.weight"]), P[f"all_modules.{m.idx}.bias"]); rec(m.idx, temb)
+    m = next(it); h = rnd(F.conv2d(rnd(x), rnd(P[f"all_modules.{m.idx}.weight"]), P[f"all_modules.{m.idx}.bias"], padding=1)); rec(m.idx, h)
     hs = [h]
     res = IMG
     for lvl in range(len(CH_MULT)):
         for _ in range(NUM_RES):
-            m = next(it); h = res_block(hs[-1], temb, P, f"all_modules.{m.idx}.", m); rec(m.idx, h)
+            m = next(it); h = res_block(hs[-1], temb, P, f"all_modules.{m.idx}.", m, rnd); rec(m.idx, h)
             if res in ATTN_RES:
-                m = next(it); h = attn_block(h, P, f"all_modules.{m.idx}."); rec(m.idx, h)
+                m = next(it); h = attn_block(h, P, f"all_modules.{m.idx}.", rnd); rec(m.idx, h)
             hs.append(h)
         if lvl != len(CH_MULT) - 1:
-            m = next(it); h = res_block(hs[-1], temb, P, f"all_modules.{m.idx}.", m); rec(m.idx, h)
+            m = next(it); h = res_block(hs[-1], temb, P, f"all_modules.{m.idx}.", m, rnd); rec(m.idx, h)
             res //= 2
             hs.append(h)
     h = hs[-1]
-    m = next(it); h = res_block(h, temb, P, f"all_modules.{m.idx}.", m); rec(m.idx, h)
-    m = next(it); h = attn_block(h, P, f"all_modules.{m.idx}."); rec(m.idx, h)
-    m = next(it); h = res_block(h, temb, P, f"all_modules.{m.idx}.", m); rec(m.idx, h)
+    m = next(it); h = res_block(h, temb, P, f"all_modules.{m.idx}.", m, rnd); rec(m.idx, h)
+    m = next(it); h = attn_block(h, P, f"all_modules.{m.idx}.", rnd); rec(m.idx, h)
+    m = next(it); h = res_block(h, temb, P, f"all_modules.{m.idx}.", m, rnd); rec(m.idx, h)
     for lvl in reversed(range(len(CH_MULT))):
         for _ in range(NUM_RES + 1):
-            m = next(it); h = res_block(torch.cat([h, hs.pop()], dim=1), temb, P, f"all_modules.{m.idx}.", m); rec(m.idx, h)
+            m = next(it); h = res_block(torch.cat([h, hs.pop()], dim=1), temb, P, f"all_modules.{m.idx}.", m, rnd); rec(m.idx, h)
         if res in ATTN_RES:
-            m = next(it); h = attn_block(h, P, f"all_modules.{m.idx}."); rec(m.idx, h)
+            m = next(it); h = attn_block(h, P, f"all_modules.{m.idx}.", rnd); rec(m.idx, h)
         if lvl != 0:
-            m = next(it); h = res_block(h, temb, P, f"all_modules.{m.idx}.", m); rec(m.idx, h)
+            m = next(it); h = res_block(h, temb, P, f"all_modules.{m.idx}.", m, rnd); rec(m.idx, h)
             res *= 2
     assert not hs
     m = next(it); h = F.group_norm(h, 32, P[f"all_modules.{m.idx}.weight"], P[f"all_modules.{m.idx}.bias"], eps=GN_EPS); rec(m.idx, h)
-    h = F.silu(h)
-    m = next(it); h = F.conv2d(h, P[f"all_modules.{m.idx}.weight"], P[f"all_modules.{m.idx}.bias"], padding=1); rec(m.idx, h)
+    h = rnd(F.silu(h))
+    m = next(it); h = F.conv2d(h, rnd(P[f"all_modules.{m.idx}.weight"]), P[f"all_modules.{m.idx}.bias"], padding=1); rec(m.idx, h)
     assert next(it, None) is None
     return h
 
 
-def model_fn_from_params(P: Dict[str, torch.Tensor]):
+def model_fn_from_params(P: Dict[str, torch.Tensor], rnd=_same):
     """``model_fn(x, labels)`` closure for the NI oracle (CPU fp32)."""
     def fn(x, labels):
-        return forward(P, x.detach().to("cpu", torch.float32), labels.detach().to("cpu", torch.float32)).to(x.device)
+        return forward(P, x.detach().to("cpu", torch.float32), labels.detach().to("cpu", torch.float32), rnd=rnd).to(x.device)
     return fn
 
 
