@@ -270,10 +270,15 @@ def main():
             d = (got - final64).abs()
             pg, pr = O.to_pixel(got).to(torch.int16), O.to_pixel(final64).to(torch.int16)
             pd = (pg - pr).abs()
-            line["accuracy"] = {"what": "final x of 15-step NI (step_15_weight_173), 64 images, HIP bf16 engine vs fp32 oracle, identical noise",
-                                "max_abs": round(float(d.max()), 5), "mean_abs": round(float(d.mean()), 6), "x_abs_max": round(float(final64.abs().max()), 3),
-                                "uint8_pixels_differing": round(float((pd > 0).float().mean()), 4), "uint8_max_diff": int(pd.max()),
-                                "uint8_mean_abs_diff": round(float(pd.float().mean()), 4), "fid": "blocked: checkpoint_8.pth / Inception weights / cifar10_mu_sigma.npz absent"}
+            rms = lambda t: float((t.double() ** 2).mean().sqrt())
+            line["accuracy"] = {"what": "final x of 15-step NI (step_15_weight_173), the 64 images of the cpu_baseline sample, HIP bf16 engine vs the fp32 "
+                                        "oracle on identical noise.  The synthetic network is not a denoiser (|x| reaches 1e3), so the numbers are relative; "
+                                        "tests/test_gpu_accuracy.py has the image-level figures with a well-conditioned denoiser (256 images: mean |dx| "
+                                        "0.0075, 0.67 uint8 steps per pixel) and shows the error equals that of an fp32-accumulate model with bf16 operands",
+                                "rel_rms": round(rms(got - final64) / rms(final64), 5), "rel_max": round(float(d.max() / final64.abs().max()), 5),
+                                "x_abs_max": round(float(final64.abs().max()), 1), "uint8_pixels_differing": round(float((pd > 0).float().mean()), 4),
+                                "uint8_mean_abs_diff": round(float(pd.float().mean()), 4),
+                                "fid": "blocked: checkpoint_8.pth / Inception weights / cifar10_mu_sigma.npz absent"}
 
     if rank == 0:
         print(json.dumps(line), flush=True)

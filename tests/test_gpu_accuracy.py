@@ -1,16 +1,19 @@
-"""Image-level accuracy of the bf16 gfx950 engine over a whole 15-step Natural Inference run (BASELINE config 2), as the
-stand-in for the FID-10k delta that is blocked on assets (checkpoint_8.pth, Inception weights, cifar10_mu_sigma.npz).
+"""Accuracy of the bf16 gfx950 engine over a whole 15-step Natural Inference run (BASELINE config 2), as the stand-in for the
+FID-10k delta that is blocked on assets (checkpoint_8.pth, Inception weights, cifar10_mu_sigma.npz are not in the image).
 
-256 images, ``weights/step_15_weight_173.npz``, identical noise on both sides:
+``weights/step_15_weight_173.npz``, identical noise on both sides:
   HIP path      NCSN++ engine (bf16 MFMA operands, fp32 accumulation / statistics) + natinf_step_f64hist
   fp32 oracle   oracle.ncsnpp_oracle (pinned to the reference nn.Module) + the reference's fp64 recurrence (ni_oracle)
-and, on a 32-image subset, the oracle run with its matmul operands and stored activations rounded to bf16
-(``ncsnpp_oracle.bf16_round``: fp32 accumulation, fp32 statistics -- an "fp32-accumulate-only" model of the engine): if the
-engine's distance from the fp32 oracle is operand rounding and nothing else, (i) that model sits as far from the fp32 oracle as
-the engine does, and (ii) the engine is much closer to the model than to the fp32 oracle... up to the chaotic part: two bf16
-computations that round at slightly different places decorrelate over 15 steps x 50 layers, so (ii) is asserted as "not
-farther", and (i) carries the claim.
-Thresholds (observed values are printed and written to gpurun_out/accuracy_r02.json)."""
+
+(A) the synthetic network as the denoiser, 64 images.  A random network is not a denoiser -- x0_hat = (x - sigma eps) / alpha is
+    amplified 160x at t ~ 1 and the samples reach |x| ~ 1e3 -- so the numbers that mean something are RELATIVE, and the comparison
+    with the oracle run under ``ncsnpp_oracle.bf16_round`` (operands and stored activations rounded to bf16, fp32 accumulation and
+    statistics: an "fp32-accumulate-only" model of the engine): the engine must sit as far from the fp32 oracle as that model
+    does -- its error is operand rounding and nothing else.
+(B) a well-conditioned denoiser, 256 images: eps_hat = analytic VP denoiser + g(t) * network, g(t) = 0.25 alpha(t) / sigma(t), i.e.
+    x0_hat = (analytic x0) - 0.25 * network -- the network contributes a bounded "texture" to every x0_hat, as a trained one does, and
+    its bf16 error enters every step.  Here the image-level numbers (uint8 pixels) are meaningful.
+Observed values are printed and written to gpurun_out/accuracy_r02.json; thresholds are ~2x the observed ones."""
 import json
 import os
 
@@ -21,7 +24,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_fifteen_step_samples_match_the_fp32_oracle_at_image_level(repo_root):
+def _stats(a, b, O):
+    d = (a - b).abs()
+    pd = (O.to_pixel(a).to(torch.int16) - O.to_pixel(b).to(torch.int16)).abs()
+    return dict(max_abs=float(d.max()), mean_abs=float(d.mean()), rms=float((d ** 2).mean().sqrt()),
+                rel_rms=float((d ** 2).mean().sqrt() / (b ** 2).mean().sqrt()), rel_max=float(d.max() / b.abs().max()),
+                px_frac=float((pd > 0).float().mean()), px_max=int(pd.max()), px_mean=float(pd.float().mean()),
+                px_gt1=float((pd > 1).float().mean()), px_gt2=float((pd > 2).float().mean()))
+
+
+def test_fifteen_step_samples_match_the_fp32_oracle(repo_root):
     from oracle import ni_oracle as O, ncsnpp_oracle as N
     from naturaldiffusion_amd.coeff import load_coeff_npz
     from naturaldiffusion_amd.ncsnpp import NCSNppEngine
@@ -29,40 +41,53 @@ def test_fifteen_step_samples_match_the_fp32_oracle_at_image_level(repo_root):
     from naturaldiffusion_amd.synth import synthetic_flat_params, synthetic_state_dict
     dev = torch.device("cuda:0")
     C, B, node = load_coeff_npz(repo_root / "weights" / "step_15_weight_173.npz")
-    n_img, n_sub = 256, 32
-    z = torch.randn(n_img, 3, 32, 32, generator=torch.Generator().manual_seed(888))
-    eng = NCSNppEngine(synthetic_flat_params(0), max_batch=n_img, device=dev)
-    got = CifarNI(C, B, node, n_img * 3 * 32 * 32, device=dev).run(eng, z.to(dev)).cpu()
-    assert torch.isfinite(got).all()
+    nA, nAm, nB = 64, 32, 256
+    z = torch.randn(nB, 3, 32, 32, generator=torch.Generator().manual_seed(888))
+    eng = NCSNppEngine(synthetic_flat_params(0), max_batch=nB, device=dev)
+    P = synthetic_state_dict(0)
+    net32, netbf = N.model_fn_from_params(P), N.model_fn_from_params(P, rnd=N.bf16_round)
+    ana = O.analytic_vp_model()
+
+    def g_of(labels):                                        # 0.25 alpha / sigma of the VP schedule (sde_lib.py:141-145), per sample
+        t = labels.detach().to("cpu", torch.float64) / 999
+        lm = -0.25 * t * t * (20.0 - 0.1) - 0.5 * t * 0.1
+        return (0.25 * torch.exp(lm) / torch.sqrt(1 - torch.exp(2 * lm))).to(torch.float32)[:, None, None, None]
+
+    def hybrid(net):
+        def fn(x, labels):
+            out = ana(x, labels).to("cpu") + g_of(labels) * net(x, labels).to("cpu", torch.float32)
+            return out.to(x.device)
+        return fn
+    run_gpu = lambda model, zz: CifarNI(C, B, node, zz.numel(), device=dev).run(model, zz.to(dev)).cpu()
+    gotA = run_gpu(eng, z[:nA])
+    gotB = run_gpu(hybrid(eng), z)
+    assert torch.isfinite(gotA).all() and torch.isfinite(gotB).all()
 
     saved = torch.get_num_threads()
-    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))           # the oracle at 256 images: ~2 minutes at 32 threads
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))           # the fp32 oracle at 256 images: ~2 minutes at 32 threads
     try:
-        P = synthetic_state_dict(0)
-        ref = O.cifar_ni_trajectory(N.model_fn_from_params(P), z, C, B, node)[-1]
-        mod = O.cifar_ni_trajectory(N.model_fn_from_params(P, rnd=N.bf16_round), z[:n_sub], C, B, node)[-1]
+        refA = O.cifar_ni_trajectory(net32, z[:nA], C, B, node)[-1]
+        modA = O.cifar_ni_trajectory(netbf, z[:nAm], C, B, node)[-1]
+        refB = O.cifar_ni_trajectory(hybrid(net32), z, C, B, node)[-1]
     finally:
         torch.set_num_threads(saved)
-
-    def stats(a, b):
-        d = (a - b).abs()
-        pa, pb = O.to_pixel(a).to(torch.int16), O.to_pixel(b).to(torch.int16)
-        pd = (pa - pb).abs()
-        return dict(max_abs=float(d.max()), mean_abs=float(d.mean()), rms=float((d ** 2).mean().sqrt()),
-                    px_frac=float((pd > 0).float().mean()), px_max=int(pd.max()), px_mean=float(pd.float().mean()),
-                    px_gt2=float((pd > 2).float().mean()))
-    rep = {"images": n_img, "x_abs_max": float(ref.abs().max()), "x_rms": float((ref ** 2).mean().sqrt()),
-           "engine_vs_fp32": stats(got, ref), "engine_vs_fp32_subset": stats(got[:n_sub], ref[:n_sub]),
-           "bf16_operand_model_vs_fp32": stats(mod, ref[:n_sub]), "engine_vs_bf16_operand_model": stats(got[:n_sub], mod)}
+    rep = {"A_images": nA, "A_x_abs_max": float(refA.abs().max()), "A_x_rms": float((refA ** 2).mean().sqrt()),
+           "A_engine_vs_fp32": _stats(gotA, refA, O), "A_engine_vs_fp32_subset": _stats(gotA[:nAm], refA[:nAm], O),
+           "A_bf16_operand_model_vs_fp32": _stats(modA, refA[:nAm], O), "A_engine_vs_bf16_operand_model": _stats(gotA[:nAm], modA, O),
+           "B_images": nB, "B_x_abs_max": float(refB.abs().max()), "B_x_rms": float((refB ** 2).mean().sqrt()),
+           "B_pixels_saturated": float(((refB <= -1) | (refB >= 1)).float().mean()), "B_engine_vs_fp32": _stats(gotB, refB, O)}
     os.makedirs(repo_root / "gpurun_out", exist_ok=True)
     (repo_root / "gpurun_out" / "accuracy_r02.json").write_text(json.dumps(rep, indent=1))
     print(json.dumps(rep))
-    e, m, em = rep["engine_vs_fp32"], rep["bf16_operand_model_vs_fp32"], rep["engine_vs_bf16_operand_model"]
-    # image level: the samples are the same images.  x lives in about [-1.3, 1.3]; one uint8 step is 2/255 = 0.0078
-    assert e["mean_abs"] <= 0.02 and e["rms"] <= 0.03, e
-    assert e["max_abs"] <= 0.5, e
-    assert e["px_mean"] <= 2.5 and e["px_gt2"] <= 0.25, e                  # mean pixel difference in uint8 steps; share of pixels off by > 2
-    # operand rounding accounts for it: the fp32-accumulate model with bf16 operands is as far from fp32 as the engine is
-    es = rep["engine_vs_fp32_subset"]
-    assert 0.4 * m["rms"] <= es["rms"] <= 2.5 * m["rms"], (es, m)
-    assert em["rms"] <= 1.6 * max(es["rms"], m["rms"]), (em, es, m)
+    # (A) relative error of the samples, and: the engine's error IS operand rounding
+    e, es, m, em = rep["A_engine_vs_fp32"], rep["A_engine_vs_fp32_subset"], rep["A_bf16_operand_model_vs_fp32"], rep["A_engine_vs_bf16_operand_model"]
+    assert e["rel_rms"] <= 1.5e-2 and e["rel_max"] <= 3e-2, e
+    assert 0.6 * m["rms"] <= es["rms"] <= 1.6 * m["rms"], (es, m)
+    assert em["rms"] <= 1.6 * max(es["rms"], m["rms"]), (em, es, m)        # two bf16 computations: at most sqrt(2) apart, plus slack
+    # (B) image level: x in about [-1, 1], one uint8 step = 2/255 = 0.0078
+    b = rep["B_engine_vs_fp32"]
+    assert rep["B_pixels_saturated"] <= 0.5                                 # the images are not clipped flat: the pixel statistics mean something
+    # observed: mean |dx| 0.0075 (one uint8 step), rms 0.011, a handful of outliers up to 0.58; 46 % of the uint8 pixels differ,
+    # by 0.67 steps on average, 14 % by more than one step, 4 % by more than two
+    assert b["mean_abs"] <= 1.5e-2 and b["rms"] <= 2.5e-2 and b["max_abs"] <= 1.2, b
+    assert b["px_mean"] <= 1.5 and b["px_gt1"] <= 0.3 and b["px_gt2"] <= 0.10, b
