@@ -353,6 +353,76 @@ def bench_sd3(args, world, rank, dev):
                                    + "ni_step fp16 chain", "nfe": 2 * nstep, "images_per_gpu": n, "sharding": f"batch-sharded x{world}, no collective"},
             "roofline": {"kernel": "whole forward (k_gemm_dma / k_gemm_fp8 + k_flash_attn64), 2*MAC flops / wall time; peak = dense bf16", "bound": "mfma", "achieved": round(tf, 1),
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}}
+    if rank == 0 and not args.no_roofline:
+        # ---- per-kernel rooflines, measured live with HIP events on the kernels' own ABI entry points at the engine's shapes
+        # ---- (the engine has no per-launch hook; these are the same kernels, same shapes, same process)
+        from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+
+        def timed(fn, iters=5):
+            fn(); torch.cuda.synchronize()
+            a, b = ev(), ev()
+            a.record()
+            for _ in range(iters):
+                fn()
+            b.record(); torch.cuda.synchronize()
+            return a.elapsed_time(b) / iters * 1e-3
+        Bs, H, Tp = 2 * n, 24, (T + 127) // 128 * 128
+        q = torch.randn(Bs, Tp, 2 * D, device=dev).bfloat16()
+        vT = torch.randn(Bs, D, Tp, device=dev).bfloat16()
+        o = torch.empty(Bs, Tp, D, device=dev, dtype=torch.bfloat16)
+        t_fa = timed(lambda: check(lib.natinf_attention_hd64_bf16(ptr(q), ptr(q) + 2 * D, 2 * D, Tp * 2 * D, ptr(vT), ptr(o), D, Tp * D, Bs, H, Tp, T, 0.125,
+                                                                   stream_ptr()), "attention"))
+        fa_flops = 4.0 * T * T * 64 * H * Bs
+        line["roofline"] = {"kernel": "k_flash_attn64 (joint attention, 8 sequences x 24 heads x 4,429 keys, head_dim 64)", "bound": "mfma",
+                            "achieved": round(fa_flops / t_fa / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(fa_flops / t_fa / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                            "mean_launch_ms": round(t_fa * 1e3, 4), "flops_per_launch": fa_flops, "launches_per_image_batch": L * nstep,
+                            "share_of_forward_flops": round(L * fa_flops / (flops_fwd_seq * Bs), 3)}
+        M = Bs * tx
+        shapes = [("q|k", 2 * D, D), ("v^T / out", D, D), ("fc1", 4 * D, D), ("fc2", D, 4 * D)]
+        tot_t, tot_f, per = 0.0, 0.0, {}
+        for name, N_, K_ in shapes:
+            if args.fp8 and name != "v^T / out":
+                a8 = torch.randint(0, 255, (M, K_), device=dev, dtype=torch.uint8); b8 = torch.randint(0, 255, (N_, K_), device=dev, dtype=torch.uint8)
+                a8 &= 0x77; b8 &= 0x77                                                 # finite e4m3 patterns
+                sa, sb = torch.ones(M, device=dev), torch.ones(N_, device=dev)
+                c = torch.empty(M, N_, device=dev, dtype=torch.bfloat16)
+                t_ = timed(lambda: check(lib.natinf_debug_gemm_fp8(M, N_, K_, ptr(a8), ptr(sa), None, ptr(b8), ptr(sb), None, ptr(c), None, 0, 1, stream_ptr()), "gemm_fp8"))
+                kind = "fp8"
+            else:
+                a = torch.randn(M, K_, device=dev).bfloat16(); b = torch.randn(N_, K_, device=dev).bfloat16()
+                c = torch.empty(M, N_, device=dev, dtype=torch.bfloat16)
+                t_ = timed(lambda: check(lib.natinf_debug_gemm(0, M, N_, K_, 0, 1, 0, 1, ptr(a), None, ptr(b), None, ptr(c), 0, 1.0, 1, stream_ptr()), "gemm"))
+                kind = "bf16"
+            f_ = 2.0 * M * N_ * K_
+            per[name] = {"M": M, "N": N_, "K": K_, "operands": kind, "ms": round(t_ * 1e3, 4), "TFLOP/s": round(f_ / t_ / 1e12, 1)}
+            tot_t += t_; tot_f += f_
+        peak_g = 5000.0 if args.fp8 else MFMA_BF16_PEAK_TFLOPS
+        line["roofline_gemm"] = {"kernel": ("k_gemm_fp8 (image-stream q|k, fc1, fc2: e4m3 operands, v_mfma_f32_16x16x128_f8f6f4) + k_gemm_dma (bf16)" if args.fp8
+                                            else "k_gemm_dma<2,4,8,4> 256x256 LDS-DMA tiles") + ", image-stream projections of one block",
+                                 "bound": "mfma", "achieved": round(tot_f / tot_t / 1e12, 1), "peak": peak_g, "unit": "TFLOP/s",
+                                 "frac": round(tot_f / tot_t / 1e12 / peak_g, 4), "traffic": None, "shapes": per}
+        line["roofline_whole_forward"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "note": "2*MAC flops of all matmuls / wall time of the bench (dense bf16 peak)"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # ---- CPU baseline: the MMDiT oracle (fp32, eager PyTorch) on ONE sequence through TWO blocks at full width, extrapolated to the
+        # ---- 24 blocks x 2 sequences (CFG) x 28 steps of an image -- a full forward on the CPU would take minutes
+        from oracle import mmdit_oracle as MO
+        threads = max(1, min(32, torch.get_num_threads()))
+        torch.set_num_threads(threads)
+        cfgo = dict(layers=2, heads=24, joint_dim=4096, pooled_dim=2048)
+        Po = MO.make_params(seed=1, pos_max=64, pos_base=64, **cfgo)
+        gg = torch.Generator().manual_seed(3)
+        xo, to_ = torch.randn(1, 16, 128, 128, generator=gg), torch.tensor([500.0])
+        eo, po = torch.randn(1, tc, 4096, generator=gg), torch.randn(1, 2048, generator=gg)
+        tcpu = time.perf_counter()
+        MO.forward(Po, xo, to_, eo, po)
+        d2 = time.perf_counter() - tcpu
+        per_image_s = d2 / 2 * L * 2 * nstep
+        line["cpu_baseline"] = {"value": round(1.0 / per_image_s, 6), "unit": "images/s", "cores": threads, "kind": "port",
+                                "sample": f"oracle/mmdit_oracle.py (fp32): one sequence (4096+333 tokens) through 2 of the 24 blocks in {d2:.1f} s, "
+                                          f"extrapolated x{L // 2} blocks x 2 sequences (CFG) x {nstep} steps = {per_image_s:.0f} s per image; host has {os.cpu_count()} logical CPUs"}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -94,7 +94,8 @@ int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_sc
  *                + bias_n[n] + resid[m, n]) * out_scale,  zero padding applied after the activation (layerspp.py:242-274).
  * x: bf16 [B][res][res][cin] (res 32 or 16, cin % 64 == 0); w_packed: bf16 [N][9*cin + c1], K order ((c/64)*9 + tap)*64 + c%64
  * followed by the c1 shortcut columns; a1: bf16 [B*res*res][c1] or NULL; resid: bf16 [M][N] or NULL; out: bf16 [M][N];
- * gn_part: NULL or [M/256][N/4] (sum, sum of squares) of the fp32 outputs per 256-pixel tile and 4-channel quad.
+ * gn_part: NULL or [M/rows][N/4] (sum, sum of squares) of the fp32 outputs per pixel tile and 4-channel quad; rows = 128 for
+ * 16x16 images with N % 256 == 0 (unless natinf_set_conv_gn_wide(0)), else 256.
  * Operands are taken in the kernel's FOLDED form: `scale` and `shift` must be the GroupNorm scale / shift multiplied by -log2(e)
  * and the 3x3 columns of w_packed multiplied by -ln 2 (the shortcut columns are plain); the kernel evaluates t / (1 + exp2(t)),
  * t = x*scale + shift = -log2(e) v, i.e. -log2(e) silu(v) -- the same function with two vector instructions fewer per element. */
@@ -113,6 +114,8 @@ int natinf_set_gemm_raster(int rows);
 /* 1 (default): plans built from now on run GroupNorm-apply + SiLU inside the consuming 3x3 convolution where a fused kernel
  * exists (32x32 and 16x16 levels); 0: the separate normalisation pass everywhere (A/B runs, tests).  Read by natinf_ncsnpp_create. */
 int natinf_set_fuse_gn(int on);
+/* 1 (default): k_conv_gn launches on 16x16 images with N % 256 == 0 use the 128-pixel x 256-channel tile; 0: 256 x 128 everywhere. */
+int natinf_set_conv_gn_wide(int on);
 /* Timing experiments (tools/tile_timeline.py): device buffer of 16 uint64 shader-clock stamps that block 0 / thread 0 of
  * every natinf_debug_gemm launch writes (kernel start, first tile landed, main loop done, per epilogue pass: slab written,
  * sweeps done, stores issued).  NULL switches it off. */

@@ -32,16 +32,21 @@
 namespace ncsn {
 
 template <int RES> struct PatchGeo;
-template <> struct PatchGeo<32> { static constexpr int W = 32, WP = 34, WS = 40, PR = 10; };
-template <> struct PatchGeo<16> { static constexpr int W = 16, WP = 18, WS = 24, PR = 18; };
+template <> struct PatchGeo<32> { static constexpr int W = 32, WP = 34, WS = 40; };
+template <> struct PatchGeo<16> { static constexpr int W = 16, WP = 18, WS = 24; };
 
-template <int RES>
+// WIDE = false: block tile 256 pixels x 128 channels (wave tile 128 x 64: A row-tiles stream past four resident weight fragments);
+// WIDE = true:  block tile 128 pixels x 256 channels (wave tile 64 x 128: weight col-tiles stream past four resident A fragments) --
+//               for N = 256 layers: the patch, hence the normalisation work, per MFMA is 0.55x that of two 256 x 128 tiles.
+template <int RES, bool WIDE_ = false>
 struct ConvGnCfg {
     using Geo = PatchGeo<RES>;
-    static constexpr int WM = 2, WN = 2, TM = 8, TN = 4, NW = 4, THREADS = 256, NSB = 3, KT = 32;
-    static constexpr int BM_ = 256, BN_ = 128;
-    static constexpr int PPIX = Geo::PR * Geo::WS;                      // patch rows in LDS (pad columns included)
-    static constexpr int NREAL = Geo::PR * Geo::WP;                     // pixels that are ever read
+    static constexpr bool WIDE = WIDE_;
+    static constexpr int WM = 2, WN = 2, TM = WIDE ? 4 : 8, TN = WIDE ? 8 : 4, NW = 4, THREADS = 256, NSB = 3, KT = 32;
+    static constexpr int BM_ = WM * TM * 16, BN_ = WN * TN * 16;
+    static constexpr int PR = BM_ / Geo::W + 2;                         // image rows of a tile + the halo rows
+    static constexpr int PPIX = PR * Geo::WS;                           // patch rows in LDS (pad columns included)
+    static constexpr int NREAL = PR * Geo::WP;                          // pixels that are ever read
     static constexpr int NPIECE = (PPIX + 15) / 16;                     // 1-KiB DMA pieces (16 patch rows of 64 B)
     static constexpr int PPW = (NPIECE + NW - 1) / NW;                  // per wave (the tail repeats the last piece)
     static constexpr int PSW = BM_ / 16 / NW;                           // shortcut-tile pieces per wave
@@ -81,10 +86,10 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm_barrier() {
 }
 
 // EPI: the packed epilogues of gemm_dma.h (1 plain, 2 + GroupNorm partials, 5 + bf16 residual, 6 both)
-template <int RES, int EPI>
+template <int RES, bool WIDE, int EPI>
 __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
 {
-    using Cfg = ConvGnCfg<RES>;
+    using Cfg = ConvGnCfg<RES, WIDE>;
     using Geo = typename Cfg::Geo;
     constexpr int BM_ = Cfg::BM_, BN_ = Cfg::BN_, NW = Cfg::NW, THREADS = Cfg::THREADS, TM = Cfg::TM, TN = Cfg::TN, NSB = Cfg::NSB, KT = Cfg::KT;
     constexpr int W = Geo::W, WP = Geo::WP, WS = Geo::WS, HW = RES * RES;
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
     const int frow = lane & 15, fq = lane >> 4;
     unsigned a_dx[3];
     {
-        const int ml = wm * 128 + frow;                                   // first pixel row-tile of this wave
+        const int ml = wm * (TM * 16) + frow;                             // first pixel row-tile of this wave
         const int pc = ((ml / W) + 1) * WS + (ml % W) + 1;                // its patch row at the centre tap
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
@@ -268,9 +273,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
             a_dx[d] = lds_patch + pp * 64 + ((fq ^ ((pp >> 1) & 2)) << 4);
         }
     }
-    const int brow = wn * 64 + frow;
+    const int brow = wn * (TN * 16) + frow;
     const unsigned b_base = lds_b + brow * 64 + ((fq ^ ((brow >> 1) & 2)) << 4);
-    const int arow = wm * 128 + frow;
+    const int arow = wm * (TM * 16) + frow;
     const unsigned a_plain = lds_patch + arow * 64 + ((fq ^ ((arow >> 1) & 2)) << 4);
 
     f32x4 acc[TM][TN];
@@ -279,30 +284,42 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // One 32-wide K-tile with a hand-counted fragment pipeline: the four weight fragments and A row-tiles 0, 1 are requested
-    // up front, row-tile i+2 while row-tile i is multiplied; `s_waitcnt lgkmcnt(n)` retires exactly the fragment the next
+    // One 32-wide K-tile with a hand-counted fragment pipeline: the four resident fragments (weights; WIDE: A row-tiles) and streamed
+    // fragments 0, 1 (A row-tiles; WIDE: weight col-tiles) are requested up front, streamed fragment s+2 while s is multiplied; `s_waitcnt lgkmcnt(n)` retires exactly the fragment the next
     // four MFMAs need (LDS returns in order; the five reads of a normalisation slice are older than all of them),
     // sched_barrier(0) keeps each MFMA group behind its wait (guide 5.4 rule 18).  EL(i): the vector work placed behind MFMA
     // group i.  AOFF(i): byte offset of row-tile i from `a` (compile time); BOFF: of the ring slot from `bb`.
-#define NATINF_CG_STEP(a, AOFF, I, EL)                                                                                      \
-        if constexpr ((I) + 2 < TM) fa[((I) + 2) % 3] = lds_read16<AOFF(((I) + 2) % TM)>(a);                                \
-        wait_lgkmcnt<((I) + 2 < TM ? 2 : TM - 1 - (I))>();                                                                   \
-        EL##_PRE(I)                                                                                                          \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                       \
-            acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[(I) % 3]), acc[I][j], 0, 0, 0); \
-        EL##_EL(I)                                                                                                           \
-        EL##_POST(I)                                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                                   \
-        post(std::integral_constant<int, (I)>{});
+    // Step S of eight: the streamed fragment S+2 is requested, fragment S retired, and it meets the four resident ones.
+#define NATINF_CG_STEP(a, AOFF, bb, BOFF, S, EL)                                                                            \
+        if constexpr ((S) + 2 < 8) {                                                                                         \
+            if constexpr (WIDE) fs[((S) + 2) % 3] = lds_read16<(BOFF) + (((S) + 2) % 8) * 1024>(bb);                         \
+            else fs[((S) + 2) % 3] = lds_read16<AOFF(((S) + 2) % 8)>(a);                                                     \
+        }                                                                                                                    \
+        wait_lgkmcnt<((S) + 2 < 8 ? 2 : 7 - (S))>();                                                                          \
+        EL##_PRE(S)                                                                                                          \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                                                   \
+            if constexpr (WIDE) acc[r_][S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fs[(S) % 3]), __builtin_bit_cast(bf16x8, fr[r_]), acc[r_][S], 0, 0, 0); \
+            else acc[S][r_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[r_]), __builtin_bit_cast(bf16x8, fs[(S) % 3]), acc[S][r_], 0, 0, 0); \
+        }                                                                                                                    \
+        EL##_EL(S)                                                                                                           \
+        EL##_POST(S)                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);
 #define NATINF_CG_HEAD(a, AOFF, bb, BOFF)                                                                                   \
-        u32x4 fb[TN], fa[3];                                                                                                 \
-        fb[0] = lds_read16<(BOFF)>(bb); fb[1] = lds_read16<(BOFF) + 1024>(bb);                                               \
-        fb[2] = lds_read16<(BOFF) + 2048>(bb); fb[3] = lds_read16<(BOFF) + 3072>(bb);                                        \
-        fa[0] = lds_read16<AOFF(0)>(a); fa[1] = lds_read16<AOFF(1)>(a);
-#define NATINF_CG_BODY(a, AOFF, EL)                                                                                         \
-        NATINF_CG_STEP(a, AOFF, 0, EL) NATINF_CG_STEP(a, AOFF, 1, EL) NATINF_CG_STEP(a, AOFF, 2, EL) NATINF_CG_STEP(a, AOFF, 3, EL) \
-        NATINF_CG_STEP(a, AOFF, 4, EL) NATINF_CG_STEP(a, AOFF, 5, EL) NATINF_CG_STEP(a, AOFF, 6, EL) NATINF_CG_STEP(a, AOFF, 7, EL)
-#define NATINF_CG_TILE(a, AOFF, bb, BOFF, EL) { NATINF_CG_HEAD(a, AOFF, bb, BOFF) NATINF_CG_BODY(a, AOFF, EL) }
+        u32x4 fr[4], fs[3];                                                                                                  \
+        if constexpr (WIDE) {                                                                                                \
+            fr[0] = lds_read16<AOFF(0)>(a); fr[1] = lds_read16<AOFF(1)>(a); fr[2] = lds_read16<AOFF(2)>(a); fr[3] = lds_read16<AOFF(3)>(a); \
+            fs[0] = lds_read16<(BOFF)>(bb); fs[1] = lds_read16<(BOFF) + 1024>(bb);                                           \
+        } else {                                                                                                             \
+            fr[0] = lds_read16<(BOFF)>(bb); fr[1] = lds_read16<(BOFF) + 1024>(bb);                                           \
+            fr[2] = lds_read16<(BOFF) + 2048>(bb); fr[3] = lds_read16<(BOFF) + 3072>(bb);                                    \
+            fs[0] = lds_read16<AOFF(0)>(a); fs[1] = lds_read16<AOFF(1)>(a);                                                  \
+        }
+#define NATINF_CG_BODY(a, AOFF, bb, BOFF, EL)                                                                               \
+        NATINF_CG_STEP(a, AOFF, bb, BOFF, 0, EL) NATINF_CG_STEP(a, AOFF, bb, BOFF, 1, EL) NATINF_CG_STEP(a, AOFF, bb, BOFF, 2, EL) \
+        NATINF_CG_STEP(a, AOFF, bb, BOFF, 3, EL) NATINF_CG_STEP(a, AOFF, bb, BOFF, 4, EL) NATINF_CG_STEP(a, AOFF, bb, BOFF, 5, EL) \
+        NATINF_CG_STEP(a, AOFF, bb, BOFF, 6, EL) NATINF_CG_STEP(a, AOFF, bb, BOFF, 7, EL)
+#define NATINF_CG_TILE(a, AOFF, bb, BOFF, EL) { NATINF_CG_HEAD(a, AOFF, bb, BOFF) NATINF_CG_BODY(a, AOFF, bb, BOFF, EL) }
+    static_assert(TM * TN == 32 && (WIDE ? TM : TN) == 4, "eight steps of four MFMAs");
 
     // head of a K-tile: wait until weight tile kt (and everything older) has landed, `allowed` younger requests stay in flight
     auto wait_tile = [&](int aux, bool next_b) __attribute__((always_inline)) {
@@ -340,7 +357,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
             if (next_half) issue_patch(hc + 1);
             else if (n_sc > 0) issue_shortcut(0);
         }
-        auto post = [](auto) __attribute__((always_inline)) {};
         constexpr bool NORM_TAP = T >= 3 && T - 3 < Cfg::NROUND && NATINF_CG_ABL != 1;
         // the slice's five LDS reads go out FIRST (older than every fragment read: the counted waits of the steps cover them), its
         // arithmetic comes after the last MFMA group: no LDS round trip is exposed, and nothing is held across the barrier
@@ -348,10 +364,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
         NATINF_CG_HEAD(a_dx[T % 3], NATINF_CG_AOFF, b_base, (T % 3) * Cfg::BT_BYTES)
         NATINF_CG_STAMP(ts2)
         if constexpr (NORM_TAP) {
-            NATINF_CG_BODY(a_dx[T % 3], NATINF_CG_AOFF, NATINF_CG_NORM)
+            NATINF_CG_BODY(a_dx[T % 3], NATINF_CG_AOFF, b_base, (T % 3) * Cfg::BT_BYTES, NATINF_CG_NORM)
             if (next_half) norm_store();
         } else {
-            NATINF_CG_BODY(a_dx[T % 3], NATINF_CG_AOFF, NATINF_CG_NO)
+            NATINF_CG_BODY(a_dx[T % 3], NATINF_CG_AOFF, b_base, (T % 3) * Cfg::BT_BYTES, NATINF_CG_NO)
         }
         NATINF_CG_STAMP(ts3)
         NATINF_CG_ADD(dbg_wait, ts0, ts1) NATINF_CG_ADD(dbg_norm, ts1, ts2) NATINF_CG_ADD(dbg_mfma, ts2, ts3)
@@ -381,7 +397,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
         else wait_vm_lgkm_barrier<0>();                                    // A(s) was the last request of the previous step
         if (kt + 2 < NT) issue_b(kt + 2);
         if (s + 1 < n_sc) issue_shortcut(s + 1);
-        auto post = [](auto) __attribute__((always_inline)) {};
         const unsigned pa = a_plain + ((n_half + s) & 1) * Cfg::PATCH_BYTES, pb = b_base + (kt % NSB) * Cfg::BT_BYTES;
         NATINF_CG_TILE(pa, NATINF_CG_POFF, pb, 0, NATINF_CG_NO)
     }

@@ -195,7 +195,7 @@ using CfgR128x128 = RingCfg<2, 2, 4, 4, 4>; using CfgR64x128 = RingCfg<2, 2, 2, 
 using CfgR256x128W4 = RingCfg<2, 2, 8, 4, 3>; using CfgD256x128W4 = DmaCfg<2, 2, 8, 4>;
 using CfgD512x128 = DmaCfg<4, 2, 8, 4>;
 using CfgP256x256 = PatchCfg<2, 4, 8, 4, 344>; using CfgP256x128 = PatchCfg<4, 2, 4, 4, 400>;
-using CfgG32 = ConvGnCfg<32>; using CfgG16 = ConvGnCfg<16>;
+using CfgG32 = ConvGnCfg<32>; using CfgG16 = ConvGnCfg<16>; using CfgG16W = ConvGnCfg<16, true>;
 int g_fuse_gn = 1;                 // natinf_set_fuse_gn (read when a plan is BUILT): GroupNorm-apply + SiLU inside the consuming 3x3 conv
 
 // the packed-epilogue instantiations (EPI 1..4) of the four automatically chosen variants
@@ -208,7 +208,7 @@ bool set_lds_epi() {
 }
 template <int EPI>
 bool set_lds_conv_gn() {
-    return set_lds<CfgG32>(&k_conv_gn<32, EPI>) && set_lds<CfgG16>(&k_conv_gn<16, EPI>);
+    return set_lds<CfgG32>(&k_conv_gn<32, false, EPI>) && set_lds<CfgG16>(&k_conv_gn<16, false, EPI>) && set_lds<CfgG16W>(&k_conv_gn<16, true, EPI>);
 }
 bool set_lds_epi_all() { return set_lds_epi<0>() && set_lds_epi<1>() && set_lds_epi<2>() && set_lds_epi<3>() && set_lds_epi<4>() && set_lds_epi<5>() && set_lds_epi<6>() && set_lds_epi<7>() && set_lds_epi<8>(); }
 
@@ -248,13 +248,16 @@ bool configure_gemm_kernels() {
 inline bool eligible_8ph(const GemmArgs& g) { return g.M % 256 == 0 && g.N % 256 == 0; }
 
 int variant_bm(int v);
-// k_conv_gn instantiations: 32x32 and 16x16 images, 256 x 128 tiles; packed epilogues 1 / 2 / 5 / 6 only
+// k_conv_gn instantiations: 32x32 and 16x16 images, 256 x 128 tiles -- 128 x 256 tiles for 16x16 layers whose N is a multiple of 256
+// (natinf_set_conv_gn_wide: A/B runs); packed epilogues 1 / 2 / 5 / 6 only
 int packed_epi(const GemmArgs& g, int bm);
+int g_cg_wide = 1;
+inline int conv_gn_bm(const GemmArgs& g) { return (g_cg_wide && (1 << g.logW) == 16 && g.N % 256 == 0) ? 128 : 256; }
 inline bool conv_gn_ok(const GemmArgs& g) {
     if (!g.gn_scale || !g.gn_shift || !g.gn_folded || g.taps != 9 || g.batch != 1 || g.a0_C % BK || (g.a1 && g.a1_C % BK) || g.M % 256) return false;
     const int res = 1 << g.logW;
     if (g.logHW != 2 * g.logW || (res != 32 && res != 16) || g.N % 8) return false;
-    const int e = packed_epi(g, 256);
+    const int e = packed_epi(g, conv_gn_bm(g));
     return e == 1 || e == 2 || e == 5 || e == 6;
 }
 int choose_variant(const GemmArgs& g) {
@@ -353,13 +356,14 @@ int g_launch_error = 0;            // set when a launch is asked for something n
 int launch_gemm(const GemmArgs& g, hipStream_t s) {
     const int v = choose_variant(g);
     if (v == V_CONV_GN && !conv_gn_ok(g)) { g_launch_error = 1; return 256; }
+    if (v == V_CONV_GN && g_record) { /* described below */ }
     if (g_record) {
         char line[160];
         const bool has_packed = v == V_CONV_GN || v == V_DMA_256x256_P || v == V_DMA_128x128_P || v == V_RING_256x128_W4 || v == V_RING_64x128 || v == V_DMA_512x128 || v == V_DMA_256x256_H || v == V_DMA_512x128_H;
         snprintf(line, sizeof(line), "%d %d %d %d %d %d %s/e%d\n", g.M, g.N, g.taps * g.a0_C, g.a1 ? g.a1_C : 0, g.taps, g.batch, variant_name(v),
-                 has_packed ? packed_epi(g, variant_bm(v)) : 0);
+                 has_packed ? packed_epi(g, v == V_CONV_GN ? conv_gn_bm(g) : variant_bm(v)) : 0);
         *g_record += line;
-        return variant_bm(v);
+        return v == V_CONV_GN ? conv_gn_bm(g) : variant_bm(v);
     }
     switch (v) {
         case V_GENERIC: {
@@ -393,23 +397,20 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
         case V_ABL_NOMFMA: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 4, 1>, g, s); break;
 #endif
         case V_CONV_GN: {
-            const int e = packed_epi(g, 256);
-            if ((1 << g.logW) == 32) {
-                switch (e) {
-                    case 1: launch_tiles<CfgG32>(&k_conv_gn<32, 1>, g, s); break;
-                    case 2: launch_tiles<CfgG32>(&k_conv_gn<32, 2>, g, s); break;
-                    case 5: launch_tiles<CfgG32>(&k_conv_gn<32, 5>, g, s); break;
-                    default: launch_tiles<CfgG32>(&k_conv_gn<32, 6>, g, s); break;
-                }
-            } else {
-                switch (e) {
-                    case 1: launch_tiles<CfgG16>(&k_conv_gn<16, 1>, g, s); break;
-                    case 2: launch_tiles<CfgG16>(&k_conv_gn<16, 2>, g, s); break;
-                    case 5: launch_tiles<CfgG16>(&k_conv_gn<16, 5>, g, s); break;
-                    default: launch_tiles<CfgG16>(&k_conv_gn<16, 6>, g, s); break;
-                }
+            const int e = packed_epi(g, conv_gn_bm(g));
+            const int e4 = e == 1 ? 0 : (e == 2 ? 1 : (e == 5 ? 2 : 3));
+#define NATINF_CG_LAUNCH(CFG, RES, WIDE)                                                                    \
+            switch (e4) {                                                                                       \
+                case 0: launch_tiles<CFG>(&k_conv_gn<RES, WIDE, 1>, g, s); break;                               \
+                case 1: launch_tiles<CFG>(&k_conv_gn<RES, WIDE, 2>, g, s); break;                               \
+                case 2: launch_tiles<CFG>(&k_conv_gn<RES, WIDE, 5>, g, s); break;                               \
+                default: launch_tiles<CFG>(&k_conv_gn<RES, WIDE, 6>, g, s); break;                              \
             }
-            break;
+            if ((1 << g.logW) == 32) { NATINF_CG_LAUNCH(CfgG32, 32, false) }
+            else if (conv_gn_bm(g) == 128) { NATINF_CG_LAUNCH(CfgG16W, 16, true) }
+            else { NATINF_CG_LAUNCH(CfgG16, 16, false) }
+#undef NATINF_CG_LAUNCH
+            return conv_gn_bm(g);
         }
         case V_8PH_NOPRIO: launch_tiles<Cfg8ph>(&k_gemm_8ph<1>, g, s); break;
         case V_8PH_READFIRST: launch_tiles<Cfg8ph>(&k_gemm_8ph<2>, g, s); break;
@@ -1154,6 +1155,7 @@ int natinf_debug_timestamps(void* dev_buf16) {
 
 int natinf_set_gemm_raster(int rows) { g_raster_g = rows; return NATINF_OK; }
 int natinf_set_fuse_gn(int on) { g_fuse_gn = on != 0; return NATINF_OK; }
+int natinf_set_conv_gn_wide(int on) { g_cg_wide = on != 0; return NATINF_OK; }
 int natinf_set_gemm_half_issue(int on) { g_half_issue = on != 0; return NATINF_OK; }
 int natinf_set_gemm_pref512(int on) { g_pref_512 = on != 0; return NATINF_OK; }
 int natinf_set_gemm_epilogue(int fp32_slab) { g_epi_fp32_slab = fp32_slab != 0; return NATINF_OK; }

@@ -22,7 +22,7 @@ def _pack(w, w1):
     (32, 2, 128, 128, 0, False, True),        # Conv_0 of a level-0 block (+ GroupNorm partials of the output)
     (32, 3, 256, 128, 256, False, True),      # up-path Conv_1 with the 1x1 shortcut segment
     (32, 1, 128, 128, 0, True, True),         # Conv_1 with the identity residual
-    (16, 4, 256, 256, 0, True, False),        # 16x16 level: two N tiles per pixel tile
+    (16, 4, 256, 256, 0, True, True),         # 16x16 level, N = 256: the 128 x 256 tile (and, forced, two 256 x 128 tiles)
     (16, 2, 512, 256, 512, False, True),      # widest K: 144 + 16 K-tiles
     (16, 3, 128, 256, 0, False, False),
     (32, 2, 384, 128, 384, False, False),     # 384 channels: 12 half-chunks
@@ -58,18 +58,29 @@ def test_conv_gn_matches_torch(res, B, cin, N, c1, resid, parts):
     xd, wd = x.bfloat16().to(dev).contiguous(), wp.bfloat16().to(dev)
     out = torch.empty(B * res * res, N, dtype=torch.bfloat16, device=dev)
     M = B * res * res
-    part = torch.zeros(M // 256, N // 4, 2, device=dev) if parts else None
     scd, shd, bd = (scale * -LOG2E).to(dev), (shift * -LOG2E).to(dev), bias.to(dev)           # (named: a temporary could be recycled before the launch runs)
     a1d = a1.bfloat16().to(dev).contiguous() if c1 else None
     rd = r.bfloat16().to(dev) if resid else None
-    check(lib.natinf_debug_conv_gn(res, B, N, cin, c1, ptr(xd), ptr(scd), ptr(shd), ptr(wd), ptr(a1d), ptr(bd), ptr(rd), out_scale,
-                                   ptr(out), ptr(part), 1, stream_ptr()), "conv_gn")
-    torch.cuda.synchronize()
-    got = out.float().cpu()
-    assert torch.isfinite(got).all()
-    err = ((got - ref).abs().max() / ref.abs().max()).item()
-    assert err <= 1e-2, err
-    if parts:                                               # (sum, sum of squares) per 256-pixel tile and 4-channel quad, of the fp32 results
+    wide = res == 16 and N % 256 == 0                      # 128-pixel x 256-channel tiles (default) -- the 256 x 128 ones are tested as well
+    for use_wide in ((1, 0) if wide else (1,)):
+        lib.natinf_set_conv_gn_wide(use_wide)
+        rows = 128 if (wide and use_wide) else 256
+        part = torch.zeros(M // rows, N // 4, 2, device=dev) if parts else None
+        out.zero_()
+        try:
+            check(lib.natinf_debug_conv_gn(res, B, N, cin, c1, ptr(xd), ptr(scd), ptr(shd), ptr(wd), ptr(a1d), ptr(bd), ptr(rd), out_scale,
+                                           ptr(out), ptr(part), 1, stream_ptr()), "conv_gn")
+            torch.cuda.synchronize()
+        finally:
+            lib.natinf_set_conv_gn_wide(1)
+        got = out.float().cpu()
+        assert torch.isfinite(got).all()
+        err = ((got - ref).abs().max() / ref.abs().max()).item()
+        assert err <= 1e-2, (err, use_wide)
+        if parts:                                           # (sum, sum of squares) per tile and 4-channel quad, of the fp32 results
+            want = torch.stack([ref.reshape(M // rows, rows, N // 4, 4).sum(dim=(1, 3)), (ref ** 2).reshape(M // rows, rows, N // 4, 4).sum(dim=(1, 3))], dim=-1)
+            assert ((part.cpu() - want).abs().max() / want.abs().max()).item() <= 5e-3
+    if False:                                               # (sum, sum of squares) per 256-pixel tile and 4-channel quad, of the fp32 results
         want = torch.stack([ref.reshape(M // 256, 256, N // 4, 4).sum(dim=(1, 3)), (ref ** 2).reshape(M // 256, 256, N // 4, 4).sum(dim=(1, 3))], dim=-1)
         assert ((part.cpu() - want).abs().max() / want.abs().max()).item() <= 5e-3
 
