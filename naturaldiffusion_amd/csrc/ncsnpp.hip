@@ -515,14 +515,18 @@ struct Builder {
         const int64_t p_c2w = shortcut ? take((int64_t)cout * cin) : -1, p_c2b = shortcut ? take(cout) : -1;
 
         const int K0a = 9 * cin, K1tot = 9 * cout + (shortcut ? cin : 0);
-        // GroupNorm-apply + SiLU inside the consuming convolution (conv_gn.h) where an instantiation exists: plain blocks at
-        // 32x32 and 16x16.  Resampling blocks and the 8x8 / 4x4 levels keep the k_gn_apply pass.  Folded form: the GroupNorm
-        // scale / shift carry -log2(e), the 3x3 weights -ln 2 (GemmArgs::gn_folded).
-        const bool fuse = g_fuse_gn && !m.up && !m.down && cin % BK == 0 && (ro == 32 || ro == 16);
-        const float gn_mul = fuse ? -1.4426950408889634f : 1.0f, w_mul = fuse ? -0.6931471805599453f : 1.0f;
+        // GroupNorm-apply + SiLU inside the consuming convolution (conv_gn.h) where an instantiation exists: output resolution
+        // 32x32 or 16x16.  Conv_0 of a resampling block reads a resampled tensor and keeps the k_gn_apply pass (which also
+        // produces the resampled shortcut input), Conv_1 is fused there too; the 8x8 / 4x4 levels are unfused.  Folded form: the
+        // GroupNorm scale / shift carry -log2(e), the 3x3 weights -ln 2 (GemmArgs::gn_folded).
+        const bool fusable_res = g_fuse_gn && (ro == 32 || ro == 16);
+        const bool fuse = fusable_res && !m.up && !m.down && cin % BK == 0;            // Conv_0
+        const bool fuse1 = fusable_res && cout % BK == 0;                               // Conv_1
+        const float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+        const float gn_mul = fuse ? -LOG2E : 1.0f, w_mul = fuse ? -LN2 : 1.0f, gn_mul1 = fuse1 ? -LOG2E : 1.0f, w_mul1 = fuse1 ? -LN2 : 1.0f;
         const int64_t w0 = wres((int64_t)cout * K0a * 2), w1 = wres((int64_t)cout * K1tot * 2);
         pack_conv(p_c0w, w0, cout, cin, 9, K0a, 0, cin, w_mul);
-        pack_conv(p_c1w, w1, cout, cout, 9, K1tot, 0, cout, w_mul);
+        pack_conv(p_c1w, w1, cout, cout, 9, K1tot, 0, cout, w_mul1);
         if (shortcut) pack_conv(p_c2w, w1, cout, cin, 1, K1tot, 9 * cout, cin);
         const int64_t b0 = pack_f32(p_c0b, cout), b1 = pack_f32(p_c1b, cout, shortcut ? p_c2b : -1);
         // time-embedding projection rows of this block inside the shared bank
@@ -558,9 +562,9 @@ struct Builder {
             if (pt.valid) c.part_bm[pt.id] = bm;
         });
         if (!fuse) arena.release(h.off);
-        emit_gn_stats(t, gn1, sc, sh, gn_mul);
+        emit_gn_stats(t, gn1, sc, sh, gn_mul1);
         TRef u;
-        if (!fuse) {
+        if (!fuse1) {
             u = new_act(ro, cout, 1);
             emit_gn_apply(t, sc, sh, u, nullptr, ACT_SILU, RS_NONE);
             arena.release(t.off);
@@ -568,9 +572,9 @@ struct Builder {
         if (pt.valid) arena.release(pt.off);
         const TRef xs = (m.up || m.down) ? xr : x;           // shortcut source at the output resolution
         const Part po = register_output(out);
-        op(fuse ? CLS_CONV_GN : CLS_GEMM, [=](const Ctx& c) {
+        op(fuse1 ? CLS_CONV_GN : CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
-            if (fuse) { g.a0 = c.act(t); g.a0_ld = t.ld; g.gn_scale = c.at<float>(sc); g.gn_shift = c.at<float>(sh); g.gn_ld = cout; g.gn_folded = 1; }
+            if (fuse1) { g.a0 = c.act(t); g.a0_ld = t.ld; g.gn_scale = c.at<float>(sc); g.gn_shift = c.at<float>(sh); g.gn_ld = cout; g.gn_folded = 1; }
             else { g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_padded = 1; }
             g.a0_C = cout; g.taps = 9; g.logW = logW; g.logHW = logHW;
             if (shortcut) { g.a1 = c.act(xs); g.a1_ld = xs.ld; g.a1_C = cin; }
@@ -582,7 +586,7 @@ struct Builder {
             const int bm = launch_gemm(g, c.stream);
             if (po.valid) c.part_bm[po.id] = bm;
         });
-        if (fuse) arena.release(t.off); else arena.release(u.off);
+        if (fuse1) arena.release(t.off); else arena.release(u.off);
         if (m.up || m.down) arena.release(xr.off);
         arena.release(sc); arena.release(sh);
         E.taps[m.idx] = out;

@@ -158,7 +158,7 @@ def test_bench_batch_512_runs_the_benchmarked_kernels_and_matches_golden(dev, fl
     # the families that carry the bench's device time: the fused GroupNorm+SiLU convolution (every plain res-block conv of the
     # 32x32 and 16x16 levels: 2 x 18 launches) and, for the resampling blocks / the head, the hand-pipelined LDS-DMA tiles
     assert len(chosen.get("conv_gn", [])) >= 30, {k: len(v) for k, v in chosen.items()}
-    assert len(chosen.get("dma256x256h", [])) >= 3 and len(chosen.get("dma512x128h", [])) >= 1, {k: len(v) for k, v in chosen.items()}
+    assert len(chosen.get("dma256x256h", [])) >= 2 and len(chosen.get("dma512x128h", [])) >= 1, {k: len(v) for k, v in chosen.items()}
     y = eng(x.to(dev), labels.to(dev))
     torch.cuda.synchronize()
     assert torch.isfinite(y).all()
