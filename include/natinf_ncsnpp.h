@@ -116,6 +116,11 @@ int natinf_set_gemm_raster(int rows);
 int natinf_set_fuse_gn(int on);
 /* 1 (default): k_conv_gn launches on 16x16 images with N % 256 == 0 use the 128-pixel x 256-channel tile; 0: 256 x 128 everywhere. */
 int natinf_set_conv_gn_wide(int on);
+/* 1 (default): small-M, long-K launches (the 8x8 and 4x4 levels) run as 128 x 128 tiles x 2..4 K slices + a reduce pass; 0: never. */
+int natinf_set_gemm_splitk(int on);
+/* natinf_debug_gemm / natinf_debug_gemm_fused with variant 0 may split K when given a workspace of max_slices * M * N floats
+ * (NULL = off, the default); the engines carry their own workspace. */
+int natinf_debug_set_splitk_workspace(float* ws, int max_slices);
 /* Timing experiments (tools/tile_timeline.py): device buffer of 16 uint64 shader-clock stamps that block 0 / thread 0 of
  * every natinf_debug_gemm launch writes (kernel start, first tile landed, main loop done, per epilogue pass: slab written,
  * sweeps done, stores issued).  NULL switches it off. */

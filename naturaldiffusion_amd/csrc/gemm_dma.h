@@ -761,14 +761,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_ring(const GemmArgs g)
     int mt_, nt_;
     tile_coords(tile, nM, nN, g.raster_g, mt_, nt_);
     const int m0 = mt_ * BM_, n0 = nt_ * BN_;
-    const int z = blockIdx.z;
+    const int z = EPI == 9 ? 0 : blockIdx.z;
 
     const bf16* a0 = g.a0 + (int64_t)z * g.a_bs;
     const bf16* a1 = g.a1 ? g.a1 + (int64_t)z * g.a_bs : nullptr;
     const bf16* bp = g.b + (int64_t)z * g.b_bs;
     const int K0 = g.taps * g.a0_C, K1 = g.a1 ? g.a1_C : 0;
-    const int nk0 = K0 / BKR, nk = nk0 + K1 / BKR;
+    const int nk0 = K0 / BKR, nk_all = nk0 + K1 / BKR;
     const int Wp = (1 << g.logW) + 2, Hp = (1 << (g.logHW - g.logW)) + 2;
+    // EPI 9 = split-K: blockIdx.z is the K slice (batch must be 1), this block multiplies K-tiles [kt_lo, kt_lo + nk) and writes its
+    // fp32 partial tile to g.c + slice * M * N; k_splitk_reduce sums the slices and applies the fused terms
+    const int kt_lo = EPI == 9 ? (int)((int64_t)nk_all * blockIdx.z / g.splitk) : 0;
+    const int nk = EPI == 9 ? (int)((int64_t)nk_all * (blockIdx.z + 1) / g.splitk) - kt_lo : nk_all;
 
     uint64_t a_row[Cfg::PA], a_delta[Cfg::PA], b_row[Cfg::PB];
 #pragma unroll
@@ -796,8 +800,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_ring(const GemmArgs g)
     }
 
     typedef __attribute__((address_space(3))) void lds_void;
-    auto issue_tile = [&](int kt) __attribute__((always_inline)) {
-        const int slot = kt % NS;
+    auto issue_tile = [&](int kt_rel) __attribute__((always_inline)) {     // kt_rel: index inside this block's K range
+        const int slot = kt_rel % NS, kt = kt_lo + kt_rel;
         unsigned char* dA = smem + slot * Cfg::STAGE_BYTES + wave * (Cfg::PA * 1024);
         unsigned char* dB = smem + slot * Cfg::STAGE_BYTES + BM_ * BKR * 2 + wave * (Cfg::PB * 1024);
         const bool seg0 = kt < nk0;
@@ -859,7 +863,81 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_ring(const GemmArgs g)
 #endif
     }
     __syncthreads();               // every wave is done with the ring before the epilogue reuses it
-    tile_epilogue<WM, WN, TM, TN, typename Cfg::Epi, EPI>(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
+    if constexpr (EPI == 9) {
+        // split-K partial: the accumulators as they are (swapped-operand layout: a lane holds four consecutive columns of a row)
+        float* part = reinterpret_cast<float*>(g.c) + (int64_t)blockIdx.z * g.M * g.N;
+        const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * TM * 16 + i * 16 + r;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * TN * 16 + j * 16 + q * 4;
+                if (m < g.M && n < g.N) *reinterpret_cast<f32x4*>(part + (int64_t)m * g.N + n) = acc[i][j];
+            }
+        }
+    } else {
+        tile_epilogue<WM, WN, TM, TN, typename Cfg::Epi, EPI>(g, smem, acc, m0, n0, z, tid, lane, wm, wn);
+    }
+}
+
+// Second pass of a split-K GEMM: out = act((sum over slices + bias_n + rowvec[sample] + resid) * scale), bf16.  A block owns 16 rows
+// (SPLITK_ROWS) x all N columns, a thread 8 columns of 16 * (N/8) / 256 rows; slices are summed in ascending order (deterministic).
+// gn_part (optional): GroupNorm partial sums of the fp32 results, float2 [row tile of 16][N/4] like the GEMM epilogues write them.
+constexpr int SPLITK_ROWS = 16;
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ part, int S, int M, int N, const float* __restrict__ bias_n,
+                                                       const float* __restrict__ rowvec, int rowvec_ld, int log_rows_per_sample,
+                                                       const bf16* __restrict__ resid, int resid_ld, float scale, int act,
+                                                       bf16* __restrict__ c, int c_ld, float2* __restrict__ gn_part, int gn_quads)
+{
+    __shared__ float2 red[512];                              // [row lane][quad], 256 / cpr row lanes x 2 * cpr quads = 512 entries
+    const int cpr = N >> 3, tid = threadIdx.x;               // host guarantees 256 % cpr == 0
+    const int cx = tid % cpr, ry = tid / cpr, rp = 256 / cpr, n = cx * 8;
+    float bn[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bn[q] = bias_n ? bias_n[n + q] : 0.f;
+    float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};
+    for (int r = ry; r < SPLITK_ROWS; r += rp) {
+        const int m = blockIdx.x * SPLITK_ROWS + r;
+        if (m >= M) break;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < S; ++sl) {
+            const float* p = part + ((int64_t)sl * M + m) * N + n;
+            const float4 u = *reinterpret_cast<const float4*>(p), w = *reinterpret_cast<const float4*>(p + 4);
+            v[0] += u.x; v[1] += u.y; v[2] += u.z; v[3] += u.w; v[4] += w.x; v[5] += w.y; v[6] += w.z; v[7] += w.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += bn[q];
+        if (rowvec) {
+            const float* rv = rowvec + (int64_t)(m >> log_rows_per_sample) * rowvec_ld + n;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += rv[q];
+        }
+        if (resid) {
+            const bf16x8 rs = *reinterpret_cast<const bf16x8*>(resid + (int64_t)m * resid_ld + n);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += (float)rs[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] *= scale;
+        apply_act8(v, act);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { gs[q >> 2] += v[q]; gq[q >> 2] += v[q] * v[q]; }
+        bf16x8 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = (bf16)v[q];
+        *reinterpret_cast<bf16x8*>(c + (int64_t)m * c_ld + n) = o;
+    }
+    if (gn_part) {
+        red[ry * 2 * cpr + cx * 2] = make_float2(gs[0], gq[0]);
+        red[ry * 2 * cpr + cx * 2 + 1] = make_float2(gs[1], gq[1]);
+        __syncthreads();
+        if (tid < 2 * cpr) {
+            float a = 0.f, b = 0.f;
+            for (int y = 0; y < rp; ++y) { const float2 t = red[y * 2 * cpr + tid]; a += t.x; b += t.y; }
+            gn_part[(int64_t)blockIdx.x * gn_quads + tid] = make_float2(a, b);
+        }
+    }
 }
 
 }  // namespace ncsn

@@ -219,6 +219,7 @@ bool configure_gemm_kernels() {
          set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4>) && set_lds<CfgR256x256>(&k_gemm_ring<2, 4, 8, 4, 4>) &&
          set_lds<CfgR256x128>(&k_gemm_ring<4, 2, 4, 4, 6>) && set_lds<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4>) &&
          set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4>) && set_lds<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3>) &&
+         set_lds<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4, 9>) &&
          set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4>) && set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 1>) &&
          set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 1>) && set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4>) &&
          set_lds<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>) && set_lds<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>) &&
@@ -352,8 +353,44 @@ int packed_epi(const GemmArgs& g, int bm) {      // resid must be 8-byte aligned
     }
 
 int g_launch_error = 0;            // set when a launch is asked for something no kernel provides (a plan-builder bug); the forward reports it
+int g_splitk = 1;                  // natinf_set_gemm_splitk: 0 = never split K
+float* g_dbg_splitk_ws = nullptr; int g_dbg_splitk_max = 0;        // natinf_debug_set_splitk_workspace
+// Split-K for launches that cannot fill the chip otherwise (the 8x8 and 4x4 levels: 32,768 / 8,192 rows x 256 columns, K = 2,304 ..
+// 4,608): 128 x 128 tiles (fill per flop of the large tile) x S slices of K >= 2 blocks per CU, then one reduce pass with the fused
+// terms.  Returns the slice count (1 = do not split).
+int splitk_slices(const GemmArgs& g) {
+    if (!g_splitk || !g.splitk_ws || g.splitk_max < 2 || g.batch != 1 || g.gn_scale || g.c_mode != OUT_BF16 || g.N % 8 || 256 % (g.N / 8)) return 1;
+    if (g.gn_part && (g.M % SPLITK_ROWS || g.act != ACT_NONE || (g.taps == 9 && (1 << g.logHW) % SPLITK_ROWS))) return 1;
+    if (g.bias_m || g.gate || g.resid_f32 || g.deq_m || g.deq_n) return 1;
+    const int K0 = g.taps * g.a0_C, K1 = g.a1 ? g.a1_C : 0;
+    if (K0 % 64 || K1 % 64 || (g.taps == 9 && !g.a0_padded) || K0 + K1 < 2048) return 1;
+    const int64_t tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+    if (tiles >= 2 * NUM_CU) return 1;
+    int S = (int)((2 * NUM_CU + tiles - 1) / tiles);
+    if (S > g.splitk_max) S = g.splitk_max;
+    while (S > 1 && (K0 + K1) / 32 / S < 16) --S;                       // at least 16 K-tiles per slice
+    return S;
+}
 // returns the block-tile row count of the variant used
-int launch_gemm(const GemmArgs& g, hipStream_t s) {
+int launch_gemm(const GemmArgs& g0, hipStream_t s) {
+    const int S = g_force_variant == V_AUTO ? splitk_slices(g0) : 1;
+    if (S > 1) {
+        if (g_record) {
+            char line[160];
+            snprintf(line, sizeof(line), "%d %d %d %d %d %d splitk%d_ring128x128/e9\n", g0.M, g0.N, g0.taps * g0.a0_C, g0.a1 ? g0.a1_C : 0, g0.taps, g0.batch, S);
+            *g_record += line;
+            return SPLITK_ROWS;
+        }
+        GemmArgs p = g0;
+        p.splitk = S; p.c = g0.splitk_ws; p.c_mode = OUT_F32; p.batch = S;
+        p.bias_n = nullptr; p.rowvec = nullptr; p.resid = nullptr; p.scale = 1.0f; p.act = ACT_NONE; p.gn_part = nullptr;
+        launch_tiles<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4, 9>, p, s);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((g0.M + SPLITK_ROWS - 1) / SPLITK_ROWS)), dim3(256), 0, s, g0.splitk_ws, S, g0.M, g0.N,
+                           g0.bias_n, g0.rowvec, g0.rowvec_ld, g0.log_rows_per_sample, reinterpret_cast<const bf16*>(g0.resid), g0.resid_ld, g0.scale,
+                           g0.act, reinterpret_cast<bf16*>(g0.c), g0.c_ld, reinterpret_cast<float2*>(g0.gn_part), g0.gn_quads);
+        return SPLITK_ROWS;
+    }
+    const GemmArgs& g = g0;
     const int v = choose_variant(g);
     if (v == V_CONV_GN && !conv_gn_ok(g)) { g_launch_error = 1; return 256; }
     if (v == V_CONV_GN && g_record) { /* described below */ }
@@ -544,6 +581,9 @@ struct Builder {
             emit_gn_apply(x, sc, sh, h, (m.up || m.down) ? &xr : nullptr, ACT_SILU, m.up ? RS_UP : (m.down ? RS_DOWN : RS_NONE));
         }
 
+        // split-K workspace for the low-resolution levels (launch_gemm decides per launch): 4 slices of fp32 partial sums
+        const int SK_MAX = 4;
+        const int64_t skws = (ro <= 8) ? arena.alloc((int64_t)SK_MAX * ro * ro * cout * 4) : -1;
         TRef t = new_act(ro, cout);
         const Part pt = register_output(t);
         const int logW = ilog2(ro), logHW = 2 * logW, HWo = ro * ro;
@@ -556,6 +596,7 @@ struct Builder {
             g.M = c.B * HWo; g.N = cout; g.b = c.w<bf16>(w0); g.b_ld = K0a;
             g.bias_n = c.w<float>(b0);
             g.rowvec = c.at<float>(dout) + drow; g.rowvec_ld = dtotal; g.log_rows_per_sample = logHW;
+            if (skws >= 0) { g.splitk_ws = c.at<float>(skws); g.splitk_max = SK_MAX; }
             g.c = c.act(t); g.c_ld = t.ld;
             if (pt.valid) { g.gn_part = c.at<float>(pt.off); g.gn_quads = pt.quads; }
             const int bm = launch_gemm(g, c.stream);
@@ -581,11 +622,13 @@ struct Builder {
             else { g.resid = c.act(xs); g.resid_ld = xs.ld; }
             g.M = c.B * HWo; g.N = cout; g.b = c.w<bf16>(w1); g.b_ld = K1tot;
             g.bias_n = c.w<float>(b1); g.scale = INV_SQRT2;
+            if (skws >= 0) { g.splitk_ws = c.at<float>(skws); g.splitk_max = SK_MAX; }
             g.c = c.act(out); g.c_ld = out.ld;
             if (po.valid) { g.gn_part = c.at<float>(po.off); g.gn_quads = po.quads; }
             const int bm = launch_gemm(g, c.stream);
             if (po.valid) c.part_bm[po.id] = bm;
         });
+        if (skws >= 0) arena.release(skws);
         if (fuse1) arena.release(t.off); else arena.release(u.off);
         if (m.up || m.down) arena.release(xr.off);
         arena.release(sc); arena.release(sh);
@@ -1072,6 +1115,7 @@ int natinf_debug_gemm(int variant, int M, int N, int K0, int K1, int taps, int l
     if (batch > 1) { g.a_bs = (int64_t)M * g.a0_ld; g.b_bs = (int64_t)N * g.b_ld; g.c_bs = (int64_t)M * N; }
     g.bias_n = bias_n; g.scale = scale; g.c = c; g.c_ld = N; g.c_mode = c_f32 == 1 ? OUT_F32 : (c_f32 >= 2 ? 100 + c_f32 : OUT_BF16);      // >= 2: timing experiments (tools/bench_gemm.py)
     g.dbg_ts = g_dbg_ts;
+    g.splitk_ws = g_dbg_splitk_ws; g.splitk_max = g_dbg_splitk_max;
     const int saved = g_force_variant;
     g_force_variant = variant;
     for (int i = 0; i < iters; ++i) launch_gemm(g, (hipStream_t)stream);
@@ -1093,6 +1137,7 @@ int natinf_debug_gemm_fused(int variant, int M, int N, int K, const void* a, con
     g.resid = (const bf16*)resid_bf16; g.resid_ld = N; g.resid_f32 = resid_f32; g.resid_f32_ld = N;
     g.scale = scale; g.act = act; g.c = c; g.c_ld = N; g.c_mode = c_f32 ? OUT_F32 : OUT_BF16;
     g.gn_part = gn_part; g.gn_quads = N / 4; g.epi_fp32_slab = fp32_slab != 0;
+    g.splitk_ws = g_dbg_splitk_ws; g.splitk_max = g_dbg_splitk_max;
     const int saved = g_force_variant;
     g_force_variant = variant;
     const int bm = launch_gemm(g, (hipStream_t)stream);
@@ -1160,6 +1205,8 @@ int natinf_debug_timestamps(void* dev_buf16) {
 int natinf_set_gemm_raster(int rows) { g_raster_g = rows; return NATINF_OK; }
 int natinf_set_fuse_gn(int on) { g_fuse_gn = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_wide(int on) { g_cg_wide = on != 0; return NATINF_OK; }
+int natinf_set_gemm_splitk(int on) { g_splitk = on != 0; return NATINF_OK; }
+int natinf_debug_set_splitk_workspace(float* ws, int max_slices) { g_dbg_splitk_ws = ws; g_dbg_splitk_max = ws ? max_slices : 0; return NATINF_OK; }
 int natinf_set_gemm_half_issue(int on) { g_half_issue = on != 0; return NATINF_OK; }
 int natinf_set_gemm_pref512(int on) { g_pref_512 = on != 0; return NATINF_OK; }
 int natinf_set_gemm_epilogue(int fp32_slab) { g_epi_fp32_slab = fp32_slab != 0; return NATINF_OK; }

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 V_DMA256P, V_DMA128P, V_RING256W4, V_RING64, V_DMA512 = 16, 17, 9, 8, 13
 
 
-def _run(variant, M, N, K, lrs, terms, act=0, c_f32=False, fp32_slab=False, scale=1.0, seed=0):
+def _run(variant, M, N, K, lrs, terms, act=0, c_f32=False, fp32_slab=False, scale=1.0, seed=0, splitk=0):
     from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
     g = torch.Generator(device="cuda").manual_seed(seed)
     a = torch.randn(M, K, device="cuda", generator=g).bfloat16(); b = (torch.randn(N, K, device="cuda", generator=g) * 0.1).bfloat16()
@@ -19,7 +19,9 @@ def _run(variant, M, N, K, lrs, terms, act=0, c_f32=False, fp32_slab=False, scal
          "resid": torch.randn(M, N, device="cuda", generator=g).bfloat16(), "resid_f32": torch.randn(M, N, device="cuda", generator=g)}
     has = lambda k: k in terms
     c = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32 if c_f32 else torch.bfloat16)
-    part = torch.zeros(((M + 63) // 64) * (N // 4) * 2, device="cuda") if has("gn") else None
+    part = torch.zeros(((M + 15) // 16) * (N // 4) * 2, device="cuda") if has("gn") else None
+    ws = torch.full((splitk * M * N,), float("nan"), device="cuda") if splitk else None
+    check(lib.natinf_debug_set_splitk_workspace(ptr(ws) if splitk else None, splitk), "set_splitk_workspace")
     bm = C.c_int(0)
     check(lib.natinf_debug_gemm_fused(variant, M, N, K, ptr(a), ptr(b), ptr(t["bias_n"]) if has("bias_n") else None,
                                       ptr(t["bias_m"]) if has("bias_m") else None, ptr(t["rowvec"]) if has("rowvec") else None,
@@ -27,6 +29,7 @@ def _run(variant, M, N, K, lrs, terms, act=0, c_f32=False, fp32_slab=False, scal
                                       ptr(t["resid_f32"]) if has("resid_f32") else None, scale, act, ptr(c), int(c_f32),
                                       ptr(part) if part is not None else None, C.byref(bm), int(fp32_slab), stream_ptr()), "debug_gemm_fused")
     torch.cuda.synchronize()
+    check(lib.natinf_debug_set_splitk_workspace(None, 0), "set_splitk_workspace")
     v = a.float() @ b.float().t()
     rows = torch.arange(M, device="cuda") >> lrs
     if has("bias_n"): v = v + t["bias_n"]
@@ -81,3 +84,32 @@ def test_packed_epilogue_is_deterministic():
     a = _run(V_DMA256P, 1024, 512, 128, 8, ("bias_n", "rowvec", "gn"))
     b = _run(V_DMA256P, 1024, 512, 128, 8, ("bias_n", "rowvec", "gn"))
     assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+
+
+SPLITK_CASES = [   # (M, N, K, log2 rows per sample, fused terms): the shapes of the 8x8 / 4x4 levels and ragged relatives
+    (2048, 256, 2304, 6, ("bias_n", "rowvec", "gn")),               # Conv_0 at 8x8, 32 samples: 32 tiles -> 4 slices
+    (512, 256, 4608, 4, ("bias_n", "resid", "gn")),                 # Conv_1 at 4x4 with the residual
+    (1000, 136, 2560, 30, ("bias_n", "rowvec", "resid")),           # ragged M and N (no statistics), N / 8 = 17 does not divide 256 -> not split
+    (1000, 128, 2560, 30, ("bias_n", "rowvec", "resid")),           # ragged M
+]
+
+
+@pytest.mark.parametrize("M,N,K,lrs,terms", SPLITK_CASES)
+def test_splitk_matches_fp32_reference_and_the_unsplit_launch(M, N, K, lrs, terms):
+    out, ref, part, bm = _run(0, M, N, K, lrs, terms, splitk=4)
+    out1, _, part1, bm1 = _run(0, M, N, K, lrs, terms)
+    tol = 2 ** -8 * ref.abs().max().item() + 1e-5
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() <= tol and (out1 - ref).abs().max().item() <= tol
+    assert (out - out1).abs().max().item() <= 2 ** -7 * ref.abs().max().item()       # one bf16 rounding each, fp32 sums in another order
+    if N % 8 == 0 and 256 % (N // 8) == 0:
+        assert bm == 16
+    if part is not None:
+        assert M % bm == 0
+        want = ref.reshape(M // bm, bm, N // 4, 4)
+        s, q = want.sum(dim=(1, 3)), (want * want).sum(dim=(1, 3))
+        got = part[: (M // bm) * (N // 4) * 2].reshape(M // bm, N // 4, 2)
+        assert (got[..., 0] - s).abs().max().item() <= 2e-3 * q.sqrt().max().item() + 1e-3
+        assert (got[..., 1] - q).abs().max().item() <= 2e-3 * q.max().item()
+    again = _run(0, M, N, K, lrs, terms, splitk=4)
+    assert torch.equal(again[0], out)                                  # slices are summed in a fixed order
