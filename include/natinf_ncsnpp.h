@@ -98,8 +98,11 @@ int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_sc
  * 16x16 images with N % 256 == 0 (unless natinf_set_conv_gn_wide(0)), else 256.
  * Operands are taken in the kernel's FOLDED form: `scale` and `shift` must be the GroupNorm scale / shift multiplied by -log2(e)
  * and the 3x3 columns of w_packed multiplied by -ln 2 (the shortcut columns are plain); the kernel evaluates t / (1 + exp2(t)),
- * t = x*scale + shift = -log2(e) v, i.e. -log2(e) silu(v) -- the same function with two vector instructions fewer per element. */
-int natinf_debug_conv_gn(int res, int B, int N, int cin, int c1, const void* x, const float* scale, const float* shift, const void* w_packed,
+ * t = x*scale + shift = -log2(e) v, i.e. -log2(e) silu(v) -- the same function with two vector instructions fewer per element.
+ * w_frag: NULL -> k_conv_gn (weights through an LDS ring); else a buffer of N * (9*cin + c1) bf16 that receives the fragment-major
+ * copy of w_packed (k_pack_frag) and k_conv_gn2 runs (weights streamed through registers, csrc/conv_gn2.h) when N is a multiple of
+ * its column tile (128; 256 for the 128-row tile) and natinf_set_conv_gn_regw is 1 (default). */
+int natinf_debug_conv_gn(int res, int B, int N, int cin, int c1, const void* x, const float* scale, const float* shift, const void* w_packed, void* w_frag,
                          const void* a1, const float* bias_n, const void* resid, float out_scale, void* out, float* gn_part, int iters,
                          natinf_stream_t stream);
 int natinf_set_gemm_variant(int variant);
@@ -116,6 +119,7 @@ int natinf_set_gemm_raster(int rows);
 int natinf_set_fuse_gn(int on);
 /* 1 (default): k_conv_gn launches on 16x16 images with N % 256 == 0 use the 128-pixel x 256-channel tile; 0: 256 x 128 everywhere. */
 int natinf_set_conv_gn_wide(int on);
+int natinf_set_conv_gn_regw(int on);
 /* 1 (default): small-M, long-K launches (the 8x8 and 4x4 levels) run as 128 x 128 tiles x 2..4 K slices + a reduce pass; 0: never. */
 int natinf_set_gemm_splitk(int on);
 /* natinf_debug_gemm / natinf_debug_gemm_fused with variant 0 may split K when given a workspace of max_slices * M * N floats

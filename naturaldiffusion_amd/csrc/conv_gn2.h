@@ -1,0 +1,361 @@
+// conv_gn2.h -- k_conv_gn2: the fused GroupNorm-apply + SiLU + 3x3 convolution of conv_gn.h with the WEIGHTS STREAMED THROUGH
+// REGISTERS instead of an LDS ring.
+//
+// What bounded k_conv_gn (tools/conv_gn_timeline.py, profiles/r02): its only per-tap stream was the 128 x 64 B weight tile, but that
+// stream put an `s_waitcnt + s_barrier` in front of every 32-wide K step (nine per half-chunk) and two LDS-DMA instructions per wave
+// and tap (60-185 issue cycles each) on the waves that also issue the MFMAs.  Here
+//   * the weights are stored FRAGMENT-MAJOR (k_pack_frag: one contiguous 1-KiB block per (16 output channels, 32-wide K step), lane l
+//     holds its MFMA operand at l * 16): a wave fetches the four fragments of its 64 output channels for tap t+1 with four coalesced
+//     `global_load_dwordx4` straight into registers while it multiplies tap t (two register sets; an L2-warm load returns in 160-330
+//     cycles, a tap lasts ~1,000) -- no LDS ring, no LDS fragment reads for the weights, no cross-wave dependency;
+//   * a wave normalises exactly the patch pieces IT requested (piece j * 4 + wave: the LDS-DMA destination is lane-linear, so the 16
+//     bytes a lane fetched are the 16 bytes it normalises in place), so the raw patch needs no hand-off between waves either;
+//   * what is left is ONE barrier per half-chunk (nine taps, 288 MFMAs per wave): "the normalised patch of half-chunk h is complete
+//     and everyone is done reading the buffer of h-1".
+// Both tile shapes use the same wave tile (128 pixels x 64 channels: eight A row-tiles stream past four resident weight fragments):
+// 256 x 128 = 2 x 2 waves, 128 x 256 (N = 256 layers at 16x16) = 1 x 4 waves, all four reading the same A fragments.
+// Arithmetic (folded SiLU form, K order, swizzle, epilogues): as conv_gn.h.
+#pragma once
+#include "conv_gn.h"
+
+namespace ncsn {
+
+template <int RES, bool WIDE_ = false>
+struct ConvGn2Cfg {
+    using Geo = PatchGeo<RES>;
+    static constexpr bool WIDE = WIDE_;
+    static constexpr int WM = WIDE ? 1 : 2, WN = WIDE ? 4 : 2, TM = 8, TN = 4, NW = 4, THREADS = 256, KT = 32;
+    static constexpr int BM_ = WM * TM * 16, BN_ = WN * TN * 16;
+    static constexpr int PR = BM_ / Geo::W + 2;                         // image rows of a tile + the halo rows
+    static constexpr int PLAST = (PR - 1) * Geo::WS + Geo::WP;          // patch rows that are ever read
+    static constexpr int NPIECE = (PLAST + 15) / 16;                    // 1-KiB DMA pieces (16 patch rows of 64 B)
+    static constexpr int NROUND = (NPIECE + NW - 1) / NW;               // piece j * NW + wave belongs to wave `wave`, round j
+    static constexpr int NFULL = NPIECE / NW;                           // rounds in which every wave has a piece
+    static constexpr int PSW = BM_ / 16 / NW;                           // shortcut-tile pieces per wave
+    static constexpr int PATCH_BYTES = (NPIECE > BM_ / 16 ? NPIECE : BM_ / 16) * 1024, TAB_BYTES = 256;
+    static constexpr int TILES_BYTES = 2 * PATCH_BYTES + 2 * TAB_BYTES;
+    using Epi = EpiCfg<WM, WN, TM, TN, 81920>;
+    static constexpr int LDS_BYTES = TILES_BYTES > Epi::PACK_BYTES ? TILES_BYTES : Epi::PACK_BYTES;
+    static_assert(RES * RES % BM_ == 0, "a tile lies inside one image");
+    static_assert(NROUND <= 7, "the rounds run behind taps 2..8");
+    static_assert(Epi::PACK_OK && LDS_BYTES <= 81920, "two blocks per CU");
+};
+
+// Weights [N][ld] bf16 in the engine's K order ((c / 64) * 9 + tap) * 64 + c % 64 (+ the c1 shortcut columns at 9 * cin) -> fragment-major
+// [N / 16][NT][64 lanes][8]: K step kt = (half-chunk hc, tap t) reads columns ((hc >> 1) * 9 + t) * 64 + (hc & 1) * 32 .. + 31, the shortcut
+// steps follow; lane l of a block holds row (l & 15), columns 8 * (l >> 4) .. + 7 of the step: the A operand of v_mfma_f32_16x16x32_bf16.
+__global__ __launch_bounds__(256) void k_pack_frag(const bf16* __restrict__ w, bf16* __restrict__ wf, int N, int ld, int cin, int c1)
+{
+    const int nk = 9 * (cin / 32), NT = nk + c1 / 32;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)(N / 16) * NT * 64) return;
+    const int lane = (int)(idx & 63), kt = (int)((idx >> 6) % NT), nt = (int)((idx >> 6) / NT);
+    int col;
+    if (kt < nk) { const int hc = kt / 9, t = kt - 9 * hc; col = ((hc >> 1) * 9 + t) * 64 + (hc & 1) * 32; }
+    else col = 9 * cin + (kt - nk) * 32;
+    const uint4 v = *reinterpret_cast<const uint4*>(w + (int64_t)(nt * 16 + (lane & 15)) * ld + col + (lane >> 4) * 8);
+    *reinterpret_cast<uint4*>(wf + idx * 8) = v;
+}
+
+// (functions, not asm statements inside the kernel's generic lambdas: clang rejects asm operands that name captured variables there)
+__device__ __forceinline__ u32x4 gload16(unsigned voff, const void* sbase) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+    return v;
+}
+template <int OFF> __device__ __forceinline__ void lds_write16(unsigned addr, u32x4 v) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void fresh4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+
+// EPI: the packed epilogues of gemm_dma.h (1 plain, 2 + GroupNorm partials, 5 + bf16 residual, 6 both).  g.b_frag = k_pack_frag's output.
+template <int RES, bool WIDE, int EPI>
+__global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
+{
+    using Cfg = ConvGn2Cfg<RES, WIDE>;
+    using Geo = typename Cfg::Geo;
+    constexpr int BM_ = Cfg::BM_, BN_ = Cfg::BN_, NW = Cfg::NW, TM = Cfg::TM, TN = Cfg::TN, KT = Cfg::KT;
+    constexpr int W = Geo::W, WS = Geo::WS, HW = RES * RES;
+    constexpr int PSW = Cfg::PSW, NROUND = Cfg::NROUND, NPIECE = Cfg::NPIECE, NFULL = Cfg::NFULL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const sPatch = smem;                                   // [2][PATCH_BYTES]
+    unsigned char* const sTab = smem + 2 * Cfg::PATCH_BYTES;              // [2][scale 32 | shift 32] fp32
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = WIDE ? 0 : wave >> 1, wn = WIDE ? wave : wave & 1;
+    const int nN = (g.N + BN_ - 1) / BN_, nM = g.M / BM_;
+    const int tile = xcd_remap(blockIdx.x, nM * nN);
+    const int mt = tile / nN, nt = tile - mt * nN;
+    const int m0 = mt * BM_, n0 = nt * BN_;
+    const int b = m0 / HW, y0 = (m0 % HW) / W;                            // image and first image row of this tile
+    const bf16* const img = g.a0 + (int64_t)b * HW * g.a0_ld;
+    const float* const gsc = g.gn_scale + (int64_t)b * g.gn_ld;
+    const float* const gsh = g.gn_shift + (int64_t)b * g.gn_ld;
+    const int n_half = g.a0_C / KT, n_sc = g.a1 ? g.a1_C / KT : 0;
+    const int nk = 9 * n_half, NT = nk + n_sc;
+
+    // Every LDS access, every LDS-DMA and every weight load of the K loop is inline asm with hand-counted waits (conv_gn.h explains
+    // why: hipcc drains vmcnt in front of any LDS access it can see while an LDS-DMA is in flight).
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    auto lds_addr = [](const unsigned char* p) __attribute__((always_inline)) { return (unsigned)(uintptr_t)((lds_u8*)const_cast<unsigned char*>(p)); };
+    auto glds16 = [](unsigned voff, const void* sbase, unsigned lds_dst) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    };
+    const unsigned lds_patch = lds_addr(sPatch), lds_tab = lds_addr(sTab);
+
+    // ---- weight fragments: two register sets, set (kt & 1) holds K step kt ---------------------------------------------------
+    u32x4 bw[2][TN];
+    unsigned boff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) boff[j] = (unsigned)(((n0 >> 4) + wn * TN + j) * NT) * 1024u + (unsigned)lane * 16u;
+    const unsigned char* const wfrag = reinterpret_cast<const unsigned char*>(g.b_frag);
+    auto load_b = [&](auto set_tag, int kt) __attribute__((always_inline)) {
+        constexpr int P = decltype(set_tag)::value;
+        const unsigned char* base = wfrag + (int64_t)kt * 1024;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bw[P][j] = gload16(boff[j], base);
+    };
+
+    // ---- requests: the (scale | shift) table + this wave's patch pieces of half-chunk hc -> buffers hc & 1 ---------------------
+    auto issue_patch = [&](int hc) __attribute__((always_inline)) {
+        const int buf = hc & 1;
+        int l = lane;
+        asm volatile("" : "+v"(l));                                          // addresses recomputed per request (once per nine taps): no registers held
+        {
+            const float* src = (l < 32 ? gsc : gsh - 32) + (unsigned)(hc * KT + l);
+            const unsigned dst = lds_tab + buf * Cfg::TAB_BYTES;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(src), "s"(dst) : "memory");
+        }
+        const bf16* base = img + hc * KT;
+        const int prow = l >> 2, pslot = l & 3;
+#pragma unroll
+        for (int j = 0; j < NROUND; ++j) {
+            const int q = j * NW + wave;                                      // wave-uniform piece index
+            if (j >= NFULL && q >= NPIECE) continue;
+            const int pp = q * 16 + prow;
+            const int yy = pp / WS, xx = pp - yy * WS;
+            const int y = min(max(y0 - 1 + yy, 0), RES - 1), x = min(max(xx - 1, 0), RES - 1);      // halo / pad: any readable pixel
+            glds16((unsigned)((y * W + x) * g.a0_ld + ((pslot ^ ((pp >> 1) & 2)) << 3)) * 2u, base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
+        }
+    };
+    auto issue_shortcut = [&](int s) __attribute__((always_inline)) {        // plain [BM][32] tile of a1 -> patch buffer s & 1 (n_half is even)
+        const unsigned dst = lds_patch + (s & 1) * Cfg::PATCH_BYTES + wave * (PSW * 1024);
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int prow = l >> 2, pslot = l & 3;
+        const bf16* base = g.a1 + (int64_t)m0 * g.a1_ld + s * KT;
+#pragma unroll
+        for (int j = 0; j < PSW; ++j) {
+            const int pp = (wave * PSW + j) * 16 + prow;
+            glds16((unsigned)(pp * g.a1_ld + ((pslot ^ ((pp >> 1) & 2)) << 3)) * 2u, base, dst + j * 1024);
+        }
+    };
+
+    // ---- in-place normalisation, round j: the wave's piece j * NW + wave, lane l its bytes l * 16 .. + 15 = patch row q * 16 + (l >> 2),
+    // ---- slot l & 3, which holds channel chunk (l & 3) ^ 2 * bit 4 of l (bit 2 of the patch row is bit 4 of the lane).
+    const unsigned nbase = lds_patch + wave * 1024 + lane * 16;
+    const unsigned tbase = lds_tab + (((lane & 3) ^ ((lane >> 3) & 2)) * 32);
+    unsigned nmask = 0;                                                      // bit j: the pixel of round j lies inside the image
+#pragma unroll
+    for (int j = 0; j < NROUND; ++j) {
+        const int pp = (j * NW + wave) * 16 + (lane >> 2);
+        const int yy = pp / WS, xx = pp - yy * WS;
+        if ((unsigned)(y0 - 1 + yy) < (unsigned)RES && (unsigned)(xx - 1) < (unsigned)RES) nmask |= 1u << j;
+    }
+    u32x4 nv = {0u, 0u, 0u, 0u}, ns0 = nv, ns1 = nv, nh0 = nv, nh1 = nv;
+    unsigned npk[4] = {0u, 0u, 0u, 0u};
+    float nf_even = 0.f;
+    auto norm_load = [&](auto j_tag, auto buf_tag) __attribute__((always_inline)) {
+        constexpr int J = decltype(j_tag)::value, BUF = decltype(buf_tag)::value;
+        nv = lds_read16<BUF * Cfg::PATCH_BYTES + J * NW * 1024>(nbase);
+        ns0 = lds_read16<BUF * Cfg::TAB_BYTES>(tbase); ns1 = lds_read16<BUF * Cfg::TAB_BYTES + 16>(tbase);
+        nh0 = lds_read16<BUF * Cfg::TAB_BYTES + 128>(tbase); nh1 = lds_read16<BUF * Cfg::TAB_BYTES + 144>(tbase);
+    };
+#define NATINF_CG_NORM_PRE(I) asm volatile("" : "+v"(nv), "+v"(ns0), "+v"(ns1), "+v"(nh0), "+v"(nh1));
+#define NATINF_CG_NORM_EL(I)                                                                                                \
+        {                                                                                                                    \
+            const unsigned w_ = nv[(I) >> 1];                                                                                \
+            const float x_ = __uint_as_float(((I) & 1) ? (w_ & 0xffff0000u) : (w_ << 16));                                   \
+            const float t_ = x_ * __uint_as_float((I) < 4 ? ns0[(I) & 3] : ns1[(I) & 3]) + __uint_as_float((I) < 4 ? nh0[(I) & 3] : nh1[(I) & 3]); \
+            const float y_ = t_ * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t_));                                  \
+            if constexpr (((I) & 1) == 0) nf_even = y_;                                                                      \
+            else {                                                                                                           \
+                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));                                                 \
+                const bf16x2_t pr_ = {(bf16)nf_even, (bf16)y_};                                                              \
+                npk[(I) >> 1] = __builtin_bit_cast(unsigned, pr_);                                                           \
+            }                                                                                                                \
+        }                                                                                                                    \
+        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                                   \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       /* one MFMA */                                           \
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);       /* two vector instructions */                            \
+        }
+#define NATINF_CG_NORM_POST(I) if constexpr (((I) & 1) == 0) asm volatile("" : "+v"(nf_even)); else asm volatile("" : "+v"(npk[(I) >> 1]));
+    auto norm_store = [&](auto j_tag, auto buf_tag) __attribute__((always_inline)) {
+        constexpr int J = decltype(j_tag)::value, BUF = decltype(buf_tag)::value;
+        u32x4 ou = {npk[0], npk[1], npk[2], npk[3]};
+        if (!((nmask >> J) & 1u)) ou = u32x4{0u, 0u, 0u, 0u};
+        lds_write16<BUF * Cfg::PATCH_BYTES + J * NW * 1024>(nbase, ou);
+    };
+    auto norm_round = [&](auto j_tag, auto buf_tag) __attribute__((always_inline)) {   // a whole round at once (prologue)
+        norm_load(j_tag, buf_tag);
+        wait_lgkmcnt<0>();
+#define NATINF_CG_NORM_ONE(I) NATINF_CG_NORM_PRE(I) NATINF_CG_NORM_EL(I) NATINF_CG_NORM_POST(I) __builtin_amdgcn_sched_barrier(0);
+        NATINF_CG_NORM_ONE(0) NATINF_CG_NORM_ONE(1) NATINF_CG_NORM_ONE(2) NATINF_CG_NORM_ONE(3)
+        NATINF_CG_NORM_ONE(4) NATINF_CG_NORM_ONE(5) NATINF_CG_NORM_ONE(6) NATINF_CG_NORM_ONE(7)
+#undef NATINF_CG_NORM_ONE
+        norm_store(j_tag, buf_tag);
+    };
+#define NATINF_CG_NO_PRE(I)
+#define NATINF_CG_NO_POST(I)
+#define NATINF_CG_NO_EL(I)
+
+    // ---- A fragment addresses: three per-lane bases (dx = -1, 0, +1) at dy = -1; everything else is an immediate -------------
+    const int frow = lane & 15, fq = lane >> 4;
+    unsigned a_dx[3];
+    {
+        const int ml = wm * (TM * 16) + frow;                             // first pixel row-tile of this wave
+        const int pc = ((ml / W) + 1) * WS + (ml % W) + 1;                // its patch row at the centre tap
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int pp = pc - WS + d - 1;
+            a_dx[d] = lds_patch + pp * 64 + ((fq ^ ((pp >> 1) & 2)) << 4);
+        }
+    }
+    const int arow = wm * (TM * 16) + frow;
+    const unsigned a_plain = lds_patch + arow * 64 + ((fq ^ ((arow >> 1) & 2)) << 4);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // One 32-wide K step: A row-tiles 0, 1 are requested up front, row-tile s+2 while s is multiplied with the four resident weight
+    // fragments of register set P; `s_waitcnt lgkmcnt(n)` retires exactly the fragment the next four MFMAs need (LDS returns in
+    // order; the five reads of a normalisation round are older than all of them).  EL(i): the vector work placed behind MFMA group i.
+#define NATINF_CG_STEP(a, AOFF, P, S, EL)                                                                                   \
+        if constexpr ((S) + 2 < 8) fs[((S) + 2) % 3] = lds_read16<AOFF((S) + 2)>(a);                                         \
+        wait_lgkmcnt<((S) + 2 < 8 ? 2 : 7 - (S))>();                                                                          \
+        EL##_PRE(S)                                                                                                          \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                                     \
+            acc[S][r_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[P][r_]), __builtin_bit_cast(bf16x8, fs[(S) % 3]), acc[S][r_], 0, 0, 0); \
+        EL##_EL(S)                                                                                                           \
+        EL##_POST(S)                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);
+#define NATINF_CG_HEAD(a, AOFF) u32x4 fs[3]; fs[0] = lds_read16<AOFF(0)>(a); fs[1] = lds_read16<AOFF(1)>(a);
+#define NATINF_CG_BODY(a, AOFF, P, EL)                                                                                      \
+        NATINF_CG_STEP(a, AOFF, P, 0, EL) NATINF_CG_STEP(a, AOFF, P, 1, EL) NATINF_CG_STEP(a, AOFF, P, 2, EL) NATINF_CG_STEP(a, AOFF, P, 3, EL) \
+        NATINF_CG_STEP(a, AOFF, P, 4, EL) NATINF_CG_STEP(a, AOFF, P, 5, EL) NATINF_CG_STEP(a, AOFF, P, 6, EL) NATINF_CG_STEP(a, AOFF, P, 7, EL)
+    // the weight fragments of set P have landed (the wait in front of this): from here on they are new values to hipcc
+#define NATINF_CG_BW_READY(P) fresh4(bw[P][0], bw[P][1], bw[P][2], bw[P][3]);
+
+    // ---- prologue: this wave's table + patch pieces of half-chunk 0 and weight step 0; its pieces are normalised before the loop ----
+    using std::integral_constant;
+    issue_patch(0);
+    load_b(integral_constant<int, 0>{}, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        auto b0 = integral_constant<int, 0>{};
+        norm_round(integral_constant<int, 0>{}, b0);
+        if constexpr (NROUND > 1) if (1 < NFULL || 1 * NW + wave < NPIECE) norm_round(integral_constant<int, 1>{}, b0);
+        if constexpr (NROUND > 2) if (2 < NFULL || 2 * NW + wave < NPIECE) norm_round(integral_constant<int, 2>{}, b0);
+        if constexpr (NROUND > 3) if (3 < NFULL || 3 * NW + wave < NPIECE) norm_round(integral_constant<int, 3>{}, b0);
+        if constexpr (NROUND > 4) if (4 < NFULL || 4 * NW + wave < NPIECE) norm_round(integral_constant<int, 4>{}, b0);
+        if constexpr (NROUND > 5) if (5 < NFULL || 5 * NW + wave < NPIECE) norm_round(integral_constant<int, 5>{}, b0);
+        if constexpr (NROUND > 6) if (6 < NFULL || 6 * NW + wave < NPIECE) norm_round(integral_constant<int, 6>{}, b0);
+    }
+
+    // ---- the nine taps of one half-chunk; BUF (its patch buffer) and the tap index are compile-time: all offsets are immediates.
+    // Weight set of K step kt = hc * 9 + T: (kt & 1) = (T + BUF) & 1 (hc and BUF have the same parity).
+#define NATINF_CG_AOFF(i) (BUF * Cfg::PATCH_BYTES + ((RES == 32 ? ((i) >> 1) * WS + ((i) & 1) * 16 : (i) * WS) + (T / 3) * WS) * 64)
+    auto tap = [&](auto buf_tag, auto t_tag, int hc, bool next_half) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_tag)::value, T = decltype(t_tag)::value, P = (T + BUF) & 1;
+        const int kt = hc * 9 + T;
+        // Weight step kt has landed.  Younger requests: the aux request of tap 0 (at T = 1: it stays in flight; every wave issued at
+        // least 1 + NFULL / PSW of them).  Tap 0 is the hand-off: every wave's normalised pieces of this half-chunk are written
+        // (lgkmcnt) and nobody reads the other buffer any more -> the next half-chunk's raw patch may land in it.
+        if constexpr (T == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if constexpr (T == 1) {
+            if (next_half) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 + NFULL) : "memory");
+            else if (n_sc > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PSW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        NATINF_CG_BW_READY(P)
+        if (kt + 1 < NT) load_b(integral_constant<int, P ^ 1>{}, kt + 1);
+        if constexpr (T == 0) {
+            if (next_half) issue_patch(hc + 1);
+            else if (n_sc > 0) issue_shortcut(0);
+        }
+        constexpr bool NORM_TAP = T >= 2 && T - 2 < NROUND && NATINF_CG_ABL != 1;
+        constexpr int J = NORM_TAP ? T - 2 : 0;
+        const bool live = NORM_TAP && next_half && (J < NFULL || J * NW + wave < NPIECE);
+        if constexpr (NORM_TAP) { if (live) norm_load(integral_constant<int, J>{}, integral_constant<int, BUF ^ 1>{}); }
+        NATINF_CG_HEAD(a_dx[T % 3], NATINF_CG_AOFF)
+        if constexpr (NORM_TAP) {
+            NATINF_CG_BODY(a_dx[T % 3], NATINF_CG_AOFF, P, NATINF_CG_NORM)
+            if (live) norm_store(integral_constant<int, J>{}, integral_constant<int, BUF ^ 1>{});
+        } else {
+            NATINF_CG_BODY(a_dx[T % 3], NATINF_CG_AOFF, P, NATINF_CG_NO)
+        }
+    };
+    auto half_chunk = [&](auto buf_tag, int hc) __attribute__((always_inline)) {
+        const bool next_half = hc + 1 < n_half;
+        tap(buf_tag, integral_constant<int, 0>{}, hc, next_half); tap(buf_tag, integral_constant<int, 1>{}, hc, next_half);
+        tap(buf_tag, integral_constant<int, 2>{}, hc, next_half); tap(buf_tag, integral_constant<int, 3>{}, hc, next_half);
+        tap(buf_tag, integral_constant<int, 4>{}, hc, next_half); tap(buf_tag, integral_constant<int, 5>{}, hc, next_half);
+        tap(buf_tag, integral_constant<int, 6>{}, hc, next_half); tap(buf_tag, integral_constant<int, 7>{}, hc, next_half);
+        tap(buf_tag, integral_constant<int, 8>{}, hc, next_half);
+    };
+    for (int hc = 0; hc < n_half; hc += 2) {                              // a0_C is a multiple of 64: half-chunks come in pairs
+        half_chunk(integral_constant<int, 0>{}, hc);
+        half_chunk(integral_constant<int, 1>{}, hc + 1);
+    }
+#undef NATINF_CG_AOFF
+    // ---- 1x1 shortcut segment: plain [BM][32] A tiles through the two patch buffers (tile s+1 requested at the head of tile s; every
+    // ---- wave fetches a quarter of a tile, so each tile is a hand-off), weights through the register sets as before; a1_C % 64 == 0
+#define NATINF_CG_POFF(i) (BUF * Cfg::PATCH_BYTES + (i) * 1024)
+    auto sc_tile = [&](auto buf_tag, int s) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_tag)::value, P = BUF;            // nk is even: K step nk + s lives in set s & 1
+        const int kt = nk + s;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        NATINF_CG_BW_READY(P)
+        if (kt + 1 < NT) load_b(integral_constant<int, P ^ 1>{}, kt + 1);
+        if (s + 1 < n_sc) issue_shortcut(s + 1);
+        NATINF_CG_HEAD(a_plain, NATINF_CG_POFF)
+        NATINF_CG_BODY(a_plain, NATINF_CG_POFF, P, NATINF_CG_NO)
+    };
+    for (int s = 0; s < n_sc; s += 2) {
+        sc_tile(integral_constant<int, 0>{}, s);
+        sc_tile(integral_constant<int, 1>{}, s + 1);
+    }
+#undef NATINF_CG_POFF
+#undef NATINF_CG_STEP
+#undef NATINF_CG_HEAD
+#undef NATINF_CG_BODY
+#undef NATINF_CG_BW_READY
+#undef NATINF_CG_NO_EL
+#undef NATINF_CG_NO_PRE
+#undef NATINF_CG_NO_POST
+#undef NATINF_CG_NORM_PRE
+#undef NATINF_CG_NORM_EL
+#undef NATINF_CG_NORM_POST
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done with the tiles before the epilogue reuses them
+    // the epilogue's arguments are fetched from the kernel-argument segment HERE (conv_gn.h: kept in scalar registers across the K
+    // loop they end up spilled into vector-register lanes)
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const unsigned __attribute__((address_space(4))) *kernarg_u32_t;
+    kernarg_u32_t gp = (kernarg_u32_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(gp));
+    GemmArgs ge;
+    {
+        unsigned* d = reinterpret_cast<unsigned*>(&ge);
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(GemmArgs) / 4; ++i) d[i] = gp[i];
+    }
+#else
+    const GemmArgs ge = g;
+#endif
+    tile_epilogue<Cfg::WM, Cfg::WN, TM, TN, typename Cfg::Epi, EPI>(ge, smem, acc, m0, n0, 0, tid, lane, wm, wn);
+}
+
+}  // namespace ncsn

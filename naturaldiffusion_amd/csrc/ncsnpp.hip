@@ -30,6 +30,7 @@
 #include "gemm_dma.h"
 #include "conv_patch.h"
 #include "conv_gn.h"
+#include "conv_gn2.h"
 #include "gemm_8phase.h"
 #include "gemm_fp8.h"
 #include "attn_fused.h"
@@ -196,6 +197,7 @@ using CfgR256x128W4 = RingCfg<2, 2, 8, 4, 3>; using CfgD256x128W4 = DmaCfg<2, 2,
 using CfgD512x128 = DmaCfg<4, 2, 8, 4>;
 using CfgP256x256 = PatchCfg<2, 4, 8, 4, 344>; using CfgP256x128 = PatchCfg<4, 2, 4, 4, 400>;
 using CfgG32 = ConvGnCfg<32>; using CfgG16 = ConvGnCfg<16>; using CfgG16W = ConvGnCfg<16, true>;
+using CfgH32 = ConvGn2Cfg<32>; using CfgH16 = ConvGn2Cfg<16>; using CfgH16W = ConvGn2Cfg<16, true>;
 int g_fuse_gn = 1;                 // natinf_set_fuse_gn (read when a plan is BUILT): GroupNorm-apply + SiLU inside the consuming 3x3 conv
 
 // the packed-epilogue instantiations (EPI 1..4) of the four automatically chosen variants
@@ -208,7 +210,8 @@ bool set_lds_epi() {
 }
 template <int EPI>
 bool set_lds_conv_gn() {
-    return set_lds<CfgG32>(&k_conv_gn<32, false, EPI>) && set_lds<CfgG16>(&k_conv_gn<16, false, EPI>) && set_lds<CfgG16W>(&k_conv_gn<16, true, EPI>);
+    return set_lds<CfgG32>(&k_conv_gn<32, false, EPI>) && set_lds<CfgG16>(&k_conv_gn<16, false, EPI>) && set_lds<CfgG16W>(&k_conv_gn<16, true, EPI>) &&
+           set_lds<CfgH32>(&k_conv_gn2<32, false, EPI>) && set_lds<CfgH16>(&k_conv_gn2<16, false, EPI>) && set_lds<CfgH16W>(&k_conv_gn2<16, true, EPI>);
 }
 bool set_lds_epi_all() { return set_lds_epi<0>() && set_lds_epi<1>() && set_lds_epi<2>() && set_lds_epi<3>() && set_lds_epi<4>() && set_lds_epi<5>() && set_lds_epi<6>() && set_lds_epi<7>() && set_lds_epi<8>(); }
 
@@ -253,7 +256,9 @@ int variant_bm(int v);
 // (natinf_set_conv_gn_wide: A/B runs); packed epilogues 1 / 2 / 5 / 6 only
 int packed_epi(const GemmArgs& g, int bm);
 int g_cg_wide = 1;
+int g_cg_regw = 1;                 // natinf_set_conv_gn_regw: 1 = k_conv_gn2 (weights streamed through registers) where GemmArgs::b_frag is given
 inline int conv_gn_bm(const GemmArgs& g) { return (g_cg_wide && (1 << g.logW) == 16 && g.N % 256 == 0) ? 128 : 256; }
+inline bool conv_gn_regw(const GemmArgs& g) { return g_cg_regw && g.b_frag && g.N % (conv_gn_bm(g) == 128 ? 256 : 128) == 0; }
 inline bool conv_gn_ok(const GemmArgs& g) {
     if (!g.gn_scale || !g.gn_shift || !g.gn_folded || g.taps != 9 || g.batch != 1 || g.a0_C % BK || (g.a1 && g.a1_C % BK) || g.M % 256) return false;
     const int res = 1 << g.logW;
@@ -443,9 +448,22 @@ int launch_gemm(const GemmArgs& g0, hipStream_t s) {
                 case 2: launch_tiles<CFG>(&k_conv_gn<RES, WIDE, 5>, g, s); break;                               \
                 default: launch_tiles<CFG>(&k_conv_gn<RES, WIDE, 6>, g, s); break;                              \
             }
-            if ((1 << g.logW) == 32) { NATINF_CG_LAUNCH(CfgG32, 32, false) }
+#define NATINF_CG2_LAUNCH(CFG, RES, WIDE)                                                                   \
+            switch (e4) {                                                                                       \
+                case 0: launch_tiles<CFG>(&k_conv_gn2<RES, WIDE, 1>, g, s); break;                              \
+                case 1: launch_tiles<CFG>(&k_conv_gn2<RES, WIDE, 2>, g, s); break;                              \
+                case 2: launch_tiles<CFG>(&k_conv_gn2<RES, WIDE, 5>, g, s); break;                              \
+                default: launch_tiles<CFG>(&k_conv_gn2<RES, WIDE, 6>, g, s); break;                             \
+            }
+            if (conv_gn_regw(g)) {
+                if ((1 << g.logW) == 32) { NATINF_CG2_LAUNCH(CfgH32, 32, false) }
+                else if (conv_gn_bm(g) == 128) { NATINF_CG2_LAUNCH(CfgH16W, 16, true) }
+                else { NATINF_CG2_LAUNCH(CfgH16, 16, false) }
+            }
+            else if ((1 << g.logW) == 32) { NATINF_CG_LAUNCH(CfgG32, 32, false) }
             else if (conv_gn_bm(g) == 128) { NATINF_CG_LAUNCH(CfgG16W, 16, true) }
             else { NATINF_CG_LAUNCH(CfgG16, 16, false) }
+#undef NATINF_CG2_LAUNCH
 #undef NATINF_CG_LAUNCH
             return conv_gn_bm(g);
         }
@@ -484,6 +502,13 @@ struct Builder {
             const int64_t n = (int64_t)N * Cin * taps;
             hipLaunchKernelGGL(k_pack_conv, dim3(grid1d(n, 256, 1 << 30)), dim3(256), 0, p.stream, p.params + src,
                                reinterpret_cast<bf16*>(p.packed + dst), N, Cin, taps, dst_ld, koff, tapstride, chunked, wmul);
+        });
+    }
+    void pack_frag(int64_t src_packed, int64_t dst, int N, int ld, int cin, int c1) {      // packed -> packed (conv_gn2.h)
+        E.packs.push_back([=](const PackCtx& p) {
+            const int64_t n = (int64_t)(N / 16) * (9 * (cin / 32) + c1 / 32) * 64;
+            hipLaunchKernelGGL(k_pack_frag, dim3(grid1d(n, 256, 1 << 30)), dim3(256), 0, p.stream, reinterpret_cast<const bf16*>(p.packed + src_packed),
+                               reinterpret_cast<bf16*>(p.packed + dst), N, ld, cin, c1);
         });
     }
     void pack_transpose(int64_t src, int64_t dst, int K, int N, int dst_ld) {
@@ -565,6 +590,10 @@ struct Builder {
         pack_conv(p_c0w, w0, cout, cin, 9, K0a, 0, cin, w_mul);
         pack_conv(p_c1w, w1, cout, cout, 9, K1tot, 0, cout, w_mul1);
         if (shortcut) pack_conv(p_c2w, w1, cout, cin, 1, K1tot, 9 * cout, cin);
+        // k_conv_gn2 reads the weights fragment-major (after the packs above: the list runs in order)
+        const int64_t w0f = (fuse && cout % 16 == 0) ? wres((int64_t)cout * K0a * 2) : -1, w1f = (fuse1 && cout % 16 == 0) ? wres((int64_t)cout * K1tot * 2) : -1;
+        if (w0f >= 0) pack_frag(w0, w0f, cout, K0a, cin, 0);
+        if (w1f >= 0) pack_frag(w1, w1f, cout, K1tot, cout, shortcut ? cin : 0);
         const int64_t b0 = pack_f32(p_c0b, cout), b1 = pack_f32(p_c1b, cout, shortcut ? p_c2b : -1);
         // time-embedding projection rows of this block inside the shared bank
         const int drow = dense_rows_next;
@@ -594,6 +623,7 @@ struct Builder {
             else { g.a0 = c.act(h); g.a0_ld = h.ld; g.a0_padded = 1; }
             g.a0_C = cin; g.taps = 9; g.logW = logW; g.logHW = logHW;
             g.M = c.B * HWo; g.N = cout; g.b = c.w<bf16>(w0); g.b_ld = K0a;
+            if (w0f >= 0) g.b_frag = c.w<bf16>(w0f);
             g.bias_n = c.w<float>(b0);
             g.rowvec = c.at<float>(dout) + drow; g.rowvec_ld = dtotal; g.log_rows_per_sample = logHW;
             if (skws >= 0) { g.splitk_ws = c.at<float>(skws); g.splitk_max = SK_MAX; }
@@ -621,6 +651,7 @@ struct Builder {
             if (shortcut) { g.a1 = c.act(xs); g.a1_ld = xs.ld; g.a1_C = cin; }
             else { g.resid = c.act(xs); g.resid_ld = xs.ld; }
             g.M = c.B * HWo; g.N = cout; g.b = c.w<bf16>(w1); g.b_ld = K1tot;
+            if (w1f >= 0) g.b_frag = c.w<bf16>(w1f);
             g.bias_n = c.w<float>(b1); g.scale = INV_SQRT2;
             if (skws >= 0) { g.splitk_ws = c.at<float>(skws); g.splitk_max = SK_MAX; }
             g.c = c.act(out); g.c_ld = out.ld;
@@ -1154,7 +1185,7 @@ int natinf_debug_gemm_fused(int variant, int M, int N, int K, const void* a, con
 // [M / 256][N / 4] float2 partial (sum, sum of squares) of the outputs.  The kernel takes its operands in FOLDED form
 // (GemmArgs::gn_folded): the caller passes scale * -log2(e), shift * -log2(e) and the 3x3 columns of w_packed * -ln 2.
 int natinf_debug_conv_gn(int res, int B, int N, int cin, int c1, const void* x, const float* scale, const float* shift, const void* w_packed,
-                         const void* a1, const float* bias_n, const void* resid, float out_scale, void* out, float* gn_part, int iters,
+                         void* w_frag, const void* a1, const float* bias_n, const void* resid, float out_scale, void* out, float* gn_part, int iters,
                          natinf_stream_t stream) {
     if ((res != 32 && res != 16) || B <= 0 || N <= 0 || N % 8 || cin <= 0 || cin % 64 || c1 < 0 || c1 % 64 || (c1 > 0) != (a1 != nullptr) ||
         !x || !scale || !shift || !w_packed || !out || iters <= 0) return NATINF_EINVAL;
@@ -1169,6 +1200,11 @@ int natinf_debug_conv_gn(int res, int B, int N, int cin, int c1, const void* x, 
     g.gn_part = gn_part; g.gn_quads = N / 4;
     g.dbg_ts = g_dbg_ts;
     if (!conv_gn_ok(g)) return NATINF_EINVAL;
+    if (w_frag && N % 16 == 0) {             // k_conv_gn2 (used when N is a whole number of its column tiles): w_frag receives the fragment-major copy
+        const int64_t n = (int64_t)(N / 16) * (9 * (cin / 32) + c1 / 32) * 64;
+        hipLaunchKernelGGL(k_pack_frag, dim3(grid1d(n, 256, 1 << 30)), dim3(256), 0, (hipStream_t)stream, (const bf16*)w_packed, (bf16*)w_frag, N, g.b_ld, cin, c1);
+        g.b_frag = (const bf16*)w_frag;
+    }
     for (int i = 0; i < iters; ++i) launch_gemm(g, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
 }
@@ -1205,6 +1241,7 @@ int natinf_debug_timestamps(void* dev_buf16) {
 int natinf_set_gemm_raster(int rows) { g_raster_g = rows; return NATINF_OK; }
 int natinf_set_fuse_gn(int on) { g_fuse_gn = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_wide(int on) { g_cg_wide = on != 0; return NATINF_OK; }
+int natinf_set_conv_gn_regw(int on) { g_cg_regw = on != 0; return NATINF_OK; }
 int natinf_set_gemm_splitk(int on) { g_splitk = on != 0; return NATINF_OK; }
 int natinf_debug_set_splitk_workspace(float* ws, int max_slices) { g_dbg_splitk_ws = ws; g_dbg_splitk_max = ws ? max_slices : 0; return NATINF_OK; }
 int natinf_set_gemm_half_issue(int on) { g_half_issue = on != 0; return NATINF_OK; }

@@ -70,6 +70,8 @@ struct GemmArgs {
     // gn_folded: scale / shift arrive multiplied by -log2(e) and the 3x3 weights by -ln 2 (the kernel then computes t = x*scale + shift,
     // t / (1 + exp2(t)) = -log2(e) * silu(v): two vector instructions per element fewer); 0: plain scale / shift / weights
     const float* gn_scale; const float* gn_shift; int gn_ld; int gn_folded;
+    // k_conv_gn2: the weights of a gn_scale launch once more, fragment-major (k_pack_frag); NULL -> k_conv_gn (LDS weight ring)
+    const bf16* b_frag;
     // split-K (launch_gemm decides; small-M, long-K launches): `splitk_ws` = fp32 workspace for splitk_max * M * N partial sums
     float* splitk_ws; int splitk_max; int splitk;
 };

@@ -1,6 +1,6 @@
-"""Isolated timing of k_conv_gn (fused GroupNorm-apply + SiLU + 3x3 conv): bench_conv_gn.py [res B cin N c1 [iters]] ...
+"""Isolated timing of k_conv_gn2 / k_conv_gn (fused GroupNorm-apply + SiLU + 3x3 conv; env REGW=0: the LDS-ring kernel): bench_conv_gn.py [res B cin N c1 [iters]] ...
 With no arguments: the engine's shapes at B = 512.  Prints ms and TFLOP/s (2*M*N*(9*cin + c1))."""
-import sys, time
+import os, sys, time
 from pathlib import Path
 import torch
 ROOT = Path(__file__).resolve().parent.parent
@@ -16,7 +16,8 @@ def run(res, B, cin, N, c1, iters=20):
     a1 = torch.randn(M, c1, device=dev).bfloat16() if c1 else None
     bias = torch.randn(N, device=dev); out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     part = torch.zeros(M // 256, N // 4, 2, device=dev)
-    args = (res, B, N, cin, c1, ptr(x), ptr(sc), ptr(sh), ptr(w), ptr(a1), ptr(bias), None, 0.7071, ptr(out), ptr(part))
+    wf = torch.zeros_like(w) if os.environ.get('REGW', '1') != '0' else None
+    args = (res, B, N, cin, c1, ptr(x), ptr(sc), ptr(sh), ptr(w), ptr(wf), ptr(a1), ptr(bias), None, 0.7071, ptr(out), ptr(part))
     check(lib.natinf_debug_conv_gn(*args, 3, stream_ptr()), "warm")
     torch.cuda.synchronize(); t0 = time.perf_counter()
     check(lib.natinf_debug_conv_gn(*args, iters, stream_ptr()), "run")

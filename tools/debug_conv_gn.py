@@ -16,10 +16,11 @@ h = bf(F.silu(x * scale[:, None, None, :] + shift[:, None, None, :]))
 ref = (F.conv2d(h.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1).reshape(B * res * res, N) + bias.double()).float()
 dev = "cuda"
 xd, wd, scd, shd, bd = x.bfloat16().to(dev).contiguous(), _pack(w * -0.6931471805599453, None).bfloat16().to(dev), scale.to(dev), shift.to(dev), bias.to(dev)
+wf = torch.zeros_like(wd)
 out = torch.zeros(B * res * res, N, dtype=torch.bfloat16, device=dev)
 for parts in (False, True):
     part = torch.zeros(B * res * res // 256, N // 4, 2, device=dev) if parts else None
-    check(lib.natinf_debug_conv_gn(res, B, N, cin, c1, ptr(xd), ptr(scd), ptr(shd), ptr(wd), None, ptr(bd), None, 1.0, ptr(out), ptr(part), 1, stream_ptr()), "x")
+    check(lib.natinf_debug_conv_gn(res, B, N, cin, c1, ptr(xd), ptr(scd), ptr(shd), ptr(wd), ptr(wf), None, ptr(bd), None, 1.0, ptr(out), ptr(part), 1, stream_ptr()), "x")
     torch.cuda.synchronize()
     got = out.float().cpu()
     d = (got - ref).abs()
