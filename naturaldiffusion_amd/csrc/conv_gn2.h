@@ -15,6 +15,14 @@
 // Both tile shapes use the same wave tile (128 pixels x 64 channels: eight A row-tiles stream past four resident weight fragments):
 // 256 x 128 = 2 x 2 waves, 128 x 256 (N = 256 layers at 16x16) = 1 x 4 waves, all four reading the same A fragments.
 // Arithmetic (folded SiLU form, K order, swizzle, epilogues): as conv_gn.h.
+// Measured on top of this form and not kept (same-box A/B, tools/bench_conv_gn.py; DESIGN.md section 4 has the numbers):
+//   * the taps as ONE software pipeline (A fragments of tap t+1 requested in the last two steps of tap t, the four weight loads and the
+//     request items of tap 0 spread one per MFMA group): 128x256 tile 4-5 % SLOWER, 256x128 tile equal;
+//   * normalisation elements in pairs (no transcendental result consumed by the next instruction: hipcc's s_nop padding halves): equal;
+//   * v_mfma_f32_32x32x16_bf16 (half the MFMA instructions, 1.5x the vector-issue room per matrix-pipe cycle -- tools/probes/
+//     mfma_issue_probe.hip --, swizzle by patch column, 32x32 packed epilogue): 5 % fewer shader cycles (PMC), equal wall time.
+// PMC picture of the 256x128 tile (tools/pmc_conv_gn.sh): matrix pipe 48-55 % busy, LDS 25 %, L1/TA ~45 %, waves 24 % in s_waitcnt and
+// 38 % ready-but-not-issued: no unit is saturated; two waves per SIMD do not cover each other's dependency stalls.
 #pragma once
 #include "conv_gn.h"
 
@@ -119,12 +127,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     // ---- requests: the (scale | shift) table + this wave's patch pieces of half-chunk hc -> buffers hc & 1 ---------------------
     auto issue_patch = [&](int hc) __attribute__((always_inline)) {
         const int buf = hc & 1;
-        int l = lane;
-        asm volatile("" : "+v"(l));                                          // addresses recomputed per request (once per nine taps): no registers held
+        int l;                                                               // the lane id, recomputed: kept alive across the K loop it is the value hipcc spills
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));                                          // addresses recomputed per request (once per nine taps): no registers held
         {
-            const float* src = (l < 32 ? gsc : gsh - 32) + (unsigned)(hc * KT + l);
+            // the table: scale by lanes 0-31, shift by lanes 32-63 -- two half-wave requests with a scalar base and a 32-bit lane offset
+            // (one request with a per-lane 64-bit address kept a zero register alive across the loop, which hipcc then spilled)
             const unsigned dst = lds_tab + buf * Cfg::TAB_BYTES;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(src), "s"(dst) : "memory");
+            const unsigned toff = (unsigned)(l & 31) * 4u;
+            if (l < 32) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(toff), "s"(gsc + hc * KT), "s"(dst) : "memory");
+            else        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(toff), "s"(gsh + hc * KT), "s"(dst) : "memory");
         }
         const bf16* base = img + hc * KT;
         const int prow = l >> 2, pslot = l & 3;
@@ -140,8 +151,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     };
     auto issue_shortcut = [&](int s) __attribute__((always_inline)) {        // plain [BM][32] tile of a1 -> patch buffer s & 1 (n_half is even)
         const unsigned dst = lds_patch + (s & 1) * Cfg::PATCH_BYTES + wave * (PSW * 1024);
-        int l = lane;
-        asm volatile("" : "+v"(l));
+        int l;                                                               // the lane id, recomputed: kept alive across the K loop it is the value hipcc spills
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
         const int prow = l >> 2, pslot = l & 3;
         const bf16* base = g.a1 + (int64_t)m0 * g.a1_ld + s * KT;
 #pragma unroll
@@ -251,6 +262,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
 
     // ---- prologue: this wave's table + patch pieces of half-chunk 0 and weight step 0; its pieces are normalised before the loop ----
     using std::integral_constant;
+#ifdef NATINF_DEV
+    unsigned long long dbg_wait = 0, dbg_head = 0, dbg_mfma = 0;
+    const unsigned long long dbg_t0 = cg_stamp();
+#endif
     issue_patch(0);
     load_b(integral_constant<int, 0>{}, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -271,16 +286,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     auto tap = [&](auto buf_tag, auto t_tag, int hc, bool next_half) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value, T = decltype(t_tag)::value, P = (T + BUF) & 1;
         const int kt = hc * 9 + T;
+        NATINF_CG_STAMP(ts0)
         // Weight step kt has landed.  Younger requests: the aux request of tap 0 (at T = 1: it stays in flight; every wave issued at
-        // least 1 + NFULL / PSW of them).  Tap 0 is the hand-off: every wave's normalised pieces of this half-chunk are written
+        // least 2 + NFULL / PSW of them).  Tap 0 is the hand-off: every wave's normalised pieces of this half-chunk are written
         // (lgkmcnt) and nobody reads the other buffer any more -> the next half-chunk's raw patch may land in it.
         if constexpr (T == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else if constexpr (T == 1) {
-            if (next_half) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 + NFULL) : "memory");
+            if (next_half) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 + NFULL) : "memory");
             else if (n_sc > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PSW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         NATINF_CG_BW_READY(P)
+        NATINF_CG_STAMP(ts1)
         if (kt + 1 < NT) load_b(integral_constant<int, P ^ 1>{}, kt + 1);
         if constexpr (T == 0) {
             if (next_half) issue_patch(hc + 1);
@@ -291,12 +308,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
         const bool live = NORM_TAP && next_half && (J < NFULL || J * NW + wave < NPIECE);
         if constexpr (NORM_TAP) { if (live) norm_load(integral_constant<int, J>{}, integral_constant<int, BUF ^ 1>{}); }
         NATINF_CG_HEAD(a_dx[T % 3], NATINF_CG_AOFF)
+        NATINF_CG_STAMP(ts2)
         if constexpr (NORM_TAP) {
             NATINF_CG_BODY(a_dx[T % 3], NATINF_CG_AOFF, P, NATINF_CG_NORM)
             if (live) norm_store(integral_constant<int, J>{}, integral_constant<int, BUF ^ 1>{});
         } else {
             NATINF_CG_BODY(a_dx[T % 3], NATINF_CG_AOFF, P, NATINF_CG_NO)
         }
+        NATINF_CG_STAMP(ts3)
+        NATINF_CG_ADD(dbg_wait, ts0, ts1) NATINF_CG_ADD(dbg_head, ts1, ts2) NATINF_CG_ADD(dbg_mfma, ts2, ts3)
     };
     auto half_chunk = [&](auto buf_tag, int hc) __attribute__((always_inline)) {
         const bool next_half = hc + 1 < n_half;
@@ -306,6 +326,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
         tap(buf_tag, integral_constant<int, 6>{}, hc, next_half); tap(buf_tag, integral_constant<int, 7>{}, hc, next_half);
         tap(buf_tag, integral_constant<int, 8>{}, hc, next_half);
     };
+#ifdef NATINF_DEV
+    const unsigned long long dbg_t1 = cg_stamp();
+#endif
     for (int hc = 0; hc < n_half; hc += 2) {                              // a0_C is a multiple of 64: half-chunks come in pairs
         half_chunk(integral_constant<int, 0>{}, hc);
         half_chunk(integral_constant<int, 1>{}, hc + 1);
@@ -355,7 +378,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
 #else
     const GemmArgs ge = g;
 #endif
+#ifdef NATINF_DEV
+    const unsigned long long dbg_t2 = cg_stamp();
+#endif
     tile_epilogue<Cfg::WM, Cfg::WN, TM, TN, typename Cfg::Epi, EPI>(ge, smem, acc, m0, n0, 0, tid, lane, wm, wn);
+#ifdef NATINF_DEV
+    if (ge.dbg_ts && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 777)) {          // development builds: tools/conv_gn_timeline.py
+        unsigned long long* o = ge.dbg_ts + (blockIdx.x ? 8 : 0);
+        o[0] = dbg_t1 - dbg_t0; o[1] = dbg_wait; o[2] = dbg_head; o[3] = dbg_mfma; o[4] = dbg_t2 - dbg_t1; o[5] = cg_stamp() - dbg_t2; o[6] = (unsigned long long)nk;
+    }
+#endif
 }
 
 }  // namespace ncsn

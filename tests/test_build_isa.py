@@ -90,6 +90,30 @@ def test_hot_kernels_do_not_spill(listings):
             assert v["sgpr_spill"] <= 4, (n, v)                               # scalar spills live in VGPR lanes (no memory traffic): a few are tolerated
 
 
+def test_conv_gn2_k_loop_has_no_scratch_traffic(listings):
+    """k_conv_gn2 counts its vector-memory operations by hand (s_waitcnt vmcnt(N) in front of every weight set and patch piece):
+    a spill reload inside the K loop would come with hipcc's own vmcnt(0) and drain the weight stream.  The few spilled values of
+    these 256-register kernels must live outside its loops (hipcc annotates every basic block of a loop)."""
+    code = listings["ncsnpp"]
+    code = code[:code.index("amdhsa.kernels:")]
+    parts = re.split(r"^(_ZN4ncsn10k_conv_gn2\w+):\s*; @", code, flags=re.M)
+    assert len(parts) >= 2 * 12 + 1                                            # 3 tile shapes x 4 epilogues
+    for i in range(1, len(parts), 2):
+        body = parts[i + 1]
+        body = body[:body.index("s_endpgm")]
+        in_loop, bad, n_mfma_in_loops = False, [], 0
+        for ln in body.split("\n"):
+            if re.match(r"(\.LBB\d+_\d+:|; %bb\.\d+:)", ln):                # a basic-block header carries hipcc's loop annotation
+                in_loop = "in Loop:" in ln
+            elif "in Loop:" in ln:                                           # (or the comment line after it)
+                in_loop = True
+            elif in_loop and re.match(r"\s+scratch_", ln):
+                bad.append(ln.strip())
+            elif in_loop and "v_mfma" in ln:
+                n_mfma_in_loops += 1
+        assert n_mfma_in_loops >= 2 * 9 * 32 and not bad, (parts[i], bad[:4])
+
+
 def test_no_development_kernels_in_the_shipped_library(listings):
     ks = _kernels(listings["ncsnpp"])
     abl = [n for n in ks if re.search(r"k_gemm_dma<2, 4, 8, 4, [34], 1>", n)]

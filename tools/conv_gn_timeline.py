@@ -11,9 +11,10 @@ dev = "cuda"; M = B * res * res
 x = torch.randn(B, res, res, cin, device=dev).bfloat16(); sc = torch.rand(B, cin, device=dev) + 0.5; sh = torch.randn(B, cin, device=dev) * 0.3
 w = (torch.randn(N, 9 * cin + c1, device=dev) / (9 * cin) ** 0.5).bfloat16(); a1 = torch.randn(M, c1, device=dev).bfloat16() if c1 else None
 bias = torch.randn(N, device=dev); out = torch.empty(M, N, dtype=torch.bfloat16, device=dev); part = torch.zeros(M // 256, N // 4, 2, device=dev)
+wf = torch.zeros_like(w)
 ts = torch.zeros(16, dtype=torch.int64, device=dev)
 check(lib.natinf_debug_timestamps(ptr(ts)), "ts")
-args = (res, B, N, cin, c1, ptr(x), ptr(sc), ptr(sh), ptr(w), None, ptr(a1), ptr(bias), None, 0.7071, ptr(out), ptr(part))
+args = (res, B, N, cin, c1, ptr(x), ptr(sc), ptr(sh), ptr(w), ptr(wf), ptr(a1), ptr(bias), None, 0.7071, ptr(out), ptr(part))
 for _ in range(3):
     check(lib.natinf_debug_conv_gn(*args, 1, stream_ptr()), "run"); torch.cuda.synchronize()
 for blk, o in (("block 0", 0), ("block 777", 8)):
