@@ -12,7 +12,7 @@ Multi-GPU: generation batches are independent, so rank r simply runs its own bat
 collective on the data path); timing is barrier + synchronize on both sides and the max over ranks.
 
 The JSON line also carries
-  roofline          the dominant kernel (k_conv_gn, MFMA-bound): algorithmic flops per launch / mean launch
+  roofline          the dominant kernel (k_conv_gn2, MFMA-bound): algorithmic flops per launch / mean launch
                     duration, measured with HIP events on the engine's stream over a timed region
   roofline_gemm     the same for the remaining k_gemm_* launches; roofline_whole_denoiser: all flops / all device time
   roofline_ni_step  the named recurrence kernel (HBM-bound): algorithmic bytes per launch / mean duration
@@ -184,7 +184,7 @@ def main():
         ach = cg_flops / (cg_ms * 1e-3) / 1e12
         tr_cg, tr_src = profiled_traffic("k_conv_gn")
         line["roofline"] = {
-            "kernel": "k_conv_gn (3x3 convolution with GroupNorm-apply + SiLU fused into its operand path; the dominant kernel: "
+            "kernel": "k_conv_gn2 (3x3 convolution with GroupNorm-apply + SiLU fused into its operand path, weights streamed through registers; the dominant kernel: "
                       f"{100 * cg_ms / (cg_ms + gemm_ms + other_ms):.0f} % of the engine's device time)", "bound": "mfma",
             "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
             "traffic": tr_cg, "traffic_source": tr_src, "launches": int(cg_n), "mean_launch_ms": round(cg_ms / cg_n, 5),
