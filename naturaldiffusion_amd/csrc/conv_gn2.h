@@ -19,6 +19,8 @@
 //   * the taps as ONE software pipeline (A fragments of tap t+1 requested in the last two steps of tap t, the four weight loads and the
 //     request items of tap 0 spread one per MFMA group): 128x256 tile 4-5 % SLOWER, 256x128 tile equal;
 //   * normalisation elements in pairs (no transcendental result consumed by the next instruction: hipcc's s_nop padding halves): equal;
+//   * the 256x128 tile as 1 x 4 waves of 256 pixels x 32 channels (every weight fragment fetched by ONE wave: half the L1 traffic of the
+//     weight stream, twice the A fragment reads): 0-3 % slower;
 //   * v_mfma_f32_32x32x16_bf16 (half the MFMA instructions, 1.5x the vector-issue room per matrix-pipe cycle -- tools/probes/
 //     mfma_issue_probe.hip --, swizzle by patch column, 32x32 packed epilogue): 5 % fewer shader cycles (PMC), equal wall time.
 // PMC picture of the 256x128 tile (tools/pmc_conv_gn.sh): matrix pipe 48-55 % busy, LDS 25 %, L1/TA ~45 %, waves 24 % in s_waitcnt and
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     auto lds_addr = [](const unsigned char* p) __attribute__((always_inline)) { return (unsigned)(uintptr_t)((lds_u8*)const_cast<unsigned char*>(p)); };
     auto glds16 = [](unsigned voff, const void* sbase, unsigned lds_dst) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
     };
     const unsigned lds_patch = lds_addr(sPatch), lds_tab = lds_addr(sTab);
 
@@ -134,8 +136,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
             // (one request with a per-lane 64-bit address kept a zero register alive across the loop, which hipcc then spilled)
             const unsigned dst = lds_tab + buf * Cfg::TAB_BYTES;
             const unsigned toff = (unsigned)(l & 31) * 4u;
-            if (l < 32) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(toff), "s"(gsc + hc * KT), "s"(dst) : "memory");
-            else        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(toff), "s"(gsh + hc * KT), "s"(dst) : "memory");
+            if (l < 32) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(toff), "s"(gsc + hc * KT), "s"(dst) : "memory", "m0");
+            else        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(toff), "s"(gsh + hc * KT), "s"(dst) : "memory", "m0");
         }
         const bf16* base = img + hc * KT;
         const int prow = l >> 2, pslot = l & 3;
@@ -162,10 +164,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
         }
     };
 
+#ifdef NATINF_DEV
+    const unsigned long long dbg_t0 = cg_stamp();
+#endif
+    // the first requests go out NOW: the index arithmetic below (masks, fragment bases, 128 accumulator registers) runs while they fly
+    issue_patch(0);
+    load_b(std::integral_constant<int, 0>{}, 0);
+
     // ---- in-place normalisation, round j: the wave's piece j * NW + wave, lane l its bytes l * 16 .. + 15 = patch row q * 16 + (l >> 2),
     // ---- slot l & 3, which holds channel chunk (l & 3) ^ 2 * bit 4 of l (bit 2 of the patch row is bit 4 of the lane).
     const unsigned nbase = lds_patch + wave * 1024 + lane * 16;
-    const unsigned tbase = lds_tab + (((lane & 3) ^ ((lane >> 3) & 2)) * 32);
     unsigned nmask = 0;                                                      // bit j: the pixel of round j lies inside the image
 #pragma unroll
     for (int j = 0; j < NROUND; ++j) {
@@ -179,6 +187,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     auto norm_load = [&](auto j_tag, auto buf_tag) __attribute__((always_inline)) {
         constexpr int J = decltype(j_tag)::value, BUF = decltype(buf_tag)::value;
         nv = lds_read16<BUF * Cfg::PATCH_BYTES + J * NW * 1024>(nbase);
+        // the lane's row of the table: channel chunk (l & 3) ^ 2 * bit 4 of l.  Recomputed from the slot address (bits 4-9 = the lane) per
+        // round: a register held across the K loop for it is the one hipcc spills (and its reload drains the weight stream)
+        unsigned nb = nbase;
+        asm volatile("" : "+v"(nb));
+        nb -= lds_patch;
+        const unsigned tbase = lds_tab + ((((nb >> 4) & 3u) ^ ((nb >> 7) & 2u)) << 5);
         ns0 = lds_read16<BUF * Cfg::TAB_BYTES>(tbase); ns1 = lds_read16<BUF * Cfg::TAB_BYTES + 16>(tbase);
         nh0 = lds_read16<BUF * Cfg::TAB_BYTES + 128>(tbase); nh1 = lds_read16<BUF * Cfg::TAB_BYTES + 144>(tbase);
     };
@@ -207,13 +221,26 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
         if (!((nmask >> J) & 1u)) ou = u32x4{0u, 0u, 0u, 0u};
         lds_write16<BUF * Cfg::PATCH_BYTES + J * NW * 1024>(nbase, ou);
     };
-    auto norm_round = [&](auto j_tag, auto buf_tag) __attribute__((always_inline)) {   // a whole round at once (prologue)
+    // a whole round at once (prologue: no MFMAs to hide behind yet, so the eight elements are left to hipcc to interleave -- one
+    // dependent unpack-fma-exp2-add-rcp-mul chain after the other costs ~70 cycles per element, 4k cycles per tile)
+    auto norm_round = [&](auto j_tag, auto buf_tag) __attribute__((always_inline)) {
         norm_load(j_tag, buf_tag);
         wait_lgkmcnt<0>();
-#define NATINF_CG_NORM_ONE(I) NATINF_CG_NORM_PRE(I) NATINF_CG_NORM_EL(I) NATINF_CG_NORM_POST(I) __builtin_amdgcn_sched_barrier(0);
-        NATINF_CG_NORM_ONE(0) NATINF_CG_NORM_ONE(1) NATINF_CG_NORM_ONE(2) NATINF_CG_NORM_ONE(3)
-        NATINF_CG_NORM_ONE(4) NATINF_CG_NORM_ONE(5) NATINF_CG_NORM_ONE(6) NATINF_CG_NORM_ONE(7)
-#undef NATINF_CG_NORM_ONE
+        NATINF_CG_NORM_PRE(0)
+        float y_[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned w_ = nv[i >> 1];
+            const float x_ = __uint_as_float((i & 1) ? (w_ & 0xffff0000u) : (w_ << 16));
+            const float t_ = x_ * __uint_as_float(i < 4 ? ns0[i & 3] : ns1[i & 3]) + __uint_as_float(i < 4 ? nh0[i & 3] : nh1[i & 3]);
+            y_[i] = t_ * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t_));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const bf16x2_t pr_ = {(bf16)y_[2 * i], (bf16)y_[2 * i + 1]};
+            npk[i] = __builtin_bit_cast(unsigned, pr_);
+        }
         norm_store(j_tag, buf_tag);
     };
 #define NATINF_CG_NO_PRE(I)
@@ -264,11 +291,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     using std::integral_constant;
 #ifdef NATINF_DEV
     unsigned long long dbg_wait = 0, dbg_head = 0, dbg_mfma = 0;
-    const unsigned long long dbg_t0 = cg_stamp();
 #endif
-    issue_patch(0);
-    load_b(integral_constant<int, 0>{}, 0);
+    NATINF_CG_STAMP(dbg_p0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NATINF_CG_STAMP(dbg_p1)
     {
         auto b0 = integral_constant<int, 0>{};
         norm_round(integral_constant<int, 0>{}, b0);
@@ -384,8 +410,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     tile_epilogue<Cfg::WM, Cfg::WN, TM, TN, typename Cfg::Epi, EPI>(ge, smem, acc, m0, n0, 0, tid, lane, wm, wn);
 #ifdef NATINF_DEV
     if (ge.dbg_ts && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 777)) {          // development builds: tools/conv_gn_timeline.py
-        unsigned long long* o = ge.dbg_ts + (blockIdx.x ? 8 : 0);
+        // block 0: [2..4] are the epilogue's own stamps (NATINF_TS: start, slab written, copied out), [7] = the stamp in front of it
+        unsigned long long* o = ge.dbg_ts + (blockIdx.x ? 16 : 8);
         o[0] = dbg_t1 - dbg_t0; o[1] = dbg_wait; o[2] = dbg_head; o[3] = dbg_mfma; o[4] = dbg_t2 - dbg_t1; o[5] = cg_stamp() - dbg_t2; o[6] = (unsigned long long)nk;
+        if (blockIdx.x == 0) { ge.dbg_ts[7] = dbg_t2; ge.dbg_ts[5] = dbg_p0 - dbg_t0; ge.dbg_ts[6] = dbg_p1 - dbg_p0; }
     }
 #endif
 }

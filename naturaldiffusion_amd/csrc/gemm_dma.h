@@ -45,7 +45,8 @@ struct EpiCfg {
     static_assert(TM % RB == 0 && SLAB_BYTES <= AVAIL, "epilogue staging does not fit");
     // packed (bf16) whole-tile slab of the column-terms-only epilogue: rows of BN bf16 + 16 B (a 4-bank shift per row)
     static constexpr int PROW = WN * TN * 16 * 2 + 16;
-    static constexpr int PACK_BYTES = WM * TM * 16 * PROW;
+    static constexpr int PACK_SLAB = WM * TM * 16 * PROW;
+    static constexpr int PACK_BYTES = PACK_SLAB + WM * WN * TN * 4 * 8;    // + the GroupNorm partials of the WM wave rows (float2 per 4-column quad), behind the slab
     static constexpr bool PACK_OK = PACK_BYTES <= AVAIL;
     static constexpr int NEED = PACK_OK && PACK_BYTES > SLAB_BYTES ? PACK_BYTES : SLAB_BYTES;
 };
@@ -56,7 +57,7 @@ struct DmaCfg {
     static constexpr int BM_ = WM * TM * 16, BN_ = WN * TN * 16;
     static constexpr int STAGE_BYTES = (BM_ + BN_) * BK * 2;
     static constexpr int PA = BM_ / 8 / NW, PB = BN_ / 8 / NW;            // 1-KiB DMA pieces per wave per K-tile
-    using Epi = EpiCfg<WM, WN, TM, TN, 2 * STAGE_BYTES + 4096>;
+    using Epi = EpiCfg<WM, WN, TM, TN, 2 * STAGE_BYTES + 8192>;
     static constexpr int LDS_BYTES = Epi::NEED > 2 * STAGE_BYTES ? Epi::NEED : 2 * STAGE_BYTES;
     static_assert(BM_ % (8 * NW) == 0 && BN_ % (8 * NW) == 0, "DMA pieces must divide evenly over the waves");
 };
@@ -81,6 +82,14 @@ struct DmaCfg {
 // and crosses LDS once as 2-byte values -- a quarter of the fp32 slab's LDS traffic, one barrier, and sweeps that are pure
 // 16-byte LDS -> global copies.  (Tile timeline of the fp32-slab path at 256x256, shader clocks: slab writes 5.0k +
 // sweeps 11.6k + stores 2.8k = 19.5k per tile against 3.7k per 64-wide K-tile of main loop; tools/tile_timeline.py.)
+// sum over the 16 lanes of a DPP row, left in every lane of the row: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float dpp_row_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+    return v;
+}
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 // slab -> global copy of sweeps SW .. NSW-1: all LDS reads first, then the stores (template recursion instead of an array of
 // kept values: hipcc left a 16-entry uint4 array in scratch memory here)
@@ -211,6 +220,19 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
                 *reinterpret_cast<unsigned short*>(g.c_mx + (int64_t)z * g.c_mx_bs + ((int64_t)(nb >> 7) * g.c_mx_ld + m) * 4 + ((nb >> 5) & 3)) = (unsigned short)e8pair;
         }
     }
+    float2* const sred = reinterpret_cast<float2*>(smem + Cfg::PACK_SLAB);
+    if constexpr (GN) {
+        // fixed-order reduction: the 16 row-lanes of a lane group = one DPP row (pairs, quads, the two quads of a half row, the two half
+        // rows: four v_add_f32 with a DPP source each -- the ds_bpermute butterflies this replaces cost 3-5k clocks per tile), then the
+        // WM waves of a column through LDS, behind the slab: the same barrier publishes both, and nothing waits for the tile's stores
+        // (the reduction used to run after the copy-out, behind two barriers -- each of which drains the outstanding global stores)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { gs[j] = dpp_row_sum(gs[j]); gq[j] = dpp_row_sum(gq[j]); }
+        if (r == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) sred[wm * (BN_ / 4) + wn * TN * 4 + j * 4 + q] = make_float2(gs[j], gq[j]);
+        }
+    }
     __syncthreads();
     NATINF_TS(3);
     constexpr int CPR = BN_ * EB / 16, RPS = THREADS / CPR, NSW = BM_ / RPS;
@@ -229,18 +251,6 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
     }
     NATINF_TS(4);
     if constexpr (GN) {
-        // fixed-order reduction: the 16 row-lanes of a lane group (xor butterflies), then the WM waves of a column through LDS
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { gs[j] += __shfl_xor(gs[j], o); gq[j] += __shfl_xor(gq[j], o); }
-        __syncthreads();                               // every sweep has read the slab
-        float2* sred = reinterpret_cast<float2*>(smem);
-        if (r == 0) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) sred[wm * (BN_ / 4) + wn * TN * 4 + j * 4 + q] = make_float2(gs[j], gq[j]);
-        }
-        __syncthreads();
         if (tid < BN_ / 4 && n0 + tid * 4 < g.N) {
             float s = 0.f, qq = 0.f;
 #pragma unroll
