@@ -21,6 +21,8 @@
 //   * normalisation elements in pairs (no transcendental result consumed by the next instruction: hipcc's s_nop padding halves): equal;
 //   * the 256x128 tile as 1 x 4 waves of 256 pixels x 32 channels (every weight fragment fetched by ONE wave: half the L1 traffic of the
 //     weight stream, twice the A fragment reads): 0-3 % slower;
+//   * 128 x 128 tiles of 2 x 2 waves with 64 x 64 wave tiles (168 registers, THREE blocks per CU = three waves per SIMD to cover each
+//     other's stalls, for twice the weight bytes and 1.2x the patch per flop): 4-9 % slower;
 //   * v_mfma_f32_32x32x16_bf16 (half the MFMA instructions, 1.5x the vector-issue room per matrix-pipe cycle -- tools/probes/
 //     mfma_issue_probe.hip --, swizzle by patch column, 32x32 packed epilogue): 5 % fewer shader cycles (PMC), equal wall time.
 // PMC picture of the 256x128 tile (tools/pmc_conv_gn.sh): matrix pipe 48-55 % busy, LDS 25 %, L1/TA ~45 %, waves 24 % in s_waitcnt and
