@@ -23,6 +23,8 @@
 //     weight stream, twice the A fragment reads): 0-3 % slower;
 //   * 128 x 128 tiles of 2 x 2 waves with 64 x 64 wave tiles (168 registers, THREE blocks per CU = three waves per SIMD to cover each
 //     other's stalls, for twice the weight bytes and 1.2x the patch per flop): 4-9 % slower;
+//   * EPI 5 / 6: every thread touching two of the residual tile's 512 cache lines three taps before the end, so that the epilogue's
+//     residual fetch hits L2: +-0 (the +20-30 us of a residual launch are its 134 MB of extra HBM traffic, not latency);
 //   * v_mfma_f32_32x32x16_bf16 (half the MFMA instructions, 1.5x the vector-issue room per matrix-pipe cycle -- tools/probes/
 //     mfma_issue_probe.hip --, swizzle by patch column, 32x32 packed epilogue): 5 % fewer shader cycles (PMC), equal wall time.
 // PMC picture of the 256x128 tile (tools/pmc_conv_gn.sh): matrix pipe 48-55 % busy, LDS 25 %, L1/TA ~45 %, waves 24 % in s_waitcnt and
