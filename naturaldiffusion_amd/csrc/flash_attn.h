@@ -33,6 +33,15 @@
 // MFMA issue cost).  Row sums on the matrix pipe (an all-ones A operand in front of P^T: 8 MFMAs instead of 64 adds per tile and
 // lane, no final cross-lane reduction) were built too: +-1 %, not kept.  The next tile's DMA requests issued behind the S^T MFMAs
 // instead of in front of them: 3 % slower.
+// Round 2: that was built -- the whole kernel on v_mfma_f32_32x32x16_bf16 (S^T tiles of 32 keys x 32 queries with the K rows taken in the order
+// i -> i with bits 2, 3 exchanged, so that accumulator elements 8j .. 8j+7 of a lane are the eight consecutive keys of its P^T operand for PV
+// step j; one query per lane, one cross-lane step per row maximum; same LDS images and swizzles, both conflict-free for 32-row fragments;
+// 168 VGPRs, bit-level agreement with this kernel to 5e-4) -- and measured in a same-box A/B at the SD3 shape: 1,169 us against 1,169 us.
+// tools/probes/mfma_issue_probe.hip explains it: a 32x32x16 MFMA holds the SIMD's vector issue for ~11-12 cycles, not 8 (two waves per
+// SIMD: 5 plain vector instructions per MFMA are free, the 6th is not), so the issue cost per flop only drops to 0.7x, ~280 of the ~4,100
+// issue cycles a pair of waves spends per key tile (2 x (64 MFMAs x 8 + 250 VALU x 4 + 66 v_exp x 8) against 4,800 measured): inside the
+// run-to-run spread.  The vector instructions per score are the cost; the kernel sits at 0.34 of the bf16 peak with an issue-bound ceiling
+// of ~0.40 for this instruction mix.  Not kept.
 // Reference: diffusers JointAttnProcessor2_0 as called by pipe.transformer (src/SD3NaturalInference.py:210-213).
 #pragma once
 #include "ncsnpp_kernels.h"
