@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     const int mt = tile / nN, nt = tile - mt * nN;
     const int m0 = mt * BM_, n0 = nt * BN_;
     const int b = m0 / HW, y0 = (m0 % HW) / W;                            // image and first image row of this tile
-    const bf16* const img = g.a0 + (int64_t)b * HW * g.a0_ld;
+    const int ush = g.a0_up;                                              // 1: the source image has half the resolution (nearest up-sampling in the fetch)
+    const bf16* const img = g.a0 + (int64_t)b * (HW >> (2 * ush)) * g.a0_ld;
     const float* const gsc = g.gn_scale + (int64_t)b * g.gn_ld;
     const float* const gsh = g.gn_shift + (int64_t)b * g.gn_ld;
     const int n_half = g.a0_C / KT, n_sc = g.a1 ? g.a1_C / KT : 0;
@@ -115,7 +116,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     auto glds16 = [](unsigned voff, const void* sbase, unsigned lds_dst) __attribute__((always_inline)) {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
     };
-    const unsigned lds_patch = lds_addr(sPatch), lds_tab = lds_addr(sTab);
+    // (LDS byte addresses straight from the array: a cast of a generic pointer carries a null check against the shared aperture, which
+    // hipcc has mis-selected into a vector compare on an SGPR-only operand in some variants of this kernel)
+    const unsigned lds_patch = (unsigned)(uintptr_t)((lds_u8*)smem), lds_tab = lds_patch + 2 * Cfg::PATCH_BYTES;
 
     // ---- weight fragments: two register sets, set (kt & 1) holds K step kt ---------------------------------------------------
     u32x4 bw[2][TN];
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
             const int pp = q * 16 + prow;
             const int yy = pp / WS, xx = pp - yy * WS;
             const int y = min(max(y0 - 1 + yy, 0), RES - 1), x = min(max(xx - 1, 0), RES - 1);      // halo / pad: any readable pixel
-            glds16((unsigned)((y * W + x) * g.a0_ld + ((pslot ^ ((pp >> 1) & 2)) << 3)) * 2u, base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
+            glds16((unsigned)(((y >> ush) * (W >> ush) + (x >> ush)) * g.a0_ld + ((pslot ^ ((pp >> 1) & 2)) << 3)) * 2u, base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
         }
     };
     auto issue_shortcut = [&](int s) __attribute__((always_inline)) {        // plain [BM][32] tile of a1 -> patch buffer s & 1 (n_half is even)
@@ -160,11 +163,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
         int l;                                                               // the lane id, recomputed: kept alive across the K loop it is the value hipcc spills
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
         const int prow = l >> 2, pslot = l & 3;
-        const bf16* base = g.a1 + (int64_t)m0 * g.a1_ld + s * KT;
+        // a1_up: the shortcut operand lives at half the resolution too: tile row pp = pixel (y0 + pp / W, pp % W) <- source pixel (y >> 1, x >> 1)
+        const int sup = g.a1_up;
+        const bf16* base = g.a1 + (int64_t)(sup ? b * (HW >> 2) : m0) * g.a1_ld + s * KT;
 #pragma unroll
         for (int j = 0; j < PSW; ++j) {
             const int pp = (wave * PSW + j) * 16 + prow;
-            glds16((unsigned)(pp * g.a1_ld + ((pslot ^ ((pp >> 1) & 2)) << 3)) * 2u, base, dst + j * 1024);
+            const int src = sup ? ((y0 + pp / W) >> 1) * (W >> 1) + ((pp % W) >> 1) : pp;
+            glds16((unsigned)(src * g.a1_ld + ((pslot ^ ((pp >> 1) & 2)) << 3)) * 2u, base, dst + j * 1024);
         }
     };
 

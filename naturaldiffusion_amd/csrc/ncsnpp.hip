@@ -256,6 +256,7 @@ int variant_bm(int v);
 // (natinf_set_conv_gn_wide: A/B runs); packed epilogues 1 / 2 / 5 / 6 only
 int packed_epi(const GemmArgs& g, int bm);
 int g_cg_wide = 1;
+int g_fuse_up = 1;                 // natinf_set_fuse_up (read when a plan is BUILT): up blocks at 16x16 / 32x32 fetch their input up-sampled inside k_conv_gn2
 int g_cg_regw = 1;                 // natinf_set_conv_gn_regw: 1 = k_conv_gn2 (weights streamed through registers) where GemmArgs::b_frag is given
 inline int conv_gn_bm(const GemmArgs& g) { return (g_cg_wide && (1 << g.logW) == 16 && g.N % 256 == 0) ? 128 : 256; }
 inline bool conv_gn_regw(const GemmArgs& g) { return g_cg_regw && g.b_frag && g.N % (conv_gn_bm(g) == 128 ? 256 : 128) == 0; }
@@ -263,6 +264,7 @@ inline bool conv_gn_ok(const GemmArgs& g) {
     if (!g.gn_scale || !g.gn_shift || !g.gn_folded || g.taps != 9 || g.batch != 1 || g.a0_C % BK || (g.a1 && g.a1_C % BK) || g.M % 256) return false;
     const int res = 1 << g.logW;
     if (g.logHW != 2 * g.logW || (res != 32 && res != 16) || g.N % 8) return false;
+    if ((g.a0_up || g.resid_up || g.a1_up) && !conv_gn_regw(g)) return false;          // up-sampled fetches: k_conv_gn2 only
     const int e = packed_epi(g, conv_gn_bm(g));
     return e == 1 || e == 2 || e == 5 || e == 6;
 }
@@ -582,8 +584,9 @@ struct Builder {
         // produces the resampled shortcut input), Conv_1 is fused there too; the 8x8 / 4x4 levels are unfused.  Folded form: the
         // GroupNorm scale / shift carry -log2(e), the 3x3 weights -ln 2 (GemmArgs::gn_folded).
         const bool fusable_res = g_fuse_gn && (ro == 32 || ro == 16);
-        const bool fuse = fusable_res && !m.up && !m.down && cin % BK == 0;            // Conv_0
         const bool fuse1 = fusable_res && cout % BK == 0;                               // Conv_1
+        const bool fuse_up = fuse1 && g_fuse_up && m.up && cin % BK == 0 && cout % 128 == 0;   // up block: the 2x up-sampling of both branches happens in the fetches
+        const bool fuse = (fusable_res && !m.up && !m.down && cin % BK == 0) || fuse_up;            // Conv_0
         const float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
         const float gn_mul = fuse ? -LOG2E : 1.0f, w_mul = fuse ? -LN2 : 1.0f, gn_mul1 = fuse1 ? -LOG2E : 1.0f, w_mul1 = fuse1 ? -LN2 : 1.0f;
         const int64_t w0 = wres((int64_t)cout * K0a * 2), w1 = wres((int64_t)cout * K1tot * 2);
@@ -619,7 +622,7 @@ struct Builder {
         const int dtotal = dense_total; const int64_t dout = dense_out;
         op(fuse ? CLS_CONV_GN : CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
-            if (fuse) { g.a0 = c.act(x); g.a0_ld = x.ld; g.gn_scale = c.at<float>(sc); g.gn_shift = c.at<float>(sh); g.gn_ld = cin; g.gn_folded = 1; }
+            if (fuse) { g.a0 = c.act(x); g.a0_ld = x.ld; g.gn_scale = c.at<float>(sc); g.gn_shift = c.at<float>(sh); g.gn_ld = cin; g.gn_folded = 1; g.a0_up = fuse_up; }
             else { g.a0 = c.act(h); g.a0_ld = h.ld; g.a0_padded = 1; }
             g.a0_C = cin; g.taps = 9; g.logW = logW; g.logHW = logHW;
             g.M = c.B * HWo; g.N = cout; g.b = c.w<bf16>(w0); g.b_ld = K0a;
@@ -641,15 +644,15 @@ struct Builder {
             arena.release(t.off);
         }
         if (pt.valid) arena.release(pt.off);
-        const TRef xs = (m.up || m.down) ? xr : x;           // shortcut source at the output resolution
+        const TRef xs = ((m.up || m.down) && !fuse_up) ? xr : x;           // shortcut source at the output resolution (fuse_up: x itself, fetched up-sampled)
         const Part po = register_output(out);
         op(fuse1 ? CLS_CONV_GN : CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
             if (fuse1) { g.a0 = c.act(t); g.a0_ld = t.ld; g.gn_scale = c.at<float>(sc); g.gn_shift = c.at<float>(sh); g.gn_ld = cout; g.gn_folded = 1; }
             else { g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_padded = 1; }
             g.a0_C = cout; g.taps = 9; g.logW = logW; g.logHW = logHW;
-            if (shortcut) { g.a1 = c.act(xs); g.a1_ld = xs.ld; g.a1_C = cin; }
-            else { g.resid = c.act(xs); g.resid_ld = xs.ld; }
+            if (shortcut) { g.a1 = c.act(xs); g.a1_ld = xs.ld; g.a1_C = cin; g.a1_up = fuse_up; }
+            else { g.resid = c.act(xs); g.resid_ld = xs.ld; g.resid_up = fuse_up; }
             g.M = c.B * HWo; g.N = cout; g.b = c.w<bf16>(w1); g.b_ld = K1tot;
             if (w1f >= 0) g.b_frag = c.w<bf16>(w1f);
             g.bias_n = c.w<float>(b1); g.scale = INV_SQRT2;
@@ -661,7 +664,7 @@ struct Builder {
         });
         if (skws >= 0) arena.release(skws);
         if (fuse1) arena.release(t.off); else arena.release(u.off);
-        if (m.up || m.down) arena.release(xr.off);
+        if ((m.up || m.down) && !fuse_up) arena.release(xr.off);
         arena.release(sc); arena.release(sh);
         E.taps[m.idx] = out;
     }
@@ -1032,7 +1035,18 @@ natinf_ncsnpp* make_engine(int flags) {
     return e;
 }
 
-const natinf_ncsnpp& reference_engine() { static natinf_ncsnpp* e = make_engine(0); return *e; }
+// The size queries without a handle answer for the LARGEST plan (every build-time fusion on: each adds repacked weight copies), whatever the
+// A/B knobs are set to when they are first asked -- a packed buffer of that size fits every plan.
+const natinf_ncsnpp& reference_engine() {
+    static natinf_ncsnpp* e = [] {
+        const int fg = g_fuse_gn, fu = g_fuse_up;
+        g_fuse_gn = 1; g_fuse_up = 1;
+        natinf_ncsnpp* r = make_engine(0);
+        g_fuse_gn = fg; g_fuse_up = fu;
+        return r;
+    }();
+    return *e;
+}
 
 }  // namespace
 
@@ -1242,6 +1256,7 @@ int natinf_set_gemm_raster(int rows) { g_raster_g = rows; return NATINF_OK; }
 int natinf_set_fuse_gn(int on) { g_fuse_gn = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_wide(int on) { g_cg_wide = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_regw(int on) { g_cg_regw = on != 0; return NATINF_OK; }
+int natinf_set_fuse_up(int on) { g_fuse_up = on != 0; return NATINF_OK; }
 int natinf_set_gemm_splitk(int on) { g_splitk = on != 0; return NATINF_OK; }
 int natinf_debug_set_splitk_workspace(float* ws, int max_slices) { g_dbg_splitk_ws = ws; g_dbg_splitk_max = ws ? max_slices : 0; return NATINF_OK; }
 int natinf_set_gemm_half_issue(int on) { g_half_issue = on != 0; return NATINF_OK; }

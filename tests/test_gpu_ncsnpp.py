@@ -155,10 +155,11 @@ def test_bench_batch_512_runs_the_benchmarked_kernels_and_matches_golden(dev, fl
     chosen = {}
     for f in _describe_gemms(eng, 512):
         chosen.setdefault(f[6].split("/")[0], []).append((int(f[0]), int(f[1])))
-    # the families that carry the bench's device time: the fused GroupNorm+SiLU convolution (every plain res-block conv of the
-    # 32x32 and 16x16 levels: 2 x 18 launches) and, for the resampling blocks / the head, the hand-pipelined LDS-DMA tiles
-    assert len(chosen.get("conv_gn", [])) >= 30, {k: len(v) for k, v in chosen.items()}
-    assert len(chosen.get("dma256x256h", [])) >= 2 and len(chosen.get("dma512x128h", [])) >= 1, {k: len(v) for k, v in chosen.items()}
+    # the families that carry the bench's device time: the fused GroupNorm+SiLU convolution (every res-block conv of the 32x32 and
+    # 16x16 levels but Conv_0 of the down-sampling blocks: 41 launches) and, for the head, the hand-pipelined 512x128 LDS-DMA tile (the
+    # 256x256 one, variant 26, is under test in test_every_gemm_variant_gives_the_same_network and carries the SD3 engine)
+    assert len(chosen.get("conv_gn", [])) >= 40, {k: len(v) for k, v in chosen.items()}
+    assert len(chosen.get("dma512x128h", [])) >= 1, {k: len(v) for k, v in chosen.items()}
     y = eng(x.to(dev), labels.to(dev))
     torch.cuda.synchronize()
     assert torch.isfinite(y).all()
