@@ -149,11 +149,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
         const bf16* rb = g.resid + (int64_t)z * g.c_bs + n0 + wn * TN * 16 + q * 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            int m = min(m0 + wm * TM * 16 + i * 16 + r, g.M - 1);
-            if (g.resid_up) {                    // the residual lives at half the resolution: row (b, y, x) of a 2^logW-wide image <- (b, y >> 1, x >> 1)
-                const int lw = g.logW, x = m & ((1 << lw) - 1), y = (m >> lw) & ((1 << lw) - 1), bb = m >> (2 * lw);
-                m = (bb << (2 * lw - 2)) | ((y >> 1) << (lw - 1)) | (x >> 1);
-            }
+            const int m = min(m0 + wm * TM * 16 + i * 16 + r, g.M - 1);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 rs[i][j] = n0 + wn * TN * 16 + j * 16 + q * 4 < g.N ? *reinterpret_cast<const uint2*>(rb + (int64_t)m * g.resid_ld + j * 16) : make_uint2(0u, 0u);

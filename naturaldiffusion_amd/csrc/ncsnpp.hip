@@ -264,7 +264,7 @@ inline bool conv_gn_ok(const GemmArgs& g) {
     if (!g.gn_scale || !g.gn_shift || !g.gn_folded || g.taps != 9 || g.batch != 1 || g.a0_C % BK || (g.a1 && g.a1_C % BK) || g.M % 256) return false;
     const int res = 1 << g.logW;
     if (g.logHW != 2 * g.logW || (res != 32 && res != 16) || g.N % 8) return false;
-    if ((g.a0_up || g.resid_up || g.a1_up) && !conv_gn_regw(g)) return false;          // up-sampled fetches: k_conv_gn2 only
+    if ((g.a0_up || g.a1_up) && !conv_gn_regw(g)) return false;          // up-sampled fetches: k_conv_gn2 only
     const int e = packed_epi(g, conv_gn_bm(g));
     return e == 1 || e == 2 || e == 5 || e == 6;
 }
@@ -652,7 +652,7 @@ struct Builder {
             else { g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_padded = 1; }
             g.a0_C = cout; g.taps = 9; g.logW = logW; g.logHW = logHW;
             if (shortcut) { g.a1 = c.act(xs); g.a1_ld = xs.ld; g.a1_C = cin; g.a1_up = fuse_up; }
-            else { g.resid = c.act(xs); g.resid_ld = xs.ld; g.resid_up = fuse_up; }
+            else { g.resid = c.act(xs); g.resid_ld = xs.ld; }
             g.M = c.B * HWo; g.N = cout; g.b = c.w<bf16>(w1); g.b_ld = K1tot;
             if (w1f >= 0) g.b_frag = c.w<bf16>(w1f);
             g.bias_n = c.w<float>(b1); g.scale = INV_SQRT2;

@@ -73,8 +73,8 @@ struct GemmArgs {
     // k_conv_gn2: the weights of a gn_scale launch once more, fragment-major (k_pack_frag); NULL -> k_conv_gn (LDS weight ring)
     const bf16* b_frag;
     // 2x nearest up-sampling folded into the operand fetch of a gn_scale launch (k_conv_gn2 only): a0 is the tensor at HALF the resolution,
-    // patch pixel (y, x) <- (y >> 1, x >> 1); resid_up: the same for the bf16 residual rows of the packed epilogue (row m of a 2^logW-wide image)
-    int a0_up; int resid_up; int a1_up;                  // a1_up: the same for the rows of the 1x1 shortcut operand a1
+    // patch pixel (y, x) <- (y >> 1, x >> 1); a1_up: the same for the rows of the 1x1 shortcut operand a1
+    int a0_up; int a1_up;
     // split-K (launch_gemm decides; small-M, long-K launches): `splitk_ws` = fp32 workspace for splitk_max * M * N partial sums
     float* splitk_ws; int splitk_max; int splitk;
 };
