@@ -82,6 +82,30 @@ def test_conv_gn_matches_torch(res, B, cin, N, c1, resid, parts):
             want = torch.stack([ref.reshape(M // rows, rows, N // 4, 4).sum(dim=(1, 3)), (ref ** 2).reshape(M // rows, rows, N // 4, 4).sum(dim=(1, 3))], dim=-1)
             assert ((part.cpu() - want).abs().max() / want.abs().max()).item() <= 5e-3
 
+def test_fragment_major_weight_copy_layout():
+    """k_pack_frag (conv_gn2.h): [N/16][K steps][64 lanes][8] with lane l of K step kt holding row l & 15, columns col(kt) + 8 (l >> 4) .. + 7,
+    col(kt) = ((hc >> 1) * 9 + tap) * 64 + (hc & 1) * 32 for kt = hc * 9 + tap, then the shortcut columns -- checked element by element against
+    a numpy gather of the packed matrix (the copy is what k_conv_gn2 multiplies with)."""
+    from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
+    res, B, cin, N, c1 = 16, 1, 128, 256, 64
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(N, 9 * cin + c1, generator=g).bfloat16()
+    dev = "cuda"
+    x = torch.zeros(B, res, res, cin, dtype=torch.bfloat16, device=dev); a1 = torch.zeros(B * res * res, c1, dtype=torch.bfloat16, device=dev)
+    sc = torch.zeros(B, cin, device=dev); sh = torch.zeros(B, cin, device=dev); out = torch.empty(B * res * res, N, dtype=torch.bfloat16, device=dev)
+    wd = w.to(dev); wf = torch.zeros_like(wd)
+    check(lib.natinf_debug_conv_gn(res, B, N, cin, c1, ptr(x), ptr(sc), ptr(sh), ptr(wd), ptr(wf), ptr(a1), None, None, 1.0, ptr(out), None, 1, stream_ptr()), "conv_gn")
+    torch.cuda.synchronize()
+    nk, NT = 9 * (cin // 32), 9 * (cin // 32) + c1 // 32
+    col = np.array([((kt // 9 >> 1) * 9 + kt % 9) * 64 + (kt // 9 & 1) * 32 if kt < nk else 9 * cin + (kt - nk) * 32 for kt in range(NT)])
+    lane = np.arange(64)
+    rows = (np.arange(N // 16)[:, None, None, None] * 16 + (lane & 15)[None, None, :, None])                          # [N/16][1][64][1]
+    cols = col[None, :, None, None] + ((lane >> 4) * 8)[None, None, :, None] + np.arange(8)[None, None, None, :]      # [1][NT][64][8]
+    want = w.view(torch.int16).numpy()[np.broadcast_to(rows, (N // 16, NT, 64, 8)), np.broadcast_to(cols, (N // 16, NT, 64, 8))]
+    got = wf.cpu().view(torch.int16).numpy().reshape(N // 16, NT, 64, 8)
+    assert np.array_equal(got, want)
+
+
 def test_conv_gn_argument_errors():
     from naturaldiffusion_amd._lib import lib
     d = 4096
