@@ -92,8 +92,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     constexpr int W = Geo::W, WS = Geo::WS, HW = RES * RES;
     constexpr int PSW = Cfg::PSW, NROUND = Cfg::NROUND, NPIECE = Cfg::NPIECE, NFULL = Cfg::NFULL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const sPatch = smem;                                   // [2][PATCH_BYTES]
-    unsigned char* const sTab = smem + 2 * Cfg::PATCH_BYTES;              // [2][scale 32 | shift 32] fp32
+    // LDS: [2][PATCH_BYTES] patch buffers, then [2][scale 32 | shift 32] fp32 tables (the epilogue reuses all of it as its slab)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = WIDE ? 0 : wave >> 1, wn = WIDE ? wave : wave & 1;
@@ -112,7 +111,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     // Every LDS access, every LDS-DMA and every weight load of the K loop is inline asm with hand-counted waits (conv_gn.h explains
     // why: hipcc drains vmcnt in front of any LDS access it can see while an LDS-DMA is in flight).
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
-    auto lds_addr = [](const unsigned char* p) __attribute__((always_inline)) { return (unsigned)(uintptr_t)((lds_u8*)const_cast<unsigned char*>(p)); };
     auto glds16 = [](unsigned voff, const void* sbase, unsigned lds_dst) __attribute__((always_inline)) {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
     };
