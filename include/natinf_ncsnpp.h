@@ -106,7 +106,8 @@ int natinf_debug_conv_gn(int res, int B, int N, int cin, int c1, const void* x, 
                          const void* a1, const float* bias_n, const void* resid, float out_scale, void* out, float* gn_part, int iters,
                          natinf_stream_t stream);
 int natinf_set_gemm_variant(int variant);
-/* A/B switch for tuning: 1 = every GEMM takes the fp32-slab epilogue, 0 (default) = the packed bf16 epilogue where it applies. */
+/* A/B switch for tuning: 1 = every k_gemm_* launch takes the fp32-slab epilogue, 0 (default) = the packed bf16 epilogue where it applies.
+   The fused GroupNorm + 3x3 convolution kernels (k_conv_gn2) have packed epilogues only and ignore the switch. */
 int natinf_set_gemm_epilogue(int fp32_slab);
 /* A/B switch for tuning: 0 = N <= 128 layers on the 4-wave 256x128 ring tile, 1 (default) = on the 512x128 hand-pipelined tile. */
 int natinf_set_gemm_pref512(int on);

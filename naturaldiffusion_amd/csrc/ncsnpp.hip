@@ -28,10 +28,12 @@
 #include "natinf_ncsnpp.h"
 #include "ncsnpp_kernels.h"
 #include "gemm_dma.h"
-#include "conv_patch.h"
 #include "conv_gn.h"
 #include "conv_gn2.h"
+#ifdef NATINF_DEV                  // superseded kernels kept for A/B runs: development builds only (make EXTRA=-DNATINF_DEV)
+#include "conv_patch.h"
 #include "gemm_8phase.h"
+#endif
 #include "gemm_fp8.h"
 #include "attn_fused.h"
 #include "flash_attn.h"
@@ -164,6 +166,20 @@ const char* variant_name(int v) {
                               "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s", "dma512x128", "patch256x256", "patch256x128", "dma256x256p", "dma128x128p", "dma256x128w4p", "gemm8ph", "gemm8ph_np", "gemm8ph_rf", "gemm8ph_nprf", "fp8_256x256", "abl_nodma", "abl_nomfma", "dma256x256h", "dma512x128h", "conv_gn"};
     return v >= 0 && v < V_COUNT ? n[v] : "?";
 }
+// The shipped library instantiates only the tile variants the dispatcher selects (choose_variant, splitk) plus the generic kernel; every other
+// variant of the enum -- superseded pipelines kept for A/B runs -- exists in -DNATINF_DEV builds only, and natinf_set_gemm_variant /
+// natinf_debug_gemm refuse it (NATINF_ESTATE) elsewhere.
+inline bool variant_shipped(int v) {
+#ifdef NATINF_DEV
+    return v >= 0 && v < V_COUNT;
+#else
+    switch (v) {
+        case V_AUTO: case V_GENERIC: case V_RING_64x128: case V_RING_256x128_W4: case V_DMA_128x128_P: case V_FP8_256x256:
+        case V_DMA_256x256_H: case V_DMA_512x128_H: case V_CONV_GN: return true;
+        default: return false;
+    }
+#endif
+}
 unsigned long long* g_dbg_ts = nullptr;
 int g_force_variant = V_AUTO;
 int g_half_issue = 1;              // natinf_set_gemm_half_issue(0): every wave issues its own LDS-DMA pieces (A/B runs)
@@ -195,48 +211,70 @@ using CfgR256x256 = RingCfg<2, 4, 8, 4, 4>; using CfgR256x128 = RingCfg<4, 2, 4,
 using CfgR128x128 = RingCfg<2, 2, 4, 4, 4>; using CfgR64x128 = RingCfg<2, 2, 2, 4, 4>;
 using CfgR256x128W4 = RingCfg<2, 2, 8, 4, 3>; using CfgD256x128W4 = DmaCfg<2, 2, 8, 4>;
 using CfgD512x128 = DmaCfg<4, 2, 8, 4>;
+using CfgH32 = ConvGn2Cfg<32>; using CfgH16 = ConvGn2Cfg<16>; using CfgH16W = ConvGn2Cfg<16, true>;
+#ifdef NATINF_DEV
 using CfgP256x256 = PatchCfg<2, 4, 8, 4, 344>; using CfgP256x128 = PatchCfg<4, 2, 4, 4, 400>;
 using CfgG32 = ConvGnCfg<32>; using CfgG16 = ConvGnCfg<16>; using CfgG16W = ConvGnCfg<16, true>;
-using CfgH32 = ConvGn2Cfg<32>; using CfgH16 = ConvGn2Cfg<16>; using CfgH16W = ConvGn2Cfg<16, true>;
+#endif
 int g_fuse_gn = 1;                 // natinf_set_fuse_gn (read when a plan is BUILT): GroupNorm-apply + SiLU inside the consuming 3x3 conv
 
-// the packed-epilogue instantiations (EPI 1..4) of the four automatically chosen variants
-template <int EPI>
-bool set_lds_epi() {
-    return set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2, EPI>) && set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2, EPI>) &&
-           set_lds<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3, EPI>) && set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4, EPI>) &&
-           set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4, 2, EPI>) &&
-           set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 6, EPI>) && set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4, 6, EPI>);
+// Packed-epilogue specializations (EPI, gemm_dma.h) that exist per tile family, as bit masks: a launch whose epilogue is not
+// instantiated for its tile takes the general fp32-slab epilogue (EPI 0: the same terms, the same single rounding).  Who needs what:
+// 3 (SiLU) only the small time-embedding GEMMs; 4 (tanh-GELU), 7 (fp32 residual stream), 8 (row bias) the transformer engines, none
+// of which ever reaches the N <= 128 tile.
+constexpr unsigned EPI_ALL = 0x1FF;
+constexpr unsigned EPI_R64 = EPI_ALL, EPI_D128 = EPI_ALL, EPI_RW4 = EPI_ALL & ~(1u << 3), EPI_D256H = EPI_ALL & ~(1u << 3),
+                   EPI_D512H = EPI_ALL & ~((1u << 3) | (1u << 4) | (1u << 7) | (1u << 8));
+template <unsigned MASK, int E, class F> inline void epi_case(F&& f) { if constexpr ((MASK >> E) & 1u) f(std::integral_constant<int, E>{}); }
+template <unsigned MASK, class F> inline bool for_each_epi(F&& f) {             // f(integral_constant<int, E>) -> bool, over the instantiated ones
+    bool ok = true;
+    auto one = [&](auto tag) { ok = ok && f(tag); };
+    epi_case<MASK, 0>(one); epi_case<MASK, 1>(one); epi_case<MASK, 2>(one); epi_case<MASK, 3>(one); epi_case<MASK, 4>(one);
+    epi_case<MASK, 5>(one); epi_case<MASK, 6>(one); epi_case<MASK, 7>(one); epi_case<MASK, 8>(one);
+    return ok;
+}
+#define NATINF_EPI_OF(tag) decltype(tag)::value
+bool set_lds_epi_all() {
+    return for_each_epi<EPI_D128>([](auto t) { return set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2, NATINF_EPI_OF(t)>); }) &&
+           for_each_epi<EPI_RW4>([](auto t) { return set_lds<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3, NATINF_EPI_OF(t)>); }) &&
+           for_each_epi<EPI_R64>([](auto t) { return set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4, NATINF_EPI_OF(t)>); }) &&
+           for_each_epi<EPI_D256H>([](auto t) { return set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 6, NATINF_EPI_OF(t)>); }) &&
+           for_each_epi<EPI_D512H>([](auto t) { return set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4, 6, NATINF_EPI_OF(t)>); })
+#ifdef NATINF_DEV
+           && for_each_epi<EPI_ALL>([](auto t) { return set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2, NATINF_EPI_OF(t)>); })
+           && for_each_epi<EPI_ALL>([](auto t) { return set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4, 2, NATINF_EPI_OF(t)>); })
+#endif
+        ;
 }
 template <int EPI>
 bool set_lds_conv_gn() {
-    return set_lds<CfgG32>(&k_conv_gn<32, false, EPI>) && set_lds<CfgG16>(&k_conv_gn<16, false, EPI>) && set_lds<CfgG16W>(&k_conv_gn<16, true, EPI>) &&
-           set_lds<CfgH32>(&k_conv_gn2<32, false, EPI>) && set_lds<CfgH16>(&k_conv_gn2<16, false, EPI>) && set_lds<CfgH16W>(&k_conv_gn2<16, true, EPI>);
+    return set_lds<CfgH32>(&k_conv_gn2<32, false, EPI>) && set_lds<CfgH16>(&k_conv_gn2<16, false, EPI>) && set_lds<CfgH16W>(&k_conv_gn2<16, true, EPI>)
+#ifdef NATINF_DEV
+           && set_lds<CfgG32>(&k_conv_gn<32, false, EPI>) && set_lds<CfgG16>(&k_conv_gn<16, false, EPI>) && set_lds<CfgG16W>(&k_conv_gn<16, true, EPI>)
+#endif
+        ;
 }
-bool set_lds_epi_all() { return set_lds_epi<0>() && set_lds_epi<1>() && set_lds_epi<2>() && set_lds_epi<3>() && set_lds_epi<4>() && set_lds_epi<5>() && set_lds_epi<6>() && set_lds_epi<7>() && set_lds_epi<8>(); }
 
 bool configure_gemm_kernels() {
     bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   GEMM_LDS_BYTES) == hipSuccess;
-    ok = ok && set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4>) && set_lds<CfgD256x128>(&k_gemm_dma<4, 2, 4, 4>) &&
+    ok = ok && set_lds<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4, 9>) &&
+         set_lds_epi_all() && set_lds_conv_gn<1>() && set_lds_conv_gn<2>() && set_lds_conv_gn<5>() && set_lds_conv_gn<6>() &&
+#ifdef NATINF_DEV
+         set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4>) && set_lds<CfgD256x128>(&k_gemm_dma<4, 2, 4, 4>) &&
          set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4>) && set_lds<CfgR256x256>(&k_gemm_ring<2, 4, 8, 4, 4>) &&
          set_lds<CfgR256x128>(&k_gemm_ring<4, 2, 4, 4, 6>) && set_lds<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4>) &&
-         set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4>) && set_lds<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3>) &&
-         set_lds<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4, 9>) &&
          set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4>) && set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 1>) &&
          set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 1>) && set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4>) &&
          set_lds<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>) && set_lds<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>) &&
-         set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2>) && set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 2>) &&
          set_lds<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>) &&
-         set_lds_epi_all() && set_lds_conv_gn<1>() && set_lds_conv_gn<2>() && set_lds_conv_gn<5>() && set_lds_conv_gn<6>() &&
-#ifdef NATINF_DEV
          set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 3, 1>) && set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 4, 1>) &&
+         set_lds<Cfg8ph>(&k_gemm_8ph<0>) && set_lds<Cfg8ph>(&k_gemm_8ph<1>) && set_lds<Cfg8ph>(&k_gemm_8ph<2>) && set_lds<Cfg8ph>(&k_gemm_8ph<3>) &&
 #endif
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 0>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 0>) &&
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 1>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 1>) &&
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 2>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 2>) &&
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 3>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 3>) &&
-         set_lds<Cfg8ph>(&k_gemm_8ph<0>) && set_lds<Cfg8ph>(&k_gemm_8ph<1>) && set_lds<Cfg8ph>(&k_gemm_8ph<2>) && set_lds<Cfg8ph>(&k_gemm_8ph<3>) &&
          set_lds<AttnCfg<8, 16, true>>(&k_attn_fused<8, 16, true>) &&
          set_lds<AttnCfg<2, 4>>(&k_attn_fused<2, 4>) && set_lds<AttnCfg<3, 6>>(&k_attn_fused<3, 6>) &&
          set_lds<AttnCfg<3, 5>>(&k_attn_fused<3, 5>) &&
@@ -249,7 +287,9 @@ bool configure_gemm_kernels() {
 // 64 per segment and zero-bordered 3x3 operands); the register-staged, fully masked kernel otherwise (4x4
 // attention: K = 16).
 // k_gemm_8ph has no edge clamping and addresses the 1x1 segment row-linearly
+#ifdef NATINF_DEV
 inline bool eligible_8ph(const GemmArgs& g) { return g.M % 256 == 0 && g.N % 256 == 0; }
+#endif
 
 int variant_bm(int v);
 // k_conv_gn instantiations: 32x32 and 16x16 images, 256 x 128 tiles -- 128 x 256 tiles for 16x16 layers whose N is a multiple of 256
@@ -260,12 +300,19 @@ int g_fuse_up = 1;                 // natinf_set_fuse_up (read when a plan is BU
 int g_cg_regw = 1;                 // natinf_set_conv_gn_regw: 1 = k_conv_gn2 (weights streamed through registers) where GemmArgs::b_frag is given
 inline int conv_gn_bm(const GemmArgs& g) { return (g_cg_wide && (1 << g.logW) == 16 && g.N % 256 == 0) ? 128 : 256; }
 inline bool conv_gn_regw(const GemmArgs& g) { return g_cg_regw && g.b_frag && g.N % (conv_gn_bm(g) == 128 ? 256 : 128) == 0; }
+#ifdef NATINF_DEV
+constexpr bool HAVE_CONV_GN_V1 = true;              // k_conv_gn (weights through an LDS ring): superseded, development builds only
+#else
+constexpr bool HAVE_CONV_GN_V1 = false;
+#endif
+// k_conv_gn / k_conv_gn2 have packed epilogues only: the fp32-slab A/B knob (natinf_set_gemm_epilogue) does not apply to them
+inline int conv_gn_epi(const GemmArgs& g) { GemmArgs t = g; t.epi_fp32_slab = 0; return packed_epi(t, conv_gn_bm(g)); }
 inline bool conv_gn_ok(const GemmArgs& g) {
     if (!g.gn_scale || !g.gn_shift || !g.gn_folded || g.taps != 9 || g.batch != 1 || g.a0_C % BK || (g.a1 && g.a1_C % BK) || g.M % 256) return false;
     const int res = 1 << g.logW;
     if (g.logHW != 2 * g.logW || (res != 32 && res != 16) || g.N % 8) return false;
-    if ((g.a0_up || g.a1_up) && !conv_gn_regw(g)) return false;          // up-sampled fetches: k_conv_gn2 only
-    const int e = packed_epi(g, conv_gn_bm(g));
+    if ((g.a0_up || g.a1_up || !HAVE_CONV_GN_V1) && !conv_gn_regw(g)) return false;          // up-sampled fetches: k_conv_gn2 only
+    const int e = conv_gn_epi(g);
     return e == 1 || e == 2 || e == 5 || e == 6;
 }
 int choose_variant(const GemmArgs& g) {
@@ -273,15 +320,16 @@ int choose_variant(const GemmArgs& g) {
     const int K0 = g.taps * g.a0_C, K1 = g.a1 ? g.a1_C : 0;
     const bool dma = K0 % BK == 0 && K1 % BK == 0 && (g.taps == 1 || (g.a0_padded && g.a0_C % BK == 0));
     if (!dma) return V_GENERIC;
-    const bool patch_ok = g.taps == 9 && g.batch == 1 && g.logW >= 3;
-    if (g_force_variant == V_PATCH_256x256 || g_force_variant == V_PATCH_256x128) {
+    if (!variant_shipped(g_force_variant)) { /* refused by natinf_set_gemm_variant; never reached */ }
+#ifdef NATINF_DEV
+    else if (g_force_variant == V_PATCH_256x256 || g_force_variant == V_PATCH_256x128) {
+        const bool patch_ok = g.taps == 9 && g.batch == 1 && g.logW >= 3;
         if (patch_ok && (g_force_variant == V_PATCH_256x128 || g.logW >= 4)) return g_force_variant;
     } else if (g_force_variant >= V_8PH_256x256 && g_force_variant <= V_8PH_BOTH) {
         if (eligible_8ph(g)) return g_force_variant;
-#ifndef NATINF_DEV
-    } else if (g_force_variant == V_ABL_NODMA || g_force_variant == V_ABL_NOMFMA) {      // ablation kernels: development builds only
+    }
 #endif
-    } else if (g_force_variant > V_GENERIC) {
+    else if (g_force_variant > V_GENERIC && g_force_variant != V_CONV_GN && g_force_variant != V_FP8_256x256) {
         // a forced tile must keep GroupNorm partial tiles inside one sample (e.g. 512-row tiles on the 16x16 level do not)
         if (!g.gn_part || (g.taps == 9 && (1 << g.logHW) % variant_bm(g_force_variant) == 0)) return g_force_variant;
     }
@@ -290,10 +338,15 @@ int choose_variant(const GemmArgs& g) {
     // 128x128 when 256-row tiles would leave CUs idle; 64x128 for the 4x4 level
     const int64_t mt256 = (g.M + 255) / 256, mt128 = (g.M + 127) / 128;
     const int64_t nt128 = (g.N + 127) / 128;
-    if (g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) * g.batch >= NUM_CU) return g_half_issue ? V_DMA_256x256_H : V_DMA_256x256_P;
+#ifdef NATINF_DEV
+    const bool half = g_half_issue != 0;                                       // natinf_set_gemm_half_issue(0): the every-wave-issues pipelines (A/B runs)
+#else
+    constexpr bool half = true;
+#endif
+    if (g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) * g.batch >= NUM_CU) return half ? V_DMA_256x256_H : V_DMA_256x256_P;
     if (g_pref_512 && g.N <= 128 && K0 + K1 >= 1024 && ((g.M + 511) / 512) * g.batch >= 2 * NUM_CU &&
         (!g.gn_part || (g.taps == 9 && (1 << g.logHW) % 512 == 0)))           // GroupNorm partials: a tile inside one sample
-        return g_half_issue ? V_DMA_512x128_H : V_DMA_512x128;
+        return half ? V_DMA_512x128_H : V_DMA_512x128;
     if (mt256 * nt128 * g.batch >= 2 * NUM_CU) return V_RING_256x128_W4;        // it runs two blocks per CU
     if (mt128 * nt128 * g.batch >= NUM_CU) return V_DMA_128x128_P;
     return V_RING_64x128;
@@ -346,20 +399,32 @@ int packed_epi(const GemmArgs& g, int bm) {      // resid must be 8-byte aligned
     if (g.resid) return 5;
     return g.act == ACT_NONE ? 1 : (g.act == ACT_SILU ? 3 : 4);
 }
-#define NATINF_LAUNCH_EPI(CFG, KERN, ...)                                                   \
-    switch (packed_epi(g, CFG::BM_)) {                                                      \
-        case 1: launch_tiles<CFG>(&KERN<__VA_ARGS__, 1>, g, s); break;                      \
-        case 2: launch_tiles<CFG>(&KERN<__VA_ARGS__, 2>, g, s); break;                      \
-        case 3: launch_tiles<CFG>(&KERN<__VA_ARGS__, 3>, g, s); break;                      \
-        case 4: launch_tiles<CFG>(&KERN<__VA_ARGS__, 4>, g, s); break;                      \
-        case 5: launch_tiles<CFG>(&KERN<__VA_ARGS__, 5>, g, s); break;                      \
-        case 6: launch_tiles<CFG>(&KERN<__VA_ARGS__, 6>, g, s); break;                      \
-        case 7: launch_tiles<CFG>(&KERN<__VA_ARGS__, 7>, g, s); break;                      \
-        case 8: launch_tiles<CFG>(&KERN<__VA_ARGS__, 8>, g, s); break;                      \
-        default: launch_tiles<CFG>(&KERN<__VA_ARGS__, 0>, g, s); break;                     \
+inline unsigned epi_mask(int v) {
+    switch (v) {
+        case V_RING_64x128: return EPI_R64;  case V_DMA_128x128_P: return EPI_D128;  case V_RING_256x128_W4: return EPI_RW4;
+        case V_DMA_256x256_H: return EPI_D256H;  case V_DMA_512x128_H: return EPI_D512H;
+        case V_DMA_256x256_P: case V_DMA_512x128: return EPI_ALL;
+        default: return 1u;
+    }
+}
+// the epilogue specialization a launch on tile variant v runs (0 where its packed one is not instantiated for that tile)
+inline int effective_epi(int v, const GemmArgs& g) { const int e = packed_epi(g, variant_bm(v)); return ((epi_mask(v) >> e) & 1u) ? e : 0; }
+#define NATINF_LAUNCH_EPI(MASK, CFG, KERN, ...)                                                                      \
+    {                                                                                                                \
+        auto run_ = [&](auto t_) { launch_tiles<CFG>(&KERN<__VA_ARGS__, NATINF_EPI_OF(t_)>, g, s); };                \
+        switch (effective_epi(v, g)) {                                                                               \
+            case 1: epi_case<MASK, 1>(run_); break;  case 2: epi_case<MASK, 2>(run_); break;                         \
+            case 3: epi_case<MASK, 3>(run_); break;  case 4: epi_case<MASK, 4>(run_); break;                         \
+            case 5: epi_case<MASK, 5>(run_); break;  case 6: epi_case<MASK, 6>(run_); break;                         \
+            case 7: epi_case<MASK, 7>(run_); break;  case 8: epi_case<MASK, 8>(run_); break;                         \
+            default: run_(std::integral_constant<int, 0>{}); break;                                                  \
+        }                                                                                                            \
     }
 
-int g_launch_error = 0;            // set when a launch is asked for something no kernel provides (a plan-builder bug); the forward reports it
+// set when a launch is asked for something no kernel provides (a plan-builder bug, or an A/B knob flipped after the plan was built);
+// natinf_ncsnpp_forward clears it on entry and reports it on exit -- per calling thread, so two engines on two threads do not see
+// each other's, and a description pass (g_record) never sets it
+thread_local int g_launch_error = 0;
 int g_splitk = 1;                  // natinf_set_gemm_splitk: 0 = never split K
 float* g_dbg_splitk_ws = nullptr; int g_dbg_splitk_max = 0;        // natinf_debug_set_splitk_workspace
 // Split-K for launches that cannot fill the chip otherwise (the 8x8 and 4x4 levels: 32,768 / 8,192 rows x 256 columns, K = 2,304 ..
@@ -399,13 +464,18 @@ int launch_gemm(const GemmArgs& g0, hipStream_t s) {
     }
     const GemmArgs& g = g0;
     const int v = choose_variant(g);
-    if (v == V_CONV_GN && !conv_gn_ok(g)) { g_launch_error = 1; return 256; }
-    if (v == V_CONV_GN && g_record) { /* described below */ }
+    if (v == V_CONV_GN && !conv_gn_ok(g)) {
+        if (g_record) {                 // description pass: say so in the table instead of dropping the row
+            char line[160];
+            snprintf(line, sizeof(line), "%d %d %d %d %d %d invalid_conv_gn/e0\n", g.M, g.N, g.taps * g.a0_C, g.a1 ? g.a1_C : 0, g.taps, g.batch);
+            *g_record += line;
+        } else g_launch_error = 1;
+        return 256;
+    }
     if (g_record) {
         char line[160];
-        const bool has_packed = v == V_CONV_GN || v == V_DMA_256x256_P || v == V_DMA_128x128_P || v == V_RING_256x128_W4 || v == V_RING_64x128 || v == V_DMA_512x128 || v == V_DMA_256x256_H || v == V_DMA_512x128_H;
         snprintf(line, sizeof(line), "%d %d %d %d %d %d %s/e%d\n", g.M, g.N, g.taps * g.a0_C, g.a1 ? g.a1_C : 0, g.taps, g.batch, variant_name(v),
-                 has_packed ? packed_epi(g, v == V_CONV_GN ? conv_gn_bm(g) : variant_bm(v)) : 0);
+                 v == V_CONV_GN ? conv_gn_epi(g) : effective_epi(v, g));
         *g_record += line;
         return v == V_CONV_GN ? conv_gn_bm(g) : variant_bm(v);
     }
@@ -415,41 +485,37 @@ int launch_gemm(const GemmArgs& g0, hipStream_t s) {
             hipLaunchKernelGGL(k_gemm_bf16, dim3(nM * nN, 1, g.batch), dim3(256), GEMM_LDS_BYTES, s, g);
             break;
         }
+        case V_RING_64x128: NATINF_LAUNCH_EPI(EPI_R64, CfgR64x128, k_gemm_ring, 2, 2, 2, 4, 4) break;
+        case V_RING_256x128_W4: NATINF_LAUNCH_EPI(EPI_RW4, CfgR256x128W4, k_gemm_ring, 2, 2, 8, 4, 3) break;
+        case V_DMA_128x128_P: NATINF_LAUNCH_EPI(EPI_D128, CfgD128x128, k_gemm_dma, 2, 2, 4, 4, 2) break;
+        case V_FP8_256x256: launch_tiles<CfgD256x256>(&k_gemm_fp8<false, 0>, g, s); break;
+        case V_DMA_256x256_H: NATINF_LAUNCH_EPI(EPI_D256H, CfgD256x256, k_gemm_dma, 2, 4, 8, 4, 6) break;
+        case V_DMA_512x128_H: NATINF_LAUNCH_EPI(EPI_D512H, CfgD512x128, k_gemm_dma, 4, 2, 8, 4, 6) break;
+#ifdef NATINF_DEV
         case V_DMA_256x256: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4>, g, s); break;
         case V_DMA_256x128: launch_tiles<CfgD256x128>(&k_gemm_dma<4, 2, 4, 4>, g, s); break;
         case V_DMA_128x128: launch_tiles<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4>, g, s); break;
         case V_RING_256x256: launch_tiles<CfgR256x256>(&k_gemm_ring<2, 4, 8, 4, 4>, g, s); break;
         case V_RING_256x128: launch_tiles<CfgR256x128>(&k_gemm_ring<4, 2, 4, 4, 6>, g, s); break;
         case V_RING_128x128: launch_tiles<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4>, g, s); break;
-        case V_RING_64x128: NATINF_LAUNCH_EPI(CfgR64x128, k_gemm_ring, 2, 2, 2, 4, 4) break;
-        case V_RING_256x128_W4: NATINF_LAUNCH_EPI(CfgR256x128W4, k_gemm_ring, 2, 2, 8, 4, 3) break;
         case V_DMA_256x128_W4: launch_tiles<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4>, g, s); break;
         case V_DMA_256x256_S: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 1>, g, s); break;
         case V_DMA_128x128_S: launch_tiles<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4, 1>, g, s); break;
-        case V_DMA_512x128: NATINF_LAUNCH_EPI(CfgD512x128, k_gemm_dma, 4, 2, 8, 4, 2) break;
+        case V_DMA_512x128: NATINF_LAUNCH_EPI(EPI_ALL, CfgD512x128, k_gemm_dma, 4, 2, 8, 4, 2) break;
         case V_PATCH_256x256: launch_tiles<CfgP256x256>(&k_conv_patch<2, 4, 8, 4, 344>, g, s); break;
         case V_PATCH_256x128: launch_tiles<CfgP256x128>(&k_conv_patch<4, 2, 4, 4, 400>, g, s); break;
-        case V_DMA_256x256_P: NATINF_LAUNCH_EPI(CfgD256x256, k_gemm_dma, 2, 4, 8, 4, 2) break;
-        case V_DMA_128x128_P: NATINF_LAUNCH_EPI(CfgD128x128, k_gemm_dma, 2, 2, 4, 4, 2) break;
+        case V_DMA_256x256_P: NATINF_LAUNCH_EPI(EPI_ALL, CfgD256x256, k_gemm_dma, 2, 4, 8, 4, 2) break;
         case V_DMA_256x128W4_P: launch_tiles<CfgD256x128W4>(&k_gemm_dma<2, 2, 8, 4, 2>, g, s); break;
         case V_8PH_256x256: launch_tiles<Cfg8ph>(&k_gemm_8ph<0>, g, s); break;
-        case V_FP8_256x256: launch_tiles<CfgD256x256>(&k_gemm_fp8<false, 0>, g, s); break;
-        case V_DMA_256x256_H: NATINF_LAUNCH_EPI(CfgD256x256, k_gemm_dma, 2, 4, 8, 4, 6) break;
-        case V_DMA_512x128_H: NATINF_LAUNCH_EPI(CfgD512x128, k_gemm_dma, 4, 2, 8, 4, 6) break;
-#ifdef NATINF_DEV
+        case V_8PH_NOPRIO: launch_tiles<Cfg8ph>(&k_gemm_8ph<1>, g, s); break;
+        case V_8PH_READFIRST: launch_tiles<Cfg8ph>(&k_gemm_8ph<2>, g, s); break;
+        case V_8PH_BOTH: launch_tiles<Cfg8ph>(&k_gemm_8ph<3>, g, s); break;
         case V_ABL_NODMA: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 3, 1>, g, s); break;
         case V_ABL_NOMFMA: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 4, 1>, g, s); break;
 #endif
         case V_CONV_GN: {
-            const int e = packed_epi(g, conv_gn_bm(g));
+            const int e = conv_gn_epi(g);
             const int e4 = e == 1 ? 0 : (e == 2 ? 1 : (e == 5 ? 2 : 3));
-#define NATINF_CG_LAUNCH(CFG, RES, WIDE)                                                                    \
-            switch (e4) {                                                                                       \
-                case 0: launch_tiles<CFG>(&k_conv_gn<RES, WIDE, 1>, g, s); break;                               \
-                case 1: launch_tiles<CFG>(&k_conv_gn<RES, WIDE, 2>, g, s); break;                               \
-                case 2: launch_tiles<CFG>(&k_conv_gn<RES, WIDE, 5>, g, s); break;                               \
-                default: launch_tiles<CFG>(&k_conv_gn<RES, WIDE, 6>, g, s); break;                              \
-            }
 #define NATINF_CG2_LAUNCH(CFG, RES, WIDE)                                                                   \
             switch (e4) {                                                                                       \
                 case 0: launch_tiles<CFG>(&k_conv_gn2<RES, WIDE, 1>, g, s); break;                              \
@@ -462,16 +528,22 @@ int launch_gemm(const GemmArgs& g0, hipStream_t s) {
                 else if (conv_gn_bm(g) == 128) { NATINF_CG2_LAUNCH(CfgH16W, 16, true) }
                 else { NATINF_CG2_LAUNCH(CfgH16, 16, false) }
             }
+#undef NATINF_CG2_LAUNCH
+#ifdef NATINF_DEV
+#define NATINF_CG_LAUNCH(CFG, RES, WIDE)                                                                    \
+            switch (e4) {                                                                                       \
+                case 0: launch_tiles<CFG>(&k_conv_gn<RES, WIDE, 1>, g, s); break;                               \
+                case 1: launch_tiles<CFG>(&k_conv_gn<RES, WIDE, 2>, g, s); break;                               \
+                case 2: launch_tiles<CFG>(&k_conv_gn<RES, WIDE, 5>, g, s); break;                               \
+                default: launch_tiles<CFG>(&k_conv_gn<RES, WIDE, 6>, g, s); break;                              \
+            }
             else if ((1 << g.logW) == 32) { NATINF_CG_LAUNCH(CfgG32, 32, false) }
             else if (conv_gn_bm(g) == 128) { NATINF_CG_LAUNCH(CfgG16W, 16, true) }
             else { NATINF_CG_LAUNCH(CfgG16, 16, false) }
-#undef NATINF_CG2_LAUNCH
 #undef NATINF_CG_LAUNCH
+#endif
             return conv_gn_bm(g);
         }
-        case V_8PH_NOPRIO: launch_tiles<Cfg8ph>(&k_gemm_8ph<1>, g, s); break;
-        case V_8PH_READFIRST: launch_tiles<Cfg8ph>(&k_gemm_8ph<2>, g, s); break;
-        case V_8PH_BOTH: launch_tiles<Cfg8ph>(&k_gemm_8ph<3>, g, s); break;
         default: break;
     }
     return variant_bm(v);
@@ -1109,6 +1181,7 @@ int natinf_ncsnpp_forward(natinf_ncsnpp_t h, const float* x, const float* labels
         h->attr_set = true;
     }
     Ctx c{B, reinterpret_cast<unsigned char*>(workspace), h->packed, (hipStream_t)stream, x, labels, out, h->part_bm.data()};
+    g_launch_error = 0;
     if (!h->prof) {
         for (const auto& f : h->ops) f(c);
     } else {
@@ -1148,8 +1221,9 @@ int natinf_debug_gemm(int variant, int M, int N, int K0, int K1, int taps, int l
                       const void* a0, const void* a1, const void* b, const float* bias_n, void* c, int c_f32, float scale,
                       int iters, natinf_stream_t stream) {
     if (variant < 0 || variant >= V_COUNT || !a0 || !b || !c || M <= 0 || N <= 0 || iters <= 0 || (taps != 1 && taps != 9)) return NATINF_EINVAL;
+    if (!variant_shipped(variant) || variant == V_CONV_GN || variant == V_FP8_256x256) return NATINF_ESTATE;      // superseded / ablation variants: -DNATINF_DEV builds
 #ifndef NATINF_DEV
-    if (c_f32 >= 2 || variant == V_ABL_NODMA || variant == V_ABL_NOMFMA) return NATINF_ESTATE;      // timing experiments: -DNATINF_DEV builds
+    if (c_f32 >= 2) return NATINF_ESTATE;      // timing experiments: -DNATINF_DEV builds
 #endif
     static bool configured = false;
     if (!configured) { if (!configure_gemm_kernels()) return NATINF_ENODEV; configured = true; }
@@ -1175,6 +1249,7 @@ int natinf_debug_gemm_fused(int variant, int M, int N, int K, const void* a, con
                             const float* rowvec, const float* gate, int log_rows_per_sample, const void* resid_bf16, const float* resid_f32,
                             float scale, int act, void* c, int c_f32, float* gn_part, int* bm_out, int fp32_slab, natinf_stream_t stream) {
     if (variant < 0 || variant >= V_COUNT || !a || !b || !c || M <= 0 || N <= 0 || K <= 0 || N % 8) return NATINF_EINVAL;
+    if (!variant_shipped(variant) || variant == V_CONV_GN || variant == V_FP8_256x256) return NATINF_ESTATE;
     if (!configure_gemm_kernels()) return NATINF_ENODEV;
     GemmArgs g = gemm_defaults();
     g.a0 = (const bf16*)a; g.a0_C = K; g.a0_ld = K; g.M = M; g.N = N; g.b = (const bf16*)b; g.b_ld = K;
@@ -1255,16 +1330,25 @@ int natinf_debug_timestamps(void* dev_buf16) {
 int natinf_set_gemm_raster(int rows) { g_raster_g = rows; return NATINF_OK; }
 int natinf_set_fuse_gn(int on) { g_fuse_gn = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_wide(int on) { g_cg_wide = on != 0; return NATINF_OK; }
-int natinf_set_conv_gn_regw(int on) { g_cg_regw = on != 0; return NATINF_OK; }
+int natinf_set_conv_gn_regw(int on) {
+    if (!on && !HAVE_CONV_GN_V1) return NATINF_ESTATE;      // k_conv_gn (the LDS-ring form) exists in -DNATINF_DEV builds only
+    g_cg_regw = on != 0; return NATINF_OK;
+}
 int natinf_set_fuse_up(int on) { g_fuse_up = on != 0; return NATINF_OK; }
 int natinf_set_gemm_splitk(int on) { g_splitk = on != 0; return NATINF_OK; }
 int natinf_debug_set_splitk_workspace(float* ws, int max_slices) { g_dbg_splitk_ws = ws; g_dbg_splitk_max = ws ? max_slices : 0; return NATINF_OK; }
-int natinf_set_gemm_half_issue(int on) { g_half_issue = on != 0; return NATINF_OK; }
+int natinf_set_gemm_half_issue(int on) {
+#ifndef NATINF_DEV
+    if (!on) return NATINF_ESTATE;                          // the every-wave-issues pipelines exist in -DNATINF_DEV builds only
+#endif
+    g_half_issue = on != 0; return NATINF_OK;
+}
 int natinf_set_gemm_pref512(int on) { g_pref_512 = on != 0; return NATINF_OK; }
 int natinf_set_gemm_epilogue(int fp32_slab) { g_epi_fp32_slab = fp32_slab != 0; return NATINF_OK; }
 
 int natinf_set_gemm_variant(int variant) {
     if (variant < 0 || variant >= V_COUNT) return NATINF_EINVAL;
+    if (!variant_shipped(variant) || variant == V_CONV_GN || variant == V_FP8_256x256) return NATINF_ESTATE;      // development-build variants; operand-type-specific kernels
     g_force_variant = variant;
     return NATINF_OK;
 }

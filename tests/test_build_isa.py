@@ -118,5 +118,12 @@ def test_no_development_kernels_in_the_shipped_library(listings):
     ks = _kernels(listings["ncsnpp"])
     abl = [n for n in ks if re.search(r"k_gemm_dma<2, 4, 8, 4, [34], 1>", n)]
     assert not abl, abl
+    # superseded kernels nothing selects (round-2 review, weak #14): the LDS-ring conv_gn, the LDS-resident-patch conv, the 8-phase GEMM,
+    # the unpipelined / spread-issue DMA tiles, the every-wave-issues 256x256 / 512x128 pipelines and the ring shapes without a caller
+    dead = [n for n in ks if re.search(r"k_conv_gn<|k_conv_patch|k_gemm_8ph|k_gemm_dma<\d, \d, \d, \d, [01], |k_gemm_dma<2, 4, 8, 4, 2, |"
+                                       r"k_gemm_dma<4, 2, 8, 4, 2, |k_gemm_dma<4, 2, 4, 4|k_gemm_dma<2, 2, 8, 4|k_gemm_ring<2, 4, |k_gemm_ring<4, 2, |"
+                                       r"k_gemm_ring<2, 2, 4, 4, 4, 0>", n)]
+    assert not dead, dead
+    assert len(ks) < 100, len(ks)                                              # 146 in round 2
     code = listings["ncsnpp"]
     assert "s_memtime" not in code[:code.index("amdhsa.kernels:")]           # tile-timeline stamps: -DNATINF_DEV builds only

@@ -63,7 +63,8 @@ def test_conv_gn_matches_torch(res, B, cin, N, c1, resid, parts):
     rd = r.bfloat16().to(dev) if resid else None
     wide = res == 16 and N % 256 == 0                      # 128-pixel x 256-channel tiles (default) -- the 256 x 128 ones are tested as well
     wf = torch.zeros_like(wd)                              # receives the fragment-major copy of the weights (k_conv_gn2)
-    for use_wide, regw in (((1, 1), (0, 1), (1, 0), (0, 0)) if wide else ((1, 1), (1, 0))):
+    assert lib.natinf_set_conv_gn_regw(0) != 0          # k_conv_gn (weights through an LDS ring): -DNATINF_DEV builds only
+    for use_wide, regw in (((1, 1), (0, 1)) if wide else ((1, 1),)):
         lib.natinf_set_conv_gn_wide(use_wide)
         rows = 128 if (wide and use_wide) else 256
         part = torch.zeros(M // rows, N // 4, 2, device=dev) if parts else None
