@@ -482,6 +482,52 @@ def group_k5():
     np.savez_compressed(HERE / "k5_classical.npz", **out)
 
 
+def group_ddim_vp():
+    """BASELINE config 3 names "DDIM / DPMSolver++ coeff-matrix equivalents": DDIM on the CONTINUOUS VP grid has no shipped matrix
+    (results/ddim/* are the discrete DiT schedule), so it comes from naturaldiffusion_amd.coeffgen.ddim_vp_continuous.  Pinned here
+    against the vendored solver itself: ``orig`` / ``orig_pp`` = DPM_Solver.dpm_solver_first_update (deps/dpm_solver_pytorch.py:547-592,
+    "DPM-Solver-1 (equivalent to DDIM)") in its noise-prediction and data-prediction forms over the time grid; ``ni`` = the
+    reference's data_fn / weighted_sum loop (src/CIFAR10NaturalInference.py:292-304) with the generated matrix, same noise, same
+    analytic denoiser.  Two grids: linspace(1, 1e-3, 19) (the solver's uniform-time grid) and the quadratic 15-step grid of the
+    shipped weights/step_15_*.npz."""
+    import numpy as np
+    import torch
+    _stub_cifar_env()
+    import CIFAR10NaturalInference as R
+    from oracle import ni_oracle as O
+    from naturaldiffusion_amd import coeffgen as G
+    model_fn = O.analytic_vp_model()
+    sde = R.VPSDE(beta_min=0.1, beta_max=20.0, N=1000)
+    score_fn = R.mutils.get_score_fn(sde, model_fn_module(model_fn), train=False, continuous=True)
+    noise_fn = lambda x, t: model_fn(x, t * 999)
+    ns = R.NoiseScheduleVP('linear', continuous_beta_0=sde.beta_0, continuous_beta_1=sde.beta_1)
+    out = {}
+    g = torch.Generator().manual_seed(777)
+    for key, ts in (("lin18", np.linspace(1.0, 1e-3, 19)), ("quad15", G.quadratic_time_grid(15))):
+        C, B, node = G.ddim_vp_continuous(ts)
+        noise = torch.randn(2, 3, 32, 32, generator=g)
+        grid = torch.from_numpy(np.asarray(ts, np.float64)).float()
+        res = {}
+        for tag, alg in (("orig", "dpmsolver"), ("orig_pp", "dpmsolver++")):
+            solver = R.DPM_Solver(noise_fn, ns, algorithm_type=alg)
+            x = noise
+            with torch.no_grad():
+                for i in range(len(ts) - 1):
+                    x = solver.dpm_solver_first_update(x, grid[i:i + 1], grid[i + 1:i + 2])
+            res[tag] = x.numpy()
+        seq_x0, y = [], noise
+        for kk in range(node.shape[0] - 1):
+            seq_x0.append(R.data_fn(score_fn, y, node[kk, 0], node[kk, 1], node[kk, 2], "cpu"))
+            y = R.weighted_sum(C[kk], seq_x0) + B[kk, 0] * noise
+        out[f"{key}_ts"], out[f"{key}_C"], out[f"{key}_B"], out[f"{key}_node"] = np.asarray(ts, np.float64), C, B, node
+        out[f"{key}_noise"] = noise.numpy()
+        out[f"{key}_stds"] = np.array([float(sde.marginal_prob(torch.zeros(1), torch.ones(1) * t)[1][0]) for t in node[:-1, 0]], np.float32)
+        out[f"{key}_orig"], out[f"{key}_orig_pp"], out[f"{key}_ni"] = res["orig"], res["orig_pp"], y.numpy()
+        print(f"ddim_vp: {key}: |orig - ni| max {np.abs(res['orig'] - y.numpy()).max():.3e}, |orig_pp - ni| max {np.abs(res['orig_pp'] - y.numpy()).max():.3e}"
+              f"  (|orig| max {np.abs(res['orig']).max():.3f})")
+    np.savez_compressed(HERE / "ddim_vp.npz", **out)
+
+
 def group_ckpt():
     """A score_sde checkpoint made the way the reference's training loop makes one (utils.save_checkpoint, utils.py:22-29):
     {'optimizer', 'model' (DataParallel state_dict, 'module.' keys), 'ema' (ExponentialMovingAverage.state_dict(),
@@ -541,7 +587,7 @@ def group_ckpt():
     print("ckpt:", len(layout), "parameters at nf=128;", flat.size, "floats at nf=8; loader agrees")
 
 
-GROUPS = dict(k5=group_k5, ckpt=group_ckpt, dit=group_dit, loaders=group_loaders, cifar=group_cifar, validate=group_validate, sd3=group_sd3, ncsnpp=group_ncsnpp)
+GROUPS = dict(k5=group_k5, ddim_vp=group_ddim_vp, ckpt=group_ckpt, dit=group_dit, loaders=group_loaders, cifar=group_cifar, validate=group_validate, sd3=group_sd3, ncsnpp=group_ncsnpp)
 
 if __name__ == "__main__":
     assert REF.exists(), "the reference is only mounted in the build container"

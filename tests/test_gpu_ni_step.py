@@ -74,6 +74,23 @@ def test_ni_equals_the_vendored_classical_solver(dev, golden_dir, repo_root, rel
     assert np.abs(out - fx[f"{key}_orig"]).max() <= 2e-5
 
 
+@pytest.mark.parametrize("key", ["lin18", "quad15"])
+def test_ddim_on_the_vp_grid_through_the_hip_path(dev, golden_dir, tmp_path, key):
+    """BASELINE config 3's DDIM leg on the HIP path: natinf_step_f64hist driven by the matrix coeffgen.ddim_vp_continuous writes in the
+    reference's .npz format -- bit-exact against the reference's NI loop, within 2e-5 of the vendored DPM_Solver.dpm_solver_first_update
+    (deps/dpm_solver_pytorch.py:547-592; tests/golden/make_golden.py group ddim_vp), dense and zero-skipped rows alike."""
+    from naturaldiffusion_amd import coeffgen as G
+    from naturaldiffusion_amd.CIFAR10NaturalInference import natural_inference
+    fx = np.load(golden_dir / "ddim_vp.npz")
+    C, B, node = G.ddim_vp_continuous(fx[f"{key}_ts"])
+    path = tmp_path / f"ddim_vp_{key}.npz"
+    G.save_coeff_matrix(path, C, B, node)
+    noise = torch.from_numpy(fx[f"{key}_noise"]).to(dev)
+    out = natural_inference(O.analytic_vp_model(), noise, path, stds=fx[f"{key}_stds"]).cpu().numpy()
+    assert np.array_equal(out, fx[f"{key}_ni"])
+    assert np.abs(out - fx[f"{key}_orig"]).max() <= 2e-5 and np.abs(out - fx[f"{key}_orig_pp"]).max() <= 2e-5
+
+
 def test_data_fn_and_weighted_sum_mirrors(dev, cifar, repo_root):
     from naturaldiffusion_amd import CIFAR10NaturalInference as M
     C, B, node = O.load_coeff_npz(repo_root / "weights/step_15_weight_173.npz")

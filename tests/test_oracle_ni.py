@@ -99,6 +99,22 @@ def test_k5_ni_equals_the_vendored_classical_solver(golden_dir, repo_root, rel):
     assert np.abs(xs[-1].numpy() - fx[f"{key}_orig"]).max() <= 2e-5      # == the classical solver (absolute; |x| ~ 2)
 
 
+@pytest.mark.parametrize("key", ["lin18", "quad15"])
+def test_ddim_on_the_vp_grid_equals_the_vendored_first_order_solver(golden_dir, key):
+    """BASELINE config 3 "DDIM ... coeff-matrix equivalents": the matrix of coeffgen.ddim_vp_continuous against the reference's own
+    DPM_Solver.dpm_solver_first_update (deps/dpm_solver_pytorch.py:547-592, "DPM-Solver-1 (equivalent to DDIM)"; captured by
+    make_golden.py group ddim_vp in both its noise- and data-prediction forms).  The generator reproduces the fixture's matrix, the
+    oracle the reference's NI loop bit for bit, and NI equals the classical solver within the survey's 2e-5."""
+    from naturaldiffusion_amd import coeffgen as G
+    fx = np.load(golden_dir / "ddim_vp.npz")
+    C, B, node = G.ddim_vp_continuous(fx[f"{key}_ts"])
+    assert np.array_equal(C, fx[f"{key}_C"]) and np.array_equal(B, fx[f"{key}_B"]) and np.array_equal(node, fx[f"{key}_node"])
+    xs = O.cifar_ni_trajectory(O.analytic_vp_model(), torch.from_numpy(fx[f"{key}_noise"]), C, B, node, stds=fx[f"{key}_stds"])
+    assert np.array_equal(xs[-1].numpy(), fx[f"{key}_ni"])
+    assert np.abs(xs[-1].numpy() - fx[f"{key}_orig"]).max() <= 2e-5
+    assert np.abs(xs[-1].numpy() - fx[f"{key}_orig_pp"]).max() <= 2e-5
+
+
 def test_k3_weighted_sum_validate(validate):
     seq = [torch.from_numpy(a) for a in validate["k3_seq"]]
     got = O.validate_weighted_sum(validate["k3_w"], seq)
