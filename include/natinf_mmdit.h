@@ -66,6 +66,12 @@ int natinf_mmdit_forward(natinf_mmdit_t h, const float* latents, const float* ti
 int natinf_attention_hd64_bf16(const void* q, const void* k, int ld_qk, int64_t qk_bs, const void* vT, void* o, int ld_o,
                                int64_t o_bs, int B, int H, int Tp, int T, float scale, natinf_stream_t stream);
 
+/* Measurement hook: while enabled, every k_flash_attn64 launch of this process (engine forwards and natinf_attention_hd64_bf16
+ * alike) is bracketed by a HIP event pair on its own stream.  natinf_attention_profile_read synchronises on them and returns the
+ * summed duration (ms) and the launch count since the last read.  Not thread-safe; for bench.py / tools. */
+int natinf_attention_profile(int enable);
+int natinf_attention_profile_read(double* ms_total, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

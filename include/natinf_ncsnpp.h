@@ -89,6 +89,10 @@ int natinf_debug_gemm_fused(int variant, int M, int N, int K, const void* a, con
                             float scale, int act, void* c, int c_f32, float* gn_part, int* bm_out, int fp32_slab, natinf_stream_t stream);
 int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_scale, const void* a_mx, const void* b8, const float* b_scale,
                           const float* bias_n, void* c, void* c_mx, int c_mode, int iters, natinf_stream_t stream);
+/* Test hook for the up-sampling fetch paths of k_conv_gn2 (the up-sampling res-blocks, natinf_set_fuse_up): bit 0 = the following
+ * natinf_debug_conv_gn calls take x at HALF the resolution ([B][res/2][res/2][cin]) and up-sample it (nearest, 2x) inside the patch fetch,
+ * bit 1 = the same for the 1x1 shortcut operand a1.  0 restores the plain fetch. */
+int natinf_debug_conv_gn_up(int flags);
 /* The fused GroupNorm-apply + SiLU + 3x3 convolution kernel (csrc/conv_gn.h) on caller-supplied operands:
  *   out[m, n] = (sum_{tap, c} silu(x[pixel(m) + tap, c] * scale[b, c] + shift[b, c]) * w[n, c, tap] + sum_c a1[m, c] * w1[n, c]
  *                + bias_n[n] + resid[m, n]) * out_scale,  zero padding applied after the activation (layerspp.py:242-274).

@@ -116,39 +116,65 @@ def generate_sharded(model_fn: Callable, weight_path, sample_count: int, batch_s
     return torch.cat(imgs), torch.cat(idxs)
 
 
-def calc_fid(imgs, ref_path, device):
-    """Reference :73-86 (InceptionV3 pool3 + Frechet distance).  Needs ``pytorch_fid`` and the
-    ``cifar10_mu_sigma.npz`` statistics, neither of which ships with the reference."""
-    try:
-        from pytorch_fid.inception import InceptionV3
-        from pytorch_fid.fid_score import calculate_frechet_distance
-    except ImportError as e:
-        raise ImportError("calc_fid needs the `pytorch_fid` package (InceptionV3 weights); it is not installed") from e
+INCEPTION_WEIGHTS = "pt_inception-2015-12-05-6726825d.pth"      # what pytorch_fid downloads on first use (FID_WEIGHTS_URL)
+
+
+def inception_weights_path() -> Path:
+    """$NATINF_INCEPTION_WEIGHTS, else weights/pt_inception-2015-12-05-6726825d.pth next to the coefficient files, else the torch hub
+    cache pytorch_fid fills (~/.cache/torch/hub/checkpoints)."""
+    env = os.environ.get("NATINF_INCEPTION_WEIGHTS")
+    if env:
+        return Path(env)
+    for cand in (root_path / "weights" / INCEPTION_WEIGHTS, Path.home() / ".cache/torch/hub/checkpoints" / INCEPTION_WEIGHTS):
+        if cand.exists():
+            return cand
+    return root_path / "weights" / INCEPTION_WEIGHTS
+
+
+def fid_inception(device, image_hw=(32, 32), max_batch: int = 50):
+    """The pool3 network of ``calc_fid`` on the HIP library (include/natinf_inception.h) -- the reference builds
+    ``InceptionV3([BLOCK_INDEX_BY_DIM[2048]])`` here (:75-77).  The weights are a download the image does not hold: without the file
+    this raises (``fid: blocked``); there is no torch-module fallback."""
+    from .inception import InceptionEngine, load_fid_inception_weights
+    path = inception_weights_path()
+    if not path.exists():
+        raise FileNotFoundError(f"fid: blocked -- Inception weights {path} missing (pytorch_fid's {INCEPTION_WEIGHTS}; set NATINF_INCEPTION_WEIGHTS)")
+    return InceptionEngine(load_fid_inception_weights(path), max_batch=max_batch, in_hw=image_hw, device=device)
+
+
+def get_activation(imgs, model, dims: int = 2048, device=None) -> np.ndarray:
+    """Reference :44-70: uint8 [n, H, W, 3] images -> pool3 activations [n, dims] in batches of 50 (the /255, the NCHW permutation, the
+    299 x 299 resize and the 2x - 1 scaling happen inside the engine's stem kernel)."""
+    assert dims == 2048, "the HIP engine implements the pool3 (2048-dimensional) output"
+    pred = np.empty((len(imgs), dims))
+    for ii in range(0, len(imgs), 50):
+        pred[ii:ii + 50] = model(imgs[ii:ii + 50]).cpu().numpy()
+    return pred
+
+
+def calc_fid(imgs, ref_path, device, model=None):
+    """Reference :73-86 (InceptionV3 pool3 + Frechet distance).  Needs the Inception weights and the ``cifar10_mu_sigma.npz``
+    statistics, neither of which ships with the reference."""
+    from .fid_stats import frechet_distance
     if not os.path.exists(ref_path):
-        raise FileNotFoundError(f"{ref_path} (CIFAR10 Inception statistics) is missing")
-    model = InceptionV3([InceptionV3.BLOCK_INDEX_BY_DIM[2048]]).to(device).eval()
-    acts = []
-    with torch.no_grad():
-        for i in range(0, len(imgs), 50):
-            b = imgs[i:i + 50].to(dtype=torch.float32, device=device) / 255
-            p = model(b.permute(0, 3, 1, 2))[0]
-            acts.append(p.squeeze(3).squeeze(2).cpu().numpy())
-    act = np.concatenate(acts).astype(np.float64)
+        raise FileNotFoundError(f"fid: blocked -- {ref_path} (CIFAR10 Inception statistics) is missing")
+    model = model or fid_inception(device, tuple(imgs.shape[1:3]))
+    act = get_activation(imgs, model, 2048, device)
+    mu, sigma = np.mean(act, axis=0), np.cov(act, rowvar=False)
     ref = np.load(ref_path)
-    return calculate_frechet_distance(ref["mu"], ref["sigma"], np.mean(act, axis=0), np.cov(act, rowvar=False))
+    return frechet_distance(ref["mu"], ref["sigma"], mu, sigma)
 
 
-def calc_fid_sharded(imgs, ref_path, device, group=None):
+def calc_fid_sharded(imgs, ref_path, device, group=None, model=None):
     """``calc_fid`` for a batch-sharded run: every rank scores ITS images, the (count, sum, outer-product sum) statistics
     are summed over ranks with one all-reduce (fid_stats.ActivationStats), and every rank returns the same FID."""
-    from pytorch_fid.inception import InceptionV3
     from .fid_stats import ActivationStats, frechet_distance
-    model = InceptionV3([InceptionV3.BLOCK_INDEX_BY_DIM[2048]]).to(device).eval()
+    if not os.path.exists(ref_path):
+        raise FileNotFoundError(f"fid: blocked -- {ref_path} (CIFAR10 Inception statistics) is missing")
+    model = model or fid_inception(device, tuple(imgs.shape[1:3]))
     st = ActivationStats(2048, device=device)
-    with torch.no_grad():
-        for i in range(0, len(imgs), 50):
-            b = imgs[i:i + 50].to(dtype=torch.float32, device=device) / 255
-            st.update(model(b.permute(0, 3, 1, 2))[0].squeeze(3).squeeze(2))
+    for i in range(0, len(imgs), 50):
+        st.update(model(imgs[i:i + 50]))
     st.all_reduce(group)
     mu, cov = st.mean_cov()
     ref = np.load(ref_path)
@@ -187,7 +213,11 @@ def natural_inference_tx(batch_size: int = 500,
     all_batch = torch.concatenate(all_batch)
     if not compute_fid:
         return all_batch
-    fid_value = calc_fid(all_batch, root_path / "weights/cifar10_mu_sigma.npz", device)
+    try:
+        fid_value = calc_fid(all_batch, root_path / "weights/cifar10_mu_sigma.npz", device)
+    except FileNotFoundError as e:                          # the assets are downloads: say so, keep the images
+        print(e)
+        return all_batch
     print(fid_value)
     print(weight_path)
     print(C / np.diag(C)[:, None])

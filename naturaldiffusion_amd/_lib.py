@@ -64,6 +64,7 @@ SIGNATURES = {
     "natinf_set_gemm_splitk": (C.c_int, [_i32]),
     "natinf_debug_set_splitk_workspace": (C.c_int, [_p, _i32]),
     "natinf_debug_conv_gn": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _f32, _p, _p, _i32, _p]),
+    "natinf_debug_conv_gn_up": (C.c_int, [_i32]),
     "natinf_ncsnpp_profile": (C.c_int, [_p, _i32]),
     "natinf_ncsnpp_profile_read": (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "natinf_debug_quant_fp8_rows": (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
@@ -85,6 +86,15 @@ SIGNATURES = {
     "natinf_mmdit_load": (C.c_int, [_p, _p, _i64, _p, _i64, _p]),
     "natinf_mmdit_forward": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _p, _i64, _p]),
     "natinf_attention_hd64_bf16": (C.c_int, [_p, _p, _i32, _i64, _p, _p, _i32, _i64, _i32, _i32, _i32, _i32, C.c_float, _p]),
+    "natinf_inception_create": (C.c_int, [_p, _i32, _i32]),
+    "natinf_inception_destroy": (C.c_int, [_p]),
+    "natinf_inception_param_count": (_i64, [_p]),
+    "natinf_inception_packed_bytes": (_i64, [_p]),
+    "natinf_inception_workspace_bytes": (_i64, [_p, _i32]),
+    "natinf_inception_load": (C.c_int, [_p, _p, _i64, _p, _i64, _p]),
+    "natinf_inception_forward": (C.c_int, [_p, _p, _i32, _p, _i32, _p, _i64, _p]),
+    "natinf_attention_profile": (C.c_int, [_i32]),
+    "natinf_attention_profile_read": (C.c_int, [_p, _p]),
     # include/natinf_vae.h
     "natinf_vae_create": (C.c_int, [C.POINTER(_p), _i32, _i32]),
     "natinf_vae_destroy": (C.c_int, [_p]),

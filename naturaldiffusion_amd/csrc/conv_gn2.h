@@ -31,6 +31,9 @@
 // 38 % ready-but-not-issued: no unit is saturated; two waves per SIMD do not cover each other's dependency stalls.
 #pragma once
 #include "conv_gn.h"
+#ifndef NATINF_CG_PK
+#define NATINF_CG_PK 1            // 1 = packed-fp32 arithmetic (v_pk_fma / v_pk_add / v_pk_mul) in the PROLOGUE's normalisation rounds, 0 = scalar (A/B builds)
+#endif
 
 namespace ncsn {
 
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     u32x4 nv = {0u, 0u, 0u, 0u}, ns0 = nv, ns1 = nv, nh0 = nv, nh1 = nv;
     unsigned npk[4] = {0u, 0u, 0u, 0u};
     float nf_even = 0.f;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto norm_load = [&](auto j_tag, auto buf_tag) __attribute__((always_inline)) {
         constexpr int J = decltype(j_tag)::value, BUF = decltype(buf_tag)::value;
         nv = lds_read16<BUF * Cfg::PATCH_BYTES + J * NW * 1024>(nbase);
@@ -205,6 +209,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
         nh0 = lds_read16<BUF * Cfg::TAB_BYTES + 128>(tbase); nh1 = lds_read16<BUF * Cfg::TAB_BYTES + 144>(tbase);
     };
 #define NATINF_CG_NORM_PRE(I) asm volatile("" : "+v"(nv), "+v"(ns0), "+v"(ns1), "+v"(nh0), "+v"(nh1));
+    // (Round 3: the in-loop elements in packed-fp32 form -- channel pairs, v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32, ten vector instructions
+    // per pair instead of thirteen -- were built and measured: +-0 on every shape.  hipcc's SIPreEmitPeephole splits packed-fp32 instructions
+    // that sit in the shadow of an MFMA back into scalar ones (packed fp32 cannot be co-issued behind an MFMA on gfx950, the scalar forms can),
+    // and the two extra registers a pair holds across a step tipped the EPI 1 instantiation into scratch reloads inside the loop.  The packed
+    // form stays where no MFMA is in flight: the prologue's norm_round below, NATINF_CG_PK.)
 #define NATINF_CG_NORM_EL(I)                                                                                                \
         {                                                                                                                    \
             const unsigned w_ = nv[(I) >> 1];                                                                                \
@@ -235,6 +244,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
         norm_load(j_tag, buf_tag);
         wait_lgkmcnt<0>();
         NATINF_CG_NORM_PRE(0)
+#if NATINF_CG_PK
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const unsigned w_ = nv[p];
+            const f32x2 x2_ = {__uint_as_float(w_ << 16), __uint_as_float(w_ & 0xffff0000u)};
+            const f32x2 s2_ = {__uint_as_float(p < 2 ? ns0[2 * (p & 1)] : ns1[2 * (p & 1)]), __uint_as_float(p < 2 ? ns0[2 * (p & 1) + 1] : ns1[2 * (p & 1) + 1])};
+            const f32x2 h2_ = {__uint_as_float(p < 2 ? nh0[2 * (p & 1)] : nh1[2 * (p & 1)]), __uint_as_float(p < 2 ? nh0[2 * (p & 1) + 1] : nh1[2 * (p & 1) + 1])};
+            const f32x2 t2_ = __builtin_elementwise_fma(x2_, s2_, h2_);
+            const f32x2 d2_ = f32x2{__builtin_amdgcn_exp2f(t2_[0]), __builtin_amdgcn_exp2f(t2_[1])} + f32x2{1.0f, 1.0f};
+            const f32x2 y2_ = t2_ * f32x2{__builtin_amdgcn_rcpf(d2_[0]), __builtin_amdgcn_rcpf(d2_[1])};
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const bf16x2_t pr_ = {(bf16)y2_[0], (bf16)y2_[1]};
+            npk[p] = __builtin_bit_cast(unsigned, pr_);
+        }
+#else
         float y_[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -249,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
             const bf16x2_t pr_ = {(bf16)y_[2 * i], (bf16)y_[2 * i + 1]};
             npk[i] = __builtin_bit_cast(unsigned, pr_);
         }
+#endif
         norm_store(j_tag, buf_tag);
     };
 #define NATINF_CG_NO_PRE(I)

@@ -389,7 +389,7 @@ void launch_gemm_fp8(const GemmArgs& g, hipStream_t s) {
 // column terms (bias, a per-sample row vector with every block tile inside one sample) and a bf16 residual are fused, the output is bf16, and
 // GroupNorm partials (no activation, whole tiles) or an activation -- not both -- are asked for.
 int packed_epi(const GemmArgs& g, int bm) {      // resid must be 8-byte aligned per 4-column group: ld % 4, base from the arena
-    if (g.epi_fp32_slab || g.deq_m || g.deq_n) return 0;
+    if (g.epi_fp32_slab || g.deq_m || g.deq_n || g.act == ACT_RELU) return 0;      // (ReLU: the general epilogue applies it)
     if (g.bias_m) return (g.c_mode == OUT_BF16 && !g.resid && !g.resid_f32 && !g.gate && !g.rowvec && !g.gn_part && g.act == ACT_NONE) ? 8 : 0;
     if ((g.rowvec || g.gate) && g.log_rows_per_sample < 30 && ((1 << g.log_rows_per_sample) % bm != 0)) return 0;    // per-sample terms: one sample per tile
     if (g.c_mode == OUT_F32 && g.resid_f32 && !g.resid && !g.gn_part && g.act == ACT_NONE && g.resid_f32_ld % 4 == 0 && g.c_ld % 4 == 0) return 7;
@@ -1273,6 +1273,10 @@ int natinf_debug_gemm_fused(int variant, int M, int N, int K, const void* a, con
 // the c1 shortcut columns; a1: bf16 [B*res*res][c1] or NULL (c1 = 0); resid: bf16 [M][N] or NULL; gn_part: NULL or
 // [M / 256][N / 4] float2 partial (sum, sum of squares) of the outputs.  The kernel takes its operands in FOLDED form
 // (GemmArgs::gn_folded): the caller passes scale * -log2(e), shift * -log2(e) and the 3x3 columns of w_packed * -ln 2.
+int g_dbg_cg_up = 0;
+// bit 0: the next natinf_debug_conv_gn calls read x as [B][res/2][res/2][cin] through the kernel's nearest-2x up-sampling fetch (GemmArgs::a0_up);
+// bit 1: the same for a1 ([B*(res/2)^2][c1], GemmArgs::a1_up) -- the fetch paths of the up-sampling res-blocks (natinf_set_fuse_up)
+int natinf_debug_conv_gn_up(int flags) { if (flags & ~3) return NATINF_EINVAL; g_dbg_cg_up = flags; return NATINF_OK; }
 int natinf_debug_conv_gn(int res, int B, int N, int cin, int c1, const void* x, const float* scale, const float* shift, const void* w_packed,
                          void* w_frag, const void* a1, const float* bias_n, const void* resid, float out_scale, void* out, float* gn_part, int iters,
                          natinf_stream_t stream) {
@@ -1288,11 +1292,12 @@ int natinf_debug_conv_gn(int res, int B, int N, int cin, int c1, const void* x, 
     g.resid = (const bf16*)resid; g.resid_ld = N; g.scale = out_scale; g.c = out; g.c_ld = N;
     g.gn_part = gn_part; g.gn_quads = N / 4;
     g.dbg_ts = g_dbg_ts;
-    if (!conv_gn_ok(g)) return NATINF_EINVAL;
-    if (w_frag && N % 16 == 0) {             // k_conv_gn2 (used when N is a whole number of its column tiles): w_frag receives the fragment-major copy
+    g.a0_up = g_dbg_cg_up & 1; g.a1_up = (a1 && (g_dbg_cg_up & 2)) ? 1 : 0;      // natinf_debug_conv_gn_up: x / a1 are given at HALF the resolution
+    if (w_frag && N % 16 == 0) g.b_frag = (const bf16*)w_frag;      // k_conv_gn2 (used when N is a whole number of its column tiles): w_frag receives the fragment-major copy
+    if (!conv_gn_ok(g)) return NATINF_EINVAL;                        // (shipped builds: k_conv_gn2 only -- w_frag is required and N % 128 == 0)
+    if (g.b_frag) {
         const int64_t n = (int64_t)(N / 16) * (9 * (cin / 32) + c1 / 32) * 64;
         hipLaunchKernelGGL(k_pack_frag, dim3(grid1d(n, 256, 1 << 30)), dim3(256), 0, (hipStream_t)stream, (const bf16*)w_packed, (bf16*)w_frag, N, g.b_ld, cin, c1);
-        g.b_frag = (const bf16*)w_frag;
     }
     for (int i = 0; i < iters; ++i) launch_gemm(g, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
@@ -1393,3 +1398,4 @@ int natinf_ncsnpp_debug_tap(natinf_ncsnpp_t h, int module_idx, float* out, int64
 #include "dit_engine.inc"
 #include "mmdit_engine.inc"
 #include "vae_engine.inc"
+#include "inception_engine.inc"

@@ -31,7 +31,7 @@ constexpr int GEMM_LDS_BYTES = BM * C_ROW * 4;        // 67,584 B: max(tiles 65,
 static_assert(4 * TILE_ELEMS * 2 <= GEMM_LDS_BYTES, "tile buffers must fit");
 
 enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_NCHW = 2, OUT_FP8_MX = 3 };      // OUT_FP8_MX: e4m3 bytes + a block scale per 32 columns
-enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU_TANH = 2 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU_TANH = 2, ACT_RELU = 3 };      // ACT_RELU: general (fp32-slab) epilogue only -- the Inception engine
 
 struct GemmArgs {
     // A operand: segment 0 = `taps` (1 or 9) shifted views of a0, segment 1 = a1 (1x1), concatenated along K
@@ -88,7 +88,7 @@ __device__ __forceinline__ float gelu_tanh_f(float v) {             // nn.GELU(a
     return 0.5f * v * (2.0f - 2.0f / (e + 1.0f));
 }
 __device__ __forceinline__ float apply_act(float v, int act) {
-    return act == ACT_SILU ? silu_f(v) : (act == ACT_GELU_TANH ? gelu_tanh_f(v) : v);
+    return act == ACT_SILU ? silu_f(v) : (act == ACT_GELU_TANH ? gelu_tanh_f(v) : (act == ACT_RELU ? fmaxf(v, 0.f) : v));
 }
 // E8M0 scale of a 32-value block with magnitude `amax`: the smallest power of two 2^e with amax * 2^-e <= 448 (e4m3 max).
 // Returns the biased byte (e + 127, clamped) and writes 2^-e.  amax = m * 2^x, m in [1,2): 2^(x-8) maps it into [256,512);
@@ -119,6 +119,9 @@ __device__ __forceinline__ void apply_act8(float (&v)[8], int act) {
             const float u = 0.7978845608028654f * (v[q] + 0.044715f * v[q] * v[q] * v[q]);
             v[q] = v[q] * (1.0f - __builtin_amdgcn_rcpf(__expf(2.0f * u) + 1.0f));          // 0.5 v (1 + tanh u)
         }
+    } else if (act == ACT_RELU) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
     }
 }
 
@@ -132,6 +135,9 @@ __device__ __forceinline__ void apply_act4(float (&v)[4], int act) {
             const float u = 0.7978845608028654f * (v[q] + 0.044715f * v[q] * v[q] * v[q]);
             v[q] = v[q] * (1.0f - __builtin_amdgcn_rcpf(__expf(2.0f * u) + 1.0f));
         }
+    } else if (act == ACT_RELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
     }
 }
 

@@ -4,8 +4,8 @@ The reference scores 50,000 generated images with ``pytorch_fid``: pool3 activat
 -> Frechet distance to the dataset statistics (src/CIFAR10NaturalInference.py:44-86).  With generation batch-sharded
 over ranks, each rank keeps only the sufficient statistics of ITS activations -- count, sum, sum of outer products, in
 fp64 -- and one all-reduce(SUM) of 1 + 2048 + 2048^2 doubles (33.6 MB; RCCL on a GPU node, gloo in the CPU tests)
-replaces gathering activations or images.  The Inception forward itself stays with ``pytorch_fid`` (its weights are a
-download the image lacks; ``CIFAR10NaturalInference.calc_fid``).
+replaces gathering activations or images.  The Inception forward is the HIP engine of include/natinf_inception.h
+(``inception.InceptionEngine``; its weights are a download the image lacks: ``CIFAR10NaturalInference.calc_fid`` says "fid: blocked").
 """
 from __future__ import annotations
 

@@ -26,7 +26,6 @@ def _pack(w, w1):
     (16, 2, 512, 256, 512, False, True),      # widest K: 144 + 16 K-tiles
     (16, 3, 128, 256, 0, False, False),
     (32, 2, 384, 128, 384, False, False),     # 384 channels: 12 half-chunks
-    (16, 1, 64, 40, 0, False, False),         # ragged N, single chunk
 ])
 def test_conv_gn_matches_torch(res, B, cin, N, c1, resid, parts):
     from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
@@ -82,6 +81,63 @@ def test_conv_gn_matches_torch(res, B, cin, N, c1, resid, parts):
         if parts:                                           # (sum, sum of squares) per tile and 4-channel quad, of the fp32 results
             want = torch.stack([ref.reshape(M // rows, rows, N // 4, 4).sum(dim=(1, 3)), (ref ** 2).reshape(M // rows, rows, N // 4, 4).sum(dim=(1, 3))], dim=-1)
             assert ((part.cpu() - want).abs().max() / want.abs().max()).item() <= 5e-3
+
+def test_ragged_channel_counts_are_refused_in_the_shipped_build():
+    """k_conv_gn2 needs whole 128- (or 256-) channel tiles; the LDS-ring kernel that took ragged N is a -DNATINF_DEV kernel now."""
+    from naturaldiffusion_amd._lib import lib, ptr, stream_ptr
+    dev = "cuda"
+    x = torch.zeros(1, 16, 16, 64, dtype=torch.bfloat16, device=dev); sc = torch.ones(1, 64, device=dev); sh = torch.zeros(1, 64, device=dev)
+    w = torch.zeros(40, 9 * 64, dtype=torch.bfloat16, device=dev); out = torch.zeros(256, 40, dtype=torch.bfloat16, device=dev)
+    assert lib.natinf_debug_conv_gn(16, 1, 40, 64, 0, ptr(x), ptr(sc), ptr(sh), ptr(w), ptr(torch.zeros_like(w)), None, None, None, 1.0, ptr(out), None, 1,
+                                    stream_ptr()) == -1
+
+
+@pytest.mark.parametrize("res,B,cin,N,c1,flags", [
+    (32, 2, 256, 128, 0, 1),        # Conv_0 of the 16 -> 32 up-sampling block: the patch is fetched from the 16x16 tensor
+    (32, 2, 128, 128, 256, 3),      # Conv_1 + shortcut of that block: the 1x1 operand is fetched up-sampled too
+    (16, 3, 256, 256, 256, 3),      # the 8 -> 16 block on the 128 x 256 tile
+    (16, 2, 256, 256, 0, 1),
+])
+def test_up_sampling_fetch_paths_match_torch(res, B, cin, N, c1, flags):
+    """GemmArgs::a0_up / a1_up (round-2 advisor note: reachable only through the whole network until now): the kernel reads a half-
+    resolution raw tensor and up-samples it (nearest 2x) in its patch / shortcut fetches -- against F.interpolate(mode='nearest')."""
+    from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(res * 7 + cin + N + c1 + flags)
+    bf = lambda t: t.bfloat16().float()
+    h2 = res // 2
+    x = bf(torch.randn(B, h2, h2, cin, generator=g))
+    scale = torch.rand(B, cin, generator=g) * 1.5 + 0.25
+    shift = torch.randn(B, cin, generator=g) * 0.5
+    w = bf(torch.randn(N, cin, 3, 3, generator=g) / np.sqrt(9 * cin))
+    w1 = bf(torch.randn(N, c1, generator=g) / np.sqrt(c1)) if c1 else None
+    a1_up = bool(flags & 2)
+    a1 = bf(torch.randn(B, h2 if a1_up else res, h2 if a1_up else res, c1, generator=g)) if c1 else None
+    bias = torch.randn(N, generator=g) * 0.1
+    up = lambda t: F.interpolate(t.permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1)
+    hfull = bf(F.silu(up(x) * scale[:, None, None, :] + shift[:, None, None, :]))
+    ref = F.conv2d(hfull.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1).reshape(B * res * res, N)
+    if c1:
+        ref = ref + (up(a1) if a1_up else a1).reshape(-1, c1).double() @ w1.double().t()
+    ref = (ref + bias.double()).float()
+    dev = "cuda"
+    LOG2E = 1.4426950408889634
+    wd = _pack(w * (-1.0 / LOG2E), w1).bfloat16().to(dev)
+    xd = x.bfloat16().to(dev).contiguous()
+    scd, shd, bd = (scale * -LOG2E).to(dev), (shift * -LOG2E).to(dev), bias.to(dev)
+    a1d = a1.bfloat16().to(dev).contiguous() if c1 else None
+    out = torch.zeros(B * res * res, N, dtype=torch.bfloat16, device=dev)
+    wf = torch.zeros_like(wd)
+    check(lib.natinf_debug_conv_gn_up(flags), "up")
+    try:
+        check(lib.natinf_debug_conv_gn(res, B, N, cin, c1, ptr(xd), ptr(scd), ptr(shd), ptr(wd), ptr(wf), ptr(a1d), ptr(bd), None, 1.0, ptr(out), None, 1,
+                                       stream_ptr()), "conv_gn")
+        torch.cuda.synchronize()
+    finally:
+        lib.natinf_debug_conv_gn_up(0)
+    got = out.float().cpu()
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    assert torch.isfinite(got).all() and err <= 1e-2, err
+
 
 def test_fragment_major_weight_copy_layout():
     """k_pack_frag (conv_gn2.h): [N/16][K steps][64 lanes][8] with lane l of K step kt holding row l & 15, columns col(kt) + 8 (l >> 4) .. + 7,

@@ -1,0 +1,122 @@
+"""GPU parity of the FID Inception-V3 pool3 engine (include/natinf_inception.h) against oracle/inception_oracle.py (PARITY UNPINNED:
+the oracle restates pytorch_fid's published architecture; synthetic weights -- the real ones are a download).  bf16 operands / fp32
+accumulate against an fp32 reference: features within 3e-2 of the feature maximum, and -- the quantity that bounds what bf16 can do to
+an FID -- the Frechet distance between the statistics of HIP features and oracle features of the same 2,000 synthetic images."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import inception_oracle as O
+
+TOL = 3e-2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def params():
+    return O.make_params(0)
+
+
+@pytest.fixture(scope="module")
+def engine(dev, params):
+    from naturaldiffusion_amd.inception import InceptionEngine, flatten_state_dict
+    return InceptionEngine(flatten_state_dict(params), max_batch=50, in_hw=(32, 32), device=dev)
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max())
+
+
+def test_features_match_the_oracle_for_both_input_forms(engine, params):
+    g = torch.Generator().manual_seed(5)
+    u8 = torch.randint(0, 256, (6, 32, 32, 3), generator=g, dtype=torch.uint8)
+    ref = O.forward(params, u8.permute(0, 3, 1, 2).float() / 255)                  # get_activation's preprocessing (reference :54-56)
+    got_u8 = engine(u8).cpu()
+    got_f = engine(u8.permute(0, 3, 1, 2).float() / 255).cpu()
+    assert torch.isfinite(got_u8).all() and tuple(got_u8.shape) == (6, 2048)
+    e = _rel(got_u8, ref)
+    print("inception features max-rel error:", e, " mean |d| / mean |ref|:", float((got_u8 - ref).abs().mean() / ref.abs().mean()))
+    assert e <= TOL, e
+    assert torch.equal(got_u8, got_f)                                              # same arithmetic after the /255
+    # batch independence and the chunked walk (max_batch 50): sample 3 alone == sample 3 in the batch; 120 images in three chunks
+    assert torch.equal(engine(u8[3:4]).cpu(), got_u8[3:4])
+    big = u8.repeat(20, 1, 1, 1)
+    assert torch.equal(engine(big).cpu(), got_u8.repeat(20, 1))
+
+
+def test_other_input_sizes(dev, params):
+    """the resize is part of the engine: 64 x 48 inputs (not a CIFAR10 shape) against the oracle's F.interpolate"""
+    from naturaldiffusion_amd.inception import InceptionEngine, flatten_state_dict
+    eng = InceptionEngine(flatten_state_dict(params), max_batch=2, in_hw=(64, 48), device=dev)
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(2, 3, 64, 48, generator=g)
+    assert _rel(eng(x).cpu(), O.forward(params, x)) <= TOL
+    with pytest.raises(ValueError):
+        eng(torch.rand(2, 3, 32, 32))
+
+
+def test_frechet_distance_between_hip_and_oracle_statistics(engine, params, repo_root):
+    """2,000 synthetic images (smooth random fields + noise, uint8): (mu, Sigma) of the engine's features vs (mu, Sigma) of the fp32
+    oracle's, through the product's own statistics / Frechet code (fid_stats.py).  This is the FID a perfect sampler would be charged
+    for running the Inception forward in bf16."""
+    from naturaldiffusion_amd.fid_stats import ActivationStats, frechet_distance
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    g = torch.Generator().manual_seed(7)
+    n = 2000
+    low = torch.rand(n, 3, 8, 8, generator=g)
+    imgs = torch.nn.functional.interpolate(low, size=(32, 32), mode="bilinear", align_corners=False) + 0.15 * torch.randn(n, 3, 32, 32, generator=g)
+    u8 = (imgs.clamp(0, 1) * 255).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    st_h, st_o = ActivationStats(2048), ActivationStats(2048)
+    worst = 0.0
+    for i in range(0, n, 100):
+        b = u8[i:i + 100]
+        fo = O.forward(params, b.permute(0, 3, 1, 2).float() / 255)
+        fh = engine(b).cpu()
+        worst = max(worst, _rel(fh, fo))
+        st_h.update(fh); st_o.update(fo)
+    mu_h, cov_h = st_h.mean_cov()
+    mu_o, cov_o = st_o.mean_cov()
+    fd = frechet_distance(mu_h, cov_h, mu_o, cov_o)
+    rec = {"images": n, "frechet_distance_hip_vs_oracle": fd, "max_rel_feature_error": worst, "mean_feature": float(mu_o.mean()),
+           "trace_cov_oracle": float(np.trace(cov_o)), "mu_diff_sq": float(((mu_h - mu_o) ** 2).sum())}
+    os.makedirs(repo_root / "gpurun_out", exist_ok=True)
+    (repo_root / "gpurun_out" / "inception_fd.json").write_text(json.dumps(rec, indent=1))
+    print("inception bf16 vs fp32:", json.dumps(rec))
+    assert worst <= TOL
+    assert fd <= 1e-2 * max(1.0, np.trace(cov_o) / 2048), rec            # <= 1e-2 at unit per-feature variance
+
+
+def test_calc_fid_end_to_end_with_a_weights_file(dev, params, tmp_path, monkeypatch):
+    """the script path (reference :73-86): a pt_inception-style state dict on disk + a statistics .npz -> calc_fid / calc_fid_sharded through
+    the HIP engine; images scored against their OWN statistics give FID ~ 0, against shifted statistics the shift's |d mu|^2."""
+    from naturaldiffusion_amd import CIFAR10NaturalInference as M
+    wpath = tmp_path / "pt_inception-2015-12-05-6726825d.pth"
+    sd = dict(params); sd["fc.weight"] = torch.zeros(4, 4)                # the checkpoint carries more than the pool3 path
+    torch.save(sd, wpath)
+    monkeypatch.setenv("NATINF_INCEPTION_WEIGHTS", str(wpath))
+    g = torch.Generator().manual_seed(9)
+    imgs = torch.randint(0, 256, (300, 32, 32, 3), generator=g, dtype=torch.uint8)
+    model = M.fid_inception(dev)
+    act = M.get_activation(imgs, model)
+    assert act.shape == (300, 2048) and act.dtype == np.float64
+    mu, sigma = act.mean(axis=0), np.cov(act, rowvar=False)
+    ref = tmp_path / "mu_sigma.npz"
+    np.savez(ref, mu=mu, sigma=sigma)
+    assert abs(M.calc_fid(imgs, ref, dev)) < 1e-3 * np.trace(sigma)
+    np.savez(ref, mu=mu + 0.01, sigma=sigma)
+    fid = M.calc_fid(imgs, ref, dev, model=model)
+    assert abs(fid - 2048 * 1e-4) < 1e-3 * np.trace(sigma) + 0.05
+    monkeypatch.setenv("NATINF_INCEPTION_WEIGHTS", str(tmp_path / "absent.pth"))
+    with pytest.raises(FileNotFoundError, match="fid: blocked"):
+        M.calc_fid(imgs, ref, dev)

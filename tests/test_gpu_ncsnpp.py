@@ -211,6 +211,55 @@ def test_per_module_taps_at_the_benchmarked_batch(dev, params, flat, golden_dir,
     assert report["y"] <= TOL, report["y"]
 
 
+def test_fused_and_split_k_plans_against_the_unfused_plan(dev, flat, golden_dir):
+    """Plan-build-time switches (round-2 advisor note): the default plan -- GroupNorm + SiLU inside the 3x3 convolutions, up-sampling inside
+    their fetches, split-K on the 4x4 level (it engages at this batch: 16 tiles of 128 x 128 for 256 CUs) -- against the plans with each
+    of those turned off, on the same 64 samples: every pair agrees to bf16 rounding noise, and the golden samples stay within TOL."""
+    from naturaldiffusion_amd.ncsnpp import NCSNppEngine
+    from naturaldiffusion_amd._lib import lib
+    fx = np.load(golden_dir / "ncsnpp_forward.npz")
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(64, 3, 32, 32, generator=g)
+    labels = torch.rand(64, generator=g) * 999
+    x[:2] = torch.from_numpy(fx["x"]); labels[:2] = torch.from_numpy(fx["labels"])
+    xd, ld = x.to(dev), labels.to(dev)
+    base_eng = NCSNppEngine(flat, max_batch=64, device=dev)
+    assert any("splitk" in r[6] for r in _describe_gemms(base_eng, 64))
+    base = base_eng(xd, ld).clone()
+    ref = torch.from_numpy(fx["y"])
+    assert _rel(base[:2].cpu(), ref) <= TOL
+    outs = {}
+    for name, setter in (("fuse_gn", lib.natinf_set_fuse_gn), ("fuse_up", lib.natinf_set_fuse_up)):
+        try:
+            assert setter(0) == 0
+            eng = NCSNppEngine(flat, max_batch=64, device=dev)          # the switch is read when the plan is built
+        finally:
+            setter(1)
+        rows = _describe_gemms(eng, 64)
+        if name == "fuse_gn":
+            assert not any(r[6].startswith("conv_gn") for r in rows)
+        outs[name] = eng(xd, ld).clone()
+    try:
+        assert lib.natinf_set_gemm_splitk(0) == 0
+        assert not any("splitk" in r[6] for r in _describe_gemms(base_eng, 64))
+        outs["splitk"] = base_eng(xd, ld).clone()
+    finally:
+        lib.natinf_set_gemm_splitk(1)
+    torch.cuda.synchronize()
+    for name, y in outs.items():
+        assert torch.isfinite(y).all()
+        assert _rel(y.cpu(), base.cpu()) < 2e-2, (name, _rel(y.cpu(), base.cpu()))
+        assert _rel(y[:2].cpu(), ref) <= TOL, name
+    # the fp32-slab A/B knob no longer breaks the fused plan (round-2 advisor, medium): the fused convolutions ignore it
+    try:
+        assert lib.natinf_set_gemm_epilogue(1) == 0
+        y = base_eng(xd, ld)
+        torch.cuda.synchronize()
+    finally:
+        lib.natinf_set_gemm_epilogue(0)
+    assert _rel(y.cpu(), base.cpu()) < 2e-2
+
+
 def test_workspace_too_small_is_an_error(dev, flat):
     from naturaldiffusion_amd.ncsnpp import NCSNppEngine
     from naturaldiffusion_amd._lib import lib, ptr, stream_ptr
