@@ -128,6 +128,9 @@ int natinf_set_conv_gn_regw(int on);
 /* 1 (default; read when a plan is built): the up-sampling blocks at 16x16 / 32x32 read their half-resolution input inside the fused
  * convolution (nearest up-sampling in the patch fetch and in the residual fetch); 0: through the separate GroupNorm-apply + up-sample pass. */
 int natinf_set_fuse_up(int on);
+/* 1 (default; read when a plan is built): the output head -- GroupNorm + SiLU + the 128 -> 3 convolution, fp32 NCHW -- is ONE launch
+ * (k_head_conv); 0: GroupNorm-apply pass + implicit GEMM on an N = 3 column tile. */
+int natinf_set_fuse_head(int on);
 /* 1 (default): small-M, long-K launches (the 8x8 and 4x4 levels) run as 128 x 128 tiles x 2..4 K slices + a reduce pass; 0: never. */
 int natinf_set_gemm_splitk(int on);
 /* natinf_debug_gemm / natinf_debug_gemm_fused with variant 0 may split K when given a workspace of max_slices * M * N floats

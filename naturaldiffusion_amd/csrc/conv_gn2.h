@@ -37,9 +37,17 @@
 
 namespace ncsn {
 
+// Patch geometry of k_conv_gn2: patch rows follow each other WITHOUT pad columns (row stride WS = W + 2 pixels; k_conv_gn pads the stride
+// to a multiple of 8: 40 / 24).  What made the padding necessary there was the swizzle key -- bit 2 of the linear patch-row index p, which a
+// dy shift (p += WS) must not change.  Keyed on bit 2 of the pixel COLUMN xx = p % WS instead, the swizzle is dy-invariant for any stride, and
+// still conflict-free: a fragment read covers 16 consecutive columns of ONE patch row, rows of equal bank quarter (p & 3) are four columns
+// apart, and bit 2 of xx alternates along them exactly as bit 2 of p did.  Patch rows per tile: 340 instead of 400 (32x32), 180 / 324 instead
+// of 240 / 432 (16x16): 15-25 % less to fetch, to normalise and to keep in LDS.
+template <int RES> struct PatchGeo2 { static constexpr int W = RES, WP = RES + 2, WS = RES + 2; };
+
 template <int RES, bool WIDE_ = false>
 struct ConvGn2Cfg {
-    using Geo = PatchGeo<RES>;
+    using Geo = PatchGeo2<RES>;
     static constexpr bool WIDE = WIDE_;
     static constexpr int WM = WIDE ? 1 : 2, WN = WIDE ? 4 : 2, TM = 8, TN = 4, NW = 4, THREADS = 256, KT = 32;
     static constexpr int BM_ = WM * TM * 16, BN_ = WN * TN * 16;
@@ -148,15 +156,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
             else        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(toff), "s"(gsh + hc * KT), "s"(dst) : "memory", "m0");
         }
         const bf16* base = img + hc * KT;
-        const int prow = l >> 2, pslot = l & 3;
 #pragma unroll
         for (int j = 0; j < NROUND; ++j) {
             const int q = j * NW + wave;                                      // wave-uniform piece index
             if (j >= NFULL && q >= NPIECE) continue;
+            int lj = l;
+            asm volatile("" : "+v"(lj));                                      // one piece's address arithmetic at a time: hoisted together, the pieces' temporaries spill inside the loop
+            const int prow = lj >> 2, pslot = lj & 3;
             const int pp = q * 16 + prow;
             const int yy = pp / WS, xx = pp - yy * WS;
             const int y = min(max(y0 - 1 + yy, 0), RES - 1), x = min(max(xx - 1, 0), RES - 1);      // halo / pad: any readable pixel
-            glds16((unsigned)(((y >> ush) * (W >> ush) + (x >> ush)) * g.a0_ld + ((pslot ^ ((pp >> 1) & 2)) << 3)) * 2u, base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
+            glds16((unsigned)(((y >> ush) * (W >> ush) + (x >> ush)) * g.a0_ld + ((pslot ^ ((xx >> 1) & 2)) << 3)) * 2u, base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
         }
     };
     auto issue_shortcut = [&](int s) __attribute__((always_inline)) {        // plain [BM][32] tile of a1 -> patch buffer s & 1 (n_half is even)
@@ -183,28 +193,34 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     load_b(std::integral_constant<int, 0>{}, 0);
 
     // ---- in-place normalisation, round j: the wave's piece j * NW + wave, lane l its bytes l * 16 .. + 15 = patch row q * 16 + (l >> 2),
-    // ---- slot l & 3, which holds channel chunk (l & 3) ^ 2 * bit 4 of l (bit 2 of the patch row is bit 4 of the lane).
-    const unsigned nbase = lds_patch + wave * 1024 + lane * 16;
-    unsigned nmask = 0;                                                      // bit j: the pixel of round j lies inside the image
+    // ---- slot l & 3, which holds channel chunk (l & 3) ^ 2 * (bit 2 of that row's patch column: nmask bit 8 + j).
+    // One register for both per-lane constants of the normalisation rounds: bits 0-15 = the lane's slot address in piece 0 of buffer 0
+    // (lds_patch + wave * 1024 + lane * 16 < 64 KiB), bits 16-31 = nmask.  Held apart, the second register is the one hipcc spills in the
+    // 16x16 / N = 128 instantiation -- and reloads inside the K loop behind a vmcnt(0) of its own.
+    unsigned nmask = 0;                                                      // bit j: the pixel of round j lies inside the image; bit 8 + j: bit 2 of its patch column (the swizzle key)
 #pragma unroll
     for (int j = 0; j < NROUND; ++j) {
         const int pp = (j * NW + wave) * 16 + (lane >> 2);
         const int yy = pp / WS, xx = pp - yy * WS;
         if ((unsigned)(y0 - 1 + yy) < (unsigned)RES && (unsigned)(xx - 1) < (unsigned)RES) nmask |= 1u << j;
+        nmask |= (unsigned)((xx >> 2) & 1) << (8 + j);
     }
+    const unsigned npack = (lds_patch + wave * 1024 + lane * 16) | (nmask << 16);
     u32x4 nv = {0u, 0u, 0u, 0u}, ns0 = nv, ns1 = nv, nh0 = nv, nh1 = nv;
     unsigned npk[4] = {0u, 0u, 0u, 0u};
     float nf_even = 0.f;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto norm_load = [&](auto j_tag, auto buf_tag) __attribute__((always_inline)) {
         constexpr int J = decltype(j_tag)::value, BUF = decltype(buf_tag)::value;
-        nv = lds_read16<BUF * Cfg::PATCH_BYTES + J * NW * 1024>(nbase);
-        // the lane's row of the table: channel chunk (l & 3) ^ 2 * bit 4 of l.  Recomputed from the slot address (bits 4-9 = the lane) per
+        unsigned np_ = npack;
+        asm volatile("" : "+v"(np_));                                         // (opaque: or the unpacked halves are hoisted out of the loop again)
+        unsigned nb = np_ & 0xffffu;
+        const unsigned nm = np_ >> 16;
+        nv = lds_read16<BUF * Cfg::PATCH_BYTES + J * NW * 1024>(nb);
+        // the lane's row of the table: channel chunk (l & 3) ^ 2 * (bit 2 of the patch column).  Recomputed from the slot address (bits 4-9 = the lane) per
         // round: a register held across the K loop for it is the one hipcc spills (and its reload drains the weight stream)
-        unsigned nb = nbase;
-        asm volatile("" : "+v"(nb));
         nb -= lds_patch;
-        const unsigned tbase = lds_tab + ((((nb >> 4) & 3u) ^ ((nb >> 7) & 2u)) << 5);
+        const unsigned tbase = lds_tab + ((((nb >> 4) & 3u) ^ ((nm >> (7 + J)) & 2u)) << 5);
         ns0 = lds_read16<BUF * Cfg::TAB_BYTES>(tbase); ns1 = lds_read16<BUF * Cfg::TAB_BYTES + 16>(tbase);
         nh0 = lds_read16<BUF * Cfg::TAB_BYTES + 128>(tbase); nh1 = lds_read16<BUF * Cfg::TAB_BYTES + 144>(tbase);
     };
@@ -235,8 +251,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     auto norm_store = [&](auto j_tag, auto buf_tag) __attribute__((always_inline)) {
         constexpr int J = decltype(j_tag)::value, BUF = decltype(buf_tag)::value;
         u32x4 ou = {npk[0], npk[1], npk[2], npk[3]};
-        if (!((nmask >> J) & 1u)) ou = u32x4{0u, 0u, 0u, 0u};
-        lds_write16<BUF * Cfg::PATCH_BYTES + J * NW * 1024>(nbase, ou);
+        unsigned np_ = npack;
+        asm volatile("" : "+v"(np_));
+        if (!((np_ >> (16 + J)) & 1u)) ou = u32x4{0u, 0u, 0u, 0u};
+        lds_write16<BUF * Cfg::PATCH_BYTES + J * NW * 1024>(np_ & 0xffffu, ou);
     };
     // a whole round at once (prologue: no MFMAs to hide behind yet, so the eight elements are left to hipcc to interleave -- one
     // dependent unpack-fma-exp2-add-rcp-mul chain after the other costs ~70 cycles per element, 4k cycles per tile)
@@ -289,11 +307,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int pp = pc - WS + d - 1;
-            a_dx[d] = lds_patch + pp * 64 + ((fq ^ ((pp >> 1) & 2)) << 4);
+            const int xx = (ml % W) + d;                                  // patch column of this lane's pixel at tap column d (row-tile / dy offsets keep its bit 2)
+            a_dx[d] = lds_patch + pp * 64 + ((fq ^ ((xx >> 1) & 2)) << 4);
         }
     }
-    const int arow = wm * (TM * 16) + frow;
-    const unsigned a_plain = lds_patch + arow * 64 + ((fq ^ ((arow >> 1) & 2)) << 4);
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -399,6 +416,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     auto sc_tile = [&](auto buf_tag, int s) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value, P = BUF;            // nk is even: K step nk + s lives in set s & 1
         const int kt = nk + s;
+        // the lane's fragment base in a plain [BM][32] tile, recomputed from an opaque lane id per tile: held across the main loop it is one
+        // register too many (the 16x16 / N = 128 instantiation then reloads a spilled value inside the loop, behind hipcc's own vmcnt(0))
+        int l2;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l2));
+        const int arow = wm * (TM * 16) + (l2 & 15);
+        const unsigned a_plain = lds_patch + arow * 64 + (((l2 >> 4) ^ ((arow >> 1) & 2)) << 4);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         NATINF_CG_BW_READY(P)
         if (kt + 1 < NT) load_b(integral_constant<int, P ^ 1>{}, kt + 1);

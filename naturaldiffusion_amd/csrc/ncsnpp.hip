@@ -30,6 +30,7 @@
 #include "gemm_dma.h"
 #include "conv_gn.h"
 #include "conv_gn2.h"
+#include "head_conv.h"
 #ifdef NATINF_DEV                  // superseded kernels kept for A/B runs: development builds only (make EXTRA=-DNATINF_DEV)
 #include "conv_patch.h"
 #include "gemm_8phase.h"
@@ -216,6 +217,7 @@ using CfgH32 = ConvGn2Cfg<32>; using CfgH16 = ConvGn2Cfg<16>; using CfgH16W = Co
 using CfgP256x256 = PatchCfg<2, 4, 8, 4, 344>; using CfgP256x128 = PatchCfg<4, 2, 4, 4, 400>;
 using CfgG32 = ConvGnCfg<32>; using CfgG16 = ConvGnCfg<16>; using CfgG16W = ConvGnCfg<16, true>;
 #endif
+int g_fuse_head = 1;               // natinf_set_fuse_head (read when a plan is BUILT): GroupNorm + SiLU + the 128 -> 3 output convolution as ONE launch (head_conv.h)
 int g_fuse_gn = 1;                 // natinf_set_fuse_gn (read when a plan is BUILT): GroupNorm-apply + SiLU inside the consuming 3x3 conv
 
 // Packed-epilogue specializations (EPI, gemm_dma.h) that exist per tile family, as bit masks: a launch whose epilogue is not
@@ -258,7 +260,8 @@ bool set_lds_conv_gn() {
 bool configure_gemm_kernels() {
     bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   GEMM_LDS_BYTES) == hipSuccess;
-    ok = ok && set_lds<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4, 9>) &&
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_conv), hipFuncAttributeMaxDynamicSharedMemorySize, HeadConvCfg::LDS_BYTES) == hipSuccess &&
+         set_lds<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4, 9>) &&
          set_lds_epi_all() && set_lds_conv_gn<1>() && set_lds_conv_gn<2>() && set_lds_conv_gn<5>() && set_lds_conv_gn<6>() &&
 #ifdef NATINF_DEV
          set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4>) && set_lds<CfgD256x128>(&k_gemm_dma<4, 2, 4, 4>) &&
@@ -1059,10 +1062,28 @@ struct Builder {
             pack_conv(pw, w, 3, mc.cin, 9, Kf, 0, mc.cin);
             const int64_t b = pack_f32(pb, 3);
             const int64_t sc = arena.alloc((int64_t)mg.cin * 4), sh = arena.alloc((int64_t)mg.cin * 4);
+            const int logW = ilog2(res), cinf = mc.cin;
+            if (g_fuse_head && res == HeadConvCfg::RES && mc.cin == HeadConvCfg::C) {
+                // one launch (head_conv.h): raw tensor in, fp32 NCHW out; folded GroupNorm form (scale / shift x -log2 e, weights x -ln 2)
+                const int64_t w16 = wres((int64_t)16 * Kf * 2);
+                pack_zero(w16, (int64_t)16 * Kf);
+                pack_conv(pw, w16, 3, mc.cin, 9, Kf, 0, mc.cin, -0.6931471805599453f);
+                emit_gn_stats(last, gn, sc, sh, -1.4426950408889634f);
+                const TRef src = last;
+                op(CLS_GEMM, [=](const Ctx& c) {
+                    if (g_record) {
+                        char line[160];
+                        snprintf(line, sizeof(line), "%d %d %d %d %d %d head_conv/e0\n", c.B * res * res, 3, Kf, 0, 9, 1);
+                        *g_record += line;
+                        return;
+                    }
+                    hipLaunchKernelGGL(k_head_conv, dim3((unsigned)(c.B * (HeadConvCfg::RES / HeadConvCfg::ROWS))), dim3(256), HeadConvCfg::LDS_BYTES, c.stream,
+                                       c.act(src), src.ld, c.at<float>(sc), c.at<float>(sh), c.w<bf16>(w16), c.w<float>(b), c.out);
+                });
+            } else {
             emit_gn_stats(last, gn, sc, sh);
             TRef u = new_act(res, mg.cin, 1);
             emit_gn_apply(last, sc, sh, u, nullptr, ACT_SILU, RS_NONE);
-            const int logW = ilog2(res), cinf = mc.cin;
             op(CLS_GEMM, [=](const Ctx& c) {
                 GemmArgs g = gemm_defaults();
                 g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_C = cinf; g.taps = 9; g.logW = logW; g.logHW = 2 * logW; g.a0_padded = 1;
@@ -1070,6 +1091,7 @@ struct Builder {
                 g.c = c.out; g.c_mode = OUT_F32_NCHW;
                 launch_gemm(g, c.stream);
             });
+            }
             E.taps[mg.idx] = last;          // (pre-norm tensor; the GN module's own output is internal)
         }
         E.n_params = poff;
@@ -1111,10 +1133,10 @@ natinf_ncsnpp* make_engine(int flags) {
 // A/B knobs are set to when they are first asked -- a packed buffer of that size fits every plan.
 const natinf_ncsnpp& reference_engine() {
     static natinf_ncsnpp* e = [] {
-        const int fg = g_fuse_gn, fu = g_fuse_up;
-        g_fuse_gn = 1; g_fuse_up = 1;
+        const int fg = g_fuse_gn, fu = g_fuse_up, fh = g_fuse_head;
+        g_fuse_gn = 1; g_fuse_up = 1; g_fuse_head = 1;
         natinf_ncsnpp* r = make_engine(0);
-        g_fuse_gn = fg; g_fuse_up = fu;
+        g_fuse_gn = fg; g_fuse_up = fu; g_fuse_head = fh;
         return r;
     }();
     return *e;
@@ -1334,6 +1356,7 @@ int natinf_debug_timestamps(void* dev_buf16) {
 
 int natinf_set_gemm_raster(int rows) { g_raster_g = rows; return NATINF_OK; }
 int natinf_set_fuse_gn(int on) { g_fuse_gn = on != 0; return NATINF_OK; }
+int natinf_set_fuse_head(int on) { g_fuse_head = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_wide(int on) { g_cg_wide = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_regw(int on) {
     if (!on && !HAVE_CONV_GN_V1) return NATINF_ESTATE;      // k_conv_gn (the LDS-ring form) exists in -DNATINF_DEV builds only

@@ -114,6 +114,46 @@ def test_conv_gn2_k_loop_has_no_scratch_traffic(listings):
         assert n_mfma_in_loops >= 2 * 9 * 32 and not bad, (parts[i], bad[:4])
 
 
+def _vregs(text):
+    regs = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+        regs.update(range(int(a), int(b) + 1))
+    regs.update(int(a) for a in re.findall(r"\bv(\d+)\b", text))
+    return regs
+
+
+def test_conv_gn2_weight_registers_are_untouched_between_load_and_wait(listings):
+    """k_conv_gn2 streams its weight fragments with asm `global_load_dwordx4` into registers that hipcc believes are valid at once; the
+    hand-counted `s_waitcnt vmcnt` comes a whole tap later (round-2 advisor note).  Nothing may read, copy or overwrite a destination
+    register between its load and the next vmcnt wait: checked on the built ISA of every instantiation."""
+    code = listings["ncsnpp"]
+    code = code[:code.index("amdhsa.kernels:")]
+    parts = re.split(r"^(_ZN4ncsn10k_conv_gn2\w+):\s*; @", code, flags=re.M)
+    checked = 0
+    for i in range(1, len(parts), 2):
+        body = parts[i + 1]
+        lines = [ln.split(";")[0].strip() for ln in body[:body.index("s_endpgm")].split("\n")]
+        lines = [ln for ln in lines if ln and not ln.startswith((".", "#"))]
+        pending = {}                                                         # register -> line number of its load
+        for k, ln in enumerate(lines):
+            if re.match(r"s_waitcnt.*vmcnt", ln):
+                pending.clear()
+                continue
+            m = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\]", ln)
+            touched = _vregs(ln)
+            if m:
+                dst = set(range(int(m.group(1)), int(m.group(2)) + 1))
+                assert not (touched - dst) & set(pending), (parts[i], k, ln)  # (its address operand is not a pending destination)
+                assert not dst & set(pending), (parts[i], k, ln, "a destination is reloaded before the previous load was waited for")
+                for r in dst:
+                    pending[r] = k
+                checked += 1
+                continue
+            bad = touched & set(pending)
+            assert not bad, (parts[i], k, ln, sorted(bad))
+    assert checked >= 12 * 4 * 10                                            # every instantiation, four fragments per weight set, many sets
+
+
 def test_no_development_kernels_in_the_shipped_library(listings):
     ks = _kernels(listings["ncsnpp"])
     abl = [n for n in ks if re.search(r"k_gemm_dma<2, 4, 8, 4, [34], 1>", n)]

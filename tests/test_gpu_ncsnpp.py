@@ -159,10 +159,10 @@ def test_bench_batch_512_runs_the_benchmarked_kernels_and_matches_golden(dev, fl
     for f in _describe_gemms(eng, 512):
         chosen.setdefault(f[6].split("/")[0], []).append((int(f[0]), int(f[1])))
     # the families that carry the bench's device time: the fused GroupNorm+SiLU convolution (every res-block conv of the 32x32 and
-    # 16x16 levels but Conv_0 of the down-sampling blocks: 41 launches) and, for the head, the hand-pipelined 512x128 LDS-DMA tile (the
-    # 256x256 one, variant 26, is under test in test_every_gemm_variant_gives_the_same_network and carries the SD3 engine)
+    # 16x16 levels but Conv_0 of the down-sampling blocks: 41 launches) and the fused output head (k_head_conv).  The hand-pipelined 512x128 /
+    # 256x256 LDS-DMA tiles (variants 27 / 26) are under test in test_every_gemm_variant_gives_the_same_network and carry the VAE / SD3 engines
     assert len(chosen.get("conv_gn", [])) >= 40, {k: len(v) for k, v in chosen.items()}
-    assert len(chosen.get("dma512x128h", [])) >= 1, {k: len(v) for k, v in chosen.items()}
+    assert len(chosen.get("head_conv", [])) == 1, {k: len(v) for k, v in chosen.items()}      # (round 3: the 128 -> 3 head left the 512x128 tile for k_head_conv)
     y = eng(x.to(dev), labels.to(dev))
     torch.cuda.synchronize()
     assert torch.isfinite(y).all()
@@ -229,7 +229,8 @@ def test_fused_and_split_k_plans_against_the_unfused_plan(dev, flat, golden_dir)
     ref = torch.from_numpy(fx["y"])
     assert _rel(base[:2].cpu(), ref) <= TOL
     outs = {}
-    for name, setter in (("fuse_gn", lib.natinf_set_fuse_gn), ("fuse_up", lib.natinf_set_fuse_up)):
+    assert any(r[6].startswith("head_conv") for r in _describe_gemms(base_eng, 64))
+    for name, setter in (("fuse_gn", lib.natinf_set_fuse_gn), ("fuse_up", lib.natinf_set_fuse_up), ("fuse_head", lib.natinf_set_fuse_head)):
         try:
             assert setter(0) == 0
             eng = NCSNppEngine(flat, max_batch=64, device=dev)          # the switch is read when the plan is built
@@ -238,6 +239,8 @@ def test_fused_and_split_k_plans_against_the_unfused_plan(dev, flat, golden_dir)
         rows = _describe_gemms(eng, 64)
         if name == "fuse_gn":
             assert not any(r[6].startswith("conv_gn") for r in rows)
+        if name == "fuse_head":
+            assert not any(r[6].startswith("head_conv") for r in rows)
         outs[name] = eng(xd, ld).clone()
     try:
         assert lib.natinf_set_gemm_splitk(0) == 0
