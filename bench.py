@@ -114,7 +114,7 @@ def timed_region(one_step, steps, warmup, world, sync, dist, dev):
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     return dt, out
@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--no-sd3", action="store_true", help="default workload: leave out the sd3 / sd3_fp8 objects")
     ap.add_argument("--sd3-steps", type=int, default=2, help="timed 4-image batches of each SD3 configuration inside the default line")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process-group backend (gloo: the selftest workload on CPU)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="functional test of the N > 1 path on a ONE-GPU box: every rank uses cuda:0 (gloo backend only: RCCL refuses two ranks on one device)")
     ap.add_argument("--selftest-fail-rank", type=int, default=-1, help="selftest: this rank exits non-zero (launcher error-path test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the event-instrumented replica (for rocprof runs)")
@@ -153,11 +155,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
     if args.workload == "selftest":
         return bench_selftest(args, world, rank)
+    if args.same_device:
+        if args.backend != "gloo":
+            raise SystemExit("--same-device needs --backend gloo")
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, device_id=dev)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if args.workload == "sd3":
         line = bench_sd3(args, world, rank, dev, fp8=args.fp8, steps=args.steps, warmup=args.warmup)
@@ -384,6 +393,56 @@ def bench_cifar(args, world, rank, dev):
     return line
 
 
+def sd3_reduced_depth_accuracy(dev, weights_csv="sd3_step_28_weight_sharp.csv", n=2, seed=3):
+    """What fp8 operands cost over a whole 28-step SD3-form Natural Inference run, at a depth the fp32 CPU oracle finishes in seconds:
+    a 4-block / 256-wide MMDiT (4 heads x 64, 16x16 image tokens + 29 text tokens, 16-channel 32x32 latents), CFG 7, the shipped
+    coefficient file -- final latents of the HIP engine with bf16 operands and with NATINF_MMDIT_FP8 against oracle/mmdit_oracle.py
+    (fp32; PARITY UNPINNED) + the oracle's restatement of the loop (src/SD3NaturalInference.py:198-223) on identical noise.
+    Checker code: only bench.py's accuracy leg and tests/ call this."""
+    import numpy as np
+    import torch
+    from oracle import mmdit_oracle as MO, ni_oracle as O
+    from naturaldiffusion_amd.coeff import load_sd3_csv
+    from naturaldiffusion_amd.mmdit import MMDiTEngine, flatten_state_dict
+    from naturaldiffusion_amd.sampler import SD3NI
+    cfg = dict(layers=4, heads=4, joint_dim=128, pooled_dim=64)
+    grid, tc, nstep = 16, 29, 28
+    P = MO.make_params(seed=11, pos_max=32, pos_base=16, **cfg)
+    P = dict(P); P["proj_out.weight"] = P["proj_out.weight"] * 0.2          # O(1) velocities: a well-conditioned 28-step fp16 chain
+    g = torch.Generator().manual_seed(seed)
+    pe, ne = torch.randn(n, tc, 128, generator=g), torch.randn(n, tc, 128, generator=g)
+    ppe, npe = torch.randn(n, 64, generator=g), torch.randn(n, 64, generator=g)
+    noises = torch.randn(n, 16, 2 * grid, 2 * grid, generator=g).half()
+    W = load_sd3_csv(ROOT / "weights" / weights_csv)
+    ts, sig = O.sd3_sigma_schedule(nstep)
+
+    def vel(x, t, cond):
+        tt = torch.as_tensor(t, dtype=torch.float32).expand(n)
+        return MO.forward(P, x.float(), tt, pe if cond else ne, ppe if cond else npe).half()
+    ref = O.sd3_ni(vel, noises, W, sig, ts).float()
+    flat = flatten_state_dict(P, grid, **cfg)
+    text, pooled = torch.cat([pe, ne]).to(dev), torch.cat([ppe, npe]).to(dev)
+    out = {}
+    for name, fp8 in (("bf16", False), ("fp8", True)):
+        eng = MMDiTEngine(flat, max_batch=2 * n, grid=grid, ctx_tokens=tc, device=dev, fp8=fp8, **cfg)
+        ni = SD3NI(W, sig.to(dev), noises.numel(), device=dev, cfg=7.0)
+        zflat = noises.to(dev).reshape(-1)
+        x = ni.first_input(zflat)
+        for k in range(nstep):
+            xx = x.view(n, 16, 2 * grid, 2 * grid)
+            v = eng.forward(torch.cat([xx, xx]), ts[k].to(dev).expand(2 * n), text, pooled)
+            mean, x = ni.step(k, x, v[:n].reshape(-1), v[n:].reshape(-1), zflat, want_next=k + 1 < nstep)
+        got = mean.view(n, 16, 2 * grid, 2 * grid).float().cpu()
+        d = got - ref
+        out[name] = {"rel_rms": round(float((d ** 2).mean().sqrt() / (ref ** 2).mean().sqrt()), 5), "rel_max": round(float(d.abs().max() / ref.abs().max()), 5),
+                     "mean_abs": round(float(d.abs().mean()), 5), "finite": bool(torch.isfinite(got).all())}
+        del eng
+    out["what"] = (f"final latents of 28-step SD3-form NI ({weights_csv}, CFG 7, {n} images, 32x32x16 latents) through a 4-block / 256-wide MMDiT: HIP engine "
+                   "(bf16 operands | fp8 e4m3 image-stream GEMM operands) vs the fp32 oracle + oracle loop on identical noise; latents rms "
+                   f"{float((ref ** 2).mean().sqrt()):.3f}, max {float(ref.abs().max()):.3f}")
+    return out
+
+
 def bench_sd3(args, world, rank, dev, fp8=False, steps=2, warmup=1, flat=None):
     """BASELINE config 4: SD3NaturalInference 28-step (weights/sd3_step_28_weight.csv), 1024x1024 (latents
     [4,16,128,128] fp16), CFG 7 -> per step ONE batched MMDiT forward of 8 sequences (4,096 image + 333 text tokens) +
@@ -523,6 +582,10 @@ def bench_sd3(args, world, rank, dev, fp8=False, steps=2, warmup=1, flat=None):
         line["cpu_baseline"] = {"value": round(1.0 / per_image_s, 6), "unit": "images/s", "cores": threads, "kind": "port",
                                 "sample": f"oracle/mmdit_oracle.py (fp32): one sequence (4096+333 tokens) through 2 of the 24 blocks in {d2:.1f} s, "
                                           f"extrapolated x{L // 2} blocks x 2 sequences (CFG) x {nstep} steps = {per_image_s:.0f} s per image; host has {os.cpu_count()} logical CPUs"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        del eng
+        line["accuracy"] = sd3_reduced_depth_accuracy(dev, wname)
+        eng = None
     del eng, ni
     return line
 

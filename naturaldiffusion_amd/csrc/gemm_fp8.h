@@ -169,6 +169,62 @@ __global__ __launch_bounds__(256) void k_ln_modulate_fp8(const float* __restrict
     }
 }
 
+// The same for D = NC * 256 with 16-byte loads and 4-byte stores (k_ln_modulate_v4's access pattern, dit_engine.inc)
+template <int NC>
+__global__ __launch_bounds__(256) void k_ln_modulate_fp8_v4(const float* __restrict__ x, const float* __restrict__ shift,
+                                                            const float* __restrict__ scale, int mod_ld, uint8_t* __restrict__ h,
+                                                            float* __restrict__ row_scale, int64_t rows, int rows_per_sample)
+{
+    constexpr int D = NC * 256;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * D) + lane;
+    float4 v[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) { v[i] = xr[64 * i]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)D;
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const float a = v[i].x - mean, b_ = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        qq += (a * a + b_ * b_) + (c * c + d * d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o);
+    const float rstd = 1.0f / sqrtf(qq / (float)D + 1e-6f);
+    const int64_t b = row / rows_per_sample;
+    const float4* sh = reinterpret_cast<const float4*>(shift + b * mod_ld) + lane;
+    const float4* sc = reinterpret_cast<const float4*>(scale + b * mod_ld) + lane;
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const float4 g = sc[64 * i], t = sh[64 * i];
+        v[i].x = (v[i].x - mean) * rstd * (1.0f + g.x) + t.x; v[i].y = (v[i].y - mean) * rstd * (1.0f + g.y) + t.y;
+        v[i].z = (v[i].z - mean) * rstd * (1.0f + g.z) + t.z; v[i].w = (v[i].w - mean) * rstd * (1.0f + g.w) + t.w;
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const float qs = amax > 0.f ? amax / 448.0f : 1.0f, inv = 1.0f / qs;
+    if (lane == 0) row_scale[row] = qs;
+    unsigned* out = reinterpret_cast<unsigned*>(h + row * D) + lane;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) out[64 * i] = pack_fp8x4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+}
+inline void launch_ln_modulate_fp8(const float* x, const float* shift, const float* scale, int mod_ld, uint8_t* h, float* row_scale, int D, int64_t rows,
+                                   int rows_per_sample, hipStream_t s)
+{
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    const bool al = mod_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(scale)) % 16 == 0;
+    if (D == 1536 && al) hipLaunchKernelGGL(k_ln_modulate_fp8_v4<6>, grid, dim3(256), 0, s, x, shift, scale, mod_ld, h, row_scale, rows, rows_per_sample);
+    else if (D == 256 && al) hipLaunchKernelGGL(k_ln_modulate_fp8_v4<1>, grid, dim3(256), 0, s, x, shift, scale, mod_ld, h, row_scale, rows, rows_per_sample);
+    else hipLaunchKernelGGL(k_ln_modulate_fp8, grid, dim3(256), 0, s, x, shift, scale, mod_ld, h, row_scale, D, rows, rows_per_sample);
+}
+
 // weights: W fp32 [N][K] -> fp8 bytes [N][K] + one scale per output channel
 __global__ __launch_bounds__(256) void k_pack_fp8_rows(const float* __restrict__ W, uint8_t* __restrict__ q, float* __restrict__ row_scale, int N, int K)
 {
