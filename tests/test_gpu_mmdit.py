@@ -301,6 +301,7 @@ def test_fp8_accuracy_over_a_whole_28_step_run(csv, repo_root):
     (repo_root / "gpurun_out" / f"sd3_accuracy_{csv.split('.')[0]}.json").write_text(json.dumps(rep, indent=1))
     print(json.dumps(rep))
     assert rep["bf16"]["finite"] and rep["fp8"]["finite"]
-    assert rep["bf16"]["rel_rms"] <= 2e-2 and rep["bf16"]["rel_max"] <= 6e-2, rep
-    assert rep["fp8"]["rel_rms"] <= 8e-2 and rep["fp8"]["rel_max"] <= 2.5e-1, rep
+    # observed (MI355X, round 3): bf16 rel_rms 2.9e-3 / rel_max 3.4-4.5e-3; fp8 rel_rms 1.43-1.46e-2 / rel_max 1.4-1.6e-2
+    assert rep["bf16"]["rel_rms"] <= 6e-3 and rep["bf16"]["rel_max"] <= 1e-2, rep
+    assert rep["fp8"]["rel_rms"] <= 3e-2 and rep["fp8"]["rel_max"] <= 3.5e-2, rep
     assert rep["fp8"]["rel_rms"] >= rep["bf16"]["rel_rms"] * 0.5                   # fp8 cannot be (much) more accurate than bf16: a sanity check on the comparison

@@ -14,7 +14,7 @@ shapes = []
 for l in buf.value.decode().strip().split("\n"):
     M, N, K0, K1, taps, batch, k = l.split()       # k = variant/e<epilogue code, 0 = fp32 slab>
     shapes.append((int(M), int(N), int(K0) + int(K1), int(batch), k))
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_gemm" in r["Kernel_Name"] or "k_conv_gn" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_gemm" in r["Kernel_Name"] or "k_conv_gn" in r["Kernel_Name"] or "k_head_conv" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 assert len(rows) % len(shapes) == 0, (len(rows), len(shapes))
 agg = defaultdict(lambda: [0, 0.0, 0.0])

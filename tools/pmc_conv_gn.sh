@@ -1,18 +1,38 @@
 #!/bin/bash
-# SQ counters of k_conv_gn* on one shape (GPU box): tools/pmc_conv_gn.sh "32 512 256 128 0" [tag]   (env REGW=0: k_conv_gn instead of k_conv_gn2)
+# SQ counters of k_conv_gn2 on one shape (GPU box): tools/pmc_conv_gn.sh "32 512 256 128 0" [tag]
+# Three separate --pmc passes (counter slots), kernel trace only (gpurun refuses --pmc with the runtime traces).  Writes the per-counter
+# means over the kernel's launches to gpurun_out/pmc_cg/<shape>/summary.json; copy it to profiles/rNN/conv_gn2_pmc_<shape>.json.
 export TMPDIR=/tmp; cd /tmp
 R=$GRAFT_REPO_ROOT; spec=${1:-"32 512 256 128 0"}; tag=$(echo $spec | tr ' ' '_'); O=$R/gpurun_out/pmc_cg/${tag}${2:+_$2}; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/sq1 -- python3 $R/tools/bench_conv_gn.py $spec 3 > $O/sq1.log 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM --output-format csv -d $O/sq2 -- python3 $R/tools/bench_conv_gn.py $spec 3 > $O/sq2.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAVES SQ_INST_LEVEL_LDS --output-format csv -d $O/sq3 -- python3 $R/tools/bench_conv_gn.py $spec 3 > $O/sq3.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/tools/bench_conv_gn.py $spec 3 > $O/stats.log 2>&1
 python3 - <<PY
-import csv, glob
+import csv, glob, json
 from collections import defaultdict
+out = {"shape": "$spec (res B cin N c1)", "command": "tools/bench_conv_gn.py $spec 3 under rocprofv3 --kernel-trace --pmc (three passes)", "counters": {}}
 for d in ("sq1", "sq2", "sq3"):
-    fs = glob.glob("$O/" + d + "/*/*counter_collection.csv")
+    fs = glob.glob("$O/" + d + "/**/*counter_collection.csv", recursive=True)
     if not fs: print(d, "no data"); continue
     agg = defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        if "k_conv_gn" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in agg.items(): print(f"{k:28s} {sum(v)/len(v):16.0f}  (n={len(v)})")
+        if "k_conv_gn2" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        out["counters"][k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+        print(f"{k:28s} {sum(v)/len(v):16.0f}  (n={len(v)})")
+fs = glob.glob("$O/stats/**/*kernel_stats.csv", recursive=True)
+if fs:
+    for r in csv.DictReader(open(fs[0])):
+        if "k_conv_gn2" in r["Name"]: out["kernel_avg_ns"] = float(r["AverageNs"]); out["kernel_calls"] = int(r["Calls"])
+c = {k: v["mean_per_launch"] for k, v in out["counters"].items()}
+der = {}
+if c.get("SQ_BUSY_CYCLES") and c.get("SQ_VALU_MFMA_BUSY_CYCLES"): der["mfma_busy_frac_of_sq_busy"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CYCLES"]
+if c.get("SQ_WAVE_CYCLES"):
+    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
+        if c.get(k): der[k.lower() + "_frac_of_wave_cycles"] = c[k] / c["SQ_WAVE_CYCLES"]
+if c.get("SQ_LDS_IDX_ACTIVE") and c.get("SQ_LDS_BANK_CONFLICT") is not None: der["lds_bank_conflict_frac"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+out["derived"] = der
+json.dump(out, open("$O/summary.json", "w"), indent=1)
+print(json.dumps(der))
 PY
