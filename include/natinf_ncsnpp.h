@@ -32,11 +32,17 @@ typedef struct natinf_ncsnpp* natinf_ncsnpp_t;
 /* keep every module's output alive in the workspace (bump allocation, no reuse) so that
  * natinf_ncsnpp_debug_tap can read any of them after a forward; tests only. */
 #define NATINF_NCSNPP_KEEP_ACTIVATIONS 1
+/* the `ddpm` score network (deps/score_sde_pytorch/models/ddpm.py:39-181 under configs/vp/ddpm/cifar10_continuous.py: two ResnetBlockDDPM per
+ * level, AttnBlock, Downsample / Upsample convolutions; 35,218,947 parameters) instead of NCSN++ / DDPM++ -- the network of the checkpoint the
+ * reference's docstring names (src/CIFAR10NaturalInference.py:416).  Sizes of such a handle: natinf_ncsnpp_handle_param_count / _packed_bytes. */
+#define NATINF_NCSNPP_DDPM 2
 
 /* Number of fp32 parameters (61,804,419) in the flat order documented at natinf_ncsnpp_load. */
 int64_t natinf_ncsnpp_param_count(void);
 /* Bytes of device memory for the packed (bf16, GEMM-ready) weights + fp32 biases / affine terms. */
 int64_t natinf_ncsnpp_packed_bytes(void);
+int64_t natinf_ncsnpp_handle_param_count(natinf_ncsnpp_t h);      /* of THIS handle's network (NCSN++ or `ddpm`) */
+int64_t natinf_ncsnpp_handle_packed_bytes(natinf_ncsnpp_t h);
 /* Bytes of device workspace a forward at batch <= max_batch needs (depends on the handle's flags). */
 int64_t natinf_ncsnpp_workspace_bytes(natinf_ncsnpp_t h, int max_batch);
 

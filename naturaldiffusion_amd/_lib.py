@@ -42,6 +42,8 @@ SIGNATURES = {
     "natinf_ncsnpp_param_count": (C.c_int64, []),
     "natinf_ncsnpp_workspace_bytes": (C.c_int64, [_p, _i32]),
     "natinf_ncsnpp_packed_bytes": (C.c_int64, []),
+    "natinf_ncsnpp_handle_param_count": (_i64, [_p]),
+    "natinf_ncsnpp_handle_packed_bytes": (_i64, [_p]),
     "natinf_ncsnpp_create": (C.c_int, [C.POINTER(_p), _i32]),
     "natinf_ncsnpp_describe": (C.c_int, [_p, C.c_char_p, _i32]),
     "natinf_ncsnpp_destroy": (C.c_int, [_p]),

@@ -41,17 +41,33 @@ __global__ __launch_bounds__(256, 3) void k_head_conv(const bf16* __restrict__ x
         __syncthreads();                                                         // the previous half's fragment reads are done
         if (tid < 128) tab[tid] = (tid < 64 ? sc : sh)[(int64_t)b * C + h * 64 + (tid & 63)];
         __syncthreads();
-        for (int i = tid; i < NPIX * 8; i += 256) {
+        // all of this thread's 16-byte chunks of the half are requested BEFORE the first one is used: one HBM round trip per half instead of
+        // one per chunk (the first form, a load -> normalise -> store loop, ran at 1.5 TB/s: 91 us per launch at B = 512)
+        constexpr int NIT = (NPIX * 8 + 255) / 256;
+        uint4 raw[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            const int p = i >> 3, c8 = i & 7;
+            const int yy = p / PW, xx = p - yy * PW;
+            const int y = y0 - 1 + yy, xg = xx - 1;
+            raw[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < NPIX * 8 && (unsigned)y < (unsigned)RES && (unsigned)xg < (unsigned)RES)
+                raw[it] = *reinterpret_cast<const uint4*>(img + (int64_t)(y * RES + xg) * ld + h * 64 + c8 * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            if (i >= NPIX * 8) break;
             const int p = i >> 3, c8 = i & 7;
             const int yy = p / PW, xx = p - yy * PW;
             const int y = y0 - 1 + yy, xg = xx - 1;
             uint4 o = make_uint4(0u, 0u, 0u, 0u);
             if ((unsigned)y < (unsigned)RES && (unsigned)xg < (unsigned)RES) {
-                const uint4 raw = *reinterpret_cast<const uint4*>(img + (int64_t)(y * RES + xg) * ld + h * 64 + c8 * 8);
                 const float4 s0 = *reinterpret_cast<const float4*>(tab + c8 * 8), s1 = *reinterpret_cast<const float4*>(tab + c8 * 8 + 4);
                 const float4 h0 = *reinterpret_cast<const float4*>(tab + 64 + c8 * 8), h1 = *reinterpret_cast<const float4*>(tab + 64 + c8 * 8 + 4);
                 const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, hh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-                const unsigned wd[4] = {raw.x, raw.y, raw.z, raw.w};
+                const unsigned wd[4] = {raw[it].x, raw[it].y, raw[it].z, raw[it].w};
                 unsigned pk[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {

@@ -43,7 +43,7 @@ using namespace ncsn;
 
 namespace {
 
-constexpr int NF = 128, NUM_RES = 4, IMG = 32, TEMB = 512, NLEVEL = 4;
+constexpr int NF = 128, IMG = 32, TEMB = 512, NLEVEL = 4;      // res-blocks per level: 4 (cifar10_ddpmpp_continuous) or 2 (the `ddpm` network), Builder::NUM_RES
 constexpr int CH_MULT[NLEVEL] = {1, 2, 2, 2};
 constexpr float GN_EPS = 1e-6f;
 constexpr float INV_SQRT2 = 0.70710678118654752440f;
@@ -51,8 +51,8 @@ inline bool attn_at(int res) { return res == 16; }
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
-enum Kind { K_LIN, K_CONV, K_RES, K_ATTN, K_GN };
-const char* kind_name(int k) { static const char* n[] = {"lin", "conv", "res", "attn", "gn"}; return n[k]; }
+enum Kind { K_LIN, K_CONV, K_RES, K_ATTN, K_GN, K_DOWN, K_UP };      // K_DOWN / K_UP: the plain resampling convolutions of the `ddpm` network
+const char* kind_name(int k) { static const char* n[] = {"lin", "conv", "res", "attn", "gn", "down", "up"}; return n[k]; }
 
 struct Mod { int idx, kind, cin, cout, up, down, res; int64_t poff; };
 
@@ -566,7 +566,14 @@ struct Builder {
     // time-embedding projection bank
     int dense_total = 0; int64_t dense_w = 0, dense_b = 0, dense_out = 0;
 
-    explicit Builder(natinf_ncsnpp& e) : E(e) { arena.keep = (e.flags & NATINF_NCSNPP_KEEP_ACTIVATIONS) != 0; }
+    // NATINF_NCSNPP_DDPM: the `ddpm` network (ddpm.py:39-181; configs/vp/ddpm/cifar10_continuous.py) -- two ResnetBlockDDPM per level (no
+    // 1/sqrt(2) rescale, NIN shortcut), AttnBlock without rescale, Downsample / Upsample as plain 3x3 convolutions -- on the same kernels
+    const bool ddpm;
+    const int NUM_RES;
+    const float res_scale;               // 1/sqrt(2) (skip_rescale of the ++ blocks) or 1
+    explicit Builder(natinf_ncsnpp& e) : E(e), ddpm((e.flags & NATINF_NCSNPP_DDPM) != 0), NUM_RES(ddpm ? 2 : 4), res_scale(ddpm ? 1.0f : INV_SQRT2) {
+        arena.keep = (e.flags & NATINF_NCSNPP_KEEP_ACTIVATIONS) != 0;
+    }
 
     void op(int cls, OpFn f) { E.ops.push_back(std::move(f)); E.op_cls.push_back(cls); }
     int64_t wres(int64_t bytes) { const int64_t o = wtop; wtop += align_up(bytes, 256); return o; }
@@ -594,6 +601,7 @@ struct Builder {
                                p.params + src, reinterpret_cast<bf16*>(p.packed + dst), K, N, dst_ld);
         });
     }
+    void pack_transpose_at(int64_t src, int64_t dst_bytes, int K, int N, int dst_ld) { pack_transpose(src, dst_bytes, K, N, dst_ld); }
     void pack_zero(int64_t dst, int64_t n) {
         E.packs.push_back([=](const PackCtx& p) {
             hipLaunchKernelGGL(k_fill_bf16_zero, dim3(grid1d(n, 256, 1 << 30)), dim3(256), 0, p.stream,
@@ -667,7 +675,8 @@ struct Builder {
         const int64_t w0 = wres((int64_t)cout * K0a * 2), w1 = wres((int64_t)cout * K1tot * 2);
         pack_conv(p_c0w, w0, cout, cin, 9, K0a, 0, cin, w_mul);
         pack_conv(p_c1w, w1, cout, cout, 9, K1tot, 0, cout, w_mul1);
-        if (shortcut) pack_conv(p_c2w, w1, cout, cin, 1, K1tot, 9 * cout, cin);
+        if (shortcut && !ddpm) pack_conv(p_c2w, w1, cout, cin, 1, K1tot, 9 * cout, cin);
+        if (shortcut && ddpm) pack_transpose_at(p_c2w, w1 + (int64_t)9 * cout * 2, cin, cout, K1tot);      // NIN_0.W is [in][out] (layers.py:546-555)
         // k_conv_gn2 reads the weights fragment-major (after the packs above: the list runs in order)
         const int64_t w0f = (fuse && cout % 16 == 0) ? wres((int64_t)cout * K0a * 2) : -1, w1f = (fuse1 && cout % 16 == 0) ? wres((int64_t)cout * K1tot * 2) : -1;
         if (w0f >= 0) pack_frag(w0, w0f, cout, K0a, cin, 0);
@@ -720,6 +729,7 @@ struct Builder {
         }
         if (pt.valid) arena.release(pt.off);
         const TRef xs = ((m.up || m.down) && !fuse_up) ? xr : x;           // shortcut source at the output resolution (fuse_up: x itself, fetched up-sampled)
+        const float rs = res_scale;
         const Part po = register_output(out);
         op(fuse1 ? CLS_CONV_GN : CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
@@ -730,7 +740,7 @@ struct Builder {
             else { g.resid = c.act(xs); g.resid_ld = xs.ld; }
             g.M = c.B * HWo; g.N = cout; g.b = c.w<bf16>(w1); g.b_ld = K1tot;
             if (w1f >= 0) g.b_frag = c.w<bf16>(w1f);
-            g.bias_n = c.w<float>(b1); g.scale = INV_SQRT2;
+            g.bias_n = c.w<float>(b1); g.scale = rs;
             if (skws >= 0) { g.splitk_ws = c.at<float>(skws); g.splitk_max = SK_MAX; }
             g.c = c.act(out); g.c_ld = out.ld;
             if (po.valid) { g.gn_part = c.at<float>(po.off); g.gn_quads = po.quads; }
@@ -816,17 +826,86 @@ struct Builder {
             arena.release(P); arena.release(vT); arena.release(qk);
         }
         const Part po = register_output(out);
-        op(CLS_GEMM, [=](const Ctx& c) {             // out = (x + O W3 + b3) / sqrt(2)
+        const float rs = res_scale;
+        op(CLS_GEMM, [=](const Ctx& c) {             // out = (x + O W3 + b3) / sqrt(2)   (`ddpm`: no rescale)
             GemmArgs g = gemm_defaults();
             g.a0 = c.act(O); g.a0_ld = C; g.a0_C = C; g.M = c.B * T; g.N = C;
             g.b = c.w<bf16>(w3); g.b_ld = C; g.bias_n = c.w<float>(b3);
-            g.resid = c.act(x); g.resid_ld = x.ld; g.scale = INV_SQRT2;
+            g.resid = c.act(x); g.resid_ld = x.ld; g.scale = rs;
             g.c = c.act(out); g.c_ld = out.ld;
             if (po.valid) { g.gn_part = c.at<float>(po.off); g.gn_quads = po.quads; }
             const int bm = launch_gemm(g, c.stream);
             if (po.valid) c.part_bm[po.id] = bm;
         });
         arena.release(O.off); arena.release(sc); arena.release(sh);
+        E.taps[m.idx] = out;
+    }
+
+    // ---- `ddpm` resampling modules (layers.py:586-612) ------------------------------------------------
+    // Downsample: 3x3 convolution, stride 2, 'SAME' padding emulated by one zero row / column at the bottom / right.  Three launches per
+    // forward: an im2col pass (k_inc_im2col, K order tap-major) + one GEMM of the shared tile family.
+    void emit_downconv(const Mod& m, const TRef& x, const TRef& out) {
+        const int C = m.cin, ro = m.res / 2, Kd = 9 * C;
+        const int64_t pw = take((int64_t)C * C * 9), pb = take(C);
+        const int64_t w = wres((int64_t)C * Kd * 2);
+        E.packs.push_back([=](const PackCtx& p) {              // k = tap * C + c (the im2col order)
+            const int64_t n = (int64_t)C * C * 9;
+            hipLaunchKernelGGL(k_pack_conv, dim3(grid1d(n, 256, 1 << 30)), dim3(256), 0, p.stream, p.params + pw, reinterpret_cast<bf16*>(p.packed + w), C, C, 9, Kd, 0, C, 0, 1.0f);
+        });
+        const int64_t b = pack_f32(pb, C);
+        const int64_t col = arena.alloc((int64_t)ro * ro * Kd * 2);
+        const Part po = register_output(out);
+        const int rin = m.res;
+        op(CLS_GEMM, [=](const Ctx& c) {
+            const int64_t M = (int64_t)c.B * ro * ro;
+            if (!g_record) {
+                const int64_t total = M * (Kd / 8);
+                hipLaunchKernelGGL(k_inc_im2col, dim3(grid1d(total, 256, 1 << 30)), dim3(256), 0, c.stream, c.act(x), rin, rin, x.ld, C, 3, 3, 2, 0, 0, ro, ro, Kd,
+                                   c.at<bf16>(col), total);
+            }
+            GemmArgs g = gemm_defaults();
+            g.a0 = c.at<bf16>(col); g.a0_ld = Kd; g.a0_C = Kd; g.M = (int)M; g.N = C; g.b = c.w<bf16>(w); g.b_ld = Kd; g.bias_n = c.w<float>(b);
+            g.log_rows_per_sample = 2 * ilog2(ro); g.logHW = 2 * ilog2(ro); g.logW = ilog2(ro);
+            g.c = c.act(out); g.c_ld = out.ld;
+            if (po.valid) { g.gn_part = c.at<float>(po.off); g.gn_quads = po.quads; }
+            const int bm = launch_gemm(g, c.stream);
+            if (po.valid) c.part_bm[po.id] = bm;
+        });
+        arena.release(col);
+        E.taps[m.idx] = out;
+    }
+    // Upsample: nearest 2x, then a 3x3 convolution: the resampling pass (identity scale / shift, no activation) writes the zero-bordered
+    // up-sampled copy the implicit GEMM reads
+    int64_t ident_sc = -1, ident_sh = -1;
+    void emit_upconv(const Mod& m, const TRef& x, const TRef& out) {
+        const int C = m.cin, ro = m.res * 2, Ku = 9 * C;
+        const int64_t pw = take((int64_t)C * C * 9), pb = take(C);
+        const int64_t w = wres((int64_t)C * Ku * 2);
+        pack_conv(pw, w, C, C, 9, Ku, 0, C);
+        const int64_t b = pack_f32(pb, C);
+        if (ident_sc < 0) {                                   // per (sample, channel) scale 1 / shift 0, filled once per forward
+            ident_sc = arena.alloc((int64_t)2 * NF * 4); ident_sh = arena.alloc((int64_t)2 * NF * 4);
+            const int64_t isc = ident_sc, ish = ident_sh;
+            op(CLS_OTHER, [=](const Ctx& c) {
+                const int64_t n = (int64_t)c.B * 2 * NF;
+                hipLaunchKernelGGL(k_fill_f32, dim3(grid1d(n, 256, 1 << 30)), dim3(256), 0, c.stream, c.at<float>(isc), 1.0f, n);
+                hipLaunchKernelGGL(k_fill_f32, dim3(grid1d(n, 256, 1 << 30)), dim3(256), 0, c.stream, c.at<float>(ish), 0.0f, n);
+            });
+        }
+        TRef u = new_act(ro, C, 1);
+        emit_gn_apply(x, ident_sc, ident_sh, u, nullptr, ACT_NONE, RS_UP);
+        const Part po = register_output(out);
+        const int logW = ilog2(ro);
+        op(CLS_GEMM, [=](const Ctx& c) {
+            GemmArgs g = gemm_defaults();
+            g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_C = C; g.taps = 9; g.logW = logW; g.logHW = 2 * logW; g.a0_padded = 1;
+            g.M = c.B * ro * ro; g.N = C; g.b = c.w<bf16>(w); g.b_ld = Ku; g.bias_n = c.w<float>(b); g.log_rows_per_sample = 2 * logW;
+            g.c = c.act(out); g.c_ld = out.ld;
+            if (po.valid) { g.gn_part = c.at<float>(po.off); g.gn_quads = po.quads; }
+            const int bm = launch_gemm(g, c.stream);
+            if (po.valid) c.part_bm[po.id] = bm;
+        });
+        arena.release(u.off);
         E.taps[m.idx] = out;
     }
 
@@ -888,13 +967,13 @@ struct Builder {
                 if (attn_at(res)) add(K_ATTN, ch, ch, 0, 0, res);
                 skip.push_back(ch);
             }
-            if (l != NLEVEL - 1) { add(K_RES, ch, ch, 0, 1, res); res /= 2; skip.push_back(ch); }
+            if (l != NLEVEL - 1) { if (ddpm) add(K_DOWN, ch, ch, 0, 0, res); else add(K_RES, ch, ch, 0, 1, res); res /= 2; skip.push_back(ch); }
         }
         add(K_RES, ch, ch, 0, 0, res); add(K_ATTN, ch, ch, 0, 0, res); add(K_RES, ch, ch, 0, 0, res);
         for (int l = NLEVEL - 1; l >= 0; --l) {
             for (int b = 0; b < NUM_RES + 1; ++b) { add(K_RES, ch + skip.back(), NF * CH_MULT[l], 0, 0, res); skip.pop_back(); ch = NF * CH_MULT[l]; }
             if (attn_at(res)) add(K_ATTN, ch, ch, 0, 0, res);
-            if (l != 0) { add(K_RES, ch, ch, 1, 0, res); res *= 2; }
+            if (l != 0) { if (ddpm) add(K_UP, ch, ch, 0, 0, res); else add(K_RES, ch, ch, 1, 0, res); res *= 2; }
         }
         add(K_GN, ch, ch, 0, 0, res); add(K_CONV, ch, 3, 0, 0, res);
     }
@@ -1013,7 +1092,7 @@ struct Builder {
             if (l != NLEVEL - 1) {
                 const Mod& m = M[mi++];
                 const TRef dst = skip_slot(si++);
-                emit_res(m, cur, dst);
+                if (ddpm) emit_downconv(m, cur, dst); else emit_res(m, cur, dst);
                 cur = dst; res /= 2;
             }
         }
@@ -1047,7 +1126,7 @@ struct Builder {
             }
             if (l != 0) {
                 const Mod& m = M[mi++];
-                emit_res(m, last, h_slot(j));
+                if (ddpm) emit_upconv(m, last, h_slot(j)); else emit_res(m, last, h_slot(j));
                 arena.release(last.off);
                 res *= 2;
             }
@@ -1107,6 +1186,7 @@ int64_t module_param_count(const Mod& m) {
         case K_LIN: return (int64_t)m.cout * m.cin + m.cout;
         case K_CONV: return (int64_t)m.cout * m.cin * 9 + m.cout;
         case K_GN: return 2 * (int64_t)m.cin;
+        case K_DOWN: case K_UP: return (int64_t)m.cout * m.cin * 9 + m.cout;
         case K_ATTN: return 2 * (int64_t)m.cin + 4 * ((int64_t)m.cin * m.cin + m.cin);
         case K_RES: {
             int64_t n = 2 * (int64_t)m.cin + (int64_t)m.cout * m.cin * 9 + m.cout + (int64_t)m.cout * TEMB + m.cout +
@@ -1149,13 +1229,16 @@ extern "C" {
 int64_t natinf_ncsnpp_param_count(void) { return reference_engine().n_params; }
 int64_t natinf_ncsnpp_packed_bytes(void) { return reference_engine().packed_bytes; }
 
+int64_t natinf_ncsnpp_handle_param_count(natinf_ncsnpp_t h) { return h ? h->n_params : NATINF_EINVAL; }
+int64_t natinf_ncsnpp_handle_packed_bytes(natinf_ncsnpp_t h) { return h ? h->packed_bytes : NATINF_EINVAL; }
+
 int64_t natinf_ncsnpp_workspace_bytes(natinf_ncsnpp_t h, int max_batch) {
     if (!h || max_batch <= 0) return NATINF_EINVAL;
     return h->ws_per_image * (int64_t)max_batch;
 }
 
 int natinf_ncsnpp_create(natinf_ncsnpp_t* out, int flags) {
-    if (!out || (flags & ~NATINF_NCSNPP_KEEP_ACTIVATIONS)) return NATINF_EINVAL;
+    if (!out || (flags & ~(NATINF_NCSNPP_KEEP_ACTIVATIONS | NATINF_NCSNPP_DDPM))) return NATINF_EINVAL;
     natinf_ncsnpp* e = make_engine(flags);
     if (!e) return NATINF_ESTATE;
     *out = e;

@@ -685,6 +685,31 @@ __global__ void k_fill_bf16_zero(bf16* __restrict__ dst, int64_t n)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = (bf16)0.0f;
 }
+__global__ void k_fill_f32(float* __restrict__ p, float v, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// generic im2col: x [B][H][W][ld] (channels coff .. coff+C-1, C % 8 == 0) -> out [B*Ho*Wo][Kp], k = (ky*kw + kx)*C + c, zero for padding and k >= K.
+// One thread per 8 consecutive k (16 bytes).
+__global__ __launch_bounds__(256) void k_inc_im2col(const bf16* __restrict__ x, int H, int W, int ld, int C, int kh, int kw, int stride, int ph, int pw,
+                                                    int Ho, int Wo, int Kp, bf16* __restrict__ out, int64_t total)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int kc = Kp >> 3;
+    const int k = (int)(i % kc) * 8; const int64_t row = i / kc;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (k < kh * kw * C) {
+        const int tap = k / C, c = k - tap * C, ky = tap / kw, kx = tap - ky * kw;
+        const int ox = (int)(row % Wo), oy = (int)((row / Wo) % Ho); const int64_t b = row / ((int64_t)Wo * Ho);
+        const int y = oy * stride - ph + ky, xx = ox * stride - pw + kx;
+        if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) v = *reinterpret_cast<const uint4*>(x + (((int64_t)b * H + y) * W + xx) * ld + c);
+    }
+    *reinterpret_cast<uint4*>(out + row * Kp + k) = v;
+}
+
 // dst = a (+ b)
 __global__ void k_copy_add_f32(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ dst, int n)
 {

@@ -16,14 +16,16 @@ from . import _lib
 from ._lib import lib, check, ptr, stream_ptr
 
 KEEP_ACTIVATIONS = 1
+DDPM = 2            # NATINF_NCSNPP_DDPM: the `ddpm` network (models/ddpm.py) instead of NCSN++ / DDPM++
+ARCH_FLAGS = {"ncsnpp": 0, "ddpm": DDPM}
 
 
-def module_table(handle=None) -> List[Tuple[int, str, int, int, int, int, int, int]]:
+def module_table(handle=None, arch: str = "ncsnpp") -> List[Tuple[int, str, int, int, int, int, int, int]]:
     """(idx, kind, cin, cout, up, down, res, param_offset) per ``all_modules`` entry, from the engine's plan."""
     own = handle is None
     if own:
         h = C.c_void_p()
-        check(lib.natinf_ncsnpp_create(C.byref(h), 0), "natinf_ncsnpp_create")
+        check(lib.natinf_ncsnpp_create(C.byref(h), ARCH_FLAGS[arch]), "natinf_ncsnpp_create")
         handle = h
     buf = C.create_string_buffer(1 << 14)
     n = lib.natinf_ncsnpp_describe(handle, buf, len(buf))
@@ -38,7 +40,7 @@ def module_table(handle=None) -> List[Tuple[int, str, int, int, int, int, int, i
     return rows
 
 
-def param_layout(nf: int = 128) -> List[Tuple[str, Tuple[int, ...]]]:
+def param_layout(nf: int = 128, arch: str = "ncsnpp") -> List[Tuple[str, Tuple[int, ...]]]:
     """Flat parameter order the engine expects: ``all_modules`` order, leaves in registration order
     (= ``model.parameters()`` order = EMA ``shadow_params`` order, ema.py:28-29).  ``nf`` is ``config.model.nf``
     (configs/vp/cifar10_ddpmpp_continuous.py:47): the engine is built for 128; other widths only serve the host-side
@@ -46,7 +48,7 @@ def param_layout(nf: int = 128) -> List[Tuple[str, Tuple[int, ...]]]:
     out: List[Tuple[str, Tuple[int, ...]]] = []
     sc = lambda c: c if c == 3 else c * nf // 128           # image channels stay 3; every feature width is a multiple of nf
     TEMB = 4 * nf
-    for idx, kind, cin, cout, up, down, res, _ in module_table():
+    for idx, kind, cin, cout, up, down, res, _ in module_table(arch=arch):
         cin, cout = sc(cin), sc(cout)
         p = f"all_modules.{idx}."
         if kind == "lin":
@@ -65,19 +67,24 @@ def param_layout(nf: int = 128) -> List[Tuple[str, Tuple[int, ...]]]:
                     (p + "Dense_0.weight", (cout, TEMB)), (p + "Dense_0.bias", (cout,)),
                     (p + "GroupNorm_1.weight", (cout,)), (p + "GroupNorm_1.bias", (cout,)),
                     (p + "Conv_1.weight", (cout, cout, 3, 3)), (p + "Conv_1.bias", (cout,))]
-            if cin != cout or up or down:
+            if arch == "ddpm":
+                if cin != cout:                             # ResnetBlockDDPM's NIN shortcut (layers.py:632-636): W is [in][out]
+                    out += [(p + "NIN_0.W", (cin, cout)), (p + "NIN_0.b", (cout,))]
+            elif cin != cout or up or down:
                 out += [(p + "Conv_2.weight", (cout, cin, 1, 1)), (p + "Conv_2.bias", (cout,))]
+        elif kind in ("down", "up"):                        # `ddpm` Downsample / Upsample with resamp_with_conv (layers.py:586-612)
+            out += [(p + "Conv_0.weight", (cout, cin, 3, 3)), (p + "Conv_0.bias", (cout,))]
         else:
             raise RuntimeError(f"unknown module kind {kind}")
     return out
 
 
-def flatten_state_dict(sd: Dict[str, torch.Tensor]) -> torch.Tensor:
+def flatten_state_dict(sd: Dict[str, torch.Tensor], arch: str = "ncsnpp") -> torch.Tensor:
     """name -> tensor dict (reference keys, with or without the DataParallel ``module.`` prefix,
     models/utils.py:93) -> one fp32 CPU vector in engine order.  Shapes are checked."""
     sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
     parts = []
-    for name, shape in param_layout():
+    for name, shape in param_layout(arch=arch):
         if name not in sd:
             raise KeyError(f"checkpoint lacks {name}")
         t = sd[name]
@@ -87,9 +94,9 @@ def flatten_state_dict(sd: Dict[str, torch.Tensor]) -> torch.Tensor:
     return torch.cat(parts)
 
 
-def flatten_ema(shadow_params: List[torch.Tensor], nf: int = 128) -> torch.Tensor:
+def flatten_ema(shadow_params: List[torch.Tensor], nf: int = 128, arch: str = "ncsnpp") -> torch.Tensor:
     """EMA list of the score_sde checkpoint (``state['ema']['shadow_params']``, ema.py:91-97)."""
-    layout = param_layout(nf)
+    layout = param_layout(nf, arch)
     if len(shadow_params) != len(layout):
         raise ValueError(f"EMA list has {len(shadow_params)} tensors, the model has {len(layout)} parameters")
     parts = []
@@ -100,7 +107,7 @@ def flatten_ema(shadow_params: List[torch.Tensor], nf: int = 128) -> torch.Tenso
     return torch.cat(parts)
 
 
-def load_score_sde_checkpoint(path: str, nf: int = 128) -> torch.Tensor:
+def load_score_sde_checkpoint(path: str, nf: int = 128, arch: str = "ncsnpp") -> torch.Tensor:
     """``restore_checkpoint`` + ``ema.copy_to`` (deps/score_sde_pytorch/utils.py:7-19, ema.py:53-64):
     the weights the reference samples with are the EMA shadow parameters.  The pickle's ``model`` entry (DataParallel
     ``module.`` keys plus the ``sigmas`` buffer) is only used to cross-check the names and shapes of the EMA list."""
@@ -110,25 +117,28 @@ def load_score_sde_checkpoint(path: str, nf: int = 128) -> torch.Tensor:
             raise KeyError(f"{path}: not a score_sde checkpoint (no '{key}' entry; utils.py:22-29)")
     shadow = list(state["ema"]["shadow_params"])
     model_sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state["model"].items()}
-    for (name, shape), t in zip(param_layout(nf), shadow):
+    for (name, shape), t in zip(param_layout(nf, arch), shadow):
         if name in model_sd and tuple(model_sd[name].shape) != tuple(t.shape):
             raise ValueError(f"{path}: EMA entry for {name} has shape {tuple(t.shape)}, the model's is {tuple(model_sd[name].shape)}")
-    return flatten_ema(shadow, nf)
+    return flatten_ema(shadow, nf, arch)
 
 
 class NCSNppEngine:
-    def __init__(self, flat_params: torch.Tensor, max_batch: int, device="cuda:0", keep_activations: bool = False):
+    def __init__(self, flat_params: torch.Tensor, max_batch: int, device="cuda:0", keep_activations: bool = False, arch: str = "ncsnpp"):
+        """``arch``: "ncsnpp" (configs/vp/cifar10_ddpmpp_continuous.py, what the reference script imports) or "ddpm"
+        (configs/vp/ddpm/cifar10_continuous.py, the checkpoint its docstring names)."""
         _lib.require_gpu()
         self.device = torch.device(device)
         self.max_batch = int(max_batch)
+        self.arch = arch
         self._h = C.c_void_p()
-        check(lib.natinf_ncsnpp_create(C.byref(self._h), KEEP_ACTIVATIONS if keep_activations else 0), "natinf_ncsnpp_create")
-        n = lib.natinf_ncsnpp_param_count()
+        check(lib.natinf_ncsnpp_create(C.byref(self._h), (KEEP_ACTIVATIONS if keep_activations else 0) | ARCH_FLAGS[arch]), "natinf_ncsnpp_create")
+        n = lib.natinf_ncsnpp_handle_param_count(self._h)
         if flat_params.numel() != n:
             raise ValueError(f"expected {n} parameters, got {flat_params.numel()}")
         with torch.cuda.device(self.device):
             params = flat_params.to(self.device, torch.float32).contiguous()
-            self._packed = torch.empty(lib.natinf_ncsnpp_packed_bytes(), dtype=torch.uint8, device=self.device)
+            self._packed = torch.empty(lib.natinf_ncsnpp_handle_packed_bytes(self._h), dtype=torch.uint8, device=self.device)
             check(lib.natinf_ncsnpp_load(self._h, ptr(params), n, ptr(self._packed), self._packed.numel(), stream_ptr()),
                   "natinf_ncsnpp_load")
             torch.cuda.current_stream().synchronize()      # params may be freed after this

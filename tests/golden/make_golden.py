@@ -528,6 +528,53 @@ def group_ddim_vp():
     np.savez_compressed(HERE / "ddim_vp.npz", **out)
 
 
+def group_ddpm():
+    """The reference's ``DDPM`` class (deps/score_sde_pytorch/models/ddpm.py:39-181, registered as 'ddpm'; configuration
+    configs/vp/ddpm/cifar10_continuous.py) on the synthetic weights of oracle/ddpm_oracle.py: the network of the checkpoint the
+    reference's docstring names (src/CIFAR10NaturalInference.py:416).  Output, statistics / head of every module output, a few
+    activations in full (a width-changing res-block with its NIN shortcut, Downsample, attention, a concat-input block, Upsample)."""
+    import numpy as np
+    import torch
+    _stub_cifar_env()
+    import CIFAR10NaturalInference as R                      # brings models.utils / layers onto the path
+    from configs.vp.ddpm import cifar10_continuous as ddpm_cfg
+    from models import ddpm as ddpm_mod                      # registers 'ddpm'
+    from oracle import ddpm_oracle as D
+    torch.set_num_threads(8)
+    config = ddpm_cfg.get_config()
+    config.device = torch.device("cpu")
+    net = R.mutils.create_model(config).module
+    assert type(net).__name__ == "DDPM"
+    P = D.make_params(seed=0)
+    sd = dict(P); sd["sigmas"] = net.sigmas
+    net.load_state_dict(sd, strict=True)
+    n_param = sum(p.numel() for p in net.parameters())
+    net.eval()
+    taps = {}
+    hooks = [m.register_forward_hook(lambda mod, i, o, k=k: taps.__setitem__(k, o.detach())) for k, m in enumerate(net.all_modules)]
+    g = torch.Generator().manual_seed(8765)
+    x = torch.randn(2, 3, 32, 32, generator=g)
+    labels = torch.tensor([0.81 * 999, 0.0123 * 999], dtype=torch.float32)
+    with torch.no_grad():
+        y = net(x, labels)
+    for h in hooks:
+        h.remove()
+    out = dict(x=x.numpy(), labels=labels.numpy(), y=y.numpy(), n_param=np.int64(n_param), n_modules=np.int64(len(net.all_modules)),
+               names=np.array([n for n, _ in net.named_parameters()]))
+    for k, t in taps.items():
+        t = t.float()
+        out[f"tap{k:02d}_stats"] = np.array([t.mean().item(), t.std().item(), t.abs().max().item()], np.float64)
+        out[f"tap{k:02d}_head"] = t.flatten()[:32].numpy()
+        out[f"tap{k:02d}_shape"] = np.array(t.shape, np.int64)
+    kinds = {m.idx: m.kind for m in D.plan()}
+    full = [next(k for k in kinds if kinds[k] == "down"), next(k for k in kinds if kinds[k] == "attn"), next(k for k in kinds if kinds[k] == "up")]
+    full += [m.idx for m in D.plan() if m.kind == "res" and m.cin != m.cout][:2] + [m.idx for m in D.plan() if m.kind == "res" and m.cin > 256][:1]
+    for k in sorted(set(full)):
+        out[f"tap{k:02d}_full"] = taps[k].numpy()
+    np.savez_compressed(HERE / "ddpm_forward.npz", **out)
+    print("ddpm: params", n_param, "| modules", len(net.all_modules), "| y absmax", float(np.abs(out["y"]).max()), "| full taps", sorted(set(full)))
+
+
 def group_ckpt():
     """A score_sde checkpoint made the way the reference's training loop makes one (utils.save_checkpoint, utils.py:22-29):
     {'optimizer', 'model' (DataParallel state_dict, 'module.' keys), 'ema' (ExponentialMovingAverage.state_dict(),
@@ -587,7 +634,7 @@ def group_ckpt():
     print("ckpt:", len(layout), "parameters at nf=128;", flat.size, "floats at nf=8; loader agrees")
 
 
-GROUPS = dict(k5=group_k5, ddim_vp=group_ddim_vp, ckpt=group_ckpt, dit=group_dit, loaders=group_loaders, cifar=group_cifar, validate=group_validate, sd3=group_sd3, ncsnpp=group_ncsnpp)
+GROUPS = dict(k5=group_k5, ddim_vp=group_ddim_vp, ddpm=group_ddpm, ckpt=group_ckpt, dit=group_dit, loaders=group_loaders, cifar=group_cifar, validate=group_validate, sd3=group_sd3, ncsnpp=group_ncsnpp)
 
 if __name__ == "__main__":
     assert REF.exists(), "the reference is only mounted in the build container"

@@ -74,7 +74,7 @@ def test_workspace_queries():
     hk = C.c_void_p()
     assert lib.natinf_ncsnpp_create(C.byref(hk), 1) == 0
     assert lib.natinf_ncsnpp_workspace_bytes(hk, 1) > w1
-    assert lib.natinf_ncsnpp_create(C.byref(C.c_void_p()), 2) == -1
+    assert lib.natinf_ncsnpp_create(C.byref(C.c_void_p()), 4) == -1                  # flags: 1 = keep activations, 2 = the `ddpm` network
     # forward before load -> ESTATE; bad args -> EINVAL (no launch happens)
     assert lib.natinf_ncsnpp_forward(h, 1, 1, 1, 1, 1, 1 << 40, None) == -4
     assert lib.natinf_ncsnpp_forward(h, None, None, None, 1, None, 0, None) == -1

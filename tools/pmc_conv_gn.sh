@@ -27,11 +27,20 @@ if fs:
         if "k_conv_gn2" in r["Name"]: out["kernel_avg_ns"] = float(r["AverageNs"]); out["kernel_calls"] = int(r["Calls"])
 c = {k: v["mean_per_launch"] for k, v in out["counters"].items()}
 der = {}
-if c.get("SQ_BUSY_CYCLES") and c.get("SQ_VALU_MFMA_BUSY_CYCLES"): der["mfma_busy_frac_of_sq_busy"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CYCLES"]
+# units (MI355X_MICROARCH.md): SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles summed over the 1,024 SIMDs; GRBM_GUI_ACTIVE counts cycles summed over the 8
+# XCDs; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves
+if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+    kcyc = c["GRBM_GUI_ACTIVE"] / 8.0
+    der["kernel_shader_cycles"] = kcyc
+    der["mfma_pipe_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * kcyc)
+    if c.get("SQ_INSTS_MFMA"): der["mfma_cycles_per_instruction"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_INSTS_MFMA"]
 if c.get("SQ_WAVE_CYCLES"):
-    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
+    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"):
         if c.get(k): der[k.lower() + "_frac_of_wave_cycles"] = c[k] / c["SQ_WAVE_CYCLES"]
 if c.get("SQ_LDS_IDX_ACTIVE") and c.get("SQ_LDS_BANK_CONFLICT") is not None: der["lds_bank_conflict_frac"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+if c.get("SQ_INSTS_MFMA"):
+    for k in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_SALU"):
+        if c.get(k): der[k.lower() + "_per_mfma"] = c[k] / c["SQ_INSTS_MFMA"]
 out["derived"] = der
 json.dump(out, open("$O/summary.json", "w"), indent=1)
 print(json.dumps(der))
