@@ -45,23 +45,31 @@ namespace ncsn {
 // of 240 / 432 (16x16): 15-25 % less to fetch, to normalise and to keep in LDS.
 template <int RES> struct PatchGeo2 { static constexpr int W = RES, WP = RES + 2, WS = RES + 2; };
 
+// RES = 8 (round 3): a 128-pixel tile holds TWO whole 8x8 images.  Each image has its own patch -- (8+2) x (8+2) pixels, padded to 112 patch
+// rows so that a 16-row DMA piece never straddles two images -- its own (scale | shift) table, its own row of the time-embedding vector and its
+// own GroupNorm partials (tile_epilogue's NSAMP); a 16-pixel row-tile is two image rows, which the per-lane fragment bases absorb.  Swizzle key
+// for 10-pixel patch rows: xx & 2 (searched over every 2 x 8 window and ds_read_b128 lane group: conflict-free; bit 2 of the column is not).
 template <int RES, bool WIDE_ = false>
 struct ConvGn2Cfg {
     using Geo = PatchGeo2<RES>;
     static constexpr bool WIDE = WIDE_;
     static constexpr int WM = WIDE ? 1 : 2, WN = WIDE ? 4 : 2, TM = 8, TN = 4, NW = 4, THREADS = 256, KT = 32;
     static constexpr int BM_ = WM * TM * 16, BN_ = WN * TN * 16;
-    static constexpr int PR = BM_ / Geo::W + 2;                         // image rows of a tile + the halo rows
-    static constexpr int PLAST = (PR - 1) * Geo::WS + Geo::WP;          // patch rows that are ever read
+    static constexpr int NIMG = RES * RES >= BM_ ? 1 : BM_ / (RES * RES);   // whole images per tile (RES = 8: 2)
+    static constexpr int IMGP = NIMG > 1 ? ((RES + 2) * (RES + 2) + 15) / 16 * 16 : 0;      // patch rows per image when a tile holds several
+    static constexpr int PR = BM_ / Geo::W + 2;                         // image rows of a tile + the halo rows (NIMG == 1)
+    static constexpr int PLAST = NIMG > 1 ? NIMG * IMGP : (PR - 1) * Geo::WS + Geo::WP;          // patch rows that are ever read
     static constexpr int NPIECE = (PLAST + 15) / 16;                    // 1-KiB DMA pieces (16 patch rows of 64 B)
     static constexpr int NROUND = (NPIECE + NW - 1) / NW;               // piece j * NW + wave belongs to wave `wave`, round j
     static constexpr int NFULL = NPIECE / NW;                           // rounds in which every wave has a piece
     static constexpr int PSW = BM_ / 16 / NW;                           // shortcut-tile pieces per wave
-    static constexpr int PATCH_BYTES = (NPIECE > BM_ / 16 ? NPIECE : BM_ / 16) * 1024, TAB_BYTES = 256;
+    static constexpr int PATCH_BYTES = (NPIECE > BM_ / 16 ? NPIECE : BM_ / 16) * 1024, TAB_IMG_BYTES = 256, TAB_BYTES = NIMG * TAB_IMG_BYTES;
     static constexpr int TILES_BYTES = 2 * PATCH_BYTES + 2 * TAB_BYTES;
     using Epi = EpiCfg<WM, WN, TM, TN, 81920>;
-    static constexpr int LDS_BYTES = TILES_BYTES > Epi::PACK_BYTES ? TILES_BYTES : Epi::PACK_BYTES;
-    static_assert(RES * RES % BM_ == 0, "a tile lies inside one image");
+    static constexpr int EPI_BYTES = Epi::PACK_BYTES + (NIMG - 1) * WN * TN * 4 * 8;      // + the partial-sum rows of the further samples
+    static constexpr int LDS_BYTES = TILES_BYTES > EPI_BYTES ? TILES_BYTES : EPI_BYTES;
+    static constexpr int swz_key(int xx) { return RES == 8 ? (xx & 2) : ((xx >> 1) & 2); }
+    static_assert(RES * RES % BM_ == 0 || (BM_ % (RES * RES) == 0 && WM == 1 && NIMG == 2), "a tile lies inside one image, or holds two whole images");
     static_assert(NROUND <= 7, "the rounds run behind taps 2..8");
     static_assert(Epi::PACK_OK && LDS_BYTES <= 81920, "two blocks per CU");
 };
@@ -101,17 +109,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     using Geo = typename Cfg::Geo;
     constexpr int BM_ = Cfg::BM_, BN_ = Cfg::BN_, NW = Cfg::NW, TM = Cfg::TM, TN = Cfg::TN, KT = Cfg::KT;
     constexpr int W = Geo::W, WS = Geo::WS, HW = RES * RES;
-    constexpr int PSW = Cfg::PSW, NROUND = Cfg::NROUND, NPIECE = Cfg::NPIECE, NFULL = Cfg::NFULL;
+    constexpr int PSW = Cfg::PSW, NROUND = Cfg::NROUND, NPIECE = Cfg::NPIECE, NFULL = Cfg::NFULL, NIMG = Cfg::NIMG, IMGP = Cfg::IMGP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS: [2][PATCH_BYTES] patch buffers, then [2][scale 32 | shift 32] fp32 tables (the epilogue reuses all of it as its slab)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = WIDE ? 0 : wave >> 1, wn = WIDE ? wave : wave & 1;
-    const int nN = (g.N + BN_ - 1) / BN_, nM = g.M / BM_;
+    const int nN = (g.N + BN_ - 1) / BN_, nM = (g.M + BM_ - 1) / BM_;      // (M is a whole number of tiles but for RES = 8 with an odd batch: the last tile holds one image)
     const int tile = xcd_remap(blockIdx.x, nM * nN);
     const int mt = tile / nN, nt = tile - mt * nN;
     const int m0 = mt * BM_, n0 = nt * BN_;
-    const int b = m0 / HW, y0 = (m0 % HW) / W;                            // image and first image row of this tile
+    const int b = m0 / HW, y0 = (m0 % HW) / W;                            // (first) image and first image row of this tile
+    const int bdelta = (NIMG > 1 && m0 + HW < g.M) ? 1 : 0;               // RES = 8: the tile's second image (an odd batch ends on half a tile: it re-reads the first, nothing of it is stored)
     const int ush = g.a0_up;                                              // 1: the source image has half the resolution (nearest up-sampling in the fetch)
     const bf16* const img = g.a0 + (int64_t)b * (HW >> (2 * ush)) * g.a0_ld;
     const float* const gsc = g.gn_scale + (int64_t)b * g.gn_ld;
@@ -149,11 +158,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));                                          // addresses recomputed per request (once per nine taps): no registers held
         {
             // the table: scale by lanes 0-31, shift by lanes 32-63 -- two half-wave requests with a scalar base and a 32-bit lane offset
-            // (one request with a per-lane 64-bit address kept a zero register alive across the loop, which hipcc then spilled)
-            const unsigned dst = lds_tab + buf * Cfg::TAB_BYTES;
+            // (one request with a per-lane 64-bit address kept a zero register alive across the loop, which hipcc then spilled); one table per image
             const unsigned toff = (unsigned)(l & 31) * 4u;
-            if (l < 32) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(toff), "s"(gsc + hc * KT), "s"(dst) : "memory", "m0");
-            else        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(toff), "s"(gsh + hc * KT), "s"(dst) : "memory", "m0");
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im) {
+                const unsigned dst = lds_tab + buf * Cfg::TAB_BYTES + im * Cfg::TAB_IMG_BYTES;
+                const int64_t io = (int64_t)(im ? bdelta : 0) * g.gn_ld;
+                if (l < 32) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(toff), "s"(gsc + io + hc * KT), "s"(dst) : "memory", "m0");
+                else        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(toff), "s"(gsh + io + hc * KT), "s"(dst) : "memory", "m0");
+            }
         }
         const bf16* base = img + hc * KT;
 #pragma unroll
@@ -164,9 +177,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
             asm volatile("" : "+v"(lj));                                      // one piece's address arithmetic at a time: hoisted together, the pieces' temporaries spill inside the loop
             const int prow = lj >> 2, pslot = lj & 3;
             const int pp = q * 16 + prow;
-            const int yy = pp / WS, xx = pp - yy * WS;
-            const int y = min(max(y0 - 1 + yy, 0), RES - 1), x = min(max(xx - 1, 0), RES - 1);      // halo / pad: any readable pixel
-            glds16((unsigned)(((y >> ush) * (W >> ush) + (x >> ush)) * g.a0_ld + ((pslot ^ ((xx >> 1) & 2)) << 3)) * 2u, base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
+            if constexpr (NIMG > 1) {
+                // several whole images per tile: patch row pp = image im, pixel (yy - 1, xx - 1) of it; rows past the (RES + 2)^2 real ones are padding
+                const int im = q >= IMGP / 16 ? 1 : 0;                        // (a piece never straddles two images: IMGP % 16 == 0)
+                const int rem = pp - im * IMGP;
+                const int yy = rem / WS, xx = rem - yy * WS;
+                const int y = min(max(yy - 1, 0), RES - 1), x = min(max(xx - 1, 0), RES - 1);
+                glds16((unsigned)(((im ? bdelta : 0) * HW + y * W + x) * g.a0_ld + ((pslot ^ Cfg::swz_key(xx)) << 3)) * 2u, base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
+            } else {
+                const int yy = pp / WS, xx = pp - yy * WS;
+                const int y = min(max(y0 - 1 + yy, 0), RES - 1), x = min(max(xx - 1, 0), RES - 1);      // halo / pad: any readable pixel
+                glds16((unsigned)(((y >> ush) * (W >> ush) + (x >> ush)) * g.a0_ld + ((pslot ^ Cfg::swz_key(xx)) << 3)) * 2u, base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
+            }
         }
     };
     auto issue_shortcut = [&](int s) __attribute__((always_inline)) {        // plain [BM][32] tile of a1 -> patch buffer s & 1 (n_half is even)
@@ -180,7 +202,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
 #pragma unroll
         for (int j = 0; j < PSW; ++j) {
             const int pp = (wave * PSW + j) * 16 + prow;
-            const int src = sup ? ((y0 + pp / W) >> 1) * (W >> 1) + ((pp % W) >> 1) : pp;
+            int src = sup ? ((y0 + pp / W) >> 1) * (W >> 1) + ((pp % W) >> 1) : pp;
+            if constexpr (NIMG > 1) src = (pp < HW || bdelta) ? pp : pp - HW;      // a last tile with one image: its second half re-reads the first
             glds16((unsigned)(src * g.a1_ld + ((pslot ^ ((pp >> 1) & 2)) << 3)) * 2u, base, dst + j * 1024);
         }
     };
@@ -201,9 +224,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
 #pragma unroll
     for (int j = 0; j < NROUND; ++j) {
         const int pp = (j * NW + wave) * 16 + (lane >> 2);
-        const int yy = pp / WS, xx = pp - yy * WS;
-        if ((unsigned)(y0 - 1 + yy) < (unsigned)RES && (unsigned)(xx - 1) < (unsigned)RES) nmask |= 1u << j;
-        nmask |= (unsigned)((xx >> 2) & 1) << (8 + j);
+        if constexpr (NIMG > 1) {
+            const int rem = pp % IMGP, yy = rem / WS, xx = rem - yy * WS;
+            if ((unsigned)(yy - 1) < (unsigned)RES && (unsigned)(xx - 1) < (unsigned)RES) nmask |= 1u << j;
+            nmask |= (unsigned)(Cfg::swz_key(xx) >> 1) << (8 + j);
+        } else {
+            const int yy = pp / WS, xx = pp - yy * WS;
+            if ((unsigned)(y0 - 1 + yy) < (unsigned)RES && (unsigned)(xx - 1) < (unsigned)RES) nmask |= 1u << j;
+            nmask |= (unsigned)(Cfg::swz_key(xx) >> 1) << (8 + j);
+        }
     }
     const unsigned npack = (lds_patch + wave * 1024 + lane * 16) | (nmask << 16);
     u32x4 nv = {0u, 0u, 0u, 0u}, ns0 = nv, ns1 = nv, nh0 = nv, nh1 = nv;
@@ -220,7 +249,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
         // the lane's row of the table: channel chunk (l & 3) ^ 2 * (bit 2 of the patch column).  Recomputed from the slot address (bits 4-9 = the lane) per
         // round: a register held across the K loop for it is the one hipcc spills (and its reload drains the weight stream)
         nb -= lds_patch;
-        const unsigned tbase = lds_tab + ((((nb >> 4) & 3u) ^ ((nm >> (7 + J)) & 2u)) << 5);
+        // (several images per tile: the piece's image, hence its table, is wave-uniform -- pieces do not straddle images)
+        const unsigned timg = (NIMG > 1 && J * NW + wave >= IMGP / 16) ? Cfg::TAB_IMG_BYTES : 0u;
+        const unsigned tbase = lds_tab + timg + ((((nb >> 4) & 3u) ^ ((nm >> (7 + J)) & 2u)) << 5);
         ns0 = lds_read16<BUF * Cfg::TAB_BYTES>(tbase); ns1 = lds_read16<BUF * Cfg::TAB_BYTES + 16>(tbase);
         nh0 = lds_read16<BUF * Cfg::TAB_BYTES + 128>(tbase); nh1 = lds_read16<BUF * Cfg::TAB_BYTES + 144>(tbase);
     };
@@ -303,12 +334,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     unsigned a_dx[3];
     {
         const int ml = wm * (TM * 16) + frow;                             // first pixel row-tile of this wave
-        const int pc = ((ml / W) + 1) * WS + (ml % W) + 1;                // its patch row at the centre tap
+        // its patch row at the centre tap, and its patch column (row-tile / dy / image offsets keep the column, hence the swizzle)
+        const int pc = NIMG > 1 ? ((frow >> 3) + 1) * WS + (frow & 7) + 1 : ((ml / W) + 1) * WS + (ml % W) + 1;
+        const int xc = NIMG > 1 ? (frow & 7) : (ml % W);
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int pp = pc - WS + d - 1;
-            const int xx = (ml % W) + d;                                  // patch column of this lane's pixel at tap column d (row-tile / dy offsets keep its bit 2)
-            a_dx[d] = lds_patch + pp * 64 + ((fq ^ ((xx >> 1) & 2)) << 4);
+            a_dx[d] = lds_patch + pp * 64 + ((fq ^ Cfg::swz_key(xc + d)) << 4);
         }
     }
 
@@ -358,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
 
     // ---- the nine taps of one half-chunk; BUF (its patch buffer) and the tap index are compile-time: all offsets are immediates.
     // Weight set of K step kt = hc * 9 + T: (kt & 1) = (T + BUF) & 1 (hc and BUF have the same parity).
-#define NATINF_CG_AOFF(i) (BUF * Cfg::PATCH_BYTES + ((RES == 32 ? ((i) >> 1) * WS + ((i) & 1) * 16 : (i) * WS) + (T / 3) * WS) * 64)
+#define NATINF_CG_AOFF(i) (BUF * Cfg::PATCH_BYTES + ((RES == 32 ? ((i) >> 1) * WS + ((i) & 1) * 16 : (RES == 16 ? (i) * WS : ((i) >> 2) * IMGP + ((i) & 3) * 2 * WS)) + (T / 3) * WS) * 64)
     auto tap = [&](auto buf_tag, auto t_tag, int hc, bool next_half) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value, T = decltype(t_tag)::value, P = (T + BUF) & 1;
         const int kt = hc * 9 + T;
@@ -368,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
         // (lgkmcnt) and nobody reads the other buffer any more -> the next half-chunk's raw patch may land in it.
         if constexpr (T == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else if constexpr (T == 1) {
-            if (next_half) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 + NFULL) : "memory");
+            if (next_half) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NIMG + NFULL) : "memory");
             else if (n_sc > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PSW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -463,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
 #ifdef NATINF_DEV
     const unsigned long long dbg_t2 = cg_stamp();
 #endif
-    tile_epilogue<Cfg::WM, Cfg::WN, TM, TN, typename Cfg::Epi, EPI>(ge, smem, acc, m0, n0, 0, tid, lane, wm, wn);
+    tile_epilogue<Cfg::WM, Cfg::WN, TM, TN, typename Cfg::Epi, EPI, NIMG>(ge, smem, acc, m0, n0, 0, tid, lane, wm, wn);
 #ifdef NATINF_DEV
     if (ge.dbg_ts && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 777)) {          // development builds: tools/conv_gn_timeline.py
         // block 0: [2..4] are the epilogue's own stamps (NATINF_TS: start, slab written, copied out), [7] = the stamp in front of it

@@ -109,12 +109,15 @@ struct SlabCopy<NSW, NSW, RPS, PROW, EDGE> {
 // DEQ (fp8 operands): acc * (deq_m[row] * deq_n[col]) first, and a row bias (bias_m) next to the column terms.
 // OUT8: the tile leaves as e4m3 bytes with one E8M0 scale per 32 columns (OUT_FP8_MX; a block = two 16-column MFMA tiles x the
 // four lanes of a row) -- the bytes cross LDS like the bf16 values do, the scale bytes are stored from the registers.
-template <int WM, int WN, int TM, int TN, class Cfg, int ACT, bool GN, bool RES, bool DEQ = false, bool OUT8 = false>
+// NSAMP = 2 (k_conv_gn2 at 8x8: WM == 1, the tile's upper / lower TM / 2 row-tiles are two samples): the per-sample row vector and the GroupNorm
+// partials exist once per sample; gn_part rows are then indexed by (m0 / BM) * NSAMP + sample.
+template <int WM, int WN, int TM, int TN, class Cfg, int ACT, bool GN, bool RES, bool DEQ = false, bool OUT8 = false, int NSAMP = 1>
 __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned char* smem, f32x4 (&acc)[TM][TN],
                                                      int m0, int n0, int z, int tid, int lane, int wm, int wn)
 {
     constexpr int BN_ = WN * TN * 16, BM_ = WM * TM * 16, THREADS = WM * WN * 64, PROW = OUT8 ? BN_ + 16 : Cfg::PROW;
     static_assert(!OUT8 || (!GN && !RES && TN % 2 == 0), "fp8 output: plain column terms only");
+    static_assert(NSAMP == 1 || (NSAMP == 2 && WM == 1 && TM % 2 == 0 && !DEQ && !OUT8), "two samples per tile: one wave row, bf16 output");
     const int r = lane & 15, q = lane >> 4;
     float dn[DEQ ? TN : 1][4], rsc[DEQ ? TM : 1], rbm[DEQ ? TM : 1];
     if constexpr (DEQ) {
@@ -132,16 +135,23 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
             rbm[i] = g.bias_m ? g.bias_m[m] : 0.f;
         }
     }
-    float ct[TN][4];
+    // (two samples per tile: the row vector differs per sample.  The residual forms never carry one -- Conv_1 of a res-block has no time-embedding
+    // row -- and keep ONE set of column terms: the second set is what tips their 256-register epilogue into dozens of spills)
+    constexpr int NCT = (NSAMP > 1 && !RES) ? NSAMP : 1;
+    float ct[NCT][TN][4];
+#pragma unroll
+    for (int sm = 0; sm < NCT; ++sm)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * TN * 16 + j * 16 + q * 4;
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f), rv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n < g.N) {
             if (g.bias_n) b = *reinterpret_cast<const float4*>(g.bias_n + n);
-            if (g.rowvec) rv = *reinterpret_cast<const float4*>(g.rowvec + (int64_t)((m0 >> g.log_rows_per_sample) + z * g.z_samples) * g.rowvec_ld + n);
+            // (NSAMP == 2: the second sample's row; a last tile that holds one sample reads the first one's again -- those rows are not stored)
+            const int srow = NSAMP > 1 ? min(m0 + sm * (BM_ / NSAMP), g.M - 1) : m0;
+            if (g.rowvec) rv = *reinterpret_cast<const float4*>(g.rowvec + (int64_t)((srow >> g.log_rows_per_sample) + z * g.z_samples) * g.rowvec_ld + n);
         }
-        ct[j][0] = b.x + rv.x; ct[j][1] = b.y + rv.y; ct[j][2] = b.z + rv.z; ct[j][3] = b.w + rv.w;
+        ct[sm][j][0] = b.x + rv.x; ct[sm][j][1] = b.y + rv.y; ct[sm][j][2] = b.z + rv.z; ct[sm][j][3] = b.w + rv.w;
     }
     // bf16 residual, fetched in the accumulator layout (8 bytes per lane: 4 columns of one row), all requests in flight at once
     uint2 rs[RES ? TM : 1][RES ? TN : 1];
@@ -155,16 +165,20 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
                 rs[i][j] = n0 + wn * TN * 16 + j * 16 + q * 4 < g.N ? *reinterpret_cast<const uint2*>(rb + (int64_t)m * g.resid_ld + j * 16) : make_uint2(0u, 0u);
         }
     }
-    float gs[TN], gq[TN];
+    float gs[NSAMP][TN], gq[NSAMP][TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
+    for (int sm = 0; sm < NSAMP; ++sm)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { gs[sm][j] = 0.f; gq[sm][j] = 0.f; }
     const float scale = g.scale;
     // the finished fp32 values of accumulator tile (i, j)
     auto value = [&](int i, int j, float (&v)[4]) __attribute__((always_inline)) {
+        const int sm = NSAMP > 1 ? (i >= TM / 2 ? 1 : 0) : 0;                  // (i is a compile-time constant at every call site)
+        const int sc_ = NCT > 1 ? sm : 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if constexpr (DEQ) v[e] = (acc[i][j][e] * (rsc[i] * dn[j][e]) + ct[j][e]) + rbm[i];
-            else v[e] = acc[i][j][e] + ct[j][e];
+            if constexpr (DEQ) v[e] = (acc[i][j][e] * (rsc[i] * dn[j][e]) + ct[sc_][j][e]) + rbm[i];
+            else v[e] = acc[i][j][e] + ct[sc_][j][e];
         }
         if constexpr (RES) {
             const bf16x4_t x = __builtin_bit_cast(bf16x4_t, rs[i][j]);
@@ -175,8 +189,8 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
         for (int e = 0; e < 4; ++e) v[e] *= scale;
         if constexpr (ACT != ACT_NONE) apply_act4(v, ACT);
         if constexpr (GN) {
-            gs[j] += (v[0] + v[1]) + (v[2] + v[3]);
-            gq[j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            gs[sm][j] += (v[0] + v[1]) + (v[2] + v[3]);
+            gq[sm][j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
         }
     };
     constexpr int EB = OUT8 ? 1 : 2;                   // bytes per output element
@@ -227,10 +241,14 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
         // WM waves of a column through LDS, behind the slab: the same barrier publishes both, and nothing waits for the tile's stores
         // (the reduction used to run after the copy-out, behind two barriers -- each of which drains the outstanding global stores)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) { gs[j] = dpp_row_sum(gs[j]); gq[j] = dpp_row_sum(gq[j]); }
+        for (int sm = 0; sm < NSAMP; ++sm)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { gs[sm][j] = dpp_row_sum(gs[sm][j]); gq[sm][j] = dpp_row_sum(gq[sm][j]); }
         if (r == 0) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) sred[wm * (BN_ / 4) + wn * TN * 4 + j * 4 + q] = make_float2(gs[j], gq[j]);
+            for (int sm = 0; sm < NSAMP; ++sm)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) sred[(NSAMP > 1 ? sm : wm) * (BN_ / 4) + wn * TN * 4 + j * 4 + q] = make_float2(gs[sm][j], gq[sm][j]);
         }
     }
     __syncthreads();
@@ -252,10 +270,17 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
     NATINF_TS(4);
     if constexpr (GN) {
         if (tid < BN_ / 4 && n0 + tid * 4 < g.N) {
-            float s = 0.f, qq = 0.f;
+            if constexpr (NSAMP > 1) {
 #pragma unroll
-            for (int w = 0; w < WM; ++w) { s += sred[w * (BN_ / 4) + tid].x; qq += sred[w * (BN_ / 4) + tid].y; }
-            reinterpret_cast<float2*>(g.gn_part)[(int64_t)(m0 / BM_) * g.gn_quads + (n0 >> 2) + tid] = make_float2(s, qq);
+                for (int sm = 0; sm < NSAMP; ++sm)
+                    if (m0 + sm * (BM_ / NSAMP) < g.M)
+                        reinterpret_cast<float2*>(g.gn_part)[(int64_t)((m0 / BM_) * NSAMP + sm) * g.gn_quads + (n0 >> 2) + tid] = sred[sm * (BN_ / 4) + tid];
+            } else {
+                float s = 0.f, qq = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) { s += sred[w * (BN_ / 4) + tid].x; qq += sred[w * (BN_ / 4) + tid].y; }
+                reinterpret_cast<float2*>(g.gn_part)[(int64_t)(m0 / BM_) * g.gn_quads + (n0 >> 2) + tid] = make_float2(s, qq);
+            }
         }
     }
 }
@@ -516,7 +541,7 @@ __device__ __forceinline__ void direct_f32_epilogue(const GemmArgs& g, f32x4 (&a
 // 7 = the direct fp32 residual-stream epilogue; 8 = packed with row terms (a row bias: the V^T = W h^T + b GEMMs).  One epilogue per kernel: with both in one
 // kernel behind a run-time branch hipcc spilled inside the packed register phase (measured: isolated GEMMs +15..23 %, the
 // network 8 % SLOWER).
-template <int WM, int WN, int TM, int TN, class Cfg, int EPI>
+template <int WM, int WN, int TM, int TN, class Cfg, int EPI, int NSAMP = 1>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, unsigned char* smem, f32x4 (&acc)[TM][TN],
                                               int m0, int n0, int z, int tid, int lane, int wm, int wn)
 {
@@ -525,7 +550,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, unsigned char* 
     else {
         static_assert(Cfg::PACK_OK, "packed epilogue needs the whole bf16 tile in LDS");
         NATINF_TS(2);
-        packed_tile_epilogue<WM, WN, TM, TN, Cfg, EPI == 3 ? ACT_SILU : (EPI == 4 ? ACT_GELU_TANH : ACT_NONE), EPI == 2 || EPI == 6, EPI == 5 || EPI == 6, EPI == 8>(
+        packed_tile_epilogue<WM, WN, TM, TN, Cfg, EPI == 3 ? ACT_SILU : (EPI == 4 ? ACT_GELU_TANH : ACT_NONE), EPI == 2 || EPI == 6, EPI == 5 || EPI == 6, EPI == 8, false, NSAMP>(
             g, smem, acc, m0, n0, z, tid, lane, wm, wn);
     }
 }

@@ -212,12 +212,13 @@ using CfgR256x256 = RingCfg<2, 4, 8, 4, 4>; using CfgR256x128 = RingCfg<4, 2, 4,
 using CfgR128x128 = RingCfg<2, 2, 4, 4, 4>; using CfgR64x128 = RingCfg<2, 2, 2, 4, 4>;
 using CfgR256x128W4 = RingCfg<2, 2, 8, 4, 3>; using CfgD256x128W4 = DmaCfg<2, 2, 8, 4>;
 using CfgD512x128 = DmaCfg<4, 2, 8, 4>;
-using CfgH32 = ConvGn2Cfg<32>; using CfgH16 = ConvGn2Cfg<16>; using CfgH16W = ConvGn2Cfg<16, true>;
+using CfgH32 = ConvGn2Cfg<32>; using CfgH16 = ConvGn2Cfg<16>; using CfgH16W = ConvGn2Cfg<16, true>; using CfgH8W = ConvGn2Cfg<8, true>;
 #ifdef NATINF_DEV
 using CfgP256x256 = PatchCfg<2, 4, 8, 4, 344>; using CfgP256x128 = PatchCfg<4, 2, 4, 4, 400>;
 using CfgG32 = ConvGnCfg<32>; using CfgG16 = ConvGnCfg<16>; using CfgG16W = ConvGnCfg<16, true>;
 #endif
 int g_fuse_head = 1;               // natinf_set_fuse_head (read when a plan is BUILT): GroupNorm + SiLU + the 128 -> 3 output convolution as ONE launch (head_conv.h)
+int g_fuse_gn8 = 1;                // natinf_set_fuse_gn8 (read when a plan is BUILT): the 8x8 level on the fused kernel too (two images per 128-pixel tile)
 int g_fuse_gn = 1;                 // natinf_set_fuse_gn (read when a plan is BUILT): GroupNorm-apply + SiLU inside the consuming 3x3 conv
 
 // Packed-epilogue specializations (EPI, gemm_dma.h) that exist per tile family, as bit masks: a launch whose epilogue is not
@@ -250,7 +251,8 @@ bool set_lds_epi_all() {
 }
 template <int EPI>
 bool set_lds_conv_gn() {
-    return set_lds<CfgH32>(&k_conv_gn2<32, false, EPI>) && set_lds<CfgH16>(&k_conv_gn2<16, false, EPI>) && set_lds<CfgH16W>(&k_conv_gn2<16, true, EPI>)
+    return set_lds<CfgH32>(&k_conv_gn2<32, false, EPI>) && set_lds<CfgH16>(&k_conv_gn2<16, false, EPI>) && set_lds<CfgH16W>(&k_conv_gn2<16, true, EPI>) &&
+           set_lds<CfgH8W>(&k_conv_gn2<8, true, EPI>)
 #ifdef NATINF_DEV
            && set_lds<CfgG32>(&k_conv_gn<32, false, EPI>) && set_lds<CfgG16>(&k_conv_gn<16, false, EPI>) && set_lds<CfgG16W>(&k_conv_gn<16, true, EPI>)
 #endif
@@ -301,19 +303,28 @@ int packed_epi(const GemmArgs& g, int bm);
 int g_cg_wide = 1;
 int g_fuse_up = 1;                 // natinf_set_fuse_up (read when a plan is BUILT): up blocks at 16x16 / 32x32 fetch their input up-sampled inside k_conv_gn2
 int g_cg_regw = 1;                 // natinf_set_conv_gn_regw: 1 = k_conv_gn2 (weights streamed through registers) where GemmArgs::b_frag is given
-inline int conv_gn_bm(const GemmArgs& g) { return (g_cg_wide && (1 << g.logW) == 16 && g.N % 256 == 0) ? 128 : 256; }
+// tile rows of the fused-convolution instantiation a launch takes: 128 x 256 tiles at 16x16 (N % 256 == 0) and at 8x8 (two images per tile), 256 x 128 elsewhere
+inline int conv_gn_bm(const GemmArgs& g) {
+    const int res = 1 << g.logW;
+    return (res == 8 || (g_cg_wide && res == 16 && g.N % 256 == 0)) ? 128 : 256;
+}
+// rows of one GroupNorm-partial table row the launch writes (what the caller divides H*W by): a tile, or one SAMPLE of the two an 8x8 tile holds
+inline int conv_gn_part_rows(const GemmArgs& g) { return (1 << g.logW) == 8 ? 64 : conv_gn_bm(g); }
 inline bool conv_gn_regw(const GemmArgs& g) { return g_cg_regw && g.b_frag && g.N % (conv_gn_bm(g) == 128 ? 256 : 128) == 0; }
 #ifdef NATINF_DEV
 constexpr bool HAVE_CONV_GN_V1 = true;              // k_conv_gn (weights through an LDS ring): superseded, development builds only
 #else
 constexpr bool HAVE_CONV_GN_V1 = false;
 #endif
-// k_conv_gn / k_conv_gn2 have packed epilogues only: the fp32-slab A/B knob (natinf_set_gemm_epilogue) does not apply to them
-inline int conv_gn_epi(const GemmArgs& g) { GemmArgs t = g; t.epi_fp32_slab = 0; return packed_epi(t, conv_gn_bm(g)); }
+// k_conv_gn / k_conv_gn2 have packed epilogues only: the fp32-slab A/B knob (natinf_set_gemm_epilogue) does not apply to them.  Per-sample terms need
+// one sample per tile -- or, at 8x8, per HALF tile (the kernel keeps both samples' row vectors and partials: NSAMP)
+inline int conv_gn_epi(const GemmArgs& g) { GemmArgs t = g; t.epi_fp32_slab = 0; return packed_epi(t, (1 << g.logW) == 8 ? 64 : conv_gn_bm(g)); }
 inline bool conv_gn_ok(const GemmArgs& g) {
-    if (!g.gn_scale || !g.gn_shift || !g.gn_folded || g.taps != 9 || g.batch != 1 || g.a0_C % BK || (g.a1 && g.a1_C % BK) || g.M % 256) return false;
+    if (!g.gn_scale || !g.gn_shift || !g.gn_folded || g.taps != 9 || g.batch != 1 || g.a0_C % BK || (g.a1 && g.a1_C % BK)) return false;
     const int res = 1 << g.logW;
-    if (g.logHW != 2 * g.logW || (res != 32 && res != 16) || g.N % 8) return false;
+    if (g.logHW != 2 * g.logW || (res != 32 && res != 16 && res != 8) || g.N % 8) return false;
+    if (res == 8 ? (g.M % 64 || g.N % 256 || g.a0_up || g.a1_up || !conv_gn_regw(g) || (g.resid && g.rowvec)) : g.M % 256 != 0) return false;      // 8x8: whole images, k_conv_gn2 only;
+    // (its residual epilogues keep one set of column terms for both samples of a tile: no per-sample row vector there)
     if ((g.a0_up || g.a1_up || !HAVE_CONV_GN_V1) && !conv_gn_regw(g)) return false;          // up-sampled fetches: k_conv_gn2 only
     const int e = conv_gn_epi(g);
     return e == 1 || e == 2 || e == 5 || e == 6;
@@ -480,7 +491,7 @@ int launch_gemm(const GemmArgs& g0, hipStream_t s) {
         snprintf(line, sizeof(line), "%d %d %d %d %d %d %s/e%d\n", g.M, g.N, g.taps * g.a0_C, g.a1 ? g.a1_C : 0, g.taps, g.batch, variant_name(v),
                  v == V_CONV_GN ? conv_gn_epi(g) : effective_epi(v, g));
         *g_record += line;
-        return v == V_CONV_GN ? conv_gn_bm(g) : variant_bm(v);
+        return v == V_CONV_GN ? conv_gn_part_rows(g) : variant_bm(v);
     }
     switch (v) {
         case V_GENERIC: {
@@ -527,7 +538,8 @@ int launch_gemm(const GemmArgs& g0, hipStream_t s) {
                 default: launch_tiles<CFG>(&k_conv_gn2<RES, WIDE, 6>, g, s); break;                             \
             }
             if (conv_gn_regw(g)) {
-                if ((1 << g.logW) == 32) { NATINF_CG2_LAUNCH(CfgH32, 32, false) }
+                if ((1 << g.logW) == 8) { NATINF_CG2_LAUNCH(CfgH8W, 8, true) }
+                else if ((1 << g.logW) == 32) { NATINF_CG2_LAUNCH(CfgH32, 32, false) }
                 else if (conv_gn_bm(g) == 128) { NATINF_CG2_LAUNCH(CfgH16W, 16, true) }
                 else { NATINF_CG2_LAUNCH(CfgH16, 16, false) }
             }
@@ -545,7 +557,7 @@ int launch_gemm(const GemmArgs& g0, hipStream_t s) {
             else { NATINF_CG_LAUNCH(CfgG16, 16, false) }
 #undef NATINF_CG_LAUNCH
 #endif
-            return conv_gn_bm(g);
+            return conv_gn_part_rows(g);
         }
         default: break;
     }
@@ -666,9 +678,9 @@ struct Builder {
         // 32x32 or 16x16.  Conv_0 of a resampling block reads a resampled tensor and keeps the k_gn_apply pass (which also
         // produces the resampled shortcut input), Conv_1 is fused there too; the 8x8 / 4x4 levels are unfused.  Folded form: the
         // GroupNorm scale / shift carry -log2(e), the 3x3 weights -ln 2 (GemmArgs::gn_folded).
-        const bool fusable_res = g_fuse_gn && (ro == 32 || ro == 16);
+        const bool fusable_res = g_fuse_gn && (ro == 32 || ro == 16 || (ro == 8 && g_fuse_gn8 && cout % 256 == 0));
         const bool fuse1 = fusable_res && cout % BK == 0;                               // Conv_1
-        const bool fuse_up = fuse1 && g_fuse_up && m.up && cin % BK == 0 && cout % 128 == 0;   // up block: the 2x up-sampling of both branches happens in the fetches
+        const bool fuse_up = fuse1 && ro != 8 && g_fuse_up && m.up && cin % BK == 0 && cout % 128 == 0;   // up block: the 2x up-sampling of both branches happens in the fetches
         const bool fuse = (fusable_res && !m.up && !m.down && cin % BK == 0) || fuse_up;            // Conv_0
         const float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
         const float gn_mul = fuse ? -LOG2E : 1.0f, w_mul = fuse ? -LN2 : 1.0f, gn_mul1 = fuse1 ? -LOG2E : 1.0f, w_mul1 = fuse1 ? -LN2 : 1.0f;
@@ -701,7 +713,7 @@ struct Builder {
         const int SK_MAX = 4;
         const int64_t skws = (ro <= 8) ? arena.alloc((int64_t)SK_MAX * ro * ro * cout * 4) : -1;
         TRef t = new_act(ro, cout);
-        const Part pt = register_output(t);
+        const Part pt = register_output(t, fuse);
         const int logW = ilog2(ro), logHW = 2 * logW, HWo = ro * ro;
         const int dtotal = dense_total; const int64_t dout = dense_out;
         op(fuse ? CLS_CONV_GN : CLS_GEMM, [=](const Ctx& c) {
@@ -730,7 +742,7 @@ struct Builder {
         if (pt.valid) arena.release(pt.off);
         const TRef xs = ((m.up || m.down) && !fuse_up) ? xr : x;           // shortcut source at the output resolution (fuse_up: x itself, fetched up-sampled)
         const float rs = res_scale;
-        const Part po = register_output(out);
+        const Part po = register_output(out, fuse1);
         op(fuse1 ? CLS_CONV_GN : CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
             if (fuse1) { g.a0 = c.act(t); g.a0_ld = t.ld; g.gn_scale = c.at<float>(sc); g.gn_shift = c.at<float>(sh); g.gn_ld = cout; g.gn_folded = 1; }
@@ -922,9 +934,11 @@ struct Builder {
         return p;
     }
     // called for EVERY module output so that a stale table can never be matched to a later tensor at the same place
-    Part register_output(const TRef& out) {
+    // fused8: the producer is the fused convolution at 8x8, whose epilogue writes one partial row per SAMPLE (two per tile); any other producer's
+    // 128-row tiles span two 8x8 samples, and its consumers take the streaming statistics kernel
+    Part register_output(const TRef& out, bool fused8 = false) {
         Part p;
-        if (fusable(out.res)) p = new_part(out.res, out.C);
+        if (fusable(out.res) || (out.res == 8 && fused8)) p = new_part(out.res, out.C);
         parts[{out.off, out.coff}] = p;
         return p;
     }
@@ -1213,10 +1227,10 @@ natinf_ncsnpp* make_engine(int flags) {
 // A/B knobs are set to when they are first asked -- a packed buffer of that size fits every plan.
 const natinf_ncsnpp& reference_engine() {
     static natinf_ncsnpp* e = [] {
-        const int fg = g_fuse_gn, fu = g_fuse_up, fh = g_fuse_head;
-        g_fuse_gn = 1; g_fuse_up = 1; g_fuse_head = 1;
+        const int fg = g_fuse_gn, fu = g_fuse_up, fh = g_fuse_head, f8 = g_fuse_gn8;
+        g_fuse_gn = 1; g_fuse_up = 1; g_fuse_head = 1; g_fuse_gn8 = 1;
         natinf_ncsnpp* r = make_engine(0);
-        g_fuse_gn = fg; g_fuse_up = fu; g_fuse_head = fh;
+        g_fuse_gn = fg; g_fuse_up = fu; g_fuse_head = fh; g_fuse_gn8 = f8;
         return r;
     }();
     return *e;
@@ -1385,7 +1399,7 @@ int natinf_debug_conv_gn_up(int flags) { if (flags & ~3) return NATINF_EINVAL; g
 int natinf_debug_conv_gn(int res, int B, int N, int cin, int c1, const void* x, const float* scale, const float* shift, const void* w_packed,
                          void* w_frag, const void* a1, const float* bias_n, const void* resid, float out_scale, void* out, float* gn_part, int iters,
                          natinf_stream_t stream) {
-    if ((res != 32 && res != 16) || B <= 0 || N <= 0 || N % 8 || cin <= 0 || cin % 64 || c1 < 0 || c1 % 64 || (c1 > 0) != (a1 != nullptr) ||
+    if ((res != 32 && res != 16 && res != 8) || B <= 0 || N <= 0 || N % 8 || cin <= 0 || cin % 64 || c1 < 0 || c1 % 64 || (c1 > 0) != (a1 != nullptr) ||
         !x || !scale || !shift || !w_packed || !out || iters <= 0) return NATINF_EINVAL;
     static bool configured = false;
     if (!configured) { if (!configure_gemm_kernels()) return NATINF_ENODEV; configured = true; }
@@ -1439,6 +1453,7 @@ int natinf_debug_timestamps(void* dev_buf16) {
 
 int natinf_set_gemm_raster(int rows) { g_raster_g = rows; return NATINF_OK; }
 int natinf_set_fuse_gn(int on) { g_fuse_gn = on != 0; return NATINF_OK; }
+int natinf_set_fuse_gn8(int on) { g_fuse_gn8 = on != 0; return NATINF_OK; }
 int natinf_set_fuse_head(int on) { g_fuse_head = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_wide(int on) { g_cg_wide = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_regw(int on) {

@@ -230,7 +230,8 @@ def test_fused_and_split_k_plans_against_the_unfused_plan(dev, flat, golden_dir)
     assert _rel(base[:2].cpu(), ref) <= TOL
     outs = {}
     assert any(r[6].startswith("head_conv") for r in _describe_gemms(base_eng, 64))
-    for name, setter in (("fuse_gn", lib.natinf_set_fuse_gn), ("fuse_up", lib.natinf_set_fuse_up), ("fuse_head", lib.natinf_set_fuse_head)):
+    for name, setter in (("fuse_gn", lib.natinf_set_fuse_gn), ("fuse_up", lib.natinf_set_fuse_up), ("fuse_head", lib.natinf_set_fuse_head),
+                         ("fuse_gn8", lib.natinf_set_fuse_gn8)):
         try:
             assert setter(0) == 0
             eng = NCSNppEngine(flat, max_batch=64, device=dev)          # the switch is read when the plan is built
@@ -241,6 +242,9 @@ def test_fused_and_split_k_plans_against_the_unfused_plan(dev, flat, golden_dir)
             assert not any(r[6].startswith("conv_gn") for r in rows)
         if name == "fuse_head":
             assert not any(r[6].startswith("head_conv") for r in rows)
+        if name == "fuse_gn8":                                       # without it the 8x8 level is back on the LDS-DMA implicit GEMM
+            n8 = lambda rr: sum(1 for r in rr if r[6].startswith("conv_gn") and int(r[0]) == 64 * 64)
+            assert n8(rows) == 0 and n8(_describe_gemms(base_eng, 64)) >= 18
         outs[name] = eng(xd, ld).clone()
     try:
         assert lib.natinf_set_gemm_splitk(0) == 0

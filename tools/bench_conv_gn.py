@@ -15,7 +15,7 @@ def run(res, B, cin, N, c1, iters=20):
     w = (torch.randn(N, 9 * cin + c1, device=dev) / (9 * cin) ** 0.5).bfloat16()
     a1 = torch.randn(M, c1, device=dev).bfloat16() if c1 else None
     bias = torch.randn(N, device=dev); out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    part = torch.zeros(M // 256, N // 4, 2, device=dev)
+    part = torch.zeros(M // 64, N // 4, 2, device=dev)          # (one row per tile; per 64-pixel sample at res 8)
     wf = torch.zeros_like(w) if os.environ.get('REGW', '1') != '0' else None
     args = (res, B, N, cin, c1, ptr(x), ptr(sc), ptr(sh), ptr(w), ptr(wf), ptr(a1), ptr(bias), None, 0.7071, ptr(out), ptr(part))
     check(lib.natinf_debug_conv_gn(*args, 3, stream_ptr()), "warm")
@@ -30,5 +30,5 @@ if len(sys.argv) > 1:
     run(*a)
 else:
     for spec in ((32, 512, 128, 128, 0), (32, 512, 256, 128, 0), (32, 512, 128, 128, 256), (32, 512, 384, 128, 0), (16, 512, 256, 256, 0),
-                 (16, 512, 512, 256, 0), (16, 512, 256, 256, 512), (16, 512, 128, 256, 0)):
+                 (16, 512, 512, 256, 0), (16, 512, 256, 256, 512), (16, 512, 128, 256, 0), (8, 512, 256, 256, 0), (8, 512, 512, 256, 0), (8, 512, 256, 256, 256)):
         run(*spec)
