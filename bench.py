@@ -54,7 +54,7 @@ def ni_step_bytes_per_element(C, s_x=4, s_h=8):
     return out
 
 
-def profiled_traffic(match):
+def profiled_traffic(match, exclude=None):
     """HBM bytes per launch from the newest committed rocprofv3 PMC summary (profiles/rNN/*_hbm_traffic.json:
     separate FETCH_SIZE / WRITE_SIZE passes over this very command, gfx950 x2 read correction applied by
     tools/summarize_profile.py).  bench.py cannot run rocprofv3 itself; returns None when no summary exists."""
@@ -62,7 +62,7 @@ def profiled_traffic(match):
     if not files:
         return None, None
     tab = json.loads(files[-1].read_text())
-    rows = [v for k, v in tab.items() if match in k]
+    rows = [v for k, v in tab.items() if match in k and not (exclude and exclude in k)]
     n = sum(v["launches"] for v in rows)
     if not n:
         return None, None
@@ -282,37 +282,50 @@ def bench_cifar(args, world, rank, dev):
         gemm_ms, gemm_n = prof["gemm"]
         other_ms, other_n = prof["other"]
         cg_ms, cg_n = prof["conv_gn"]
+        c8_ms, c8_n = prof["conv_gn8"]
         fwd = args.steps * n_step
         # algorithmic flops per launch family: 2*M*N*K of every matmul-shaped launch the plan issues at this batch
         # (natinf_ncsnpp_describe_gemms); their sum is the 21.69 GFLOP / image / forward of SURVEY section 8d
         rows = engine.describe_gemms(Bz)
         fl = lambda r: 2.0 * r[0] * r[1] * (r[2] + r[3]) * r[5]
-        cg_rows = [r for r in rows if r[6].startswith("conv_gn")]
+        is8 = lambda r: r[0] == Bz * 64                                           # the 8x8 level: 64 pixels per image
+        cg_rows = [r for r in rows if r[6].startswith("conv_gn") and not is8(r)]
+        c8_rows = [r for r in rows if r[6].startswith("conv_gn") and is8(r)]
         cg_flops = sum(fl(r) for r in cg_rows) * fwd
-        gemm_flops = GFLOP_PER_IMAGE_FORWARD * 1e9 * Bz * fwd - cg_flops          # the rest: the k_gemm_* launches and the fused attention
+        c8_flops = sum(fl(r) for r in c8_rows) * fwd
+        gemm_flops = GFLOP_PER_IMAGE_FORWARD * 1e9 * Bz * fwd - cg_flops - c8_flops          # the rest: the k_gemm_* launches, the fused attention, the head
+        all_ms = cg_ms + c8_ms + gemm_ms + other_ms
         ach = cg_flops / (cg_ms * 1e-3) / 1e12
-        tr_cg, tr_src = profiled_traffic("k_conv_gn")
+        tr_cg, tr_src = profiled_traffic("k_conv_gn", exclude="k_conv_gn2<8")
         line["roofline"] = {
-            "kernel": "k_conv_gn2 (3x3 convolution with GroupNorm-apply + SiLU fused into its operand path, weights streamed through registers; the dominant kernel: "
-                      f"{100 * cg_ms / (cg_ms + gemm_ms + other_ms):.0f} % of the engine's device time)", "bound": "mfma",
+            "kernel": "k_conv_gn2<32 | 16, ...> (3x3 convolution with GroupNorm-apply + SiLU fused into its operand path, weights streamed through registers; the 32x32 and "
+                      f"16x16 levels: the dominant kernel, {100 * cg_ms / all_ms:.0f} % of the engine's device time; its 8x8 instantiation: roofline_conv_gn8)", "bound": "mfma",
             "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-            "traffic": tr_cg, "traffic_source": tr_src, "launches": int(cg_n), "mean_launch_ms": round(cg_ms / cg_n, 5),
+            "traffic": tr_cg, "traffic_source": tr_src, "traffic_note": "HBM bytes per launch from the committed rocprofv3 PMC summary named in traffic_source (the same launches), not measured by this run",
+            "launches": int(cg_n), "mean_launch_ms": round(cg_ms / cg_n, 5),
             "flops_per_launch": cg_flops / cg_n, "device_ms_total": round(cg_ms, 3),
             "ms_per_step_instrumented": round(dt_inst / args.steps * 1e3, 3),
         }
+        if c8_n:
+            ach8 = c8_flops / (c8_ms * 1e-3) / 1e12
+            line["roofline_conv_gn8"] = {
+                "kernel": "k_conv_gn2<8, true, ...> (the same fused kernel on the 8x8 level: two whole images per 128-pixel x 256-channel tile, one block per CU at "
+                          f"B = 512; {100 * c8_ms / all_ms:.0f} % of the engine's device time)", "bound": "mfma", "achieved": round(ach8, 2),
+                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach8 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "launches": int(c8_n),
+                "mean_launch_ms": round(c8_ms / c8_n, 5), "flops_per_launch": c8_flops / c8_n, "device_ms_total": round(c8_ms, 3)}
         ach_g = gemm_flops / (gemm_ms * 1e-3) / 1e12
         tr_gemm, tr_src_g = profiled_traffic("k_gemm")
         line["roofline_gemm"] = {
-            "kernel": "k_gemm_* (LDS-DMA implicit-GEMM tile variants: resampling-block / 8x8 / 4x4 convolutions, NIN, linear) + k_attn_fused",
+            "kernel": "k_gemm_* (LDS-DMA implicit-GEMM tile variants: resampling-block / 4x4 convolutions, NIN, linear) + k_attn_fused + k_head_conv",
             "bound": "mfma", "achieved": round(ach_g, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach_g / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": tr_gemm, "traffic_source": tr_src_g, "launches": int(gemm_n),
             "mean_launch_ms": round(gemm_ms / gemm_n, 5), "flops_per_launch": gemm_flops / gemm_n, "device_ms_total": round(gemm_ms, 3),
             "other_kernels_device_ms": round(other_ms, 3), "other_launches": int(other_n),
         }
         line["roofline_whole_denoiser"] = {
-            "bound": "mfma", "achieved": round((cg_flops + gemm_flops) / ((cg_ms + gemm_ms + other_ms) * 1e-3) / 1e12, 2),
+            "bound": "mfma", "achieved": round((cg_flops + c8_flops + gemm_flops) / (all_ms * 1e-3) / 1e12, 2),
             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round((cg_flops + gemm_flops) / ((cg_ms + gemm_ms + other_ms) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "frac": round((cg_flops + c8_flops + gemm_flops) / (all_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "note": "all matmul flops of the forward / device time of ALL its kernels (normalisation, statistics, softmax included)"}
         bpe = ni_step_bytes_per_element(C)
         tot_ms = sum(a0.elapsed_time(a1) for _, a0, a1 in ev)

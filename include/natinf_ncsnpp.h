@@ -154,10 +154,10 @@ int natinf_debug_timestamps(void* dev_buf16);
  * pair on `stream`.  natinf_ncsnpp_profile_read waits for the recorded events and returns, per class
  * (0 = the implicit-GEMM kernels k_gemm_*: unfused convolutions / NIN / linear / attention products;
  * 1 = everything else: GroupNorm statistics + apply, softmax, embedding, stem im2col;
- * 2 = k_conv_gn: the 3x3 convolutions with GroupNorm-apply + SiLU fused into their operand path), the summed
- * device time in milliseconds and the number of launches since the previous read. */
+ * 2 = k_conv_gn2 at 32x32 / 16x16: the 3x3 convolutions with GroupNorm-apply + SiLU fused into their operand path;
+ * 3 = its 8x8 instantiation, two images per tile), the summed device time in milliseconds and the number of launches since the previous read. */
 int natinf_ncsnpp_profile(natinf_ncsnpp_t h, int enable);
-int natinf_ncsnpp_profile_read(natinf_ncsnpp_t h, double* ms_by_class /*[3]*/, int64_t* launches_by_class /*[3]*/);
+int natinf_ncsnpp_profile_read(natinf_ncsnpp_t h, double* ms_by_class /*[4]*/, int64_t* launches_by_class /*[4]*/);
 
 /* After a forward on a KEEP_ACTIVATIONS handle: copy the output of all_modules[module_idx]
  * (module_idx >= 2) as fp32 NCHW into `out` (capacity in elements).  Same B / workspace as the forward. */

@@ -69,7 +69,7 @@ struct Ctx {                     // per-forward launch context
     template <class T> const T* w(int64_t off) const { return reinterpret_cast<const T*>(wp + off); }
 };
 using OpFn = std::function<void(const Ctx&)>;
-enum { CLS_GEMM = 0, CLS_OTHER = 1, CLS_CONV_GN = 2, N_CLS = 3 };      // CLS_CONV_GN: launches of the fused GroupNorm + SiLU + 3x3 conv kernel
+enum { CLS_GEMM = 0, CLS_OTHER = 1, CLS_CONV_GN = 2, CLS_CONV_GN8 = 3, N_CLS = 4 };      // CLS_CONV_GN: launches of the fused GroupNorm + SiLU + 3x3 conv kernel at 32x32 / 16x16; CLS_CONV_GN8: its 8x8 instantiation
 
 struct PackCtx { const float* params; unsigned char* packed; hipStream_t stream; };
 using PackFn = std::function<void(const PackCtx&)>;
@@ -716,7 +716,7 @@ struct Builder {
         const Part pt = register_output(t, fuse);
         const int logW = ilog2(ro), logHW = 2 * logW, HWo = ro * ro;
         const int dtotal = dense_total; const int64_t dout = dense_out;
-        op(fuse ? CLS_CONV_GN : CLS_GEMM, [=](const Ctx& c) {
+        op(fuse ? (ro == 8 ? CLS_CONV_GN8 : CLS_CONV_GN) : CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
             if (fuse) { g.a0 = c.act(x); g.a0_ld = x.ld; g.gn_scale = c.at<float>(sc); g.gn_shift = c.at<float>(sh); g.gn_ld = cin; g.gn_folded = 1; g.a0_up = fuse_up; }
             else { g.a0 = c.act(h); g.a0_ld = h.ld; g.a0_padded = 1; }
@@ -743,7 +743,7 @@ struct Builder {
         const TRef xs = ((m.up || m.down) && !fuse_up) ? xr : x;           // shortcut source at the output resolution (fuse_up: x itself, fetched up-sampled)
         const float rs = res_scale;
         const Part po = register_output(out, fuse1);
-        op(fuse1 ? CLS_CONV_GN : CLS_GEMM, [=](const Ctx& c) {
+        op(fuse1 ? (ro == 8 ? CLS_CONV_GN8 : CLS_CONV_GN) : CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
             if (fuse1) { g.a0 = c.act(t); g.a0_ld = t.ld; g.gn_scale = c.at<float>(sc); g.gn_shift = c.at<float>(sh); g.gn_ld = cout; g.gn_folded = 1; }
             else { g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_padded = 1; }
@@ -1329,7 +1329,7 @@ int natinf_ncsnpp_describe_gemms(natinf_ncsnpp_t h, int B, char* buf, int cap) {
     // (a non-null fake workspace base: launches are only described, but "is this pointer set" decides the kernel variant)
     Ctx c{B, reinterpret_cast<unsigned char*>(4096), reinterpret_cast<const unsigned char*>(4096), nullptr, nullptr, nullptr, nullptr, scratch_bm.data()};
     for (size_t i = 0; i < h->ops.size(); ++i)
-        if (h->op_cls[i] == CLS_GEMM || h->op_cls[i] == CLS_CONV_GN) h->ops[i](c);          // GEMM ops only compute pointers and call launch_gemm
+        if (h->op_cls[i] == CLS_GEMM || h->op_cls[i] == CLS_CONV_GN || h->op_cls[i] == CLS_CONV_GN8) h->ops[i](c);          // GEMM ops only compute pointers and call launch_gemm
     g_record = nullptr;
     if ((int)out.size() + 1 > cap) return NATINF_EINVAL;
     memcpy(buf, out.c_str(), out.size() + 1);

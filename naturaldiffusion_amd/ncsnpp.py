@@ -166,11 +166,11 @@ class NCSNppEngine:
         check(lib.natinf_ncsnpp_profile(self._h, 1 if enable else 0), "natinf_ncsnpp_profile")
 
     def profile_read(self):
-        """-> {"gemm": (ms, launches), "other": (...), "conv_gn": (...)} since the last read (synchronises)."""
-        ms = (C.c_double * 3)()
-        n = (C.c_int64 * 3)()
+        """-> {"gemm": (ms, launches), "other": (...), "conv_gn": (...), "conv_gn8": (...)} since the last read (synchronises)."""
+        ms = (C.c_double * 4)()
+        n = (C.c_int64 * 4)()
         check(lib.natinf_ncsnpp_profile_read(self._h, ms, n), "natinf_ncsnpp_profile_read")
-        return {"gemm": (ms[0], n[0]), "other": (ms[1], n[1]), "conv_gn": (ms[2], n[2])}
+        return {"gemm": (ms[0], n[0]), "other": (ms[1], n[1]), "conv_gn": (ms[2], n[2]), "conv_gn8": (ms[3], n[3])}
 
     def describe_gemms(self, B: int):
         """[(M, N, K0, K1, taps, batch, "variant/eN")] of every matmul-shaped launch of a forward at batch B, in launch order."""
