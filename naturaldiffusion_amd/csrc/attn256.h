@@ -1,0 +1,157 @@
+// attn256.h -- k_attn256: the 16x16 self-attention of NCSN++ / ddpm (256 tokens, ONE head of 256 channels; reference AttnBlockpp,
+// layerspp.py:75-91: softmax(q k^T / sqrt(C)) v) with K and V^T STREAMED through LDS.
+//
+// k_attn_fused<8,16,true> (attn_fused.h) kept the whole K (128 KB) and then the whole V^T of a sample in LDS: one 512-thread block per CU,
+// every phase -- load K, barrier, scores, barrier, load V^T, barrier, P V -- alone on its CU with nothing to overlap it: 94 us per launch at
+// B = 512 for 8 us worth of MFMAs (14 % of the matrix peak).  Here
+//   * a block = 128 queries of one sample (4 waves x 32 queries; two blocks per sample), 64 KB of LDS, 256 registers: TWO blocks per CU;
+//   * K and V^T arrive in tiles of 64 keys ([64][256] / [256][64] bf16 = 32 KB each) by direct global->LDS DMA into a two-stage ring,
+//     tile i+1 in flight while tile i is multiplied: four K tiles (scores), then four V^T tiles (P V), one barrier per tile;
+//   * all 256 scores of a query stay in registers (128 per lane), so the softmax is the exact two-pass one -- no online rescaling --
+//     and runs while the first V^T tile is in flight;
+//   * S^T = K Q^T with the K rows of score tile (2c + h) taken in the order key = 32c + 8(r >> 2) + 4h + (r & 3) (flash_attn.h's trick):
+//     the lane's values of tiles 2c and 2c+1 are keys 32c + 8q .. 32c + 8q + 7, exactly the 16 bytes its V^T fragment read covers -- V^T
+//     needs no permutation and P never leaves the registers.
+//   LDS swizzles (chunk index XOR row hash, applied on the DMA source address and on the fragment read): K rows are 512 B (every row starts on
+//   the same bank): hash = (row & 3) | ((row >> 3) & 3) << 2, which is the lane's row number r for the permuted rows a fragment reads -- 16
+//   distinct 16-byte positions per ds_read_b128 lane group; V^T rows are 128 B: hash = (row >> 1) & 7 (flash_attn.h).
+#pragma once
+#include "ncsnpp_kernels.h"
+
+namespace ncsn {
+
+constexpr int A256_T = 256, A256_D = 256, A256_KT = 64, A256_STAGE = 32768, A256_LDS_BYTES = 2 * A256_STAGE;
+
+// qk: [B*256][qk_ld] bf16, q at column 0, k at column k_off; vT: [B][256 channels][256 tokens]; o: [B*256][o_ld].  grid = 2 B, 256 threads.
+__global__ __launch_bounds__(256, 2) void k_attn256(const bf16* __restrict__ qk, int qk_ld, int k_off, const bf16* __restrict__ vT,
+                                                    bf16* __restrict__ o, int o_ld, float scale)
+{
+    constexpr int T = A256_T, KT = A256_KT, NKT = T / KT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x >> 1, qhalf = blockIdx.x & 1;
+    const bf16* qbase = qk + (int64_t)b * T * qk_ld;
+    const bf16* kbase = qbase + k_off;
+    const bf16* vbase = vT + (int64_t)b * A256_D * T;
+
+    // tile i of the stream: i < 4: K rows [64 i, 64 i + 64) x 256 channels; i >= 4: V^T rows (channels) 0..255 x keys [64 (i - 4), + 64)
+    // per wave and tile 8 DMA pieces of 1 KiB: K: 2 rows x 512 B per piece (lane l: row 2p + (l >> 5), chunk l & 31); V^T: 8 rows x 128 B
+    auto issue = [&](int i) __attribute__((always_inline)) {
+        unsigned char* st = smem + (i & 1) * A256_STAGE;
+        int l;                                           // the lane id, recomputed per call: with every loop unrolled hipcc would otherwise keep the 16 per-lane
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));      // addresses of all eight tiles alive (22 spilled registers)
+        if (i < NKT) {
+            const bf16* base = kbase + (int64_t)(i * KT) * qk_ld;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = wave * 8 + j, row = 2 * p + (l >> 5), ch = l & 31;
+                const int h = (row & 3) | (((row >> 3) & 3) << 2);
+                __builtin_amdgcn_global_load_lds(base + row * qk_ld + ((ch ^ h) << 3), (lds_void*)(st + p * 1024), 16, 0, 0);
+            }
+        } else {
+            const bf16* base = vbase + (i - NKT) * KT;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = wave * 8 + j, d = 8 * p + (l >> 3), ch = l & 7;
+                __builtin_amdgcn_global_load_lds(base + d * T + ((ch ^ ((d >> 1) & 7)) << 3), (lds_void*)(st + p * 1024), 16, 0, 0);
+            }
+        }
+    };
+    issue(0);
+
+    // the wave's 32 queries as B operands: query (16 g + r), channels 32 c + 8 q .. + 7
+    bf16x8 qf[2][8];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            qf[g][c] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)(qhalf * 128 + wave * 32 + 16 * g + r) * qk_ld + 32 * c + 8 * q);
+
+    f32x4 acc[2][16];                                   // score tile t = 4 kt + tl: keys 64 kt + 32 (tl >> 1) + 8 q' + 4 (tl & 1) + i  (q' = lane >> 4)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { acc[0][t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int krow = 8 * (r >> 2) + (r & 3);            // (its swizzle hash is r)
+
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt has landed (the compiler does not track LDS-DMA completions)
+        __syncthreads();                                   // ... for every wave, and everyone is done with the stage tile kt + 1 goes into
+        issue(kt + 1);                                     // (kt + 1 == 4: the first V^T tile)
+        const unsigned char* sK = smem + (kt & 1) * A256_STAGE;
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int row = 32 * (tl >> 1) + 4 * (tl & 1) + krow;
+                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(sK + row * 512 + (((4 * c + q) ^ r) << 4));
+                acc[0][4 * kt + tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, qf[0][c], acc[0][4 * kt + tl], 0, 0, 0);
+                acc[1][4 * kt + tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, qf[1][c], acc[1][4 * kt + tl], 0, 0, 0);
+            }
+    }
+
+    // exact softmax over the 256 keys of each query: the lane's 64 values + the three other lanes of its query column
+    float inv[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mx = fmaxf(mx, acc[g][t][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float p = __expf((acc[g][t][i] - mx) * scale); acc[g][t][i] = p; sum += p; }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        inv[g] = 1.0f / sum;
+        __builtin_amdgcn_sched_barrier(0);               // one query group at a time: interleaved, the two exp chains and the packing overflow 256 registers
+    }
+    bf16x8 pf[2][8];                                    // P as the B operand of O^T = V^T P^T, 32-key chunk c: keys 32 c + 8 q .. + 7
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { pf[g][c][i] = (bf16)(acc[g][2 * c][i] * inv[g]); pf[g][c][4 + i] = (bf16)(acc[g][2 * c + 1][i] * inv[g]); }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 oacc[2][16];
+#pragma unroll
+    for (int dt = 0; dt < 16; ++dt) { oacc[0][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc[1][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int vt = 0; vt < NKT; ++vt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (vt + 1 < NKT) issue(NKT + vt + 1);
+        const unsigned char* sV = smem + ((NKT + vt) & 1) * A256_STAGE;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)                  // the tile's two 32-key chunks: P chunk 2 vt + cc
+#pragma unroll
+            for (int dt = 0; dt < 16; ++dt) {
+                const bf16x8 fv = *reinterpret_cast<const bf16x8*>(sV + (16 * dt + r) * 128 + (((4 * cc + q) ^ (r >> 1)) << 4));
+                oacc[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pf[0][2 * vt + cc], oacc[0][dt], 0, 0, 0);
+                oacc[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pf[1][2 * vt + cc], oacc[1][dt], 0, 0, 0);
+            }
+    }
+    // O^T's layout: a lane holds 4 consecutive channels (16 dt + 4 q + i) of query (16 g + r): 8-byte stores
+    int lane_e;                                          // lane id recomputed: r / q of the prologue would otherwise be kept alive through both MFMA phases
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int re = lane_e & 15, qe = lane_e >> 4;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt) {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = (bf16)oacc[g][dt][i];
+            *reinterpret_cast<bf16x4*>(o + ((int64_t)b * T + qhalf * 128 + wave * 32 + 16 * g + re) * o_ld + 16 * dt + 4 * qe) = w;
+        }
+}
+
+}  // namespace ncsn

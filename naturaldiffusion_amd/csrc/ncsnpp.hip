@@ -37,6 +37,7 @@
 #endif
 #include "gemm_fp8.h"
 #include "attn_fused.h"
+#include "attn256.h"
 #include "flash_attn.h"
 
 using namespace ncsn;
@@ -218,6 +219,7 @@ using CfgP256x256 = PatchCfg<2, 4, 8, 4, 344>; using CfgP256x128 = PatchCfg<4, 2
 using CfgG32 = ConvGnCfg<32>; using CfgG16 = ConvGnCfg<16>; using CfgG16W = ConvGnCfg<16, true>;
 #endif
 int g_fuse_head = 1;               // natinf_set_fuse_head (read when a plan is BUILT): GroupNorm + SiLU + the 128 -> 3 output convolution as ONE launch (head_conv.h)
+int g_attn256 = 1;                 // natinf_set_attn256: 1 = k_attn256 (K / V^T streamed through a two-stage LDS ring, two blocks per CU), 0 = k_attn_fused<8,16,true>
 int g_fuse_gn8 = 1;                // natinf_set_fuse_gn8 (read when a plan is BUILT): the 8x8 level on the fused kernel too (two images per 128-pixel tile)
 int g_fuse_gn = 1;                 // natinf_set_fuse_gn (read when a plan is BUILT): GroupNorm-apply + SiLU inside the consuming 3x3 conv
 
@@ -281,6 +283,7 @@ bool configure_gemm_kernels() {
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 2>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 2>) &&
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 3>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 3>) &&
          set_lds<AttnCfg<8, 16, true>>(&k_attn_fused<8, 16, true>) &&
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
          set_lds<AttnCfg<2, 4>>(&k_attn_fused<2, 4>) && set_lds<AttnCfg<3, 6>>(&k_attn_fused<3, 6>) &&
          set_lds<AttnCfg<3, 5>>(&k_attn_fused<3, 5>) &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess;
@@ -807,6 +810,10 @@ struct Builder {
                 using Cfg = AttnCfg<8, 16, true>;
                 auto kern = &k_attn_fused<8, 16, true>;
                 if (g_record) return;                    // natinf_ncsnpp_describe_gemms: GEMM launches only, nothing touches memory
+                if (g_attn256)
+                    hipLaunchKernelGGL(k_attn256, dim3((unsigned)(2 * c.B)), dim3(256), A256_LDS_BYTES, c.stream, c.at<bf16>(qk), 2 * C, C, c.at<bf16>(vT), c.act(O), C,
+                                       1.0f / sqrtf((float)C));
+                else
                 hipLaunchKernelGGL(kern, dim3((unsigned)c.B), dim3(Cfg::THREADS), Cfg::LDS_BYTES, c.stream, c.at<bf16>(qk), 2 * C, C,
                                    c.at<bf16>(vT), c.act(O), C, 1, C, 1.0f / sqrtf((float)C));
             });
@@ -1454,6 +1461,7 @@ int natinf_debug_timestamps(void* dev_buf16) {
 int natinf_set_gemm_raster(int rows) { g_raster_g = rows; return NATINF_OK; }
 int natinf_set_fuse_gn(int on) { g_fuse_gn = on != 0; return NATINF_OK; }
 int natinf_set_fuse_gn8(int on) { g_fuse_gn8 = on != 0; return NATINF_OK; }
+int natinf_set_attn256(int on) { g_attn256 = on != 0; return NATINF_OK; }
 int natinf_set_fuse_head(int on) { g_fuse_head = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_wide(int on) { g_cg_wide = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_regw(int on) {
