@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256, 2) void k_attn256(const bf16* __restrict__ qk,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt has landed (the compiler does not track LDS-DMA completions)
         __syncthreads();                                   // ... for every wave, and everyone is done with the stage tile kt + 1 goes into
         issue(kt + 1);                                     // (kt + 1 == 4: the first V^T tile)
+        __builtin_amdgcn_sched_barrier(0);                 // the requests go out BEFORE this tile's MFMAs: hipcc otherwise sinks them to the end of the tile, right in front of the wait
         const unsigned char* sK = smem + (kt & 1) * A256_STAGE;
 #pragma unroll
         for (int tl = 0; tl < 4; ++tl)
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256, 2) void k_attn256(const bf16* __restrict__ qk,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (vt + 1 < NKT) issue(NKT + vt + 1);
+        __builtin_amdgcn_sched_barrier(0);
         const unsigned char* sV = smem + ((NKT + vt) & 1) * A256_STAGE;
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc)                  // the tile's two 32-key chunks: P chunk 2 vt + cc
