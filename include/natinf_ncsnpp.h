@@ -143,6 +143,9 @@ int natinf_set_fuse_gn8(int on);
 /* 1 (default): the 16x16 attention (256 tokens, one head of 256 channels) runs as k_attn256 -- K and V^T streamed through a two-stage LDS ring by
  * LDS-DMA, two blocks per CU; 0: k_attn_fused<8,16,true> (whole K, then whole V^T, resident in LDS; one block per CU). */
 int natinf_set_attn256(int on);
+/* Tile of the fused kernel on the 8x8 level: 1 (default) = 64 pixels x 256 channels (one image per tile, wave tile 64 x 64, two blocks per CU at
+ * B = 512), 0 = 128 x 256 (two images per tile, one block per CU). */
+int natinf_set_conv_gn8_tile(int one_image);
 /* 1 (default): small-M, long-K launches (the 8x8 and 4x4 levels) run as 128 x 128 tiles x 2..4 K slices + a reduce pass; 0: never. */
 int natinf_set_gemm_splitk(int on);
 /* natinf_debug_gemm / natinf_debug_gemm_fused with variant 0 may split K when given a workspace of max_slices * M * N floats

@@ -66,6 +66,7 @@ SIGNATURES = {
     "natinf_set_fuse_head": (C.c_int, [_i32]),
     "natinf_set_fuse_gn8": (C.c_int, [_i32]),
     "natinf_set_attn256": (C.c_int, [_i32]),
+    "natinf_set_conv_gn8_tile": (C.c_int, [_i32]),
     "natinf_set_gemm_splitk": (C.c_int, [_i32]),
     "natinf_debug_set_splitk_workspace": (C.c_int, [_p, _i32]),
     "natinf_debug_conv_gn": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _f32, _p, _p, _i32, _p]),

@@ -49,11 +49,14 @@ template <int RES> struct PatchGeo2 { static constexpr int W = RES, WP = RES + 2
 // rows so that a 16-row DMA piece never straddles two images -- its own (scale | shift) table, its own row of the time-embedding vector and its
 // own GroupNorm partials (tile_epilogue's NSAMP); a 16-pixel row-tile is two image rows, which the per-lane fragment bases absorb.  Swizzle key
 // for 10-pixel patch rows: xx & 2 (searched over every 2 x 8 window and ds_read_b128 lane group: conflict-free; bit 2 of the column is not).
-template <int RES, bool WIDE_ = false>
+// TM_ = 4 (RES = 8 only): 64-pixel x 256-channel tiles -- ONE image per tile, wave tile 64 x 64 -- so that the 8x8 level launches two blocks per CU
+// (512 tiles at B = 512) instead of one; a normalisation round (eight elements per lane) then spans TWO taps of four MFMA groups.
+template <int RES, bool WIDE_ = false, int TM_ = 8>
 struct ConvGn2Cfg {
     using Geo = PatchGeo2<RES>;
     static constexpr bool WIDE = WIDE_;
-    static constexpr int WM = WIDE ? 1 : 2, WN = WIDE ? 4 : 2, TM = 8, TN = 4, NW = 4, THREADS = 256, KT = 32;
+    static constexpr int WM = WIDE ? 1 : 2, WN = WIDE ? 4 : 2, TM = TM_, TN = 4, NW = 4, THREADS = 256, KT = 32;
+    static_assert(TM_ == 8 || (TM_ == 4 && RES == 8 && WIDE_), "the 4-row-tile form exists for the 8x8 level only");
     static constexpr int BM_ = WM * TM * 16, BN_ = WN * TN * 16;
     static constexpr int NIMG = RES * RES >= BM_ ? 1 : BM_ / (RES * RES);   // whole images per tile (RES = 8: 2)
     static constexpr int IMGP = NIMG > 1 ? ((RES + 2) * (RES + 2) + 15) / 16 * 16 : 0;      // patch rows per image when a tile holds several
@@ -70,7 +73,8 @@ struct ConvGn2Cfg {
     static constexpr int LDS_BYTES = TILES_BYTES > EPI_BYTES ? TILES_BYTES : EPI_BYTES;
     static constexpr int swz_key(int xx) { return RES == 8 ? (xx & 2) : ((xx >> 1) & 2); }
     static_assert(RES * RES % BM_ == 0 || (BM_ % (RES * RES) == 0 && WM == 1 && NIMG == 2), "a tile lies inside one image, or holds two whole images");
-    static_assert(NROUND <= 7, "the rounds run behind taps 2..8");
+    static constexpr int TAPS_PER_ROUND = 8 / TM;                       // a round = eight elements per lane, one per MFMA group
+    static_assert(NROUND * TAPS_PER_ROUND <= 7, "the rounds run behind taps 2..8");
     static_assert(Epi::PACK_OK && LDS_BYTES <= 81920, "two blocks per CU");
 };
 
@@ -102,10 +106,10 @@ template <int OFF> __device__ __forceinline__ void lds_write16(unsigned addr, u3
 __device__ __forceinline__ void fresh4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 
 // EPI: the packed epilogues of gemm_dma.h (1 plain, 2 + GroupNorm partials, 5 + bf16 residual, 6 both).  g.b_frag = k_pack_frag's output.
-template <int RES, bool WIDE, int EPI>
+template <int RES, bool WIDE, int EPI, int TMV = 8>
 __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
 {
-    using Cfg = ConvGn2Cfg<RES, WIDE>;
+    using Cfg = ConvGn2Cfg<RES, WIDE, TMV>;
     using Geo = typename Cfg::Geo;
     constexpr int BM_ = Cfg::BM_, BN_ = Cfg::BN_, NW = Cfg::NW, TM = Cfg::TM, TN = Cfg::TN, KT = Cfg::KT;
     constexpr int W = Geo::W, WS = Geo::WS, HW = RES * RES;
@@ -335,8 +339,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     {
         const int ml = wm * (TM * 16) + frow;                             // first pixel row-tile of this wave
         // its patch row at the centre tap, and its patch column (row-tile / dy / image offsets keep the column, hence the swizzle)
-        const int pc = NIMG > 1 ? ((frow >> 3) + 1) * WS + (frow & 7) + 1 : ((ml / W) + 1) * WS + (ml % W) + 1;
-        const int xc = NIMG > 1 ? (frow & 7) : (ml % W);
+        const int pc = RES == 8 ? ((frow >> 3) + 1) * WS + (frow & 7) + 1 : ((ml / W) + 1) * WS + (ml % W) + 1;      // (RES = 8: a 16-pixel row-tile is two image rows)
+        const int xc = RES == 8 ? (frow & 7) : (ml % W);
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int pp = pc - WS + d - 1;
@@ -353,19 +357,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     // One 32-wide K step: A row-tiles 0, 1 are requested up front, row-tile s+2 while s is multiplied with the four resident weight
     // fragments of register set P; `s_waitcnt lgkmcnt(n)` retires exactly the fragment the next four MFMAs need (LDS returns in
     // order; the five reads of a normalisation round are older than all of them).  EL(i): the vector work placed behind MFMA group i.
-#define NATINF_CG_STEP(a, AOFF, P, S, EL)                                                                                   \
-        if constexpr ((S) + 2 < 8) fs[((S) + 2) % 3] = lds_read16<AOFF((S) + 2)>(a);                                         \
-        wait_lgkmcnt<((S) + 2 < 8 ? 2 : 7 - (S))>();                                                                          \
-        EL##_PRE(S)                                                                                                          \
+    // EO: element offset of the normalisation work (TM = 4: a round spans two taps, the second one handles elements 4..7)
+#define NATINF_CG_STEP(a, AOFF, P, S, EL, EO)                                                                               \
+        if constexpr ((S) + 2 < TM) fs[((S) + 2) % 3] = lds_read16<AOFF((S) + 2)>(a);                                        \
+        wait_lgkmcnt<((S) + 2 < TM ? 2 : TM - 1 - (S))>();                                                                    \
+        EL##_PRE((EO) + (S))                                                                                                 \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                                     \
             acc[S][r_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[P][r_]), __builtin_bit_cast(bf16x8, fs[(S) % 3]), acc[S][r_], 0, 0, 0); \
-        EL##_EL(S)                                                                                                           \
-        EL##_POST(S)                                                                                                         \
+        EL##_EL((EO) + (S))                                                                                                  \
+        EL##_POST((EO) + (S))                                                                                                \
         __builtin_amdgcn_sched_barrier(0);
 #define NATINF_CG_HEAD(a, AOFF) u32x4 fs[3]; fs[0] = lds_read16<AOFF(0)>(a); fs[1] = lds_read16<AOFF(1)>(a);
-#define NATINF_CG_BODY(a, AOFF, P, EL)                                                                                      \
-        NATINF_CG_STEP(a, AOFF, P, 0, EL) NATINF_CG_STEP(a, AOFF, P, 1, EL) NATINF_CG_STEP(a, AOFF, P, 2, EL) NATINF_CG_STEP(a, AOFF, P, 3, EL) \
-        NATINF_CG_STEP(a, AOFF, P, 4, EL) NATINF_CG_STEP(a, AOFF, P, 5, EL) NATINF_CG_STEP(a, AOFF, P, 6, EL) NATINF_CG_STEP(a, AOFF, P, 7, EL)
+#define NATINF_CG_BODY(a, AOFF, P, EL, EO)                                                                                  \
+        NATINF_CG_STEP(a, AOFF, P, 0, EL, EO) NATINF_CG_STEP(a, AOFF, P, 1, EL, EO) NATINF_CG_STEP(a, AOFF, P, 2, EL, EO) NATINF_CG_STEP(a, AOFF, P, 3, EL, EO) \
+        if constexpr (TM == 8) {                                                                                              \
+        NATINF_CG_STEP(a, AOFF, P, 4, EL, EO) NATINF_CG_STEP(a, AOFF, P, 5, EL, EO) NATINF_CG_STEP(a, AOFF, P, 6, EL, EO) NATINF_CG_STEP(a, AOFF, P, 7, EL, EO) }
     // the weight fragments of set P have landed (the wait in front of this): from here on they are new values to hipcc
 #define NATINF_CG_BW_READY(P) fresh4(bw[P][0], bw[P][1], bw[P][2], bw[P][3]);
 
@@ -411,17 +417,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
             if (next_half) issue_patch(hc + 1);
             else if (n_sc > 0) issue_shortcut(0);
         }
-        constexpr bool NORM_TAP = T >= 2 && T - 2 < NROUND && NATINF_CG_ABL != 1;
-        constexpr int J = NORM_TAP ? T - 2 : 0;
+        constexpr int TPR = Cfg::TAPS_PER_ROUND;                         // taps a normalisation round spans (TM = 4: two)
+        constexpr bool NORM_TAP = T >= 2 && (T - 2) / TPR < NROUND && NATINF_CG_ABL != 1;
+        constexpr int J = NORM_TAP ? (T - 2) / TPR : 0, EO = NORM_TAP ? ((T - 2) % TPR) * TM : 0;
         const bool live = NORM_TAP && next_half && (J < NFULL || J * NW + wave < NPIECE);
-        if constexpr (NORM_TAP) { if (live) norm_load(integral_constant<int, J>{}, integral_constant<int, BUF ^ 1>{}); }
+        if constexpr (NORM_TAP && EO == 0) { if (live) norm_load(integral_constant<int, J>{}, integral_constant<int, BUF ^ 1>{}); }
         NATINF_CG_HEAD(a_dx[T % 3], NATINF_CG_AOFF)
         NATINF_CG_STAMP(ts2)
         if constexpr (NORM_TAP) {
-            NATINF_CG_BODY(a_dx[T % 3], NATINF_CG_AOFF, P, NATINF_CG_NORM)
-            if (live) norm_store(integral_constant<int, J>{}, integral_constant<int, BUF ^ 1>{});
+            NATINF_CG_BODY(a_dx[T % 3], NATINF_CG_AOFF, P, NATINF_CG_NORM, EO)
+            if constexpr (EO + TM == 8) { if (live) norm_store(integral_constant<int, J>{}, integral_constant<int, BUF ^ 1>{}); }
         } else {
-            NATINF_CG_BODY(a_dx[T % 3], NATINF_CG_AOFF, P, NATINF_CG_NO)
+            NATINF_CG_BODY(a_dx[T % 3], NATINF_CG_AOFF, P, NATINF_CG_NO, 0)
         }
         NATINF_CG_STAMP(ts3)
         NATINF_CG_ADD(dbg_wait, ts0, ts1) NATINF_CG_ADD(dbg_head, ts1, ts2) NATINF_CG_ADD(dbg_mfma, ts2, ts3)
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
         if (kt + 1 < NT) load_b(integral_constant<int, P ^ 1>{}, kt + 1);
         if (s + 1 < n_sc) issue_shortcut(s + 1);
         NATINF_CG_HEAD(a_plain, NATINF_CG_POFF)
-        NATINF_CG_BODY(a_plain, NATINF_CG_POFF, P, NATINF_CG_NO)
+        NATINF_CG_BODY(a_plain, NATINF_CG_POFF, P, NATINF_CG_NO, 0)
     };
     for (int s = 0; s < n_sc; s += 2) {
         sc_tile(integral_constant<int, 0>{}, s);

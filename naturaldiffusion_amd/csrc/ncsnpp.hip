@@ -213,12 +213,13 @@ using CfgR256x256 = RingCfg<2, 4, 8, 4, 4>; using CfgR256x128 = RingCfg<4, 2, 4,
 using CfgR128x128 = RingCfg<2, 2, 4, 4, 4>; using CfgR64x128 = RingCfg<2, 2, 2, 4, 4>;
 using CfgR256x128W4 = RingCfg<2, 2, 8, 4, 3>; using CfgD256x128W4 = DmaCfg<2, 2, 8, 4>;
 using CfgD512x128 = DmaCfg<4, 2, 8, 4>;
-using CfgH32 = ConvGn2Cfg<32>; using CfgH16 = ConvGn2Cfg<16>; using CfgH16W = ConvGn2Cfg<16, true>; using CfgH8W = ConvGn2Cfg<8, true>;
+using CfgH32 = ConvGn2Cfg<32>; using CfgH16 = ConvGn2Cfg<16>; using CfgH16W = ConvGn2Cfg<16, true>; using CfgH8W = ConvGn2Cfg<8, true>; using CfgH8T = ConvGn2Cfg<8, true, 4>;
 #ifdef NATINF_DEV
 using CfgP256x256 = PatchCfg<2, 4, 8, 4, 344>; using CfgP256x128 = PatchCfg<4, 2, 4, 4, 400>;
 using CfgG32 = ConvGnCfg<32>; using CfgG16 = ConvGnCfg<16>; using CfgG16W = ConvGnCfg<16, true>;
 #endif
 int g_fuse_head = 1;               // natinf_set_fuse_head (read when a plan is BUILT): GroupNorm + SiLU + the 128 -> 3 output convolution as ONE launch (head_conv.h)
+int g_cg8_tm4 = 1;                 // natinf_set_conv_gn8_tile: 1 = 8x8 level on 64-pixel x 256-channel tiles (one image per tile, two blocks per CU), 0 = 128 x 256 (two images per tile)
 int g_attn256 = 1;                 // natinf_set_attn256: 1 = k_attn256 (K / V^T streamed through a two-stage LDS ring, two blocks per CU), 0 = k_attn_fused<8,16,true>
 int g_fuse_gn8 = 1;                // natinf_set_fuse_gn8 (read when a plan is BUILT): the 8x8 level on the fused kernel too (two images per 128-pixel tile)
 int g_fuse_gn = 1;                 // natinf_set_fuse_gn (read when a plan is BUILT): GroupNorm-apply + SiLU inside the consuming 3x3 conv
@@ -254,7 +255,7 @@ bool set_lds_epi_all() {
 template <int EPI>
 bool set_lds_conv_gn() {
     return set_lds<CfgH32>(&k_conv_gn2<32, false, EPI>) && set_lds<CfgH16>(&k_conv_gn2<16, false, EPI>) && set_lds<CfgH16W>(&k_conv_gn2<16, true, EPI>) &&
-           set_lds<CfgH8W>(&k_conv_gn2<8, true, EPI>)
+           set_lds<CfgH8W>(&k_conv_gn2<8, true, EPI>) && set_lds<CfgH8T>(&k_conv_gn2<8, true, EPI, 4>)
 #ifdef NATINF_DEV
            && set_lds<CfgG32>(&k_conv_gn<32, false, EPI>) && set_lds<CfgG16>(&k_conv_gn<16, false, EPI>) && set_lds<CfgG16W>(&k_conv_gn<16, true, EPI>)
 #endif
@@ -309,11 +310,12 @@ int g_cg_regw = 1;                 // natinf_set_conv_gn_regw: 1 = k_conv_gn2 (w
 // tile rows of the fused-convolution instantiation a launch takes: 128 x 256 tiles at 16x16 (N % 256 == 0) and at 8x8 (two images per tile), 256 x 128 elsewhere
 inline int conv_gn_bm(const GemmArgs& g) {
     const int res = 1 << g.logW;
-    return (res == 8 || (g_cg_wide && res == 16 && g.N % 256 == 0)) ? 128 : 256;
+    if (res == 8) return g_cg8_tm4 ? 64 : 128;
+    return (g_cg_wide && res == 16 && g.N % 256 == 0) ? 128 : 256;
 }
 // rows of one GroupNorm-partial table row the launch writes (what the caller divides H*W by): a tile, or one SAMPLE of the two an 8x8 tile holds
 inline int conv_gn_part_rows(const GemmArgs& g) { return (1 << g.logW) == 8 ? 64 : conv_gn_bm(g); }
-inline bool conv_gn_regw(const GemmArgs& g) { return g_cg_regw && g.b_frag && g.N % (conv_gn_bm(g) == 128 ? 256 : 128) == 0; }
+inline bool conv_gn_regw(const GemmArgs& g) { return g_cg_regw && g.b_frag && g.N % (conv_gn_bm(g) <= 128 ? 256 : 128) == 0; }
 #ifdef NATINF_DEV
 constexpr bool HAVE_CONV_GN_V1 = true;              // k_conv_gn (weights through an LDS ring): superseded, development builds only
 #else
@@ -541,7 +543,15 @@ int launch_gemm(const GemmArgs& g0, hipStream_t s) {
                 default: launch_tiles<CFG>(&k_conv_gn2<RES, WIDE, 6>, g, s); break;                             \
             }
             if (conv_gn_regw(g)) {
-                if ((1 << g.logW) == 8) { NATINF_CG2_LAUNCH(CfgH8W, 8, true) }
+                if ((1 << g.logW) == 8 && g_cg8_tm4) {
+                    switch (e4) {
+                        case 0: launch_tiles<CfgH8T>(&k_conv_gn2<8, true, 1, 4>, g, s); break;
+                        case 1: launch_tiles<CfgH8T>(&k_conv_gn2<8, true, 2, 4>, g, s); break;
+                        case 2: launch_tiles<CfgH8T>(&k_conv_gn2<8, true, 5, 4>, g, s); break;
+                        default: launch_tiles<CfgH8T>(&k_conv_gn2<8, true, 6, 4>, g, s); break;
+                    }
+                }
+                else if ((1 << g.logW) == 8) { NATINF_CG2_LAUNCH(CfgH8W, 8, true) }
                 else if ((1 << g.logW) == 32) { NATINF_CG2_LAUNCH(CfgH32, 32, false) }
                 else if (conv_gn_bm(g) == 128) { NATINF_CG2_LAUNCH(CfgH16W, 16, true) }
                 else { NATINF_CG2_LAUNCH(CfgH16, 16, false) }
@@ -1462,6 +1472,7 @@ int natinf_set_gemm_raster(int rows) { g_raster_g = rows; return NATINF_OK; }
 int natinf_set_fuse_gn(int on) { g_fuse_gn = on != 0; return NATINF_OK; }
 int natinf_set_fuse_gn8(int on) { g_fuse_gn8 = on != 0; return NATINF_OK; }
 int natinf_set_attn256(int on) { g_attn256 = on != 0; return NATINF_OK; }
+int natinf_set_conv_gn8_tile(int one_image) { g_cg8_tm4 = one_image != 0; return NATINF_OK; }
 int natinf_set_fuse_head(int on) { g_fuse_head = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_wide(int on) { g_cg_wide = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_regw(int on) {

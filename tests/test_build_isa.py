@@ -97,7 +97,7 @@ def test_conv_gn2_k_loop_has_no_scratch_traffic(listings):
     code = listings["ncsnpp"]
     code = code[:code.index("amdhsa.kernels:")]
     parts = re.split(r"^(_ZN4ncsn10k_conv_gn2\w+):\s*; @", code, flags=re.M)
-    assert len(parts) >= 2 * 12 + 1                                            # 3 tile shapes x 4 epilogues
+    assert len(parts) >= 2 * 20 + 1                                            # 5 tile shapes (32x32, 16x16 narrow / wide, 8x8 two / one image per tile) x 4 epilogues
     for i in range(1, len(parts), 2):
         body = parts[i + 1]
         body = body[:body.index("s_endpgm")]
@@ -111,7 +111,8 @@ def test_conv_gn2_k_loop_has_no_scratch_traffic(listings):
                 bad.append(ln.strip())
             elif in_loop and "v_mfma" in ln:
                 n_mfma_in_loops += 1
-        assert n_mfma_in_loops >= 2 * 9 * 32 and not bad, (parts[i], bad[:4])
+        per_tap = 16 if parts[i].endswith("ELi4EEEvNS_8GemmArgsE") else 32      # (the 64-pixel tile of the 8x8 level: four MFMA groups per tap)
+        assert n_mfma_in_loops >= 2 * 9 * per_tap and not bad, (parts[i], bad[:4])
 
 
 def _vregs(text):
@@ -151,7 +152,7 @@ def test_conv_gn2_weight_registers_are_untouched_between_load_and_wait(listings)
                 continue
             bad = touched & set(pending)
             assert not bad, (parts[i], k, ln, sorted(bad))
-    assert checked >= 12 * 4 * 10                                            # every instantiation, four fragments per weight set, many sets
+    assert checked >= 20 * 4 * 10                                            # every instantiation, four fragments per weight set, many sets
 
 
 def test_no_development_kernels_in_the_shipped_library(listings):
@@ -165,7 +166,7 @@ def test_no_development_kernels_in_the_shipped_library(listings):
                                        r"k_gemm_ring<2, 2, 4, 4, 4, 0>", n)]
     assert not dead, dead
     tiles = [n for n in ks if re.search(r"k_gemm_|k_conv_gn|k_conv_patch", n)]
-    assert len(tiles) <= 66, len(tiles)                                        # the matmul tile families: 117 instantiations in round 2
-    assert len(ks) < 110, len(ks)                                              # all kernels (146 in round 2; round 3 added the Inception, head and vectorised LayerNorm kernels)
+    assert len(tiles) <= 72, len(tiles)                                        # the matmul tile families: 117 instantiations in round 2
+    assert len(ks) < 116, len(ks)                                              # all kernels (146 in round 2; round 3 added the Inception, head and vectorised LayerNorm kernels)
     code = listings["ncsnpp"]
     assert "s_memtime" not in code[:code.index("amdhsa.kernels:")]           # tile-timeline stamps: -DNATINF_DEV builds only

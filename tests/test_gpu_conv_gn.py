@@ -68,8 +68,11 @@ def test_conv_gn_matches_torch(res, B, cin, N, c1, resid, parts):
     # (res == 8: always the 128 x 256 tile; one GroupNorm-partial row per SAMPLE of 64 pixels)
     wf = torch.zeros_like(wd)                              # receives the fragment-major copy of the weights (k_conv_gn2)
     assert lib.natinf_set_conv_gn_regw(0) != 0          # k_conv_gn (weights through an LDS ring): -DNATINF_DEV builds only
-    for use_wide, regw in (((1, 1), (0, 1)) if wide else ((1, 1),)):
-        lib.natinf_set_conv_gn_wide(use_wide)
+    # res == 8: both tiles of the 8x8 level -- 64 pixels x 256 channels (one image per tile, the default) and 128 x 256 (two images per tile)
+    for use_wide, regw in (((1, 1), (0, 1)) if (wide or res == 8) else ((1, 1),)):
+        if res == 8:
+            lib.natinf_set_conv_gn8_tile(use_wide)
+        lib.natinf_set_conv_gn_wide(use_wide if res != 8 else 1)
         rows = 64 if res == 8 else (128 if (wide and use_wide) else 256)
         part = torch.zeros(M // rows, N // 4, 2, device=dev) if parts else None
         out.zero_()
@@ -79,6 +82,7 @@ def test_conv_gn_matches_torch(res, B, cin, N, c1, resid, parts):
             torch.cuda.synchronize()
         finally:
             lib.natinf_set_conv_gn_wide(1)
+            lib.natinf_set_conv_gn8_tile(1)
         got = out.float().cpu()
         assert torch.isfinite(got).all()
         err = ((got - ref).abs().max() / ref.abs().max()).item()

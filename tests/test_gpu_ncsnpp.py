@@ -257,6 +257,14 @@ def test_fused_and_split_k_plans_against_the_unfused_plan(dev, flat, golden_dir)
         assert torch.isfinite(y).all()
         assert _rel(y.cpu(), base.cpu()) < 2e-2, (name, _rel(y.cpu(), base.cpu()))
         assert _rel(y[:2].cpu(), ref) <= TOL, name
+    # the two tiles of the fused kernel on the 8x8 level (a launch-time switch): one image per tile (default) vs two
+    try:
+        assert lib.natinf_set_conv_gn8_tile(0) == 0
+        y = base_eng(xd, ld).clone()
+        torch.cuda.synchronize()
+    finally:
+        lib.natinf_set_conv_gn8_tile(1)
+    assert _rel(y.cpu(), base.cpu()) < 2e-2 and _rel(y[:2].cpu(), ref) <= TOL
     # the fp32-slab A/B knob no longer breaks the fused plan (round-2 advisor, medium): the fused convolutions ignore it
     try:
         assert lib.natinf_set_gemm_epilogue(1) == 0
