@@ -140,11 +140,20 @@ int natinf_set_fuse_head(int on);
 /* 1 (default; read when a plan is built): the 8x8 level's 3x3 convolutions run on the fused GroupNorm + SiLU + convolution kernel as well (two whole
  * images per 128-pixel x 256-channel tile, GroupNorm partials per sample); 0: GroupNorm-apply / statistics passes + implicit GEMM. */
 int natinf_set_fuse_gn8(int on);
+/* 1 (default; read when a plan is built): the 4x4 level's 3x3 convolutions run on the fused kernel too (four whole images per 64-pixel x
+ * 256-channel tile; per-sample tables, row vectors and GroupNorm partials); 0: GroupNorm-apply pass + split-K implicit GEMM + reduce pass +
+ * statistics pass. */
+int natinf_set_fuse_gn4(int on);
+/* Bit mask by resolution (1: 4x4, 2: 8x8, 4: 16x16, 8: 32x32; read at launch) of the fused-convolution launches whose first blocks request the
+ * whole weight matrix once at kernel start, so that the K loop's one-tap-ahead weight stream hits L2 inside a forward pass (where every layer's
+ * weights are cold).  NATINF_EINVAL outside 0..15. */
+int natinf_set_conv_gn_warm(int mask);
 /* 1 (default): the 16x16 attention (256 tokens, one head of 256 channels) runs as k_attn256 -- K and V^T streamed through a two-stage LDS ring by
  * LDS-DMA, two blocks per CU; 0: k_attn_fused<8,16,true> (whole K, then whole V^T, resident in LDS; one block per CU). */
 int natinf_set_attn256(int on);
 /* Tile of the fused kernel on the 8x8 level: 1 (default) = 64 pixels x 256 channels (one image per tile, wave tile 64 x 64, two blocks per CU at
- * B = 512), 0 = 128 x 256 (two images per tile, one block per CU). */
+ * B = 512), 0 = 128 x 256 (two images per tile, one block per CU; 0.6 % slower per forward: a -DNATINF_DEV kernel -- NATINF_ESTATE in the shipped
+ * library). */
 int natinf_set_conv_gn8_tile(int one_image);
 /* 1 (default): small-M, long-K launches (the 8x8 and 4x4 levels) run as 128 x 128 tiles x 2..4 K slices + a reduce pass; 0: never. */
 int natinf_set_gemm_splitk(int on);

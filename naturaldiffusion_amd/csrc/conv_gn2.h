@@ -49,14 +49,16 @@ template <int RES> struct PatchGeo2 { static constexpr int W = RES, WP = RES + 2
 // rows so that a 16-row DMA piece never straddles two images -- its own (scale | shift) table, its own row of the time-embedding vector and its
 // own GroupNorm partials (tile_epilogue's NSAMP); a 16-pixel row-tile is two image rows, which the per-lane fragment bases absorb.  Swizzle key
 // for 10-pixel patch rows: xx & 2 (searched over every 2 x 8 window and ds_read_b128 lane group: conflict-free; bit 2 of the column is not).
-// TM_ = 4 (RES = 8 only): 64-pixel x 256-channel tiles -- ONE image per tile, wave tile 64 x 64 -- so that the 8x8 level launches two blocks per CU
+// TM_ = 4 (RES = 8 / 4): 64-pixel x 256-channel tiles, wave tile 64 x 64 -- ONE 8x8 image per tile, so that the 8x8 level launches two blocks per CU
 // (512 tiles at B = 512) instead of one; a normalisation round (eight elements per lane) then spans TWO taps of four MFMA groups.
+// RES = 4: FOUR whole 4x4 images per tile -- a 16-pixel row-tile is one image; per image a (4+2) x (4+2) patch padded to 48 patch rows (three DMA
+// pieces), its own table, row vector and partials.  Swizzle key for 6-pixel patch rows: xx & 2 as well (checked over every tap and ds_read_b128 lane group).
 template <int RES, bool WIDE_ = false, int TM_ = 8>
 struct ConvGn2Cfg {
     using Geo = PatchGeo2<RES>;
     static constexpr bool WIDE = WIDE_;
     static constexpr int WM = WIDE ? 1 : 2, WN = WIDE ? 4 : 2, TM = TM_, TN = 4, NW = 4, THREADS = 256, KT = 32;
-    static_assert(TM_ == 8 || (TM_ == 4 && RES == 8 && WIDE_), "the 4-row-tile form exists for the 8x8 level only");
+    static_assert(RES == 4 ? (TM_ == 4 && WIDE_) : (TM_ == 8 || (TM_ == 4 && RES == 8 && WIDE_)), "the 4-row-tile form exists for the 8x8 and 4x4 levels only");
     static constexpr int BM_ = WM * TM * 16, BN_ = WN * TN * 16;
     static constexpr int NIMG = RES * RES >= BM_ ? 1 : BM_ / (RES * RES);   // whole images per tile (RES = 8: 2)
     static constexpr int IMGP = NIMG > 1 ? ((RES + 2) * (RES + 2) + 15) / 16 * 16 : 0;      // patch rows per image when a tile holds several
@@ -71,8 +73,8 @@ struct ConvGn2Cfg {
     using Epi = EpiCfg<WM, WN, TM, TN, 81920>;
     static constexpr int EPI_BYTES = Epi::PACK_BYTES + (NIMG - 1) * WN * TN * 4 * 8;      // + the partial-sum rows of the further samples
     static constexpr int LDS_BYTES = TILES_BYTES > EPI_BYTES ? TILES_BYTES : EPI_BYTES;
-    static constexpr int swz_key(int xx) { return RES == 8 ? (xx & 2) : ((xx >> 1) & 2); }
-    static_assert(RES * RES % BM_ == 0 || (BM_ % (RES * RES) == 0 && WM == 1 && NIMG == 2), "a tile lies inside one image, or holds two whole images");
+    static constexpr int swz_key(int xx) { return RES <= 8 ? (xx & 2) : ((xx >> 1) & 2); }
+    static_assert(RES * RES % BM_ == 0 || (BM_ % (RES * RES) == 0 && WM == 1 && (NIMG == 2 || NIMG == 4) && TM % NIMG == 0), "a tile lies inside one image, or holds two / four whole images");
     static constexpr int TAPS_PER_ROUND = 8 / TM;                       // a round = eight elements per lane, one per MFMA group
     static_assert(NROUND * TAPS_PER_ROUND <= 7, "the rounds run behind taps 2..8");
     static_assert(Epi::PACK_OK && LDS_BYTES <= 81920, "two blocks per CU");
@@ -124,7 +126,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     const int mt = tile / nN, nt = tile - mt * nN;
     const int m0 = mt * BM_, n0 = nt * BN_;
     const int b = m0 / HW, y0 = (m0 % HW) / W;                            // (first) image and first image row of this tile
-    const int bdelta = (NIMG > 1 && m0 + HW < g.M) ? 1 : 0;               // RES = 8: the tile's second image (an odd batch ends on half a tile: it re-reads the first, nothing of it is stored)
+    // several images per tile: how many of them exist (a batch that is no multiple of NIMG ends on a partial tile: the missing images re-read the last
+    // real one, nothing of them is stored)
+    const int nval = NIMG > 1 ? min(NIMG, (g.M - m0) / HW) : 1;
     const int ush = g.a0_up;                                              // 1: the source image has half the resolution (nearest up-sampling in the fetch)
     const bf16* const img = g.a0 + (int64_t)b * (HW >> (2 * ush)) * g.a0_ld;
     const float* const gsc = g.gn_scale + (int64_t)b * g.gn_ld;
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
 #pragma unroll
             for (int im = 0; im < NIMG; ++im) {
                 const unsigned dst = lds_tab + buf * Cfg::TAB_BYTES + im * Cfg::TAB_IMG_BYTES;
-                const int64_t io = (int64_t)(im ? bdelta : 0) * g.gn_ld;
+                const int64_t io = (int64_t)min(im, nval - 1) * g.gn_ld;
                 if (l < 32) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(toff), "s"(gsc + io + hc * KT), "s"(dst) : "memory", "m0");
                 else        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(toff), "s"(gsh + io + hc * KT), "s"(dst) : "memory", "m0");
             }
@@ -183,11 +187,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
             const int pp = q * 16 + prow;
             if constexpr (NIMG > 1) {
                 // several whole images per tile: patch row pp = image im, pixel (yy - 1, xx - 1) of it; rows past the (RES + 2)^2 real ones are padding
-                const int im = q >= IMGP / 16 ? 1 : 0;                        // (a piece never straddles two images: IMGP % 16 == 0)
+                const int im = q / (IMGP / 16);                               // (a piece never straddles two images: IMGP % 16 == 0; wave-uniform)
                 const int rem = pp - im * IMGP;
                 const int yy = rem / WS, xx = rem - yy * WS;
                 const int y = min(max(yy - 1, 0), RES - 1), x = min(max(xx - 1, 0), RES - 1);
-                glds16((unsigned)(((im ? bdelta : 0) * HW + y * W + x) * g.a0_ld + ((pslot ^ Cfg::swz_key(xx)) << 3)) * 2u, base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
+                glds16((unsigned)((min(im, nval - 1) * HW + y * W + x) * g.a0_ld + ((pslot ^ Cfg::swz_key(xx)) << 3)) * 2u, base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
             } else {
                 const int yy = pp / WS, xx = pp - yy * WS;
                 const int y = min(max(y0 - 1 + yy, 0), RES - 1), x = min(max(xx - 1, 0), RES - 1);      // halo / pad: any readable pixel
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
         for (int j = 0; j < PSW; ++j) {
             const int pp = (wave * PSW + j) * 16 + prow;
             int src = sup ? ((y0 + pp / W) >> 1) * (W >> 1) + ((pp % W) >> 1) : pp;
-            if constexpr (NIMG > 1) src = (pp < HW || bdelta) ? pp : pp - HW;      // a last tile with one image: its second half re-reads the first
+            if constexpr (NIMG > 1) src = min(pp, nval * HW - 1);                  // a partial last tile: the missing images' rows re-read a real one
             glds16((unsigned)(src * g.a1_ld + ((pslot ^ ((pp >> 1) & 2)) << 3)) * 2u, base, dst + j * 1024);
         }
     };
@@ -218,6 +222,26 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     // the first requests go out NOW: the index arithmetic below (masks, fragment bases, 128 accumulator registers) runs while they fly
     issue_patch(0);
     load_b(std::integral_constant<int, 0>{}, 0);
+    // Weight warm-up (GemmArgs::w_warm).  Inside a forward pass the weights of a layer are cold: every block streams the same matrix one tap
+    // ahead, so the first round of blocks pays a memory round trip PER TAP (all of them missing on the same lines at the same time) -- at 4x4,
+    // where one round of 128 blocks is the whole launch, that doubled the kernel's time against an L2-warm measurement.  The first <= 16 blocks of
+    // an XCD (blockIdx & 7 under round-robin dispatch; a wrong guess only costs speed) touch every 128-byte line of the matrix once, in K order,
+    // split over their waves: the lines are on their way into this XCD's L2 before the K loop asks for them.
+    unsigned warm_junk = 0;                                               // ONE destination register for all of them ("+v": it stays allocated from the first request to the wait below)
+    if (g.w_warm) {
+        const int jx = (int)blockIdx.x >> 3;
+        const int nbx = min(((int)gridDim.x + 7 - ((int)blockIdx.x & 7)) >> 3, 16);
+        if (jx < nbx) {
+            const int NB16 = g.N >> 4, total = NB16 * NT;                    // 1-KiB fragment blocks; one request = 64 lines = 8 of them
+            int l;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+            int i = jx * NW + wave;
+            for (int it = 0; it < 8 && i * 8 < total; ++it, i += nbx * NW) {
+                const int pz = min(i * 8 + (l >> 3), total - 1), kt = pz / NB16, nt = pz - kt * NB16;
+                asm volatile("global_load_dword %0, %1, %2" : "+v"(warm_junk) : "v"((unsigned)((nt * NT + kt) * 1024 + (l & 7) * 128)), "s"(wfrag) : "memory");
+            }
+        }
+    }
 
     // ---- in-place normalisation, round j: the wave's piece j * NW + wave, lane l its bytes l * 16 .. + 15 = patch row q * 16 + (l >> 2),
     // ---- slot l & 3, which holds channel chunk (l & 3) ^ 2 * (bit 2 of that row's patch column: nmask bit 8 + j).
@@ -254,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
         // round: a register held across the K loop for it is the one hipcc spills (and its reload drains the weight stream)
         nb -= lds_patch;
         // (several images per tile: the piece's image, hence its table, is wave-uniform -- pieces do not straddle images)
-        const unsigned timg = (NIMG > 1 && J * NW + wave >= IMGP / 16) ? Cfg::TAB_IMG_BYTES : 0u;
+        const unsigned timg = NIMG > 1 ? (unsigned)((J * NW + wave) / (IMGP / 16)) * Cfg::TAB_IMG_BYTES : 0u;
         const unsigned tbase = lds_tab + timg + ((((nb >> 4) & 3u) ^ ((nm >> (7 + J)) & 2u)) << 5);
         ns0 = lds_read16<BUF * Cfg::TAB_BYTES>(tbase); ns1 = lds_read16<BUF * Cfg::TAB_BYTES + 16>(tbase);
         nh0 = lds_read16<BUF * Cfg::TAB_BYTES + 128>(tbase); nh1 = lds_read16<BUF * Cfg::TAB_BYTES + 144>(tbase);
@@ -339,8 +363,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     {
         const int ml = wm * (TM * 16) + frow;                             // first pixel row-tile of this wave
         // its patch row at the centre tap, and its patch column (row-tile / dy / image offsets keep the column, hence the swizzle)
-        const int pc = RES == 8 ? ((frow >> 3) + 1) * WS + (frow & 7) + 1 : ((ml / W) + 1) * WS + (ml % W) + 1;      // (RES = 8: a 16-pixel row-tile is two image rows)
-        const int xc = RES == 8 ? (frow & 7) : (ml % W);
+        const int pc = RES <= 8 ? ((frow / W) + 1) * WS + (frow % W) + 1 : ((ml / W) + 1) * WS + (ml % W) + 1;      // (RES = 8 / 4: a 16-pixel row-tile is two / four image rows)
+        const int xc = RES <= 8 ? (frow % W) : (ml % W);
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int pp = pc - WS + d - 1;
@@ -382,6 +406,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
 #endif
     NATINF_CG_STAMP(dbg_p0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" :: "v"(warm_junk));                                   // (the warm-up requests' destination register is free again from here)
     NATINF_CG_STAMP(dbg_p1)
     {
         auto b0 = integral_constant<int, 0>{};
@@ -396,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
 
     // ---- the nine taps of one half-chunk; BUF (its patch buffer) and the tap index are compile-time: all offsets are immediates.
     // Weight set of K step kt = hc * 9 + T: (kt & 1) = (T + BUF) & 1 (hc and BUF have the same parity).
-#define NATINF_CG_AOFF(i) (BUF * Cfg::PATCH_BYTES + ((RES == 32 ? ((i) >> 1) * WS + ((i) & 1) * 16 : (RES == 16 ? (i) * WS : ((i) >> 2) * IMGP + ((i) & 3) * 2 * WS)) + (T / 3) * WS) * 64)
+#define NATINF_CG_AOFF(i) (BUF * Cfg::PATCH_BYTES + ((RES == 32 ? ((i) >> 1) * WS + ((i) & 1) * 16 : (RES == 16 ? (i) * WS : (RES == 8 ? ((i) >> 2) * IMGP + ((i) & 3) * 2 * WS : (i) * IMGP))) + (T / 3) * WS) * 64)
     auto tap = [&](auto buf_tag, auto t_tag, int hc, bool next_half) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value, T = decltype(t_tag)::value, P = (T + BUF) & 1;
         const int kt = hc * 9 + T;

@@ -109,7 +109,7 @@ struct SlabCopy<NSW, NSW, RPS, PROW, EDGE> {
 // DEQ (fp8 operands): acc * (deq_m[row] * deq_n[col]) first, and a row bias (bias_m) next to the column terms.
 // OUT8: the tile leaves as e4m3 bytes with one E8M0 scale per 32 columns (OUT_FP8_MX; a block = two 16-column MFMA tiles x the
 // four lanes of a row) -- the bytes cross LDS like the bf16 values do, the scale bytes are stored from the registers.
-// NSAMP = 2 (k_conv_gn2 at 8x8: WM == 1, the tile's upper / lower TM / 2 row-tiles are two samples): the per-sample row vector and the GroupNorm
+// NSAMP = 2 / 4 (k_conv_gn2 at 8x8 / 4x4: WM == 1, every TM / NSAMP row-tiles of the tile are one sample): the per-sample row vector and the GroupNorm
 // partials exist once per sample; gn_part rows are then indexed by (m0 / BM) * NSAMP + sample.
 template <int WM, int WN, int TM, int TN, class Cfg, int ACT, bool GN, bool RES, bool DEQ = false, bool OUT8 = false, int NSAMP = 1>
 __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned char* smem, f32x4 (&acc)[TM][TN],
@@ -117,7 +117,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
 {
     constexpr int BN_ = WN * TN * 16, BM_ = WM * TM * 16, THREADS = WM * WN * 64, PROW = OUT8 ? BN_ + 16 : Cfg::PROW;
     static_assert(!OUT8 || (!GN && !RES && TN % 2 == 0), "fp8 output: plain column terms only");
-    static_assert(NSAMP == 1 || (NSAMP == 2 && WM == 1 && TM % 2 == 0 && !DEQ && !OUT8), "two samples per tile: one wave row, bf16 output");
+    static_assert(NSAMP == 1 || ((NSAMP == 2 || NSAMP == 4) && WM == 1 && TM % NSAMP == 0 && !DEQ && !OUT8), "several samples per tile: one wave row, bf16 output");
     const int r = lane & 15, q = lane >> 4;
     float dn[DEQ ? TN : 1][4], rsc[DEQ ? TM : 1], rbm[DEQ ? TM : 1];
     if constexpr (DEQ) {
@@ -147,7 +147,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f), rv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n < g.N) {
             if (g.bias_n) b = *reinterpret_cast<const float4*>(g.bias_n + n);
-            // (NSAMP == 2: the second sample's row; a last tile that holds one sample reads the first one's again -- those rows are not stored)
+            // (NSAMP > 1: the further samples' rows; a partial last tile reads the last real sample's again -- those rows are not stored)
             const int srow = NSAMP > 1 ? min(m0 + sm * (BM_ / NSAMP), g.M - 1) : m0;
             if (g.rowvec) rv = *reinterpret_cast<const float4*>(g.rowvec + (int64_t)((srow >> g.log_rows_per_sample) + z * g.z_samples) * g.rowvec_ld + n);
         }
@@ -173,7 +173,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
     const float scale = g.scale;
     // the finished fp32 values of accumulator tile (i, j)
     auto value = [&](int i, int j, float (&v)[4]) __attribute__((always_inline)) {
-        const int sm = NSAMP > 1 ? (i >= TM / 2 ? 1 : 0) : 0;                  // (i is a compile-time constant at every call site)
+        const int sm = NSAMP > 1 ? i / (TM / NSAMP) : 0;                  // (i is a compile-time constant at every call site)
         const int sc_ = NCT > 1 ? sm : 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

@@ -213,15 +213,19 @@ using CfgR256x256 = RingCfg<2, 4, 8, 4, 4>; using CfgR256x128 = RingCfg<4, 2, 4,
 using CfgR128x128 = RingCfg<2, 2, 4, 4, 4>; using CfgR64x128 = RingCfg<2, 2, 2, 4, 4>;
 using CfgR256x128W4 = RingCfg<2, 2, 8, 4, 3>; using CfgD256x128W4 = DmaCfg<2, 2, 8, 4>;
 using CfgD512x128 = DmaCfg<4, 2, 8, 4>;
-using CfgH32 = ConvGn2Cfg<32>; using CfgH16 = ConvGn2Cfg<16>; using CfgH16W = ConvGn2Cfg<16, true>; using CfgH8W = ConvGn2Cfg<8, true>; using CfgH8T = ConvGn2Cfg<8, true, 4>;
+using CfgH32 = ConvGn2Cfg<32>; using CfgH16 = ConvGn2Cfg<16>; using CfgH16W = ConvGn2Cfg<16, true>; using CfgH8T = ConvGn2Cfg<8, true, 4>; using CfgH4T = ConvGn2Cfg<4, true, 4>;
 #ifdef NATINF_DEV
+using CfgH8W = ConvGn2Cfg<8, true>;          // 8x8: two images per 128-pixel tile (superseded by the one-image tile: 0.6 % slower per forward)
 using CfgP256x256 = PatchCfg<2, 4, 8, 4, 344>; using CfgP256x128 = PatchCfg<4, 2, 4, 4, 400>;
 using CfgG32 = ConvGnCfg<32>; using CfgG16 = ConvGnCfg<16>; using CfgG16W = ConvGnCfg<16, true>;
 #endif
 int g_fuse_head = 1;               // natinf_set_fuse_head (read when a plan is BUILT): GroupNorm + SiLU + the 128 -> 3 output convolution as ONE launch (head_conv.h)
-int g_cg8_tm4 = 1;                 // natinf_set_conv_gn8_tile: 1 = 8x8 level on 64-pixel x 256-channel tiles (one image per tile, two blocks per CU), 0 = 128 x 256 (two images per tile)
+int g_cg8_tm4 = 1;                 // natinf_set_conv_gn8_tile: 1 = 8x8 level on 64-pixel x 256-channel tiles (one image per tile, two blocks per CU), 0 = 128 x 256 (two images per tile; -DNATINF_DEV builds)
 int g_attn256 = 1;                 // natinf_set_attn256: 1 = k_attn256 (K / V^T streamed through a two-stage LDS ring, two blocks per CU), 0 = k_attn_fused<8,16,true>
 int g_fuse_gn8 = 1;                // natinf_set_fuse_gn8 (read when a plan is BUILT): the 8x8 level on the fused kernel too (two images per 128-pixel tile)
+int g_cg_warm = 15;                // natinf_set_conv_gn_warm: bit mask by resolution (1: 4x4, 2: 8x8, 4: 16x16, 8: 32x32) of the fused-convolution launches that warm L2 with their weights
+int g_fuse_gn4 = 1;                // natinf_set_fuse_gn4 (read when a plan is BUILT): the 4x4 level on the fused kernel too (four images per 64-pixel tile) instead of
+                                   // k_gn_apply + split-K GEMM + k_splitk_reduce + k_gn_stats
 int g_fuse_gn = 1;                 // natinf_set_fuse_gn (read when a plan is BUILT): GroupNorm-apply + SiLU inside the consuming 3x3 conv
 
 // Packed-epilogue specializations (EPI, gemm_dma.h) that exist per tile family, as bit masks: a launch whose epilogue is not
@@ -255,8 +259,9 @@ bool set_lds_epi_all() {
 template <int EPI>
 bool set_lds_conv_gn() {
     return set_lds<CfgH32>(&k_conv_gn2<32, false, EPI>) && set_lds<CfgH16>(&k_conv_gn2<16, false, EPI>) && set_lds<CfgH16W>(&k_conv_gn2<16, true, EPI>) &&
-           set_lds<CfgH8W>(&k_conv_gn2<8, true, EPI>) && set_lds<CfgH8T>(&k_conv_gn2<8, true, EPI, 4>)
+           set_lds<CfgH8T>(&k_conv_gn2<8, true, EPI, 4>) && set_lds<CfgH4T>(&k_conv_gn2<4, true, EPI, 4>)
 #ifdef NATINF_DEV
+           && set_lds<CfgH8W>(&k_conv_gn2<8, true, EPI>)
            && set_lds<CfgG32>(&k_conv_gn<32, false, EPI>) && set_lds<CfgG16>(&k_conv_gn<16, false, EPI>) && set_lds<CfgG16W>(&k_conv_gn<16, true, EPI>)
 #endif
         ;
@@ -311,10 +316,11 @@ int g_cg_regw = 1;                 // natinf_set_conv_gn_regw: 1 = k_conv_gn2 (w
 inline int conv_gn_bm(const GemmArgs& g) {
     const int res = 1 << g.logW;
     if (res == 8) return g_cg8_tm4 ? 64 : 128;
+    if (res == 4) return 64;
     return (g_cg_wide && res == 16 && g.N % 256 == 0) ? 128 : 256;
 }
 // rows of one GroupNorm-partial table row the launch writes (what the caller divides H*W by): a tile, or one SAMPLE of the two an 8x8 tile holds
-inline int conv_gn_part_rows(const GemmArgs& g) { return (1 << g.logW) == 8 ? 64 : conv_gn_bm(g); }
+inline int conv_gn_part_rows(const GemmArgs& g) { const int res = 1 << g.logW; return res <= 8 ? res * res : conv_gn_bm(g); }
 inline bool conv_gn_regw(const GemmArgs& g) { return g_cg_regw && g.b_frag && g.N % (conv_gn_bm(g) <= 128 ? 256 : 128) == 0; }
 #ifdef NATINF_DEV
 constexpr bool HAVE_CONV_GN_V1 = true;              // k_conv_gn (weights through an LDS ring): superseded, development builds only
@@ -323,12 +329,12 @@ constexpr bool HAVE_CONV_GN_V1 = false;
 #endif
 // k_conv_gn / k_conv_gn2 have packed epilogues only: the fp32-slab A/B knob (natinf_set_gemm_epilogue) does not apply to them.  Per-sample terms need
 // one sample per tile -- or, at 8x8, per HALF tile (the kernel keeps both samples' row vectors and partials: NSAMP)
-inline int conv_gn_epi(const GemmArgs& g) { GemmArgs t = g; t.epi_fp32_slab = 0; return packed_epi(t, (1 << g.logW) == 8 ? 64 : conv_gn_bm(g)); }
+inline int conv_gn_epi(const GemmArgs& g) { GemmArgs t = g; t.epi_fp32_slab = 0; return packed_epi(t, conv_gn_part_rows(g)); }
 inline bool conv_gn_ok(const GemmArgs& g) {
     if (!g.gn_scale || !g.gn_shift || !g.gn_folded || g.taps != 9 || g.batch != 1 || g.a0_C % BK || (g.a1 && g.a1_C % BK)) return false;
     const int res = 1 << g.logW;
-    if (g.logHW != 2 * g.logW || (res != 32 && res != 16 && res != 8) || g.N % 8) return false;
-    if (res == 8 ? (g.M % 64 || g.N % 256 || g.a0_up || g.a1_up || !conv_gn_regw(g) || (g.resid && g.rowvec)) : g.M % 256 != 0) return false;      // 8x8: whole images, k_conv_gn2 only;
+    if (g.logHW != 2 * g.logW || (res != 32 && res != 16 && res != 8 && res != 4) || g.N % 8) return false;
+    if (res <= 8 ? (g.M % (res * res) || g.N % 256 || g.a0_up || g.a1_up || !conv_gn_regw(g) || (g.resid && g.rowvec)) : g.M % 256 != 0) return false;      // 8x8: whole images, k_conv_gn2 only;
     // (its residual epilogues keep one set of column terms for both samples of a tile: no per-sample row vector there)
     if ((g.a0_up || g.a1_up || !HAVE_CONV_GN_V1) && !conv_gn_regw(g)) return false;          // up-sampled fetches: k_conv_gn2 only
     const int e = conv_gn_epi(g);
@@ -533,6 +539,9 @@ int launch_gemm(const GemmArgs& g0, hipStream_t s) {
         case V_ABL_NOMFMA: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 4, 1>, g, s); break;
 #endif
         case V_CONV_GN: {
+            GemmArgs gw = g0;
+            gw.w_warm = (g_cg_warm >> (g0.logW - 2)) & 1;
+            const GemmArgs& g = gw;
             const int e = conv_gn_epi(g);
             const int e4 = e == 1 ? 0 : (e == 2 ? 1 : (e == 5 ? 2 : 3));
 #define NATINF_CG2_LAUNCH(CFG, RES, WIDE)                                                                   \
@@ -551,7 +560,17 @@ int launch_gemm(const GemmArgs& g0, hipStream_t s) {
                         default: launch_tiles<CfgH8T>(&k_conv_gn2<8, true, 6, 4>, g, s); break;
                     }
                 }
+#ifdef NATINF_DEV
                 else if ((1 << g.logW) == 8) { NATINF_CG2_LAUNCH(CfgH8W, 8, true) }
+#endif
+                else if ((1 << g.logW) == 4) {
+                    switch (e4) {
+                        case 0: launch_tiles<CfgH4T>(&k_conv_gn2<4, true, 1, 4>, g, s); break;
+                        case 1: launch_tiles<CfgH4T>(&k_conv_gn2<4, true, 2, 4>, g, s); break;
+                        case 2: launch_tiles<CfgH4T>(&k_conv_gn2<4, true, 5, 4>, g, s); break;
+                        default: launch_tiles<CfgH4T>(&k_conv_gn2<4, true, 6, 4>, g, s); break;
+                    }
+                }
                 else if ((1 << g.logW) == 32) { NATINF_CG2_LAUNCH(CfgH32, 32, false) }
                 else if (conv_gn_bm(g) == 128) { NATINF_CG2_LAUNCH(CfgH16W, 16, true) }
                 else { NATINF_CG2_LAUNCH(CfgH16, 16, false) }
@@ -691,9 +710,9 @@ struct Builder {
         // 32x32 or 16x16.  Conv_0 of a resampling block reads a resampled tensor and keeps the k_gn_apply pass (which also
         // produces the resampled shortcut input), Conv_1 is fused there too; the 8x8 / 4x4 levels are unfused.  Folded form: the
         // GroupNorm scale / shift carry -log2(e), the 3x3 weights -ln 2 (GemmArgs::gn_folded).
-        const bool fusable_res = g_fuse_gn && (ro == 32 || ro == 16 || (ro == 8 && g_fuse_gn8 && cout % 256 == 0));
+        const bool fusable_res = g_fuse_gn && (ro == 32 || ro == 16 || (ro == 8 && g_fuse_gn8 && cout % 256 == 0) || (ro == 4 && g_fuse_gn4 && cout % 256 == 0));
         const bool fuse1 = fusable_res && cout % BK == 0;                               // Conv_1
-        const bool fuse_up = fuse1 && ro != 8 && g_fuse_up && m.up && cin % BK == 0 && cout % 128 == 0;   // up block: the 2x up-sampling of both branches happens in the fetches
+        const bool fuse_up = fuse1 && ro > 8 && g_fuse_up && m.up && cin % BK == 0 && cout % 128 == 0;   // up block: the 2x up-sampling of both branches happens in the fetches
         const bool fuse = (fusable_res && !m.up && !m.down && cin % BK == 0) || fuse_up;            // Conv_0
         const float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
         const float gn_mul = fuse ? -LOG2E : 1.0f, w_mul = fuse ? -LN2 : 1.0f, gn_mul1 = fuse1 ? -LOG2E : 1.0f, w_mul1 = fuse1 ? -LN2 : 1.0f;
@@ -729,7 +748,7 @@ struct Builder {
         const Part pt = register_output(t, fuse);
         const int logW = ilog2(ro), logHW = 2 * logW, HWo = ro * ro;
         const int dtotal = dense_total; const int64_t dout = dense_out;
-        op(fuse ? (ro == 8 ? CLS_CONV_GN8 : CLS_CONV_GN) : CLS_GEMM, [=](const Ctx& c) {
+        op(fuse ? (ro <= 8 ? CLS_CONV_GN8 : CLS_CONV_GN) : CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
             if (fuse) { g.a0 = c.act(x); g.a0_ld = x.ld; g.gn_scale = c.at<float>(sc); g.gn_shift = c.at<float>(sh); g.gn_ld = cin; g.gn_folded = 1; g.a0_up = fuse_up; }
             else { g.a0 = c.act(h); g.a0_ld = h.ld; g.a0_padded = 1; }
@@ -756,7 +775,7 @@ struct Builder {
         const TRef xs = ((m.up || m.down) && !fuse_up) ? xr : x;           // shortcut source at the output resolution (fuse_up: x itself, fetched up-sampled)
         const float rs = res_scale;
         const Part po = register_output(out, fuse1);
-        op(fuse1 ? (ro == 8 ? CLS_CONV_GN8 : CLS_CONV_GN) : CLS_GEMM, [=](const Ctx& c) {
+        op(fuse1 ? (ro <= 8 ? CLS_CONV_GN8 : CLS_CONV_GN) : CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
             if (fuse1) { g.a0 = c.act(t); g.a0_ld = t.ld; g.gn_scale = c.at<float>(sc); g.gn_shift = c.at<float>(sh); g.gn_ld = cout; g.gn_folded = 1; }
             else { g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_padded = 1; }
@@ -947,7 +966,7 @@ struct Builder {
     static bool fusable(int res) { return res >= 16; }   // every block tile (<= 256 rows) lies inside one sample
     Part new_part(int res, int C) {
         Part p; p.quads = C / 4; p.res = res; p.id = n_parts++; p.valid = true;
-        p.off = arena.alloc((int64_t)(res * res / 64) * p.quads * 8);       // worst case: 64-row block tiles
+        p.off = arena.alloc((int64_t)std::max(res * res / 64, 1) * p.quads * 8);       // worst case: 64-row block tiles (4x4: one row per sample)
         return p;
     }
     // called for EVERY module output so that a stale table can never be matched to a later tensor at the same place
@@ -955,7 +974,7 @@ struct Builder {
     // 128-row tiles span two 8x8 samples, and its consumers take the streaming statistics kernel
     Part register_output(const TRef& out, bool fused8 = false) {
         Part p;
-        if (fusable(out.res) || (out.res == 8 && fused8)) p = new_part(out.res, out.C);
+        if (fusable(out.res) || (out.res <= 8 && fused8)) p = new_part(out.res, out.C);
         parts[{out.off, out.coff}] = p;
         return p;
     }
@@ -1416,7 +1435,7 @@ int natinf_debug_conv_gn_up(int flags) { if (flags & ~3) return NATINF_EINVAL; g
 int natinf_debug_conv_gn(int res, int B, int N, int cin, int c1, const void* x, const float* scale, const float* shift, const void* w_packed,
                          void* w_frag, const void* a1, const float* bias_n, const void* resid, float out_scale, void* out, float* gn_part, int iters,
                          natinf_stream_t stream) {
-    if ((res != 32 && res != 16 && res != 8) || B <= 0 || N <= 0 || N % 8 || cin <= 0 || cin % 64 || c1 < 0 || c1 % 64 || (c1 > 0) != (a1 != nullptr) ||
+    if ((res != 32 && res != 16 && res != 8 && res != 4) || B <= 0 || N <= 0 || N % 8 || cin <= 0 || cin % 64 || c1 < 0 || c1 % 64 || (c1 > 0) != (a1 != nullptr) ||
         !x || !scale || !shift || !w_packed || !out || iters <= 0) return NATINF_EINVAL;
     static bool configured = false;
     if (!configured) { if (!configure_gemm_kernels()) return NATINF_ENODEV; configured = true; }
@@ -1472,7 +1491,14 @@ int natinf_set_gemm_raster(int rows) { g_raster_g = rows; return NATINF_OK; }
 int natinf_set_fuse_gn(int on) { g_fuse_gn = on != 0; return NATINF_OK; }
 int natinf_set_fuse_gn8(int on) { g_fuse_gn8 = on != 0; return NATINF_OK; }
 int natinf_set_attn256(int on) { g_attn256 = on != 0; return NATINF_OK; }
-int natinf_set_conv_gn8_tile(int one_image) { g_cg8_tm4 = one_image != 0; return NATINF_OK; }
+int natinf_set_conv_gn_warm(int mask) { if (mask < 0 || mask > 15) return NATINF_EINVAL; g_cg_warm = mask; return NATINF_OK; }
+int natinf_set_fuse_gn4(int on) { g_fuse_gn4 = on != 0; return NATINF_OK; }
+int natinf_set_conv_gn8_tile(int one_image) {
+#ifndef NATINF_DEV
+    if (!one_image) return NATINF_ESTATE;          // the two-image tile is a development-build kernel
+#endif
+    g_cg8_tm4 = one_image != 0; return NATINF_OK;
+}
 int natinf_set_fuse_head(int on) { g_fuse_head = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_wide(int on) { g_cg_wide = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_regw(int on) {

@@ -72,6 +72,9 @@ struct GemmArgs {
     const float* gn_scale; const float* gn_shift; int gn_ld; int gn_folded;
     // k_conv_gn2: the weights of a gn_scale launch once more, fragment-major (k_pack_frag); NULL -> k_conv_gn (LDS weight ring)
     const bf16* b_frag;
+    // k_conv_gn2: 1 = the first blocks of every XCD request the whole fragment-major weight matrix once at kernel start (one 4-byte load per 128-byte
+    // line, results discarded), in K order: the K loop's one-tap-ahead weight stream then hits L2 instead of paying a memory round trip per tap
+    int w_warm;
     // 2x nearest up-sampling folded into the operand fetch of a gn_scale launch (k_conv_gn2 only): a0 is the tensor at HALF the resolution,
     // patch pixel (y, x) <- (y >> 1, x >> 1); a1_up: the same for the rows of the 1x1 shortcut operand a1
     int a0_up; int a1_up;

@@ -26,10 +26,14 @@ def _pack(w, w1):
     (16, 2, 512, 256, 512, False, True),      # widest K: 144 + 16 K-tiles
     (16, 3, 128, 256, 0, False, False),
     (32, 2, 384, 128, 384, False, False),     # 384 channels: 12 half-chunks
-    (8, 4, 256, 256, 0, False, True),         # 8x8 level (round 3): two whole images per 128-pixel tile, GroupNorm partials per sample
-    (8, 3, 512, 256, 512, False, True),       # odd batch (the last tile holds ONE image) + the 1x1 shortcut segment
+    (8, 4, 256, 256, 0, False, True),         # 8x8 level (round 3): one whole image per 64-pixel tile, GroupNorm partials per sample
+    (8, 3, 512, 256, 512, False, True),       # + the 1x1 shortcut segment
     (8, 6, 256, 256, 0, True, True),          # identity residual
-    (8, 1, 256, 256, 256, False, False),      # a single image: half a tile
+    (8, 1, 256, 256, 256, False, False),      # a single image
+    (4, 8, 256, 256, 0, False, True),         # 4x4 level: FOUR whole images per 64-pixel tile, GroupNorm partials per sample
+    (4, 5, 512, 256, 512, False, True),       # a batch that is no multiple of four (the last tile holds ONE image) + the 1x1 shortcut segment
+    (4, 7, 256, 256, 0, True, True),          # identity residual; three images in the last tile
+    (4, 2, 256, 256, 256, False, False),      # half a tile
 ])
 def test_conv_gn_matches_torch(res, B, cin, N, c1, resid, parts):
     from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
@@ -65,15 +69,12 @@ def test_conv_gn_matches_torch(res, B, cin, N, c1, resid, parts):
     a1d = a1.bfloat16().to(dev).contiguous() if c1 else None
     rd = r.bfloat16().to(dev) if resid else None
     wide = res == 16 and N % 256 == 0                      # 128-pixel x 256-channel tiles (default) -- the 256 x 128 ones are tested as well
-    # (res == 8: always the 128 x 256 tile; one GroupNorm-partial row per SAMPLE of 64 pixels)
     wf = torch.zeros_like(wd)                              # receives the fragment-major copy of the weights (k_conv_gn2)
     assert lib.natinf_set_conv_gn_regw(0) != 0          # k_conv_gn (weights through an LDS ring): -DNATINF_DEV builds only
-    # res == 8: both tiles of the 8x8 level -- 64 pixels x 256 channels (one image per tile, the default) and 128 x 256 (two images per tile)
-    for use_wide, regw in (((1, 1), (0, 1)) if (wide or res == 8) else ((1, 1),)):
-        if res == 8:
-            lib.natinf_set_conv_gn8_tile(use_wide)
-        lib.natinf_set_conv_gn_wide(use_wide if res != 8 else 1)
-        rows = 64 if res == 8 else (128 if (wide and use_wide) else 256)
+    assert lib.natinf_set_conv_gn8_tile(0) != 0         # the two-images-per-tile form of the 8x8 level: -DNATINF_DEV builds only
+    for use_wide, regw in (((1, 1), (0, 1)) if wide else ((1, 1),)):
+        lib.natinf_set_conv_gn_wide(use_wide)
+        rows = res * res if res <= 8 else (128 if (wide and use_wide) else 256)      # (8x8 / 4x4: one partial row per SAMPLE)
         part = torch.zeros(M // rows, N // 4, 2, device=dev) if parts else None
         out.zero_()
         try:
@@ -82,7 +83,6 @@ def test_conv_gn_matches_torch(res, B, cin, N, c1, resid, parts):
             torch.cuda.synchronize()
         finally:
             lib.natinf_set_conv_gn_wide(1)
-            lib.natinf_set_conv_gn8_tile(1)
         got = out.float().cpu()
         assert torch.isfinite(got).all()
         err = ((got - ref).abs().max() / ref.abs().max()).item()

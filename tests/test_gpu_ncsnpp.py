@@ -231,7 +231,7 @@ def test_fused_and_split_k_plans_against_the_unfused_plan(dev, flat, golden_dir)
     outs = {}
     assert any(r[6].startswith("head_conv") for r in _describe_gemms(base_eng, 64))
     for name, setter in (("fuse_gn", lib.natinf_set_fuse_gn), ("fuse_up", lib.natinf_set_fuse_up), ("fuse_head", lib.natinf_set_fuse_head),
-                         ("fuse_gn8", lib.natinf_set_fuse_gn8)):
+                         ("fuse_gn8", lib.natinf_set_fuse_gn8), ("fuse_gn4", lib.natinf_set_fuse_gn4)):
         try:
             assert setter(0) == 0
             eng = NCSNppEngine(flat, max_batch=64, device=dev)          # the switch is read when the plan is built
@@ -245,6 +245,9 @@ def test_fused_and_split_k_plans_against_the_unfused_plan(dev, flat, golden_dir)
         if name == "fuse_gn8":                                       # without it the 8x8 level is back on the LDS-DMA implicit GEMM
             n8 = lambda rr: sum(1 for r in rr if r[6].startswith("conv_gn") and int(r[0]) == 64 * 64)
             assert n8(rows) == 0 and n8(_describe_gemms(base_eng, 64)) >= 18
+        if name == "fuse_gn4":                                       # without it the 4x4 level is back on k_gn_apply + split-K GEMM + reduce + k_gn_stats
+            n4 = lambda rr: sum(1 for r in rr if r[6].startswith("conv_gn") and int(r[0]) == 64 * 16)
+            assert n4(rows) == 0 and n4(_describe_gemms(base_eng, 64)) >= 20
         outs[name] = eng(xd, ld).clone()
     try:
         assert lib.natinf_set_gemm_splitk(0) == 0
@@ -257,14 +260,7 @@ def test_fused_and_split_k_plans_against_the_unfused_plan(dev, flat, golden_dir)
         assert torch.isfinite(y).all()
         assert _rel(y.cpu(), base.cpu()) < 2e-2, (name, _rel(y.cpu(), base.cpu()))
         assert _rel(y[:2].cpu(), ref) <= TOL, name
-    # the two tiles of the fused kernel on the 8x8 level (a launch-time switch): one image per tile (default) vs two
-    try:
-        assert lib.natinf_set_conv_gn8_tile(0) == 0
-        y = base_eng(xd, ld).clone()
-        torch.cuda.synchronize()
-    finally:
-        lib.natinf_set_conv_gn8_tile(1)
-    assert _rel(y.cpu(), base.cpu()) < 2e-2 and _rel(y[:2].cpu(), ref) <= TOL
+    assert lib.natinf_set_conv_gn8_tile(0) != 0 and lib.natinf_set_conv_gn8_tile(1) == 0      # the two-image tile of the 8x8 level: development builds only
     # the fp32-slab A/B knob no longer breaks the fused plan (round-2 advisor, medium): the fused convolutions ignore it
     try:
         assert lib.natinf_set_gemm_epilogue(1) == 0

@@ -15,7 +15,7 @@ def run(res, B, cin, N, c1, iters=20):
     w = (torch.randn(N, 9 * cin + c1, device=dev) / (9 * cin) ** 0.5).bfloat16()
     a1 = torch.randn(M, c1, device=dev).bfloat16() if c1 else None
     bias = torch.randn(N, device=dev); out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    part = torch.zeros(M // 64, N // 4, 2, device=dev)          # (one row per tile; per 64-pixel sample at res 8)
+    part = torch.zeros(M // min(64, res * res), N // 4, 2, device=dev)          # (one row per tile; per sample at res 8 / 4)
     wf = torch.zeros_like(w) if os.environ.get('REGW', '1') != '0' else None
     args = (res, B, N, cin, c1, ptr(x), ptr(sc), ptr(sh), ptr(w), ptr(wf), ptr(a1), ptr(bias), None, 0.7071, ptr(out), ptr(part))
     check(lib.natinf_debug_conv_gn(*args, 3, stream_ptr()), "warm")

@@ -10,7 +10,7 @@ res, B, cin, N, c1 = [int(v) for v in sys.argv[1:6]]
 dev = "cuda"; M = B * res * res
 x = torch.randn(B, res, res, cin, device=dev).bfloat16(); sc = torch.rand(B, cin, device=dev) + 0.5; sh = torch.randn(B, cin, device=dev) * 0.3
 w = (torch.randn(N, 9 * cin + c1, device=dev) / (9 * cin) ** 0.5).bfloat16(); a1 = torch.randn(M, c1, device=dev).bfloat16() if c1 else None
-bias = torch.randn(N, device=dev); out = torch.empty(M, N, dtype=torch.bfloat16, device=dev); part = torch.zeros(M // 256, N // 4, 2, device=dev)
+bias = torch.randn(N, device=dev); out = torch.empty(M, N, dtype=torch.bfloat16, device=dev); part = torch.zeros(M // min(64, res * res), N // 4, 2, device=dev)
 wf = torch.zeros_like(w)
 ts = torch.zeros(24, dtype=torch.int64, device=dev)
 check(lib.natinf_debug_timestamps(ptr(ts)), "ts")
