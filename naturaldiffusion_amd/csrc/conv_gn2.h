@@ -53,11 +53,17 @@ template <int RES> struct PatchGeo2 { static constexpr int W = RES, WP = RES + 2
 // (512 tiles at B = 512) instead of one; a normalisation round (eight elements per lane) then spans TWO taps of four MFMA groups.
 // RES = 4: FOUR whole 4x4 images per tile -- a 16-pixel row-tile is one image; per image a (4+2) x (4+2) patch padded to 48 patch rows (three DMA
 // pieces), its own table, row vector and partials.  Swizzle key for 6-pixel patch rows: xx & 2 as well (checked over every tap and ds_read_b128 lane group).
-template <int RES, bool WIDE_ = false, int TM_ = 8>
+// NG_ = 2 (RES = 4): TWO groups of four waves per block, group g multiplying the half-chunks (and shortcut tiles) g, g + 2, g + 4, ... of the SAME
+// output tile, each with its own patch buffers, tables and weight stream; the second group's accumulators cross LDS once at the end and the first group
+// runs the epilogue.  The 4x4 level launches 128 tiles at B = 512 -- one block per CU on half the chip -- and a single wave per SIMD cannot cover its
+// own LDS / weight-stream latencies (tile timeline: ~930 clocks per tap for 256 clocks of MFMAs); two waves per SIMD do what the second
+// co-resident block does at the other resolutions.
+template <int RES, bool WIDE_ = false, int TM_ = 8, int NG_ = 1>
 struct ConvGn2Cfg {
     using Geo = PatchGeo2<RES>;
     static constexpr bool WIDE = WIDE_;
-    static constexpr int WM = WIDE ? 1 : 2, WN = WIDE ? 4 : 2, TM = TM_, TN = 4, NW = 4, THREADS = 256, KT = 32;
+    static constexpr int WM = WIDE ? 1 : 2, WN = WIDE ? 4 : 2, TM = TM_, TN = 4, NW = 4, NG = NG_, THREADS = 256 * NG_, KT = 32;
+    static_assert(NG_ == 1 || (NG_ == 2 && RES == 4), "K groups: the 4x4 level only");
     static_assert(RES == 4 ? (TM_ == 4 && WIDE_) : (TM_ == 8 || (TM_ == 4 && RES == 8 && WIDE_)), "the 4-row-tile form exists for the 8x8 and 4x4 levels only");
     static constexpr int BM_ = WM * TM * 16, BN_ = WN * TN * 16;
     static constexpr int NIMG = RES * RES >= BM_ ? 1 : BM_ / (RES * RES);   // whole images per tile (RES = 8: 2)
@@ -72,12 +78,13 @@ struct ConvGn2Cfg {
     static constexpr int TILES_BYTES = 2 * PATCH_BYTES + 2 * TAB_BYTES;
     using Epi = EpiCfg<WM, WN, TM, TN, 81920>;
     static constexpr int EPI_BYTES = Epi::PACK_BYTES + (NIMG - 1) * WN * TN * 4 * 8;      // + the partial-sum rows of the further samples
-    static constexpr int LDS_BYTES = TILES_BYTES > EPI_BYTES ? TILES_BYTES : EPI_BYTES;
+    static constexpr int RED_BYTES = NG > 1 ? TM * TN * 16 * 256 : 0;  // the second group's accumulators (fp32, one float4 per thread and MFMA tile)
+    static constexpr int LDS_BYTES = (NG * TILES_BYTES > EPI_BYTES ? NG * TILES_BYTES : EPI_BYTES) > RED_BYTES ? (NG * TILES_BYTES > EPI_BYTES ? NG * TILES_BYTES : EPI_BYTES) : RED_BYTES;
     static constexpr int swz_key(int xx) { return RES <= 8 ? (xx & 2) : ((xx >> 1) & 2); }
     static_assert(RES * RES % BM_ == 0 || (BM_ % (RES * RES) == 0 && WM == 1 && (NIMG == 2 || NIMG == 4) && TM % NIMG == 0), "a tile lies inside one image, or holds two / four whole images");
     static constexpr int TAPS_PER_ROUND = 8 / TM;                       // a round = eight elements per lane, one per MFMA group
     static_assert(NROUND * TAPS_PER_ROUND <= 7, "the rounds run behind taps 2..8");
-    static_assert(Epi::PACK_OK && LDS_BYTES <= 81920, "two blocks per CU");
+    static_assert(Epi::PACK_OK && LDS_BYTES <= (NG > 1 ? 163840 : 81920), "two blocks per CU (one with two K groups)");
 };
 
 // Weights [N][ld] bf16 in the engine's K order ((c / 64) * 9 + tap) * 64 + c % 64 (+ the c1 shortcut columns at 9 * cin) -> fragment-major
@@ -108,18 +115,19 @@ template <int OFF> __device__ __forceinline__ void lds_write16(unsigned addr, u3
 __device__ __forceinline__ void fresh4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 
 // EPI: the packed epilogues of gemm_dma.h (1 plain, 2 + GroupNorm partials, 5 + bf16 residual, 6 both).  g.b_frag = k_pack_frag's output.
-template <int RES, bool WIDE, int EPI, int TMV = 8>
-__global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
+template <int RES, bool WIDE, int EPI, int TMV = 8, int NGV = 1>
+__global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const GemmArgs g)
 {
-    using Cfg = ConvGn2Cfg<RES, WIDE, TMV>;
+    using Cfg = ConvGn2Cfg<RES, WIDE, TMV, NGV>;
     using Geo = typename Cfg::Geo;
     constexpr int BM_ = Cfg::BM_, BN_ = Cfg::BN_, NW = Cfg::NW, TM = Cfg::TM, TN = Cfg::TN, KT = Cfg::KT;
     constexpr int W = Geo::W, WS = Geo::WS, HW = RES * RES;
-    constexpr int PSW = Cfg::PSW, NROUND = Cfg::NROUND, NPIECE = Cfg::NPIECE, NFULL = Cfg::NFULL, NIMG = Cfg::NIMG, IMGP = Cfg::IMGP;
+    constexpr int PSW = Cfg::PSW, NROUND = Cfg::NROUND, NPIECE = Cfg::NPIECE, NFULL = Cfg::NFULL, NIMG = Cfg::NIMG, IMGP = Cfg::IMGP, NG = Cfg::NG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS: [2][PATCH_BYTES] patch buffers, then [2][scale 32 | shift 32] fp32 tables (the epilogue reuses all of it as its slab)
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = NG > 1 ? wave_all >> 2 : 0, wave = NG > 1 ? (wave_all & 3) : wave_all;      // K group, wave inside it
     const int wm = WIDE ? 0 : wave >> 1, wn = WIDE ? wave : wave & 1;
     const int nN = (g.N + BN_ - 1) / BN_, nM = (g.M + BM_ - 1) / BM_;      // (M is a whole number of tiles but for RES = 8 with an odd batch: the last tile holds one image)
     const int tile = xcd_remap(blockIdx.x, nM * nN);
@@ -133,8 +141,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     const bf16* const img = g.a0 + (int64_t)b * (HW >> (2 * ush)) * g.a0_ld;
     const float* const gsc = g.gn_scale + (int64_t)b * g.gn_ld;
     const float* const gsh = g.gn_shift + (int64_t)b * g.gn_ld;
-    const int n_half = g.a0_C / KT, n_sc = g.a1 ? g.a1_C / KT : 0;
+    const int n_half = g.a0_C / KT, n_sc = g.a1 ? g.a1_C / KT : 0;      // (the loops below count a group's OWN half-chunks / shortcut tiles: k-th one = NG * k + grp)
     const int nk = 9 * n_half, NT = nk + n_sc;
+    const int nh_g = n_half / NG, nsc_g = n_sc / NG;
 
     // Every LDS access, every LDS-DMA and every weight load of the K loop is inline asm with hand-counted waits (conv_gn.h explains
     // why: hipcc drains vmcnt in front of any LDS access it can see while an LDS-DMA is in flight).
@@ -144,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     };
     // (LDS byte addresses straight from the array: a cast of a generic pointer carries a null check against the shared aperture, which
     // hipcc has mis-selected into a vector compare on an SGPR-only operand in some variants of this kernel)
-    const unsigned lds_patch = (unsigned)(uintptr_t)((lds_u8*)smem), lds_tab = lds_patch + 2 * Cfg::PATCH_BYTES;
+    const unsigned lds_patch = (unsigned)(uintptr_t)((lds_u8*)smem) + grp * Cfg::TILES_BYTES, lds_tab = lds_patch + 2 * Cfg::PATCH_BYTES;
 
     // ---- weight fragments: two register sets, set (kt & 1) holds K step kt ---------------------------------------------------
     u32x4 bw[2][TN];
@@ -160,8 +169,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     };
 
     // ---- requests: the (scale | shift) table + this wave's patch pieces of half-chunk hc -> buffers hc & 1 ---------------------
-    auto issue_patch = [&](int hc) __attribute__((always_inline)) {
-        const int buf = hc & 1;
+    auto issue_patch = [&](int k) __attribute__((always_inline)) {
+        const int buf = k & 1, hc = NG * k + grp;
         int l;                                                               // the lane id, recomputed: kept alive across the K loop it is the value hipcc spills
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));                                          // addresses recomputed per request (once per nine taps): no registers held
         {
@@ -199,8 +208,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
             }
         }
     };
-    auto issue_shortcut = [&](int s) __attribute__((always_inline)) {        // plain [BM][32] tile of a1 -> patch buffer s & 1 (n_half is even)
-        const unsigned dst = lds_patch + (s & 1) * Cfg::PATCH_BYTES + wave * (PSW * 1024);
+    auto issue_shortcut = [&](int sk) __attribute__((always_inline)) {       // plain [BM][32] tile of a1 -> patch buffer sk & 1 (n_half is even)
+        const int s = NG * sk + grp;
+        const unsigned dst = lds_patch + (sk & 1) * Cfg::PATCH_BYTES + wave * (PSW * 1024);
         int l;                                                               // the lane id, recomputed: kept alive across the K loop it is the value hipcc spills
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
         const int prow = l >> 2, pslot = l & 3;
@@ -219,14 +229,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
 #ifdef NATINF_DEV
     const unsigned long long dbg_t0 = cg_stamp();
 #endif
-    // the first requests go out NOW: the index arithmetic below (masks, fragment bases, 128 accumulator registers) runs while they fly
-    issue_patch(0);
-    load_b(std::integral_constant<int, 0>{}, 0);
     // Weight warm-up (GemmArgs::w_warm).  Inside a forward pass the weights of a layer are cold: every block streams the same matrix one tap
     // ahead, so the first round of blocks pays a memory round trip PER TAP (all of them missing on the same lines at the same time) -- at 4x4,
     // where one round of 128 blocks is the whole launch, that doubled the kernel's time against an L2-warm measurement.  The first <= 16 blocks of
     // an XCD (blockIdx & 7 under round-robin dispatch; a wrong guess only costs speed) touch every 128-byte line of the matrix once, in K order,
     // split over their waves: the lines are on their way into this XCD's L2 before the K loop asks for them.
+    // (In FRONT of the first patch / weight requests: behind them, with their asm destination registers already "defined", the loop below raised
+    // the pressure enough in the 32x32 instantiation for hipcc to spill weight registers whose loads were still in flight.)
     unsigned warm_junk = 0;                                               // ONE destination register for all of them ("+v": it stays allocated from the first request to the wait below)
     if (g.w_warm) {
         const int jx = (int)blockIdx.x >> 3;
@@ -235,13 +244,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
             const int NB16 = g.N >> 4, total = NB16 * NT;                    // 1-KiB fragment blocks; one request = 64 lines = 8 of them
             int l;
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-            int i = jx * NW + wave;
-            for (int it = 0; it < 8 && i * 8 < total; ++it, i += nbx * NW) {
+            int i = jx * (NW * NG) + wave_all;
+            for (int it = 0; it < 8 && i * 8 < total; ++it, i += nbx * (NW * NG)) {
                 const int pz = min(i * 8 + (l >> 3), total - 1), kt = pz / NB16, nt = pz - kt * NB16;
                 asm volatile("global_load_dword %0, %1, %2" : "+v"(warm_junk) : "v"((unsigned)((nt * NT + kt) * 1024 + (l & 7) * 128)), "s"(wfrag) : "memory");
             }
         }
     }
+    // the first requests go out NOW: the index arithmetic below (masks, fragment bases, 128 accumulator registers) runs while they fly
+    issue_patch(0);
+    load_b(std::integral_constant<int, 0>{}, grp * 9);                     // the group's first K step: tap 0 of half-chunk grp
 
     // ---- in-place normalisation, round j: the wave's piece j * NW + wave, lane l its bytes l * 16 .. + 15 = patch row q * 16 + (l >> 2),
     // ---- slot l & 3, which holds channel chunk (l & 3) ^ 2 * (bit 2 of that row's patch column: nmask bit 8 + j).
@@ -422,9 +434,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     // ---- the nine taps of one half-chunk; BUF (its patch buffer) and the tap index are compile-time: all offsets are immediates.
     // Weight set of K step kt = hc * 9 + T: (kt & 1) = (T + BUF) & 1 (hc and BUF have the same parity).
 #define NATINF_CG_AOFF(i) (BUF * Cfg::PATCH_BYTES + ((RES == 32 ? ((i) >> 1) * WS + ((i) & 1) * 16 : (RES == 16 ? (i) * WS : (RES == 8 ? ((i) >> 2) * IMGP + ((i) & 3) * 2 * WS : (i) * IMGP))) + (T / 3) * WS) * 64)
-    auto tap = [&](auto buf_tag, auto t_tag, int hc, bool next_half) __attribute__((always_inline)) {
+    auto tap = [&](auto buf_tag, auto t_tag, int hc, bool next_half) __attribute__((always_inline)) {      // hc: the group's own count
         constexpr int BUF = decltype(buf_tag)::value, T = decltype(t_tag)::value, P = (T + BUF) & 1;
-        const int kt = hc * 9 + T;
+        const int kt = (NG * hc + grp) * 9 + T;
         NATINF_CG_STAMP(ts0)
         // Weight step kt has landed.  Younger requests: the aux request of tap 0 (at T = 1: it stays in flight; every wave issued at
         // least 2 + NFULL / PSW of them).  Tap 0 is the hand-off: every wave's normalised pieces of this half-chunk are written
@@ -437,7 +449,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         NATINF_CG_BW_READY(P)
         NATINF_CG_STAMP(ts1)
-        if (kt + 1 < NT) load_b(integral_constant<int, P ^ 1>{}, kt + 1);
+        // the group's next K step: the next tap; after tap 8 its next half-chunk, or its first shortcut tile
+        // (ONE load_b call site: the same asm statements reached on two paths would make hipcc merge -- copy -- registers whose loads are in flight)
+        int ktn = kt + 1;
+        bool has_next = NG > 1 ? true : kt + 1 < NT;
+        if constexpr (T == 8 && NG > 1) {
+            if (next_half) ktn = kt + 1 + 9 * (NG - 1);
+            else { ktn = nk + grp; has_next = n_sc > 0; }
+        }
+        if (has_next) load_b(integral_constant<int, P ^ 1>{}, ktn);
         if constexpr (T == 0) {
             if (next_half) issue_patch(hc + 1);
             else if (n_sc > 0) issue_shortcut(0);
@@ -459,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
         NATINF_CG_ADD(dbg_wait, ts0, ts1) NATINF_CG_ADD(dbg_head, ts1, ts2) NATINF_CG_ADD(dbg_mfma, ts2, ts3)
     };
     auto half_chunk = [&](auto buf_tag, int hc) __attribute__((always_inline)) {
-        const bool next_half = hc + 1 < n_half;
+        const bool next_half = hc + 1 < nh_g;
         tap(buf_tag, integral_constant<int, 0>{}, hc, next_half); tap(buf_tag, integral_constant<int, 1>{}, hc, next_half);
         tap(buf_tag, integral_constant<int, 2>{}, hc, next_half); tap(buf_tag, integral_constant<int, 3>{}, hc, next_half);
         tap(buf_tag, integral_constant<int, 4>{}, hc, next_half); tap(buf_tag, integral_constant<int, 5>{}, hc, next_half);
@@ -469,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
 #ifdef NATINF_DEV
     const unsigned long long dbg_t1 = cg_stamp();
 #endif
-    for (int hc = 0; hc < n_half; hc += 2) {                              // a0_C is a multiple of 64: half-chunks come in pairs
+    for (int hc = 0; hc < nh_g; hc += 2) {                                // a0_C is a multiple of 64 (128 with two K groups): a group's half-chunks come in pairs
         half_chunk(integral_constant<int, 0>{}, hc);
         half_chunk(integral_constant<int, 1>{}, hc + 1);
     }
@@ -478,8 +498,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
     // ---- wave fetches a quarter of a tile, so each tile is a hand-off), weights through the register sets as before; a1_C % 64 == 0
 #define NATINF_CG_POFF(i) (BUF * Cfg::PATCH_BYTES + (i) * 1024)
     auto sc_tile = [&](auto buf_tag, int s) __attribute__((always_inline)) {
-        constexpr int BUF = decltype(buf_tag)::value, P = BUF;            // nk is even: K step nk + s lives in set s & 1
-        const int kt = nk + s;
+        constexpr int BUF = decltype(buf_tag)::value, P = BUF;            // a group has run an even number of K steps: its s-th shortcut step lives in set s & 1
+        const int kt = nk + NG * s + grp;
         // the lane's fragment base in a plain [BM][32] tile, recomputed from an opaque lane id per tile: held across the main loop it is one
         // register too many (the 16x16 / N = 128 instantiation then reloads a spilled value inside the loop, behind hipcc's own vmcnt(0))
         int l2;
@@ -488,12 +508,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
         const unsigned a_plain = lds_patch + arow * 64 + (((l2 >> 4) ^ ((arow >> 1) & 2)) << 4);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         NATINF_CG_BW_READY(P)
-        if (kt + 1 < NT) load_b(integral_constant<int, P ^ 1>{}, kt + 1);
-        if (s + 1 < n_sc) issue_shortcut(s + 1);
+        if (s + 1 < nsc_g) { load_b(integral_constant<int, P ^ 1>{}, kt + NG); issue_shortcut(s + 1); }
         NATINF_CG_HEAD(a_plain, NATINF_CG_POFF)
         NATINF_CG_BODY(a_plain, NATINF_CG_POFF, P, NATINF_CG_NO, 0)
     };
-    for (int s = 0; s < n_sc; s += 2) {
+    for (int s = 0; s < nsc_g; s += 2) {
         sc_tile(integral_constant<int, 0>{}, s);
         sc_tile(integral_constant<int, 1>{}, s + 1);
     }
@@ -509,6 +528,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
 #undef NATINF_CG_NORM_EL
 #undef NATINF_CG_NORM_POST
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done with the tiles before the epilogue reuses them
+    if constexpr (NG > 1) {
+        // the second K group hands its partial sums over (fp32, [MFMA tile][thread] float4: lane-linear 16-byte accesses) and is done;
+        // S_BARRIER waits on the surviving waves only, so the first group's epilogue barriers work without it
+        f32x4* red = reinterpret_cast<f32x4*>(smem) + (tid & 255);
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) red[(i * TN + j) * 256] = acc[i][j];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += red[(i * TN + j) * 256];
+        __syncthreads();
+    }
     // the epilogue's arguments are fetched from the kernel-argument segment HERE (conv_gn.h: kept in scalar registers across the K
     // loop they end up spilled into vector-register lanes)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -527,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn2(const GemmArgs g)
 #ifdef NATINF_DEV
     const unsigned long long dbg_t2 = cg_stamp();
 #endif
-    tile_epilogue<Cfg::WM, Cfg::WN, TM, TN, typename Cfg::Epi, EPI, NIMG>(ge, smem, acc, m0, n0, 0, tid, lane, wm, wn);
+    tile_epilogue<Cfg::WM, Cfg::WN, TM, TN, typename Cfg::Epi, EPI, NIMG>(ge, smem, acc, m0, n0, 0, tid, lane, wm, wn);      // (two K groups: tid < 256 here)
 #ifdef NATINF_DEV
     if (ge.dbg_ts && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 777)) {          // development builds: tools/conv_gn_timeline.py
         // block 0: [2..4] are the epilogue's own stamps (NATINF_TS: start, slab written, copied out), [7] = the stamp in front of it

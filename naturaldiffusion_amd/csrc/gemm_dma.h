@@ -137,7 +137,10 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
     }
     // (two samples per tile: the row vector differs per sample.  The residual forms never carry one -- Conv_1 of a res-block has no time-embedding
     // row -- and keep ONE set of column terms: the second set is what tips their 256-register epilogue into dozens of spills)
-    constexpr int NCT = (NSAMP > 1 && !RES) ? NSAMP : 1;
+    // (four samples per tile -- the 4x4 level: every row-tile is a sample -- : ONE set of column terms (the bias) and the sample's row vector fetched
+    // per row-tile, LAZY_RV: four resident sets are 64 registers next to the 64 accumulators)
+    constexpr bool LAZY_RV = NSAMP > 2 && !RES;
+    constexpr int NCT = (NSAMP > 1 && !RES && !LAZY_RV) ? NSAMP : 1;
     float ct[NCT][TN][4];
 #pragma unroll
     for (int sm = 0; sm < NCT; ++sm)
@@ -149,7 +152,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
             if (g.bias_n) b = *reinterpret_cast<const float4*>(g.bias_n + n);
             // (NSAMP > 1: the further samples' rows; a partial last tile reads the last real sample's again -- those rows are not stored)
             const int srow = NSAMP > 1 ? min(m0 + sm * (BM_ / NSAMP), g.M - 1) : m0;
-            if (g.rowvec) rv = *reinterpret_cast<const float4*>(g.rowvec + (int64_t)((srow >> g.log_rows_per_sample) + z * g.z_samples) * g.rowvec_ld + n);
+            if (g.rowvec && !LAZY_RV) rv = *reinterpret_cast<const float4*>(g.rowvec + (int64_t)((srow >> g.log_rows_per_sample) + z * g.z_samples) * g.rowvec_ld + n);
         }
         ct[sm][j][0] = b.x + rv.x; ct[sm][j][1] = b.y + rv.y; ct[sm][j][2] = b.z + rv.z; ct[sm][j][3] = b.w + rv.w;
     }
@@ -171,6 +174,17 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
 #pragma unroll
         for (int j = 0; j < TN; ++j) { gs[sm][j] = 0.f; gq[sm][j] = 0.f; }
     const float scale = g.scale;
+    float4 lrv[LAZY_RV ? TN : 1];                       // LAZY_RV: the row vector of the sample row-tile i belongs to
+    auto fetch_rowvec = [&](int i) __attribute__((always_inline)) {
+        if constexpr (LAZY_RV) {
+            const int srow = min(m0 + (i / (TM / NSAMP)) * (BM_ / NSAMP), g.M - 1);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * TN * 16 + j * 16 + q * 4;
+                lrv[j] = (g.rowvec && n < g.N) ? *reinterpret_cast<const float4*>(g.rowvec + (int64_t)(srow >> g.log_rows_per_sample) * g.rowvec_ld + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
     // the finished fp32 values of accumulator tile (i, j)
     auto value = [&](int i, int j, float (&v)[4]) __attribute__((always_inline)) {
         const int sm = NSAMP > 1 ? i / (TM / NSAMP) : 0;                  // (i is a compile-time constant at every call site)
@@ -180,6 +194,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
             if constexpr (DEQ) v[e] = (acc[i][j][e] * (rsc[i] * dn[j][e]) + ct[sc_][j][e]) + rbm[i];
             else v[e] = acc[i][j][e] + ct[sc_][j][e];
         }
+        if constexpr (LAZY_RV) { v[0] += lrv[j].x; v[1] += lrv[j].y; v[2] += lrv[j].z; v[3] += lrv[j].w; }
         if constexpr (RES) {
             const bf16x4_t x = __builtin_bit_cast(bf16x4_t, rs[i][j]);
 #pragma unroll
@@ -197,7 +212,8 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
     unsigned char* wbase = smem + (wm * TM * 16 + r) * PROW + (wn * TN * 16 + q * 4) * EB;
     if constexpr (!OUT8) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            fetch_rowvec(i);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float v[4];
@@ -207,6 +223,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
                 for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
                 *reinterpret_cast<uint2*>(wbase + i * 16 * PROW + j * 32) = __builtin_bit_cast(uint2, o);
             }
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
