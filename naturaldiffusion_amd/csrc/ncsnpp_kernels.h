@@ -448,36 +448,48 @@ __global__ __launch_bounds__(256) void k_gn_finalize(const float2* __restrict__ 
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ scale, float* __restrict__ shift, float eps, float out_mul)
 {
-    __shared__ float s_s[128], s_q[128], s_mean[32], s_rstd[32];
+    // A launch of this kernel is pure latency (a few KB per sample): ONE barrier, and every global read requested before anything waits --
+    // the thread's gamma / beta (C <= 512: two channels per thread) first, the partial rows of its quad four at a time.  Every channel thread
+    // then sums its group's quads itself (<= 4 LDS reads) instead of waiting for a 32-thread middle phase behind a second barrier.  Same
+    // additions in the same order as the three-phase form it replaces: bit-identical tables (5.2 -> ~3.5 us per launch, 68 launches per forward).
+    __shared__ float2 s_p[128];
     const int tid = threadIdx.x, b = blockIdx.x, nq = quads0 + quads1;
+    float ga[2] = {0.f, 0.f}, be[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = tid + 256 * k;
+        if (c < C) { ga[k] = gamma[c]; be[k] = beta[c]; }
+    }
     for (int q = tid; q < nq; q += 256) {
+        const bool first = q < quads0;
+        const float2* P = first ? P0 + (int64_t)b * tps0 * quads0 + q : P1 + (int64_t)b * tps1 * quads1 + (q - quads0);
+        const int tps = first ? tps0 : tps1, st = first ? quads0 : quads1;
         float s = 0.f, qq = 0.f;
-        if (q < quads0) {
-            for (int t = 0; t < tps0; ++t) { const float2 v = P0[((int64_t)b * tps0 + t) * quads0 + q]; s += v.x; qq += v.y; }
-        } else {
-            for (int t = 0; t < tps1; ++t) { const float2 v = P1[((int64_t)b * tps1 + t) * quads1 + (q - quads0)]; s += v.x; qq += v.y; }
+        int t = 0;
+        for (; t + 4 <= tps; t += 4) {
+            const float2 v0 = P[(int64_t)t * st], v1 = P[(int64_t)(t + 1) * st], v2 = P[(int64_t)(t + 2) * st], v3 = P[(int64_t)(t + 3) * st];
+            s += v0.x; qq += v0.y; s += v1.x; qq += v1.y; s += v2.x; qq += v2.y; s += v3.x; qq += v3.y;
         }
-        s_s[q] = s; s_q[q] = qq;
+        for (; t < tps; ++t) { const float2 v = P[(int64_t)t * st]; s += v.x; qq += v.y; }
+        s_p[q] = make_float2(s, qq);
     }
     __syncthreads();
     const int cg = C >> 5, qpg = cg >> 2;
-    if (tid < 32) {
+    const float inv = 1.0f / (float)(cg * HW);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = tid + 256 * k;
+        if (c >= C) break;
+        const int gi = c / cg;
         float s = 0.f, q = 0.f;
-        for (int i = 0; i < qpg; ++i) { s += s_s[tid * qpg + i]; q += s_q[tid * qpg + i]; }
-        const float inv = 1.0f / (float)(cg * HW);
+        for (int i = 0; i < qpg; ++i) { const float2 v = s_p[gi * qpg + i]; s += v.x; q += v.y; }
         const float mean = s * inv;
         float var = q * inv - mean * mean;
         var = var < 0.f ? 0.f : var;
-        s_mean[tid] = mean;
-        s_rstd[tid] = 1.0f / sqrtf(var + eps);
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        const int gi = c / cg;
-        const float sc = s_rstd[gi] * gamma[c];
+        const float sc = (1.0f / sqrtf(var + eps)) * ga[k];
         // out_mul: 1, or -log2(e) when the consumer is k_conv_gn in folded form (it then gets exp(-v) = exp2(x*scale + shift) at once)
         scale[(int64_t)b * C + c] = sc * out_mul;
-        shift[(int64_t)b * C + c] = (beta[c] - s_mean[gi] * sc) * out_mul;
+        shift[(int64_t)b * C + c] = (be[k] - mean * sc) * out_mul;
     }
 }
 
