@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
 #ifdef NATINF_DEV
     const unsigned long long dbg_t2 = cg_stamp();
 #endif
-    tile_epilogue<Cfg::WM, Cfg::WN, TM, TN, typename Cfg::Epi, EPI, NIMG>(ge, smem, acc, m0, n0, 0, tid, lane, wm, wn);      // (two K groups: tid < 256 here)
+    tile_epilogue<Cfg::WM, Cfg::WN, TM, TN, typename Cfg::Epi, EPI, NIMG, (RES <= 8)>(ge, smem, acc, m0, n0, 0, tid, lane, wm, wn);      // (two K groups: tid < 256 here)
 #ifdef NATINF_DEV
     if (ge.dbg_ts && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 777)) {          // development builds: tools/conv_gn_timeline.py
         // block 0: [2..4] are the epilogue's own stamps (NATINF_TS: start, slab written, copied out), [7] = the stamp in front of it

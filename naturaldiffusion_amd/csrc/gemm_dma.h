@@ -111,7 +111,9 @@ struct SlabCopy<NSW, NSW, RPS, PROW, EDGE> {
 // four lanes of a row) -- the bytes cross LDS like the bf16 values do, the scale bytes are stored from the registers.
 // NSAMP = 2 / 4 (k_conv_gn2 at 8x8 / 4x4: WM == 1, every TM / NSAMP row-tiles of the tile are one sample): the per-sample row vector and the GroupNorm
 // partials exist once per sample; gn_part rows are then indexed by (m0 / BM) * NSAMP + sample.
-template <int WM, int WN, int TM, int TN, class Cfg, int ACT, bool GN, bool RES, bool DEQ = false, bool OUT8 = false, int NSAMP = 1>
+// FIN (k_conv_gn2 at 8x8 / 4x4: the tile = whole samples x all BN_ = N channels): GemmArgs::fin_* -- the consumer's GroupNorm table straight from
+// the tile's own partial sums, same additions in the same order as k_gn_finalize (bit-identical tables).
+template <int WM, int WN, int TM, int TN, class Cfg, int ACT, bool GN, bool RES, bool DEQ = false, bool OUT8 = false, int NSAMP = 1, bool FIN = false>
 __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned char* smem, f32x4 (&acc)[TM][TN],
                                                      int m0, int n0, int z, int tid, int lane, int wm, int wn)
 {
@@ -297,6 +299,28 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
 #pragma unroll
                 for (int w = 0; w < WM; ++w) { s += sred[w * (BN_ / 4) + tid].x; qq += sred[w * (BN_ / 4) + tid].y; }
                 reinterpret_cast<float2*>(g.gn_part)[(int64_t)(m0 / BM_) * g.gn_quads + (n0 >> 2) + tid] = make_float2(s, qq);
+            }
+        }
+        if constexpr (FIN) {
+            static_assert(WM == 1 && BN_ == THREADS, "one channel per thread, one wave row");
+            const int n = n0 + tid;
+            if (g.fin_scale && n < g.N) {
+                constexpr int HWS = BM_ / NSAMP;                       // rows of a sample
+                const int cg = g.fin_cg, qpg = cg >> 2, q0 = (n / cg) * qpg - (n0 >> 2);
+                const float inv = 1.0f / (float)(cg * HWS), ga = g.fin_gamma[n], be = g.fin_beta[n];
+#pragma unroll
+                for (int sm = 0; sm < NSAMP; ++sm) {
+                    if (m0 + sm * HWS >= g.M) break;
+                    float s = 0.f, qq = 0.f;
+                    for (int i = 0; i < qpg; ++i) { const float2 v = sred[sm * (BN_ / 4) + q0 + i]; s += v.x; qq += v.y; }
+                    const float mean = s * inv;
+                    float var = qq * inv - mean * mean;
+                    var = var < 0.f ? 0.f : var;
+                    const float sc = (1.0f / sqrtf(var + g.fin_eps)) * ga;
+                    const int64_t o = (int64_t)(m0 / HWS + sm) * g.fin_ld + n;
+                    g.fin_scale[o] = sc * g.fin_mul;
+                    g.fin_shift[o] = (be - mean * sc) * g.fin_mul;
+                }
             }
         }
     }
@@ -558,7 +582,7 @@ __device__ __forceinline__ void direct_f32_epilogue(const GemmArgs& g, f32x4 (&a
 // 7 = the direct fp32 residual-stream epilogue; 8 = packed with row terms (a row bias: the V^T = W h^T + b GEMMs).  One epilogue per kernel: with both in one
 // kernel behind a run-time branch hipcc spilled inside the packed register phase (measured: isolated GEMMs +15..23 %, the
 // network 8 % SLOWER).
-template <int WM, int WN, int TM, int TN, class Cfg, int EPI, int NSAMP = 1>
+template <int WM, int WN, int TM, int TN, class Cfg, int EPI, int NSAMP = 1, bool FIN = false>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, unsigned char* smem, f32x4 (&acc)[TM][TN],
                                               int m0, int n0, int z, int tid, int lane, int wm, int wn)
 {
@@ -567,7 +591,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, unsigned char* 
     else {
         static_assert(Cfg::PACK_OK, "packed epilogue needs the whole bf16 tile in LDS");
         NATINF_TS(2);
-        packed_tile_epilogue<WM, WN, TM, TN, Cfg, EPI == 3 ? ACT_SILU : (EPI == 4 ? ACT_GELU_TANH : ACT_NONE), EPI == 2 || EPI == 6, EPI == 5 || EPI == 6, EPI == 8, false, NSAMP>(
+        packed_tile_epilogue<WM, WN, TM, TN, Cfg, EPI == 3 ? ACT_SILU : (EPI == 4 ? ACT_GELU_TANH : ACT_NONE), EPI == 2 || EPI == 6, EPI == 5 || EPI == 6, EPI == 8, false, NSAMP, FIN && (EPI == 2 || EPI == 6)>(
             g, smem, acc, m0, n0, z, tid, lane, wm, wn);
     }
 }

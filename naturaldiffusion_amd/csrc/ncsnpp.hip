@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -224,6 +225,8 @@ int g_cg8_tm4 = 1;                 // natinf_set_conv_gn8_tile: 1 = 8x8 level on
 int g_attn256 = 1;                 // natinf_set_attn256: 1 = k_attn256 (K / V^T streamed through a two-stage LDS ring, two blocks per CU), 0 = k_attn_fused<8,16,true>
 int g_fuse_gn8 = 1;                // natinf_set_fuse_gn8 (read when a plan is BUILT): the 8x8 level on the fused kernel too (two images per 128-pixel tile)
 int g_cg_warm = 15;                // natinf_set_conv_gn_warm: bit mask by resolution (1: 4x4, 2: 8x8, 4: 16x16, 8: 32x32) of the fused-convolution launches that warm L2 with their weights
+int g_fuse_fin = 1;                // natinf_set_fuse_fin (read when a plan is BUILT): at 8x8 / 4x4 the fused convolution's epilogue writes the GroupNorm table of its
+                                   // output's consumer itself (whole samples x all channels per tile) instead of a k_gn_finalize launch behind it
 int g_fuse_gn4 = 1;                // natinf_set_fuse_gn4 (read when a plan is BUILT): the 4x4 level on the fused kernel too (four images per 64-pixel tile) instead of
                                    // k_gn_apply + split-K GEMM + k_splitk_reduce + k_gn_stats
 int g_fuse_gn = 1;                 // natinf_set_fuse_gn (read when a plan is BUILT): GroupNorm-apply + SiLU inside the consuming 3x3 conv
@@ -670,7 +673,8 @@ struct Builder {
     GN take_gn(int C) { GN g; g.gamma = pack_f32(take(C), C); g.beta = pack_f32(take(C), C); return g; }
 
     // GroupNorm statistics of x -> (scale, shift) per (image, channel); returns their arena offsets
-    void emit_gn_stats(const TRef& x, GN gn, int64_t sc, int64_t sh, float out_mul = 1.0f) {
+    // (sc, sh: in / out -- where the producer's epilogue writes the table itself (Part::fin) they are REPLACED by its table)
+    void emit_gn_stats(const TRef& x, GN gn, int64_t& sc, int64_t& sh, float out_mul = 1.0f) {
         if (emit_gn_from_parts(x, gn, sc, sh, out_mul)) return;
         const int HW = x.res * x.res;
         op(CLS_OTHER, [=](const Ctx& c) {
@@ -733,7 +737,8 @@ struct Builder {
         pack_f32_at(p_db, cout, dense_b + (int64_t)drow * 4);
         dense_rows_next += cout;
 
-        const int64_t sc = arena.alloc((int64_t)std::max(cin, cout) * 4), sh = arena.alloc((int64_t)std::max(cin, cout) * 4);
+        const int64_t own_sc = arena.alloc((int64_t)std::max(cin, cout) * 4), own_sh = arena.alloc((int64_t)std::max(cin, cout) * 4);
+        int64_t sc = own_sc, sh = own_sh;                 // GroupNorm_0's table: this block's buffers, or the one x's producer wrote
         emit_gn_stats(x, gn0, sc, sh, gn_mul);
         TRef h, xr;
         if (!fuse) {
@@ -760,16 +765,17 @@ struct Builder {
             g.rowvec = c.at<float>(dout) + drow; g.rowvec_ld = dtotal; g.log_rows_per_sample = logHW;
             if (skws >= 0) { g.splitk_ws = c.at<float>(skws); g.splitk_max = SK_MAX; }
             g.c = c.act(t); g.c_ld = t.ld;
-            if (pt.valid) { g.gn_part = c.at<float>(pt.off); g.gn_quads = pt.quads; }
+            if (pt.valid) { g.gn_part = c.at<float>(pt.off); g.gn_quads = pt.quads; set_fin(g, pt, c); }
             const int bm = launch_gemm(g, c.stream);
             if (pt.valid) c.part_bm[pt.id] = bm;
         });
         if (!fuse) arena.release(h.off);
-        emit_gn_stats(t, gn1, sc, sh, gn_mul1);
+        int64_t sc1 = own_sc, sh1 = own_sh;               // GroupNorm_1's table: the same buffers again, or the one Conv_0's epilogue wrote
+        emit_gn_stats(t, gn1, sc1, sh1, gn_mul1);
         TRef u;
         if (!fuse1) {
             u = new_act(ro, cout, 1);
-            emit_gn_apply(t, sc, sh, u, nullptr, ACT_SILU, RS_NONE);
+            emit_gn_apply(t, sc1, sh1, u, nullptr, ACT_SILU, RS_NONE);
             arena.release(t.off);
         }
         if (pt.valid) arena.release(pt.off);
@@ -778,7 +784,7 @@ struct Builder {
         const Part po = register_output(out, fuse1);
         op(fuse1 ? (ro <= 8 ? CLS_CONV_GN8 : CLS_CONV_GN) : CLS_GEMM, [=](const Ctx& c) {
             GemmArgs g = gemm_defaults();
-            if (fuse1) { g.a0 = c.act(t); g.a0_ld = t.ld; g.gn_scale = c.at<float>(sc); g.gn_shift = c.at<float>(sh); g.gn_ld = cout; g.gn_folded = 1; }
+            if (fuse1) { g.a0 = c.act(t); g.a0_ld = t.ld; g.gn_scale = c.at<float>(sc1); g.gn_shift = c.at<float>(sh1); g.gn_ld = cout; g.gn_folded = 1; }
             else { g.a0 = c.act(u); g.a0_ld = u.ld; g.a0_padded = 1; }
             g.a0_C = cout; g.taps = 9; g.logW = logW; g.logHW = logHW;
             if (shortcut) { g.a1 = c.act(xs); g.a1_ld = xs.ld; g.a1_C = cin; g.a1_up = fuse_up; }
@@ -788,14 +794,16 @@ struct Builder {
             g.bias_n = c.w<float>(b1); g.scale = rs;
             if (skws >= 0) { g.splitk_ws = c.at<float>(skws); g.splitk_max = SK_MAX; }
             g.c = c.act(out); g.c_ld = out.ld;
-            if (po.valid) { g.gn_part = c.at<float>(po.off); g.gn_quads = po.quads; }
+            if (po.valid) { g.gn_part = c.at<float>(po.off); g.gn_quads = po.quads; set_fin(g, po, c); }
             const int bm = launch_gemm(g, c.stream);
             if (po.valid) c.part_bm[po.id] = bm;
         });
         if (skws >= 0) arena.release(skws);
         if (fuse1) arena.release(t.off); else arena.release(u.off);
         if ((m.up || m.down) && !fuse_up) arena.release(xr.off);
-        arena.release(sc); arena.release(sh);
+        arena.release(own_sc); arena.release(own_sh);
+        if (sc != own_sc) { arena.release(sc); arena.release(sh); }          // tables written by producers' epilogues: consumed
+        if (sc1 != own_sc) { arena.release(sc1); arena.release(sh1); }
         E.taps[m.idx] = out;
     }
 
@@ -813,7 +821,8 @@ struct Builder {
         pack_f32_at(pb[0], C, bqk); pack_f32_at(pb[1], C, bqk + (int64_t)C * 4);
         const int64_t bv = pack_f32(pb[2], C), b3 = pack_f32(pb[3], C);
 
-        const int64_t sc = arena.alloc((int64_t)C * 4), sh = arena.alloc((int64_t)C * 4);
+        const int64_t own_sc = arena.alloc((int64_t)C * 4), own_sh = arena.alloc((int64_t)C * 4);
+        int64_t sc = own_sc, sh = own_sh;
         emit_gn_stats(x, gn, sc, sh);
         TRef h = new_act(m.res, C);
         emit_gn_apply(x, sc, sh, h, nullptr, ACT_NONE, RS_NONE);
@@ -886,7 +895,8 @@ struct Builder {
             const int bm = launch_gemm(g, c.stream);
             if (po.valid) c.part_bm[po.id] = bm;
         });
-        arena.release(O.off); arena.release(sc); arena.release(sh);
+        arena.release(O.off); arena.release(own_sc); arena.release(own_sh);
+        if (sc != own_sc) { arena.release(sc); arena.release(sh); }
         E.taps[m.idx] = out;
     }
 
@@ -961,7 +971,17 @@ struct Builder {
     int dense_rows_next = 0;
 
     // ---- fused GroupNorm statistics: partial tables written by GEMM epilogues ------------------------
-    struct Part { int64_t off = -1; int quads = 0, id = -1, res = 0; bool valid = false; };
+    // Fin: the producer's epilogue writes its consumer's GroupNorm table (GemmArgs::fin_*).  The table buffers are allocated with the Part -- in front
+    // of the producing launch, so they cannot alias anything that launch still reads -- and the consumer fills in its gamma / beta when it is emitted
+    // (the producer's op reads the struct when it RUNS).  Only the first single-source consumer claims it; anyone else takes k_gn_finalize.
+    struct Fin { int64_t sc = -1, sh = -1, gamma = -1, beta = -1; int C = 0; float out_mul = 1.0f; bool claimed = false; };
+    struct Part { int64_t off = -1; int quads = 0, id = -1, res = 0; bool valid = false; std::shared_ptr<Fin> fin; };
+    static void set_fin(GemmArgs& g, const Part& p, const Ctx& c) {
+        if (!p.fin || !p.fin->claimed) return;
+        const Fin& f = *p.fin;
+        g.fin_scale = c.at<float>(f.sc); g.fin_shift = c.at<float>(f.sh); g.fin_gamma = c.w<float>(f.gamma); g.fin_beta = c.w<float>(f.beta);
+        g.fin_ld = f.C; g.fin_cg = f.C / 32; g.fin_mul = f.out_mul; g.fin_eps = GN_EPS;
+    }
     std::map<std::pair<int64_t, int>, Part> parts;      // (tensor offset, channel offset) -> latest producer's table
     int n_parts = 0;
     static bool fusable(int res) { return res >= 16; }   // every block tile (<= 256 rows) lies inside one sample
@@ -976,13 +996,17 @@ struct Builder {
     Part register_output(const TRef& out, bool fused8 = false) {
         Part p;
         if (fusable(out.res) || (out.res <= 8 && fused8)) p = new_part(out.res, out.C);
+        if (p.valid && out.res <= 8 && fused8 && g_fuse_fin && out.C == 256) {      // (the fused kernel's 64-pixel x 256-channel tile: whole samples, every channel)
+            p.fin = std::make_shared<Fin>();
+            p.fin->sc = arena.alloc((int64_t)out.C * 4); p.fin->sh = arena.alloc((int64_t)out.C * 4); p.fin->C = out.C;
+        }
         parts[{out.off, out.coff}] = p;
         return p;
     }
     // statistics of x from partial tables if every channel slice of x has a valid one; otherwise the streaming kernel.
     // (Folding the tables inside k_gn_apply instead of this one-block-per-sample launch was built and measured: bit-identical,
     // 1.6 % SLOWER per forward in a same-box A/B -- every 4-row apply block then starts with two dependent load round trips.)
-    bool emit_gn_from_parts(const TRef& x, GN gn, int64_t sc, int64_t sh, float out_mul) {
+    bool emit_gn_from_parts(const TRef& x, GN gn, int64_t& sc, int64_t& sh, float out_mul) {
         std::vector<Part> src;
         int ch = 0;
         while (ch < x.C) {
@@ -994,11 +1018,18 @@ struct Builder {
         if (ch != x.C || src.empty() || src.size() > 2) return false;
         const Part p0 = src[0], p1 = src.size() > 1 ? src[1] : Part();
         const int HW = x.res * x.res, C = x.C;
+        if (src.size() == 1 && p0.fin && !p0.fin->claimed && p0.fin->C == C) {          // the producer's epilogue writes this table: no launch
+            Fin& f = *p0.fin;
+            f.gamma = gn.gamma; f.beta = gn.beta; f.out_mul = out_mul; f.claimed = true;
+            sc = f.sc; sh = f.sh;
+            return true;
+        }
+        const int64_t sc_ = sc, sh_ = sh;
         op(CLS_OTHER, [=](const Ctx& c) {
             const int tps0 = HW / c.part_bm[p0.id], tps1 = p1.valid ? HW / c.part_bm[p1.id] : 0;
             hipLaunchKernelGGL(k_gn_finalize, dim3(c.B), dim3(256), 0, c.stream, c.at<float2>(p0.off), tps0, p0.quads,
                                p1.valid ? c.at<float2>(p1.off) : (const float2*)nullptr, tps1, p1.valid ? p1.quads : 0, C, HW,
-                               c.w<float>(gn.gamma), c.w<float>(gn.beta), c.at<float>(sc), c.at<float>(sh), GN_EPS, out_mul);
+                               c.w<float>(gn.gamma), c.w<float>(gn.beta), c.at<float>(sc_), c.at<float>(sh_), GN_EPS, out_mul);
         });
         return true;
     }
@@ -1191,7 +1222,7 @@ struct Builder {
             const int64_t w = wres((int64_t)3 * Kf * 2);
             pack_conv(pw, w, 3, mc.cin, 9, Kf, 0, mc.cin);
             const int64_t b = pack_f32(pb, 3);
-            const int64_t sc = arena.alloc((int64_t)mg.cin * 4), sh = arena.alloc((int64_t)mg.cin * 4);
+            int64_t sc = arena.alloc((int64_t)mg.cin * 4), sh = arena.alloc((int64_t)mg.cin * 4);          // (32x32: never a producer-written table)
             const int logW = ilog2(res), cinf = mc.cin;
             if (g_fuse_head && res == HeadConvCfg::RES && mc.cin == HeadConvCfg::C) {
                 // one launch (head_conv.h): raw tensor in, fp32 NCHW out; folded GroupNorm form (scale / shift x -log2 e, weights x -ln 2)
@@ -1493,6 +1524,7 @@ int natinf_set_fuse_gn(int on) { g_fuse_gn = on != 0; return NATINF_OK; }
 int natinf_set_fuse_gn8(int on) { g_fuse_gn8 = on != 0; return NATINF_OK; }
 int natinf_set_attn256(int on) { g_attn256 = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_warm(int mask) { if (mask < 0 || mask > 15) return NATINF_EINVAL; g_cg_warm = mask; return NATINF_OK; }
+int natinf_set_fuse_fin(int on) { g_fuse_fin = on != 0; return NATINF_OK; }
 int natinf_set_fuse_gn4(int on) { g_fuse_gn4 = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn8_tile(int one_image) {
 #ifndef NATINF_DEV

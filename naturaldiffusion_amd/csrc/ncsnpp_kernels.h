@@ -65,6 +65,10 @@ struct GemmArgs {
     // fused GroupNorm statistics of the OUTPUT (DMA kernels, block tile inside one sample): per block tile and per
     // 4-channel quad, (sum, sum of squares) of the fp32 results -> gn_part[(m0/BM)*gn_quads + n/4] (float2)
     float* gn_part; int gn_quads;
+    // ... and, where a block tile holds WHOLE samples and every channel of the tensor (k_conv_gn2 at 8x8 / 4x4), the finished GroupNorm table of the
+    // tensor's (single) consumer, written by the same epilogue instead of a k_gn_finalize launch: fin_scale / fin_shift [sample][fin_ld] get
+    // rstd * gamma * fin_mul and (beta - mean * rstd * gamma) * fin_mul with the consumer's gamma / beta; fin_cg = channels per group
+    float* fin_scale; float* fin_shift; const float* fin_gamma; const float* fin_beta; int fin_ld; int fin_cg; float fin_mul; float fin_eps;
     // fused GroupNorm-apply + SiLU of the INPUT (k_conv_gn, conv_gn.h): a0 is the RAW, unpadded [B][H][W][a0_ld] tensor and every
     // element is read as silu(a0 * gn_scale[b*gn_ld + c] + gn_shift[b*gn_ld + c]); a1 (1x1 shortcut segment) stays raw
     // gn_folded: scale / shift arrive multiplied by -log2(e) and the 3x3 weights by -ln 2 (the kernel then computes t = x*scale + shift,
