@@ -62,7 +62,8 @@ def profiled_traffic(match, exclude=None):
     if not files:
         return None, None
     tab = json.loads(files[-1].read_text())
-    rows = [v for k, v in tab.items() if match in k and not (exclude and exclude in k)]
+    excl = (exclude,) if isinstance(exclude, str) else tuple(exclude or ())
+    rows = [v for k, v in tab.items() if match in k and not any(e in k for e in excl)]
     n = sum(v["launches"] for v in rows)
     if not n:
         return None, None
@@ -288,7 +289,7 @@ def bench_cifar(args, world, rank, dev):
         # (natinf_ncsnpp_describe_gemms); their sum is the 21.69 GFLOP / image / forward of SURVEY section 8d
         rows = engine.describe_gemms(Bz)
         fl = lambda r: 2.0 * r[0] * r[1] * (r[2] + r[3]) * r[5]
-        is8 = lambda r: r[0] == Bz * 64                                           # the 8x8 level: 64 pixels per image
+        is8 = lambda r: r[0] in (Bz * 64, Bz * 16)                                # the 8x8 and 4x4 levels: 64 / 16 pixels per image
         cg_rows = [r for r in rows if r[6].startswith("conv_gn") and not is8(r)]
         c8_rows = [r for r in rows if r[6].startswith("conv_gn") and is8(r)]
         cg_flops = sum(fl(r) for r in cg_rows) * fwd
@@ -296,10 +297,10 @@ def bench_cifar(args, world, rank, dev):
         gemm_flops = GFLOP_PER_IMAGE_FORWARD * 1e9 * Bz * fwd - cg_flops - c8_flops          # the rest: the k_gemm_* launches, the fused attention, the head
         all_ms = cg_ms + c8_ms + gemm_ms + other_ms
         ach = cg_flops / (cg_ms * 1e-3) / 1e12
-        tr_cg, tr_src = profiled_traffic("k_conv_gn", exclude="k_conv_gn2<8")
+        tr_cg, tr_src = profiled_traffic("k_conv_gn", exclude=("k_conv_gn2<8", "k_conv_gn2<4"))
         line["roofline"] = {
             "kernel": "k_conv_gn2<32 | 16, ...> (3x3 convolution with GroupNorm-apply + SiLU fused into its operand path, weights streamed through registers; the 32x32 and "
-                      f"16x16 levels: the dominant kernel, {100 * cg_ms / all_ms:.0f} % of the engine's device time; its 8x8 instantiation: roofline_conv_gn8)", "bound": "mfma",
+                      f"16x16 levels: the dominant kernel, {100 * cg_ms / all_ms:.0f} % of the engine's device time; its 8x8 / 4x4 instantiations: roofline_conv_gn8)", "bound": "mfma",
             "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
             "traffic": tr_cg, "traffic_source": tr_src, "traffic_note": "HBM bytes per launch from the committed rocprofv3 PMC summary named in traffic_source (the same launches), not measured by this run",
             "launches": int(cg_n), "mean_launch_ms": round(cg_ms / cg_n, 5),
@@ -309,14 +310,14 @@ def bench_cifar(args, world, rank, dev):
         if c8_n:
             ach8 = c8_flops / (c8_ms * 1e-3) / 1e12
             line["roofline_conv_gn8"] = {
-                "kernel": "k_conv_gn2<8, true, ...> (the same fused kernel on the 8x8 level: two whole images per 128-pixel x 256-channel tile, one block per CU at "
-                          f"B = 512; {100 * c8_ms / all_ms:.0f} % of the engine's device time)", "bound": "mfma", "achieved": round(ach8, 2),
+                "kernel": "k_conv_gn2<8 | 4, true, ..., 4> (the same fused kernel on the 8x8 and 4x4 levels: 64-pixel x 256-channel tiles = one 8x8 image, two blocks per CU / "
+                          f"four 4x4 images, two K groups of four waves per block, 128 tiles at B = 512; {100 * c8_ms / all_ms:.0f} % of the engine's device time)", "bound": "mfma", "achieved": round(ach8, 2),
                 "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach8 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "launches": int(c8_n),
                 "mean_launch_ms": round(c8_ms / c8_n, 5), "flops_per_launch": c8_flops / c8_n, "device_ms_total": round(c8_ms, 3)}
         ach_g = gemm_flops / (gemm_ms * 1e-3) / 1e12
         tr_gemm, tr_src_g = profiled_traffic("k_gemm")
         line["roofline_gemm"] = {
-            "kernel": "k_gemm_* (LDS-DMA implicit-GEMM tile variants: resampling-block / 4x4 convolutions, NIN, linear) + k_attn_fused + k_head_conv",
+            "kernel": "k_gemm_* (LDS-DMA implicit-GEMM tile variants: resampling-block convolutions, attention projections, NIN, linear) + k_attn256 + k_head_conv",
             "bound": "mfma", "achieved": round(ach_g, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach_g / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": tr_gemm, "traffic_source": tr_src_g, "launches": int(gemm_n),
             "mean_launch_ms": round(gemm_ms / gemm_n, 5), "flops_per_launch": gemm_flops / gemm_n, "device_ms_total": round(gemm_ms, 3),

@@ -31,7 +31,11 @@ __global__ __launch_bounds__(256, 2) void k_attn256(const bf16* __restrict__ qk,
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x >> 1, qhalf = blockIdx.x & 1;
+    // The two blocks of a sample read the same K and V^T (128 KB each): block ids i and i + 8 -- the same XCD under round-robin dispatch, launched in the
+    // same wave of blocks -- take the two query halves of one sample, so the second read hits that XCD's L2 (PMC, round 3: 336 MB fetched per launch at
+    // B = 512 against 201 MB of operands with the halves on neighbouring ids = different XCDs).  A tail of < 16 blocks keeps the plain order.
+    const int bid = blockIdx.x, full = (int)gridDim.x & ~15;
+    const int b = bid < full ? ((bid >> 4) << 3) + (bid & 7) : bid >> 1, qhalf = bid < full ? (bid >> 3) & 1 : bid & 1;
     const bf16* qbase = qk + (int64_t)b * T * qk_ld;
     const bf16* kbase = qbase + k_off;
     const bf16* vbase = vT + (int64_t)b * A256_D * T;
