@@ -75,7 +75,8 @@ struct ConvGn2Cfg {
     static constexpr int NFULL = NPIECE / NW;                           // rounds in which every wave has a piece
     static constexpr int PSW = BM_ / 16 / NW;                           // shortcut-tile pieces per wave
     static constexpr int PATCH_BYTES = (NPIECE > BM_ / 16 ? NPIECE : BM_ / 16) * 1024, TAB_IMG_BYTES = 256, TAB_BYTES = NIMG * TAB_IMG_BYTES;
-    static constexpr int TILES_BYTES = 2 * PATCH_BYTES + 2 * TAB_BYTES;
+    static constexpr int VOFF_BYTES = NROUND * 1024;                    // the lanes' patch-request offsets, one 32-bit word per lane, wave and round (see issue_patch)
+    static constexpr int TILES_BYTES = 2 * PATCH_BYTES + 2 * TAB_BYTES + VOFF_BYTES;
     using Epi = EpiCfg<WM, WN, TM, TN, 81920>;
     static constexpr int EPI_BYTES = Epi::PACK_BYTES + (NIMG - 1) * WN * TN * 4 * 8;      // + the partial-sum rows of the further samples
     static constexpr int RED_BYTES = NG > 1 ? TM * TN * 16 * 256 : 0;  // the second group's accumulators (fp32, one float4 per thread and MFMA tile)
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = NG > 1 ? wave_all >> 2 : 0, wave = NG > 1 ? (wave_all & 3) : wave_all;      // K group, wave inside it
+    const int tid_g = NG > 1 ? (tid & 255) : tid;
     const int wm = WIDE ? 0 : wave >> 1, wn = WIDE ? wave : wave & 1;
     const int nN = (g.N + BN_ - 1) / BN_, nM = (g.M + BM_ - 1) / BM_;      // (M is a whole number of tiles but for RES = 8 with an odd batch: the last tile holds one image)
     const int tile = xcd_remap(blockIdx.x, nM * nN);
@@ -169,7 +171,14 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
     };
 
     // ---- requests: the (scale | shift) table + this wave's patch pieces of half-chunk hc -> buffers hc & 1 ---------------------
-    auto issue_patch = [&](int k) __attribute__((always_inline)) {
+    // The per-lane source offset of a patch request -- pixel (y, x) of patch row pp, clamped, times the row stride, plus the swizzled slot -- does
+    // not depend on the half-chunk (that is the scalar base).  Recomputing it per half-chunk (a division by the patch row stride per piece) was
+    // ~150 of the ~650 vector instructions a wave issues per half-chunk at 32x32 -- in a kernel whose bound is the vector issue port -- and holding
+    // six offsets in registers is what the 256-register instantiations cannot afford.  So the prologue computes them once (FIRST) and parks them
+    // in LDS behind the tables (one word per lane: conflict-free), and the K loop reads them back: six ds_read_b32 and one wait per nine taps.
+    const unsigned lds_voff = lds_tab + 2 * Cfg::TAB_BYTES + (unsigned)tid_g * 4u;
+    auto issue_patch = [&](auto first_tag, int k) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         const int buf = k & 1, hc = NG * k + grp;
         int l;                                                               // the lane id, recomputed: kept alive across the K loop it is the value hipcc spills
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));                                          // addresses recomputed per request (once per nine taps): no registers held
@@ -186,6 +195,20 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
             }
         }
         const bf16* base = img + hc * KT;
+        if constexpr (!FIRST) {
+            unsigned vo[NROUND];
+#pragma unroll
+            for (int j = 0; j < NROUND; ++j) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(vo[j]) : "v"(lds_voff), "n"(j * 1024) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // (tap 0, behind the hand-off barrier: no other LDS read of this wave is in flight)
+#pragma unroll
+            for (int j = 0; j < NROUND; ++j) {
+                const int q = j * NW + wave;
+                if (j >= NFULL && q >= NPIECE) continue;
+                asm volatile("" : "+v"(vo[j]));
+                glds16(vo[j], base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NROUND; ++j) {
             const int q = j * NW + wave;                                      // wave-uniform piece index
@@ -200,11 +223,15 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
                 const int rem = pp - im * IMGP;
                 const int yy = rem / WS, xx = rem - yy * WS;
                 const int y = min(max(yy - 1, 0), RES - 1), x = min(max(xx - 1, 0), RES - 1);
-                glds16((unsigned)((min(im, nval - 1) * HW + y * W + x) * g.a0_ld + ((pslot ^ Cfg::swz_key(xx)) << 3)) * 2u, base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
+                const unsigned vo = (unsigned)((min(im, nval - 1) * HW + y * W + x) * g.a0_ld + ((pslot ^ Cfg::swz_key(xx)) << 3)) * 2u;
+                glds16(vo, base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
+                asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(lds_voff), "v"(vo), "n"(j * 1024) : "memory");
             } else {
                 const int yy = pp / WS, xx = pp - yy * WS;
                 const int y = min(max(y0 - 1 + yy, 0), RES - 1), x = min(max(xx - 1, 0), RES - 1);      // halo / pad: any readable pixel
-                glds16((unsigned)(((y >> ush) * (W >> ush) + (x >> ush)) * g.a0_ld + ((pslot ^ Cfg::swz_key(xx)) << 3)) * 2u, base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
+                const unsigned vo = (unsigned)(((y >> ush) * (W >> ush) + (x >> ush)) * g.a0_ld + ((pslot ^ Cfg::swz_key(xx)) << 3)) * 2u;
+                glds16(vo, base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
+                asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(lds_voff), "v"(vo), "n"(j * 1024) : "memory");
             }
         }
     };
@@ -252,7 +279,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
         }
     }
     // the first requests go out NOW: the index arithmetic below (masks, fragment bases, 128 accumulator registers) runs while they fly
-    issue_patch(0);
+    issue_patch(std::true_type{}, 0);
     load_b(std::integral_constant<int, 0>{}, grp * 9);                     // the group's first K step: tap 0 of half-chunk grp
 
     // ---- in-place normalisation, round j: the wave's piece j * NW + wave, lane l its bytes l * 16 .. + 15 = patch row q * 16 + (l >> 2),
@@ -459,7 +486,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
         }
         if (has_next) load_b(integral_constant<int, P ^ 1>{}, ktn);
         if constexpr (T == 0) {
-            if (next_half) issue_patch(hc + 1);
+            if (next_half) issue_patch(std::false_type{}, hc + 1);
             else if (n_sc > 0) issue_shortcut(0);
         }
         constexpr int TPR = Cfg::TAPS_PER_ROUND;                         // taps a normalisation round spans (TM = 4: two)
