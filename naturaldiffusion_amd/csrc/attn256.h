@@ -20,11 +20,33 @@
 
 namespace ncsn {
 
+__device__ __forceinline__ int blockIdx_pair(int b, int qhalf) { return 2 * b + qhalf; }      // GroupNorm partial row of (sample, query half): 128-row tiles in token order
+
 constexpr int A256_T = 256, A256_D = 256, A256_KT = 64, A256_STAGE = 32768, A256_LDS_BYTES = 2 * A256_STAGE;
 
+// PROJ (round 3, late): the block's output projection in the same launch -- out = (x + O W3 + b3) * out_scale (AttnBlockpp's NIN_3 + skip, layerspp.py:88-91)
+// -- so that O (67 MB at B = 512) is neither written nor read back.  out^T = W3^T O^T as a third MFMA phase: the B operand is the wave's own O, rounded
+// to bf16 exactly as the separate launch stored it -- lane (query r, q) holds channels 16 dt + 4 q + i of tile dt, so K step kc takes tiles 2 kc and
+// 2 kc + 1: K slot j <-> channel 32 kc + (j < 4 ? 4 q + j : 16 + 4 q + j - 4) -- and the A operand is W3 packed fragment-major IN THAT CHANNEL ORDER
+// (k_pack_attn_w3: [16 n-tiles][8 K steps][64 lanes][8]), streamed through the same two LDS stages as four more 32-KB tiles (lane-linear pieces:
+// no swizzle).  A lane ends up with four consecutive output channels of one query: bias, residual, scale, 8-byte store, and the GroupNorm partial
+// sums of the output (one table row per block = 128 rows: a DPP row sum over the 16 queries of a lane group, then the two query groups and four waves).
+// w3f: k_pack_attn_w3's output; resid: x [B*256][resid_ld]; gn_part (may be null): float2 [2 B][gn_quads].
+__global__ __launch_bounds__(256) void k_pack_attn_w3(const float* __restrict__ w, bf16* __restrict__ wf)      // w: NIN weight [256 in][256 out] (layers.py:546-555)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;                  // one element: [nt][kc][lane][j]
+    if (idx >= 256 * 256) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63, kc = (idx >> 9) & 7, nt = idx >> 12;
+    const int q = lane >> 4, r = lane & 15;
+    const int c = 32 * kc + (j < 4 ? 4 * q + j : 16 + 4 * q + j - 4), n = 16 * nt + r;
+    wf[idx] = (bf16)w[c * 256 + n];
+}
+
 // qk: [B*256][qk_ld] bf16, q at column 0, k at column k_off; vT: [B][256 channels][256 tokens]; o: [B*256][o_ld].  grid = 2 B, 256 threads.
+template <bool PROJ>
 __global__ __launch_bounds__(256, 2) void k_attn256(const bf16* __restrict__ qk, int qk_ld, int k_off, const bf16* __restrict__ vT,
-                                                    bf16* __restrict__ o, int o_ld, float scale)
+                                                    bf16* __restrict__ o, int o_ld, float scale, const bf16* __restrict__ w3f, const float* __restrict__ b3,
+                                                    const bf16* __restrict__ resid, int resid_ld, float out_scale, float2* __restrict__ gn_part, int gn_quads)
 {
     constexpr int T = A256_T, KT = A256_KT, NKT = T / KT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -46,7 +68,14 @@ __global__ __launch_bounds__(256, 2) void k_attn256(const bf16* __restrict__ qk,
         unsigned char* st = smem + (i & 1) * A256_STAGE;
         int l;                                           // the lane id, recomputed per call: with every loop unrolled hipcc would otherwise keep the 16 per-lane
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));      // addresses of all eight tiles alive (22 spilled registers)
-        if (i < NKT) {
+        if (PROJ && i >= 2 * NKT) {                       // W3 tile i - 8: n-tiles 4 (i - 8) .. + 3, all eight K steps: 32 fragment blocks of 1 KiB, lane-linear
+            const bf16* base = w3f + (int64_t)(i - 2 * NKT) * (A256_STAGE / 2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = wave * 8 + j;
+                __builtin_amdgcn_global_load_lds(base + p * 512 + l * 8, (lds_void*)(st + p * 1024), 16, 0, 0);
+            }
+        } else if (i < NKT) {
             const bf16* base = kbase + (int64_t)(i * KT) * qk_ld;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -132,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void k_attn256(const bf16* __restrict__ qk,
     for (int vt = 0; vt < NKT; ++vt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (vt + 1 < NKT) issue(NKT + vt + 1);
+        if (PROJ || vt + 1 < NKT) issue(NKT + vt + 1);            // (PROJ: the first W3 tile follows the last V^T tile)
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* sV = smem + ((NKT + vt) & 1) * A256_STAGE;
 #pragma unroll
@@ -143,6 +172,75 @@ __global__ __launch_bounds__(256, 2) void k_attn256(const bf16* __restrict__ qk,
                 oacc[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pf[0][2 * vt + cc], oacc[0][dt], 0, 0, 0);
                 oacc[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pf[1][2 * vt + cc], oacc[1][dt], 0, 0, 0);
             }
+    }
+    if constexpr (PROJ) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x8 of[2][8];                                  // O as the B operand of out^T = W3^T O^T (see the head of this file for the K-slot order)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { of[g][kc][i] = (bf16)oacc[g][2 * kc][i]; of[g][kc][4 + i] = (bf16)oacc[g][2 * kc + 1][i]; }
+        __builtin_amdgcn_sched_barrier(0);
+        int le;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(le));
+        const int re = le & 15, qe = le >> 4;
+        float2* const sred = reinterpret_cast<float2*>(smem);           // [4 waves][64 quads], written after the last tile
+        float2 part[16];                                  // this lane group's (sum, sum of squares) of quads 16 t + 4 ntl + qe, over the wave's 32 queries
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + 1 < 4) issue(2 * NKT + t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* sW = smem + (t & 1) * A256_STAGE;
+            f32x4 a3[2][4];
+#pragma unroll
+            for (int ntl = 0; ntl < 4; ++ntl) { a3[0][ntl] = f32x4{0.f, 0.f, 0.f, 0.f}; a3[1][ntl] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int ntl = 0; ntl < 4; ++ntl)
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) {
+                    const bf16x8 fa = *reinterpret_cast<const bf16x8*>(sW + (ntl * 8 + kc) * 1024 + le * 16);
+                    a3[0][ntl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, of[0][kc], a3[0][ntl], 0, 0, 0);
+                    a3[1][ntl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, of[1][kc], a3[1][ntl], 0, 0, 0);
+                }
+#pragma unroll
+            for (int ntl = 0; ntl < 4; ++ntl) {
+                const int n = 64 * t + 16 * ntl + 4 * qe;
+                const float4 bb = *reinterpret_cast<const float4*>(b3 + n);
+                float s = 0.f, ss = 0.f;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int64_t row = (int64_t)b * T + qhalf * 128 + wave * 32 + 16 * g + re;
+                    const bf16x4 rx = *reinterpret_cast<const bf16x4*>(resid + row * resid_ld + n);
+                    float v[4] = {a3[g][ntl][0] + bb.x, a3[g][ntl][1] + bb.y, a3[g][ntl][2] + bb.z, a3[g][ntl][3] + bb.w};
+                    bf16x4 w;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v[i] = (v[i] + (float)rx[i]) * out_scale; w[i] = (bf16)v[i]; }
+                    *reinterpret_cast<bf16x4*>(o + row * o_ld + n) = w;
+                    s += (v[0] + v[1]) + (v[2] + v[3]);
+                    ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                }
+                part[4 * t + ntl] = make_float2(dpp_row_sum(s), dpp_row_sum(ss));
+            }
+        }
+        if (gn_part) {
+            __syncthreads();                              // every wave is done with the last W3 tile
+            if (re == 0) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sred[wave * 64 + 4 * k + qe] = part[k];
+            }
+            __syncthreads();
+            if (tid < 64) {
+                float s = 0.f, ss = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { s += sred[w * 64 + tid].x; ss += sred[w * 64 + tid].y; }
+                gn_part[(int64_t)blockIdx_pair(b, qhalf) * gn_quads + tid] = make_float2(s, ss);
+            }
+        }
+        return;
     }
     // O^T's layout: a lane holds 4 consecutive channels (16 dt + 4 q + i) of query (16 g + r): 8-byte stores
     int lane_e;                                          // lane id recomputed: r / q of the prologue would otherwise be kept alive through both MFMA phases

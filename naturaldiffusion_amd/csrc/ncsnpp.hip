@@ -222,6 +222,7 @@ using CfgG32 = ConvGnCfg<32>; using CfgG16 = ConvGnCfg<16>; using CfgG16W = Conv
 #endif
 int g_fuse_head = 1;               // natinf_set_fuse_head (read when a plan is BUILT): GroupNorm + SiLU + the 128 -> 3 output convolution as ONE launch (head_conv.h)
 int g_cg8_tm4 = 1;                 // natinf_set_conv_gn8_tile: 1 = 8x8 level on 64-pixel x 256-channel tiles (one image per tile, two blocks per CU), 0 = 128 x 256 (two images per tile; -DNATINF_DEV builds)
+int g_attn_proj = 1;               // natinf_set_attn_proj (read when a plan is BUILT): the 16x16 attention's output projection + skip + GroupNorm partials inside k_attn256
 int g_attn256 = 1;                 // natinf_set_attn256: 1 = k_attn256 (K / V^T streamed through a two-stage LDS ring, two blocks per CU), 0 = k_attn_fused<8,16,true>
 int g_fuse_gn8 = 1;                // natinf_set_fuse_gn8 (read when a plan is BUILT): the 8x8 level on the fused kernel too (two images per 128-pixel tile)
 int g_cg_warm = 15;                // natinf_set_conv_gn_warm: bit mask by resolution (1: 4x4, 2: 8x8, 4: 16x16, 8: 32x32) of the fused-convolution launches that warm L2 with their weights
@@ -292,7 +293,8 @@ bool configure_gemm_kernels() {
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 2>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 2>) &&
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 3>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 3>) &&
          set_lds<AttnCfg<8, 16, true>>(&k_attn_fused<8, 16, true>) &&
-         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<false>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<true>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
          set_lds<AttnCfg<2, 4>>(&k_attn_fused<2, 4>) && set_lds<AttnCfg<3, 6>>(&k_attn_fused<3, 6>) &&
          set_lds<AttnCfg<3, 5>>(&k_attn_fused<3, 5>) &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess;
@@ -842,6 +844,18 @@ struct Builder {
             launch_gemm(g, c.stream);
         });
         arena.release(h.off);
+        // k_attn256<true>: the output projection, skip connection and GroupNorm partials in the attention launch (attn256.h); O never exists
+        const bool proj = T == 256 && C == 256 && g_attn256 && g_attn_proj;
+        int64_t w3f = -1;
+        if (proj) {
+            w3f = wres((int64_t)C * C * 2);
+            const int64_t src = pw[3];
+            E.packs.push_back([=](const PackCtx& p) {
+                hipLaunchKernelGGL(k_pack_attn_w3, dim3(256), dim3(256), 0, p.stream, p.params + src, reinterpret_cast<bf16*>(p.packed + w3f));
+            });
+        }
+        const Part po_attn = proj ? register_output(out) : Part();
+        const float rs_attn = res_scale;
         TRef O = new_act(m.res, C);
         if (T == 256 && C == 256) {
             // 16x16 attention: scores, softmax and P V of a sample in one block (attn_fused.h, two-phase: V^T follows K through LDS)
@@ -849,9 +863,15 @@ struct Builder {
                 using Cfg = AttnCfg<8, 16, true>;
                 auto kern = &k_attn_fused<8, 16, true>;
                 if (g_record) return;                    // natinf_ncsnpp_describe_gemms: GEMM launches only, nothing touches memory
-                if (g_attn256)
-                    hipLaunchKernelGGL(k_attn256, dim3((unsigned)(2 * c.B)), dim3(256), A256_LDS_BYTES, c.stream, c.at<bf16>(qk), 2 * C, C, c.at<bf16>(vT), c.act(O), C,
-                                       1.0f / sqrtf((float)C));
+                if (proj) {
+                    hipLaunchKernelGGL(k_attn256<true>, dim3((unsigned)(2 * c.B)), dim3(256), A256_LDS_BYTES, c.stream, c.at<bf16>(qk), 2 * C, C, c.at<bf16>(vT), c.act(out), out.ld,
+                                       1.0f / sqrtf((float)C), c.w<bf16>(w3f), c.w<float>(b3), (const bf16*)c.act(x), x.ld, rs_attn,
+                                       po_attn.valid ? c.at<float2>(po_attn.off) : (float2*)nullptr, po_attn.quads);
+                    if (po_attn.valid) c.part_bm[po_attn.id] = 128;
+                }
+                else if (g_attn256)
+                    hipLaunchKernelGGL(k_attn256<false>, dim3((unsigned)(2 * c.B)), dim3(256), A256_LDS_BYTES, c.stream, c.at<bf16>(qk), 2 * C, C, c.at<bf16>(vT), c.act(O), C,
+                                       1.0f / sqrtf((float)C), (const bf16*)nullptr, (const float*)nullptr, (const bf16*)nullptr, 0, 1.0f, (float2*)nullptr, 0);
                 else
                 hipLaunchKernelGGL(kern, dim3((unsigned)c.B), dim3(Cfg::THREADS), Cfg::LDS_BYTES, c.stream, c.at<bf16>(qk), 2 * C, C,
                                    c.at<bf16>(vT), c.act(O), C, 1, C, 1.0f / sqrtf((float)C));
@@ -882,6 +902,12 @@ struct Builder {
                 launch_gemm(g, c.stream);
             });
             arena.release(P); arena.release(vT); arena.release(qk);
+        }
+        if (proj) {
+            arena.release(O.off); arena.release(own_sc); arena.release(own_sh);
+            if (sc != own_sc) { arena.release(sc); arena.release(sh); }
+            E.taps[m.idx] = out;
+            return;
         }
         const Part po = register_output(out);
         const float rs = res_scale;
@@ -1524,6 +1550,7 @@ int natinf_set_fuse_gn(int on) { g_fuse_gn = on != 0; return NATINF_OK; }
 int natinf_set_fuse_gn8(int on) { g_fuse_gn8 = on != 0; return NATINF_OK; }
 int natinf_set_attn256(int on) { g_attn256 = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_warm(int mask) { if (mask < 0 || mask > 15) return NATINF_EINVAL; g_cg_warm = mask; return NATINF_OK; }
+int natinf_set_attn_proj(int on) { g_attn_proj = on != 0; return NATINF_OK; }
 int natinf_set_fuse_fin(int on) { g_fuse_fin = on != 0; return NATINF_OK; }
 int natinf_set_fuse_gn4(int on) { g_fuse_gn4 = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn8_tile(int one_image) {
