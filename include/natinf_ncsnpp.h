@@ -152,11 +152,15 @@ int natinf_set_fuse_fin(int on);
  * weights are cold).  NATINF_EINVAL outside 0..15. */
 int natinf_set_conv_gn_warm(int mask);
 /* 1 (default): the 16x16 attention (256 tokens, one head of 256 channels) runs as k_attn256 -- K and V^T streamed through a two-stage LDS ring by
- * LDS-DMA, two blocks per CU; 0: k_attn_fused<8,16,true> (whole K, then whole V^T, resident in LDS; one block per CU). */
+ * LDS-DMA, two blocks per CU; 0: k_attn_fused<8,16,true> (whole K, then whole V^T, resident in LDS; one block per CU) -- a -DNATINF_DEV kernel:
+ * NATINF_ESTATE in the shipped library. */
 int natinf_set_attn256(int on);
 /* 1 (default; read when a plan is built): k_attn256 also applies the attention block's output projection, skip connection and rescale and writes the
  * GroupNorm partials of the block's output (the O tensor is never stored); 0: a separate GEMM launch for the projection. */
 int natinf_set_attn_proj(int on);
+/* 1 (default; read when a plan is built): GroupNorm-apply and the q | k | v projections of the 16x16 attention block run as ONE launch (k_qkv256:
+ * the block input is read once, the normalised tensor is never stored); 0: k_gn_apply + the q | k GEMM + the batched V^T GEMM. */
+int natinf_set_attn_qkv(int on);
 /* Tile of the fused kernel on the 8x8 level: 1 (default) = 64 pixels x 256 channels (one image per tile, wave tile 64 x 64, two blocks per CU at
  * B = 512), 0 = 128 x 256 (two images per tile, one block per CU; 0.6 % slower per forward: a -DNATINF_DEV kernel -- NATINF_ESTATE in the shipped
  * library). */

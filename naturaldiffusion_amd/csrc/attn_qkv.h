@@ -1,0 +1,136 @@
+// attn_qkv.h -- k_qkv256: GroupNorm-apply + the q | k | v projections of the 16x16 attention block (AttnBlockpp, layerspp.py:75-87: h = GroupNorm_0(x);
+// q, k, v = NIN_0/1/2(h)) in ONE launch.
+//
+// Until round 3 (late) this was three launches, every one bound by HBM: k_gn_apply (x -> h: 67 + 67 MB at B = 512, 35 us), the q | k GEMM (h -> [q | k]:
+// 67 + 134 MB, 66 us) and the batched V^T GEMM (h -> V^T: 67 + 67 MB, 34 us).  Here x is read once and h never exists:
+//   * a block = 128 tokens of one sample (4 waves x 32 tokens; grid 2 B); a lane loads its wave's x fragments -- token 16 g + r, channels
+//     32 kc + 8 q .. + 7 -- straight into the MFMA operand layout, normalises them in registers (x * scale + shift with the sample's table, rounded to
+//     bf16 as k_gn_apply rounds h) and keeps all 256 channels of its 32 tokens as sixteen operand registers sets (64 VGPRs);
+//   * the three weight matrices arrive fragment-major (k_pack_qkv_w: [48 n-tiles][8 K steps][64 lanes][8], 384 KB, L2-resident) in twelve 32-KB tiles
+//     through a two-stage LDS ring by LDS-DMA (lane-linear 1-KiB pieces: conflict-free, no swizzle), shared by the four waves;
+//   * q | k tiles: out^T = W h^T (weights as the A operand) -- a lane ends up with four consecutive output channels of one token: 8-byte stores into
+//     [q | k] (row-major, what k_attn256 reads); v tiles: the SAME registers as the A operand and the weights as B -- a lane ends up with four
+//     consecutive TOKENS of one channel: 8-byte stores into V^T ([B][256 channels][256 tokens]).  Biases: per column for q | k, per row for V^T.
+// 768 MFMAs per wave (12 us of matrix time per CU) under ~70 us of memory traffic (67 MB in, 201 MB out): two blocks per CU, ~100 registers.
+#pragma once
+#include "ncsnpp_kernels.h"
+
+namespace ncsn {
+
+// Weight tiles of 16 KB (two n-tiles x eight K steps), two stages = 32 KB of LDS per block: FOUR blocks per CU (127 registers).  With 32-KB tiles and two
+// blocks per CU the launch took 105 us: a tile is 64 MFMAs per wave (~1k clocks), its successor's DMA (an L2 round trip, ~2-4k clocks) was requested
+// only one tile ahead, and two blocks per CU could not cover the difference.
+constexpr int QKV_STAGE = 16384, QKV_NTL = 2, QKV_TILES = 48 / QKV_NTL, QKV_LDS_BYTES = 2 * QKV_STAGE;
+
+// w0 / w1 / w2: the NIN weights of q, k, v, each [256 in][256 out] fp32 (layers.py:546-555) -> wf[nt][kc][lane][j] = W_(nt / 16)[32 kc + 8 (lane >> 4) + j][16 (nt % 16) + (lane & 15)]
+__global__ __launch_bounds__(256) void k_pack_qkv_w(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2, bf16* __restrict__ wf)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 3 * 256 * 256) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63, kc = (idx >> 9) & 7, nt = idx >> 12;
+    const float* w = nt < 16 ? w0 : (nt < 32 ? w1 : w2);
+    const int c = 32 * kc + 8 * (lane >> 4) + j, n = 16 * (nt & 15) + (lane & 15);
+    wf[idx] = (bf16)w[c * 256 + n];
+}
+
+// x: [B*256][x_ld] bf16 (raw block input); gsc / gsh: GroupNorm (scale | shift) tables [B][256] fp32; wf: k_pack_qkv_w's output; bqk: [512] (q then k), bv: [256];
+// qk: [B*256][512]; vT: [B][256][256].  grid = 2 B, 256 threads, QKV_LDS_BYTES.
+__global__ __launch_bounds__(256, 4) void k_qkv256(const bf16* __restrict__ x, int x_ld, const float* __restrict__ gsc, const float* __restrict__ gsh,
+                                                  const bf16* __restrict__ wf, const float* __restrict__ bqk, const float* __restrict__ bv,
+                                                  bf16* __restrict__ qk, bf16* __restrict__ vT)
+{
+    constexpr int T = 256, C = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x >> 1, half = blockIdx.x & 1;
+    const int tok0 = half * 128 + wave * 32;                     // the wave's first token inside the sample
+
+    auto issue = [&](int i) __attribute__((always_inline)) {     // weight tile i: n-tiles 2 i, 2 i + 1, all eight K steps
+        unsigned char* st = smem + (i & 1) * QKV_STAGE;
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        const bf16* base = wf + (int64_t)i * (QKV_STAGE / 2);
+#pragma unroll
+        for (int j = 0; j < QKV_STAGE / 4096; ++j) {
+            const int p = wave * (QKV_STAGE / 4096) + j;
+            __builtin_amdgcn_global_load_lds(base + p * 512 + l * 8, (lds_void*)(st + p * 1024), 16, 0, 0);
+        }
+    };
+    issue(0);
+
+    // the wave's 32 tokens x 256 channels, normalised, in operand layout: hf[g][kc] = token 16 g + r, channels 32 kc + 8 q .. + 7
+    bf16x8 hf[2][8];
+    {
+        const bf16* xb = x + ((int64_t)b * T + tok0 + r) * x_ld + 8 * q;
+        bf16x8 raw[2][8];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) raw[g][kc] = *reinterpret_cast<const bf16x8*>(xb + (int64_t)(16 * g) * x_ld + 32 * kc);
+        const float* sc = gsc + (int64_t)b * C + 8 * q;
+        const float* sh = gsh + (int64_t)b * C + 8 * q;
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            const float4 s0 = *reinterpret_cast<const float4*>(sc + 32 * kc), s1 = *reinterpret_cast<const float4*>(sc + 32 * kc + 4);
+            const float4 h0 = *reinterpret_cast<const float4*>(sh + 32 * kc), h1 = *reinterpret_cast<const float4*>(sh + 32 * kc + 4);
+            const float s[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hf[g][kc][j] = (bf16)((float)raw[g][kc][j] * s[j] + h[j]);
+        }
+    }
+
+    int le;                                                       // (lane id again: r / q of the prologue need not stay alive through the loop)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(le));
+    const int re = le & 15, qe = le >> 4;
+#pragma unroll 1
+    for (int t = 0; t < QKV_TILES; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // tile t has landed (the compiler does not track LDS-DMA completions)
+        __syncthreads();                                         // ... for every wave, and everyone is done with the stage tile t + 1 goes into
+        if (t + 1 < QKV_TILES) issue(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* sW = smem + (t & 1) * QKV_STAGE;
+        const bool is_v = t >= 32 / QKV_NTL;                     // (uniform: n-tiles 0-15 q, 16-31 k, 32-47 v)
+#pragma unroll
+        for (int ntl = 0; ntl < QKV_NTL; ++ntl) {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+            if (!is_v) {
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) {
+                    const bf16x8 fa = *reinterpret_cast<const bf16x8*>(sW + (ntl * 8 + kc) * 1024 + le * 16);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, hf[0][kc], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, hf[1][kc], a1, 0, 0, 0);
+                }
+                // lane (token re of group g, qe): output channels n .. n + 3
+                const int n = 16 * (QKV_NTL * t + ntl) + 4 * qe;
+                const float4 bb = *reinterpret_cast<const float4*>(bqk + n);
+                bf16* dst = qk + ((int64_t)b * T + tok0 + re) * (2 * C) + n;
+                bf16x4 w0 = {(bf16)(a0[0] + bb.x), (bf16)(a0[1] + bb.y), (bf16)(a0[2] + bb.z), (bf16)(a0[3] + bb.w)};
+                bf16x4 w1 = {(bf16)(a1[0] + bb.x), (bf16)(a1[1] + bb.y), (bf16)(a1[2] + bb.z), (bf16)(a1[3] + bb.w)};
+                *reinterpret_cast<bf16x4*>(dst) = w0;
+                *reinterpret_cast<bf16x4*>(dst + (int64_t)16 * (2 * C)) = w1;
+            } else {
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) {
+                    const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sW + (ntl * 8 + kc) * 1024 + le * 16);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[0][kc], fb, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[1][kc], fb, a1, 0, 0, 0);
+                }
+                // lane (channel re of the tile, qe): tokens 16 g + 4 qe .. + 3 of that channel
+                const int ch = 16 * (QKV_NTL * t + ntl - 32) + re;
+                const float bb = bv[ch];
+                bf16* dst = vT + ((int64_t)b * C + ch) * T + tok0 + 4 * qe;
+                bf16x4 w0 = {(bf16)(a0[0] + bb), (bf16)(a0[1] + bb), (bf16)(a0[2] + bb), (bf16)(a0[3] + bb)};
+                bf16x4 w1 = {(bf16)(a1[0] + bb), (bf16)(a1[1] + bb), (bf16)(a1[2] + bb), (bf16)(a1[3] + bb)};
+                *reinterpret_cast<bf16x4*>(dst) = w0;
+                *reinterpret_cast<bf16x4*>(dst + 16) = w1;
+            }
+        }
+    }
+}
+
+}  // namespace ncsn

@@ -39,6 +39,7 @@
 #include "gemm_fp8.h"
 #include "attn_fused.h"
 #include "attn256.h"
+#include "attn_qkv.h"
 #include "flash_attn.h"
 
 using namespace ncsn;
@@ -222,6 +223,7 @@ using CfgG32 = ConvGnCfg<32>; using CfgG16 = ConvGnCfg<16>; using CfgG16W = Conv
 #endif
 int g_fuse_head = 1;               // natinf_set_fuse_head (read when a plan is BUILT): GroupNorm + SiLU + the 128 -> 3 output convolution as ONE launch (head_conv.h)
 int g_cg8_tm4 = 1;                 // natinf_set_conv_gn8_tile: 1 = 8x8 level on 64-pixel x 256-channel tiles (one image per tile, two blocks per CU), 0 = 128 x 256 (two images per tile; -DNATINF_DEV builds)
+int g_attn_qkv = 1;                // natinf_set_attn_qkv (read when a plan is BUILT): GroupNorm-apply + the q | k | v projections of the 16x16 attention as ONE launch (attn_qkv.h)
 int g_attn_proj = 1;               // natinf_set_attn_proj (read when a plan is BUILT): the 16x16 attention's output projection + skip + GroupNorm partials inside k_attn256
 int g_attn256 = 1;                 // natinf_set_attn256: 1 = k_attn256 (K / V^T streamed through a two-stage LDS ring, two blocks per CU), 0 = k_attn_fused<8,16,true>
 int g_fuse_gn8 = 1;                // natinf_set_fuse_gn8 (read when a plan is BUILT): the 8x8 level on the fused kernel too (two images per 128-pixel tile)
@@ -292,7 +294,10 @@ bool configure_gemm_kernels() {
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 1>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 1>) &&
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 2>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 2>) &&
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 3>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 3>) &&
-         set_lds<AttnCfg<8, 16, true>>(&k_attn_fused<8, 16, true>) &&
+#ifdef NATINF_DEV
+         set_lds<AttnCfg<8, 16, true>>(&k_attn_fused<8, 16, true>) &&      // the LDS-resident K / V^T form of the 16x16 attention: superseded by k_attn256
+#endif
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_qkv256), hipFuncAttributeMaxDynamicSharedMemorySize, QKV_LDS_BYTES) == hipSuccess &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<false>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<true>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
          set_lds<AttnCfg<2, 4>>(&k_attn_fused<2, 4>) && set_lds<AttnCfg<3, 6>>(&k_attn_fused<3, 6>) &&
@@ -826,9 +831,24 @@ struct Builder {
         const int64_t own_sc = arena.alloc((int64_t)C * 4), own_sh = arena.alloc((int64_t)C * 4);
         int64_t sc = own_sc, sh = own_sh;
         emit_gn_stats(x, gn, sc, sh);
+        const bool fuse_qkv = T == 256 && C == 256 && g_attn_qkv;      // k_qkv256: x -> [q | k], V^T in one launch; h never exists
         TRef h = new_act(m.res, C);
-        emit_gn_apply(x, sc, sh, h, nullptr, ACT_NONE, RS_NONE);
+        if (!fuse_qkv) emit_gn_apply(x, sc, sh, h, nullptr, ACT_NONE, RS_NONE);
         const int64_t qk = arena.alloc((int64_t)T * 2 * C * 2), vT = arena.alloc((int64_t)C * T * 2);
+        if (fuse_qkv) {
+            const int64_t wqkvf = wres((int64_t)3 * C * C * 2);
+            const int64_t s0 = pw[0], s1 = pw[1], s2 = pw[2];
+            E.packs.push_back([=](const PackCtx& p) {
+                hipLaunchKernelGGL(k_pack_qkv_w, dim3(3 * 256), dim3(256), 0, p.stream, p.params + s0, p.params + s1, p.params + s2, reinterpret_cast<bf16*>(p.packed + wqkvf));
+            });
+            const int64_t sc_ = sc, sh_ = sh;
+            op(CLS_GEMM, [=](const Ctx& c) {
+                if (g_record) return;
+                hipLaunchKernelGGL(k_qkv256, dim3((unsigned)(2 * c.B)), dim3(256), QKV_LDS_BYTES, c.stream, (const bf16*)c.act(x), x.ld, c.at<float>(sc_), c.at<float>(sh_),
+                                   c.w<bf16>(wqkvf), c.w<float>(bqk), c.w<float>(bv), c.at<bf16>(qk), c.at<bf16>(vT));
+            });
+        }
+        if (!fuse_qkv)
         op(CLS_GEMM, [=](const Ctx& c) {             // q | k  = h Wq | h Wk
             GemmArgs g = gemm_defaults();
             g.a0 = c.act(h); g.a0_ld = C; g.a0_C = C; g.M = c.B * T; g.N = 2 * C;
@@ -836,6 +856,7 @@ struct Builder {
             g.c = c.at<bf16>(qk); g.c_ld = 2 * C;
             launch_gemm(g, c.stream);
         });
+        if (!fuse_qkv)
         op(CLS_GEMM, [=](const Ctx& c) {             // V^T[b] = Wv^T h[b]^T  (so that P V is an "A B^T" product)
             GemmArgs g = gemm_defaults();
             g.a0 = c.w<bf16>(wv); g.a0_ld = C; g.a0_C = C; g.a_bs = 0; g.M = C; g.N = T;
@@ -860,8 +881,6 @@ struct Builder {
         if (T == 256 && C == 256) {
             // 16x16 attention: scores, softmax and P V of a sample in one block (attn_fused.h, two-phase: V^T follows K through LDS)
             op(CLS_GEMM, [=](const Ctx& c) {
-                using Cfg = AttnCfg<8, 16, true>;
-                auto kern = &k_attn_fused<8, 16, true>;
                 if (g_record) return;                    // natinf_ncsnpp_describe_gemms: GEMM launches only, nothing touches memory
                 if (proj) {
                     hipLaunchKernelGGL(k_attn256<true>, dim3((unsigned)(2 * c.B)), dim3(256), A256_LDS_BYTES, c.stream, c.at<bf16>(qk), 2 * C, C, c.at<bf16>(vT), c.act(out), out.ld,
@@ -872,9 +891,13 @@ struct Builder {
                 else if (g_attn256)
                     hipLaunchKernelGGL(k_attn256<false>, dim3((unsigned)(2 * c.B)), dim3(256), A256_LDS_BYTES, c.stream, c.at<bf16>(qk), 2 * C, C, c.at<bf16>(vT), c.act(O), C,
                                        1.0f / sqrtf((float)C), (const bf16*)nullptr, (const float*)nullptr, (const bf16*)nullptr, 0, 1.0f, (float2*)nullptr, 0);
-                else
-                hipLaunchKernelGGL(kern, dim3((unsigned)c.B), dim3(Cfg::THREADS), Cfg::LDS_BYTES, c.stream, c.at<bf16>(qk), 2 * C, C,
-                                   c.at<bf16>(vT), c.act(O), C, 1, C, 1.0f / sqrtf((float)C));
+#ifdef NATINF_DEV
+                else {
+                    using Cfg = AttnCfg<8, 16, true>;
+                    hipLaunchKernelGGL((&k_attn_fused<8, 16, true>), dim3((unsigned)c.B), dim3(Cfg::THREADS), Cfg::LDS_BYTES, c.stream, c.at<bf16>(qk), 2 * C, C,
+                                       c.at<bf16>(vT), c.act(O), C, 1, C, 1.0f / sqrtf((float)C));
+                }
+#endif
             });
             arena.release(vT); arena.release(qk);
         } else {
@@ -1548,8 +1571,14 @@ int natinf_debug_timestamps(void* dev_buf16) {
 int natinf_set_gemm_raster(int rows) { g_raster_g = rows; return NATINF_OK; }
 int natinf_set_fuse_gn(int on) { g_fuse_gn = on != 0; return NATINF_OK; }
 int natinf_set_fuse_gn8(int on) { g_fuse_gn8 = on != 0; return NATINF_OK; }
-int natinf_set_attn256(int on) { g_attn256 = on != 0; return NATINF_OK; }
+int natinf_set_attn256(int on) {
+#ifndef NATINF_DEV
+    if (!on) return NATINF_ESTATE;                 // k_attn_fused<8,16,true> is a development-build kernel
+#endif
+    g_attn256 = on != 0; return NATINF_OK;
+}
 int natinf_set_conv_gn_warm(int mask) { if (mask < 0 || mask > 15) return NATINF_EINVAL; g_cg_warm = mask; return NATINF_OK; }
+int natinf_set_attn_qkv(int on) { g_attn_qkv = on != 0; return NATINF_OK; }
 int natinf_set_attn_proj(int on) { g_attn_proj = on != 0; return NATINF_OK; }
 int natinf_set_fuse_fin(int on) { g_fuse_fin = on != 0; return NATINF_OK; }
 int natinf_set_fuse_gn4(int on) { g_fuse_gn4 = on != 0; return NATINF_OK; }

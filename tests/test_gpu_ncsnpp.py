@@ -231,7 +231,7 @@ def test_fused_and_split_k_plans_against_the_unfused_plan(dev, flat, golden_dir)
     outs = {}
     assert any(r[6].startswith("head_conv") for r in _describe_gemms(base_eng, 64))
     for name, setter in (("fuse_gn", lib.natinf_set_fuse_gn), ("fuse_up", lib.natinf_set_fuse_up), ("fuse_head", lib.natinf_set_fuse_head),
-                         ("fuse_gn8", lib.natinf_set_fuse_gn8), ("fuse_gn4", lib.natinf_set_fuse_gn4), ("fuse_fin", lib.natinf_set_fuse_fin), ("attn_proj", lib.natinf_set_attn_proj)):
+                         ("fuse_gn8", lib.natinf_set_fuse_gn8), ("fuse_gn4", lib.natinf_set_fuse_gn4), ("fuse_fin", lib.natinf_set_fuse_fin), ("attn_proj", lib.natinf_set_attn_proj), ("attn_qkv", lib.natinf_set_attn_qkv)):
         try:
             assert setter(0) == 0
             eng = NCSNppEngine(flat, max_batch=64, device=dev)          # the switch is read when the plan is built
