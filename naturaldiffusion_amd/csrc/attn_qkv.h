@@ -6,12 +6,15 @@
 //   * a block = 128 tokens of one sample (4 waves x 32 tokens; grid 2 B); a lane loads its wave's x fragments -- token 16 g + r, channels
 //     32 kc + 8 q .. + 7 -- straight into the MFMA operand layout, normalises them in registers (x * scale + shift with the sample's table, rounded to
 //     bf16 as k_gn_apply rounds h) and keeps all 256 channels of its 32 tokens as sixteen operand registers sets (64 VGPRs);
-//   * the three weight matrices arrive fragment-major (k_pack_qkv_w: [48 n-tiles][8 K steps][64 lanes][8], 384 KB, L2-resident) in twelve 32-KB tiles
+//   * the three weight matrices arrive fragment-major (k_pack_qkv_w: [48 n-tiles][8 K steps][64 lanes][8], 384 KB, L2-resident) in 24 tiles of 16 KB
 //     through a two-stage LDS ring by LDS-DMA (lane-linear 1-KiB pieces: conflict-free, no swizzle), shared by the four waves;
 //   * q | k tiles: out^T = W h^T (weights as the A operand) -- a lane ends up with four consecutive output channels of one token: 8-byte stores into
 //     [q | k] (row-major, what k_attn256 reads); v tiles: the SAME registers as the A operand and the weights as B -- a lane ends up with four
 //     consecutive TOKENS of one channel: 8-byte stores into V^T ([B][256 channels][256 tokens]).  Biases: per column for q | k, per row for V^T.
-// 768 MFMAs per wave (12 us of matrix time per CU) under ~70 us of memory traffic (67 MB in, 201 MB out): two blocks per CU, ~100 registers.
+// 768 MFMAs per wave (12 us of matrix time per CU) under 67 MB in, 201 MB out: four blocks per CU, 126 registers, 82 us per launch at B = 512 (35 + 66 + 34 us
+// for the three launches it replaces), output bit-identical to theirs.  What the first forms taught (105 -> 100 -> 92 -> 82 us): 32-KB tiles at two blocks
+// per CU left the next tile's DMA exposed; a per-n-tile bias LOAD inside the loop made hipcc drain the DMA and the previous stores (vmcnt(0)) at every
+// n-tile; 8-byte stores (32 contiguous bytes per row and instruction) cost 10 us against 16-byte ones (64).
 #pragma once
 #include "ncsnpp_kernels.h"
 
@@ -20,7 +23,11 @@ namespace ncsn {
 // Weight tiles of 16 KB (two n-tiles x eight K steps), two stages = 32 KB of LDS per block: FOUR blocks per CU (127 registers).  With 32-KB tiles and two
 // blocks per CU the launch took 105 us: a tile is 64 MFMAs per wave (~1k clocks), its successor's DMA (an L2 round trip, ~2-4k clocks) was requested
 // only one tile ahead, and two blocks per CU could not cover the difference.
-constexpr int QKV_STAGE = 16384, QKV_NTL = 2, QKV_TILES = 48 / QKV_NTL, QKV_LDS_BYTES = 2 * QKV_STAGE;
+// The loop carries NO ordinary global load: with an LDS-DMA in flight hipcc answers the first use of one with `s_waitcnt vmcnt(0)` -- which waits for the
+// next tile's DMA and for every store of the previous tile (the first form loaded the bias per n-tile and ran at one memory round trip per n-tile:
+// 100 us).  The biases sit in LDS (3 KB behind the stages), the tile wait is COUNTED -- vmcnt(4): the wave's four stores of the tile before stay in
+// flight, loads / stores / LDS-DMA retire in issue order -- and the barrier is the raw s_barrier (a __syncthreads() fence drains the stores too).
+constexpr int QKV_STAGE = 16384, QKV_NTL = 2, QKV_TILES = 48 / QKV_NTL, QKV_BIAS_BYTES = 768 * 4, QKV_LDS_BYTES = 2 * QKV_STAGE + QKV_BIAS_BYTES;
 
 // w0 / w1 / w2: the NIN weights of q, k, v, each [256 in][256 out] fp32 (layers.py:546-555) -> wf[nt][kc][lane][j] = W_(nt / 16)[32 kc + 8 (lane >> 4) + j][16 (nt % 16) + (lane & 15)]
 __global__ __launch_bounds__(256) void k_pack_qkv_w(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2, bf16* __restrict__ wf)
@@ -29,7 +36,10 @@ __global__ __launch_bounds__(256) void k_pack_qkv_w(const float* __restrict__ w0
     if (idx >= 3 * 256 * 256) return;
     const int j = idx & 7, lane = (idx >> 3) & 63, kc = (idx >> 9) & 7, nt = idx >> 12;
     const float* w = nt < 16 ? w0 : (nt < 32 ? w1 : w2);
-    const int c = 32 * kc + 8 * (lane >> 4) + j, n = 16 * (nt & 15) + (lane & 15);
+    const int r = lane & 15;
+    // q / k: n-tiles 2 p, 2 p + 1 share the 32 channels 32 p ..: row r of tile 2 p + h is channel 32 p + 8 (r >> 2) + 4 h + (r & 3), so that the four rows
+    // 4 q + i a lane holds of both tiles are eight consecutive channels (one 16-byte store); v: plain order
+    const int c = 32 * kc + 8 * (lane >> 4) + j, n = nt < 32 ? 32 * ((nt & 15) >> 1) + 8 * (r >> 2) + 4 * (nt & 1) + (r & 3) : 16 * (nt & 15) + r;
     wf[idx] = (bf16)w[c * 256 + n];
 }
 
@@ -60,16 +70,22 @@ __global__ __launch_bounds__(256, 4) void k_qkv256(const bf16* __restrict__ x, i
         }
     };
     issue(0);
+    float* const sBias = reinterpret_cast<float*>(smem + 2 * QKV_STAGE);      // [512 q | k][256 v]
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    const unsigned lds_bias = (unsigned)(uintptr_t)((lds_u8*)smem) + 2 * QKV_STAGE;
+    if (tid < 192) reinterpret_cast<float4*>(sBias)[tid] = tid < 128 ? reinterpret_cast<const float4*>(bqk)[tid] : reinterpret_cast<const float4*>(bv)[tid - 128];
 
-    // the wave's 32 tokens x 256 channels, normalised, in operand layout: hf[g][kc] = token 16 g + r, channels 32 kc + 8 q .. + 7
+    // the wave's 32 tokens x 256 channels, normalised, in operand layout: hf[g][kc] = token tau(g, r) = 8 (r >> 2) + 4 g + (r & 3), channels 32 kc + 8 q .. + 7.
+    // (tau: an accumulator lane holds rows 4 q + i of a 16-row tile; with this assignment the rows of groups 0 and 1 a lane holds are EIGHT consecutive
+    // tokens -- one 16-byte store per lane into V^T instead of two 8-byte ones; every 128-byte line is then written in 64-byte halves)
     bf16x8 hf[2][8];
     {
-        const bf16* xb = x + ((int64_t)b * T + tok0 + r) * x_ld + 8 * q;
+        const bf16* xb = x + ((int64_t)b * T + tok0 + 8 * (r >> 2) + (r & 3)) * x_ld + 8 * q;
         bf16x8 raw[2][8];
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int kc = 0; kc < 8; ++kc) raw[g][kc] = *reinterpret_cast<const bf16x8*>(xb + (int64_t)(16 * g) * x_ld + 32 * kc);
+            for (int kc = 0; kc < 8; ++kc) raw[g][kc] = *reinterpret_cast<const bf16x8*>(xb + (int64_t)(4 * g) * x_ld + 32 * kc);
         const float* sc = gsc + (int64_t)b * C + 8 * q;
         const float* sh = gsh + (int64_t)b * C + 8 * q;
 #pragma unroll
@@ -89,45 +105,58 @@ __global__ __launch_bounds__(256, 4) void k_qkv256(const bf16* __restrict__ x, i
     const int re = le & 15, qe = le >> 4;
 #pragma unroll 1
     for (int t = 0; t < QKV_TILES; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // tile t has landed (the compiler does not track LDS-DMA completions)
-        __syncthreads();                                         // ... for every wave, and everyone is done with the stage tile t + 1 goes into
+        // tile t has landed (the compiler does not track LDS-DMA completions); younger than its requests are only the (at most) two stores of tile t - 1
+        if (t == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                            // ... for every wave, and everyone is done with the stage tile t + 1 goes into
         if (t + 1 < QKV_TILES) issue(t + 1);
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* sW = smem + (t & 1) * QKV_STAGE;
         const bool is_v = t >= 32 / QKV_NTL;                     // (uniform: n-tiles 0-15 q, 16-31 k, 32-47 v)
+        if (!is_v) {
+            // the tile's two n-tiles are one 32-channel group with its rows interleaved (k_pack_qkv_w): the lane ends up with EIGHT consecutive channels
+            f32x4 a[2][2];
 #pragma unroll
-        for (int ntl = 0; ntl < QKV_NTL; ++ntl) {
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-            if (!is_v) {
+            for (int ntl = 0; ntl < 2; ++ntl) {
+                a[ntl][0] = f32x4{0.f, 0.f, 0.f, 0.f}; a[ntl][1] = a[ntl][0];
 #pragma unroll
                 for (int kc = 0; kc < 8; ++kc) {
                     const bf16x8 fa = *reinterpret_cast<const bf16x8*>(sW + (ntl * 8 + kc) * 1024 + le * 16);
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, hf[0][kc], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, hf[1][kc], a1, 0, 0, 0);
+                    a[ntl][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, hf[0][kc], a[ntl][0], 0, 0, 0);
+                    a[ntl][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, hf[1][kc], a[ntl][1], 0, 0, 0);
                 }
-                // lane (token re of group g, qe): output channels n .. n + 3
-                const int n = 16 * (QKV_NTL * t + ntl) + 4 * qe;
-                const float4 bb = *reinterpret_cast<const float4*>(bqk + n);
-                bf16* dst = qk + ((int64_t)b * T + tok0 + re) * (2 * C) + n;
-                bf16x4 w0 = {(bf16)(a0[0] + bb.x), (bf16)(a0[1] + bb.y), (bf16)(a0[2] + bb.z), (bf16)(a0[3] + bb.w)};
-                bf16x4 w1 = {(bf16)(a1[0] + bb.x), (bf16)(a1[1] + bb.y), (bf16)(a1[2] + bb.z), (bf16)(a1[3] + bb.w)};
-                *reinterpret_cast<bf16x4*>(dst) = w0;
-                *reinterpret_cast<bf16x4*>(dst + (int64_t)16 * (2 * C)) = w1;
-            } else {
+            }
+            const int n = 32 * t + 8 * qe;                       // lane (token tau(g, re), qe): output channels n .. n + 7
+            // (bias from LDS by inline asm: a read hipcc can see, next to an LDS-DMA in flight, comes with its own vmcnt(0))
+            f32x4 b0, b1;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(b0), "=&v"(b1) : "v"(lds_bias + (unsigned)n * 4u) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1) :: "memory");
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                bf16x8 w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { w[i] = (bf16)(a[0][g][i] + b0[i]); w[4 + i] = (bf16)(a[1][g][i] + b1[i]); }
+                *reinterpret_cast<bf16x8*>(qk + ((int64_t)b * T + tok0 + 8 * (re >> 2) + 4 * g + (re & 3)) * (2 * C) + n) = w;
+            }
+        } else {
+#pragma unroll
+            for (int ntl = 0; ntl < QKV_NTL; ++ntl) {
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
 #pragma unroll
                 for (int kc = 0; kc < 8; ++kc) {
                     const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sW + (ntl * 8 + kc) * 1024 + le * 16);
                     a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[0][kc], fb, a0, 0, 0, 0);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[1][kc], fb, a1, 0, 0, 0);
                 }
-                // lane (channel re of the tile, qe): tokens 16 g + 4 qe .. + 3 of that channel
+                // lane (channel re of the tile, qe): rows 4 qe + i of group 0 are tokens 8 qe + i, of group 1 tokens 8 qe + 4 + i: eight consecutive tokens
                 const int ch = 16 * (QKV_NTL * t + ntl - 32) + re;
-                const float bb = bv[ch];
-                bf16* dst = vT + ((int64_t)b * C + ch) * T + tok0 + 4 * qe;
-                bf16x4 w0 = {(bf16)(a0[0] + bb), (bf16)(a0[1] + bb), (bf16)(a0[2] + bb), (bf16)(a0[3] + bb)};
-                bf16x4 w1 = {(bf16)(a1[0] + bb), (bf16)(a1[1] + bb), (bf16)(a1[2] + bb), (bf16)(a1[3] + bb)};
-                *reinterpret_cast<bf16x4*>(dst) = w0;
-                *reinterpret_cast<bf16x4*>(dst + 16) = w1;
+                float bb;
+                asm volatile("ds_read_b32 %0, %1" : "=v"(bb) : "v"(lds_bias + (unsigned)(512 + ch) * 4u) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb) :: "memory");
+                bf16x8 w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { w[i] = (bf16)(a0[i] + bb); w[4 + i] = (bf16)(a1[i] + bb); }
+                *reinterpret_cast<bf16x8*>(vT + ((int64_t)b * C + ch) * T + tok0 + 8 * qe) = w;
             }
         }
     }
