@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void k_pack_attn_w3(const float* __restrict__ 
     if (idx >= 256 * 256) return;
     const int j = idx & 7, lane = (idx >> 3) & 63, kc = (idx >> 9) & 7, nt = idx >> 12;
     const int q = lane >> 4, r = lane & 15;
-    const int c = 32 * kc + (j < 4 ? 4 * q + j : 16 + 4 * q + j - 4), n = 16 * nt + r;
+    // rows: n-tiles 2 p, 2 p + 1 share the channels 32 p ..: row r of tile 2 p + h is channel 32 p + 8 (r >> 2) + 4 h + (r & 3) -- the rows 4 q + i a lane holds
+    // of both tiles are eight consecutive channels
+    const int c = 32 * kc + (j < 4 ? 4 * q + j : 16 + 4 * q + j - 4), n = 32 * (nt >> 1) + 8 * (r >> 2) + 4 * (nt & 1) + (r & 3);
     wf[idx] = (bf16)w[c * 256 + n];
 }
 
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void k_attn256(const bf16* __restrict__ qk,
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(le));
         const int re = le & 15, qe = le >> 4;
         float2* const sred = reinterpret_cast<float2*>(smem);           // [4 waves][64 quads], written after the last tile
-        float2 part[16];                                  // this lane group's (sum, sum of squares) of quads 16 t + 4 ntl + qe, over the wave's 32 queries
+        float2 part[16];                                  // this lane group's (sum, sum of squares) of quads 16 t + 8 pr + 2 qe + h, over the wave's 32 queries
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -206,31 +208,35 @@ __global__ __launch_bounds__(256, 2) void k_attn256(const bf16* __restrict__ qk,
                     a3[0][ntl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, of[0][kc], a3[0][ntl], 0, 0, 0);
                     a3[1][ntl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, of[1][kc], a3[1][ntl], 0, 0, 0);
                 }
+            // n-tiles 2 p, 2 p + 1 are one 32-channel group with interleaved rows (k_pack_attn_w3): the lane holds EIGHT consecutive channels n .. n + 7 of its
+            // query -- 16-byte residual loads and stores (64 contiguous bytes per row and instruction; the 8-byte form cost k_qkv256 10 us)
 #pragma unroll
-            for (int ntl = 0; ntl < 4; ++ntl) {
-                const int n = 64 * t + 16 * ntl + 4 * qe;
-                const float4 bb = *reinterpret_cast<const float4*>(b3 + n);
-                float s = 0.f, ss = 0.f;
+            for (int pr = 0; pr < 2; ++pr) {
+                const int n = 64 * t + 32 * pr + 8 * qe;
+                const float4 b0 = *reinterpret_cast<const float4*>(b3 + n), b1 = *reinterpret_cast<const float4*>(b3 + n + 4);
+                float s0 = 0.f, ss0 = 0.f, s1 = 0.f, ss1 = 0.f;
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     const int64_t row = (int64_t)b * T + qhalf * 128 + wave * 32 + 16 * g + re;
-                    const bf16x4 rx = *reinterpret_cast<const bf16x4*>(resid + row * resid_ld + n);
-                    float v[4] = {a3[g][ntl][0] + bb.x, a3[g][ntl][1] + bb.y, a3[g][ntl][2] + bb.z, a3[g][ntl][3] + bb.w};
-                    bf16x4 w;
+                    const bf16x8 rx = *reinterpret_cast<const bf16x8*>(resid + row * resid_ld + n);
+                    const f32x4 lo = a3[g][2 * pr], hi = a3[g][2 * pr + 1];
+                    float v[8] = {lo[0] + b0.x, lo[1] + b0.y, lo[2] + b0.z, lo[3] + b0.w, hi[0] + b1.x, hi[1] + b1.y, hi[2] + b1.z, hi[3] + b1.w};
+                    bf16x8 w;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { v[i] = (v[i] + (float)rx[i]) * out_scale; w[i] = (bf16)v[i]; }
-                    *reinterpret_cast<bf16x4*>(o + row * o_ld + n) = w;
-                    s += (v[0] + v[1]) + (v[2] + v[3]);
-                    ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    for (int i = 0; i < 8; ++i) { v[i] = (v[i] + (float)rx[i]) * out_scale; w[i] = (bf16)v[i]; }
+                    *reinterpret_cast<bf16x8*>(o + row * o_ld + n) = w;
+                    s0 += (v[0] + v[1]) + (v[2] + v[3]);  ss0 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    s1 += (v[4] + v[5]) + (v[6] + v[7]);  ss1 += (v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]);
                 }
-                part[4 * t + ntl] = make_float2(dpp_row_sum(s), dpp_row_sum(ss));
+                part[4 * t + 2 * pr] = make_float2(dpp_row_sum(s0), dpp_row_sum(ss0));          // quads (n >> 2), (n >> 2) + 1
+                part[4 * t + 2 * pr + 1] = make_float2(dpp_row_sum(s1), dpp_row_sum(ss1));
             }
         }
         if (gn_part) {
             __syncthreads();                              // every wave is done with the last W3 tile
             if (re == 0) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) sred[wave * 64 + 4 * k + qe] = part[k];
+                for (int k = 0; k < 16; ++k) sred[wave * 64 + 8 * (k >> 1) + 2 * qe + (k & 1)] = part[k];      // part[4 t + 2 pr + h]: quad 16 t + 8 pr + 2 qe + h
             }
             __syncthreads();
             if (tid < 64) {
