@@ -171,3 +171,34 @@ def test_no_development_kernels_in_the_shipped_library(listings):
     assert len(ks) < 116, len(ks)                                              # all kernels (146 in round 2; round 3 added the Inception, head and vectorised LayerNorm kernels)
     code = listings["ncsnpp"]
     assert "s_memtime" not in code[:code.index("amdhsa.kernels:")]           # tile-timeline stamps: -DNATINF_DEV builds only
+
+
+def test_qkv256_loop_has_no_ordinary_global_load(listings):
+    """k_qkv256 (attn_qkv.h) streams its weights by LDS-DMA with a counted wait: an ordinary global load inside the tile loop would make hipcc drain the
+    DMA and the previous tile's stores with `s_waitcnt vmcnt(0)` (measured: +10 us per launch).  The built loop must hold LDS-DMA requests, 16-byte stores and
+    no other vector-memory instruction, and no full vmcnt drain."""
+    code = listings["ncsnpp"]
+    code = code[:code.index("amdhsa.kernels:")]
+    m = re.search(r"^(_ZN4ncsn8k_qkv256\w+):\s*; @", code, flags=re.M)
+    assert m
+    body = code[m.end():code.index("s_endpgm", m.end())]
+    in_loop, loads, drains, stores, dma = False, [], [], 0, 0
+    for ln in body.split("\n"):
+        if re.match(r"(\.LBB\d+_\d+:|; %bb\.\d+:)", ln):
+            in_loop = "in Loop:" in ln
+        elif "in Loop:" in ln:
+            in_loop = True
+        elif in_loop:
+            t = ln.strip()
+            if t.startswith("global_load_lds"):
+                dma += 1
+            elif t.startswith(("global_load", "flat_load", "buffer_load")):
+                loads.append(t)
+            elif t.startswith("global_store_dwordx4"):
+                stores += 1
+            elif t.startswith(("global_store", "flat_store")):
+                loads.append(t)                                              # (anything narrower than 16 bytes)
+            elif re.match(r"s_waitcnt.*vmcnt\(0\)", t):
+                drains.append(t)
+    assert dma >= 4 and stores >= 4 and not loads, (dma, stores, loads[:3])
+    assert len(drains) <= 1, drains                                           # (the t == 0 branch of the tile wait)
