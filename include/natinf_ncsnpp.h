@@ -128,8 +128,9 @@ int natinf_set_gemm_raster(int rows);
 /* 1 (default): plans built from now on run GroupNorm-apply + SiLU inside the consuming 3x3 convolution where a fused kernel
  * exists (32x32 and 16x16 levels); 0: the separate normalisation pass everywhere (A/B runs, tests).  Read by natinf_ncsnpp_create. */
 int natinf_set_fuse_gn(int on);
-/* 1 (default): k_conv_gn launches on 16x16 images with N % 256 == 0 use the 128-pixel x 256-channel tile; 0: 256 x 128 everywhere. */
-int natinf_set_conv_gn_wide(int on);
+/* Bit mask (default 3; NATINF_EINVAL outside 0..3): fused-convolution launches with N % 256 == 0 use the 128-pixel x 256-channel tile (the patch is
+ * normalised once for all 256 output channels) on 16x16 images (bit 0) and on 32x32 images (bit 1: the 16 -> 32 up-sampling block); 0: 256 x 128 tiles. */
+int natinf_set_conv_gn_wide(int mask);
 int natinf_set_conv_gn_regw(int on);
 /* 1 (default; read when a plan is built): the up-sampling blocks at 16x16 / 32x32 read their half-resolution input inside the fused
  * convolution (nearest up-sampling in the patch fetch and in the residual fetch); 0: through the separate GroupNorm-apply + up-sample pass. */

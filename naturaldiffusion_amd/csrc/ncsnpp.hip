@@ -215,7 +215,7 @@ using CfgR256x256 = RingCfg<2, 4, 8, 4, 4>; using CfgR256x128 = RingCfg<4, 2, 4,
 using CfgR128x128 = RingCfg<2, 2, 4, 4, 4>; using CfgR64x128 = RingCfg<2, 2, 2, 4, 4>;
 using CfgR256x128W4 = RingCfg<2, 2, 8, 4, 3>; using CfgD256x128W4 = DmaCfg<2, 2, 8, 4>;
 using CfgD512x128 = DmaCfg<4, 2, 8, 4>;
-using CfgH32 = ConvGn2Cfg<32>; using CfgH16 = ConvGn2Cfg<16>; using CfgH16W = ConvGn2Cfg<16, true>; using CfgH8T = ConvGn2Cfg<8, true, 4>; using CfgH4T = ConvGn2Cfg<4, true, 4, 2>;
+using CfgH32 = ConvGn2Cfg<32>; using CfgH16 = ConvGn2Cfg<16>; using CfgH16W = ConvGn2Cfg<16, true>; using CfgH32W = ConvGn2Cfg<32, true>; using CfgH8T = ConvGn2Cfg<8, true, 4>; using CfgH4T = ConvGn2Cfg<4, true, 4, 2>;
 #ifdef NATINF_DEV
 using CfgH8W = ConvGn2Cfg<8, true>;          // 8x8: two images per 128-pixel tile (superseded by the one-image tile: 0.6 % slower per forward)
 using CfgP256x256 = PatchCfg<2, 4, 8, 4, 344>; using CfgP256x128 = PatchCfg<4, 2, 4, 4, 400>;
@@ -264,7 +264,7 @@ bool set_lds_epi_all() {
 }
 template <int EPI>
 bool set_lds_conv_gn() {
-    return set_lds<CfgH32>(&k_conv_gn2<32, false, EPI>) && set_lds<CfgH16>(&k_conv_gn2<16, false, EPI>) && set_lds<CfgH16W>(&k_conv_gn2<16, true, EPI>) &&
+    return set_lds<CfgH32>(&k_conv_gn2<32, false, EPI>) && set_lds<CfgH32W>(&k_conv_gn2<32, true, EPI>) && set_lds<CfgH16>(&k_conv_gn2<16, false, EPI>) && set_lds<CfgH16W>(&k_conv_gn2<16, true, EPI>) &&
            set_lds<CfgH8T>(&k_conv_gn2<8, true, EPI, 4>) && set_lds<CfgH4T>(&k_conv_gn2<4, true, EPI, 4, 2>)
 #ifdef NATINF_DEV
            && set_lds<CfgH8W>(&k_conv_gn2<8, true, EPI>)
@@ -319,7 +319,7 @@ int variant_bm(int v);
 // k_conv_gn instantiations: 32x32 and 16x16 images, 256 x 128 tiles -- 128 x 256 tiles for 16x16 layers whose N is a multiple of 256
 // (natinf_set_conv_gn_wide: A/B runs); packed epilogues 1 / 2 / 5 / 6 only
 int packed_epi(const GemmArgs& g, int bm);
-int g_cg_wide = 1;
+int g_cg_wide = 3;                 // natinf_set_conv_gn_wide: bit 0 = 128 x 256 tiles at 16x16, bit 1 = at 32x32 (N % 256 == 0 layers: the 16 -> 32 up-sampling block)
 int g_fuse_up = 1;                 // natinf_set_fuse_up (read when a plan is BUILT): up blocks at 16x16 / 32x32 fetch their input up-sampled inside k_conv_gn2
 int g_cg_regw = 1;                 // natinf_set_conv_gn_regw: 1 = k_conv_gn2 (weights streamed through registers) where GemmArgs::b_frag is given
 // tile rows of the fused-convolution instantiation a launch takes: 128 x 256 tiles at 16x16 (N % 256 == 0) and at 8x8 (two images per tile), 256 x 128 elsewhere
@@ -327,7 +327,8 @@ inline int conv_gn_bm(const GemmArgs& g) {
     const int res = 1 << g.logW;
     if (res == 8) return g_cg8_tm4 ? 64 : 128;
     if (res == 4) return 64;
-    return (g_cg_wide && res == 16 && g.N % 256 == 0) ? 128 : 256;
+    if (res == 32) return ((g_cg_wide & 2) && g.N % 256 == 0 && g_cg_regw && g.b_frag) ? 128 : 256;      // (k_conv_gn2 only)
+    return ((g_cg_wide & 1) && res == 16 && g.N % 256 == 0) ? 128 : 256;
 }
 // rows of one GroupNorm-partial table row the launch writes (what the caller divides H*W by): a tile, or one SAMPLE of the two an 8x8 tile holds
 inline int conv_gn_part_rows(const GemmArgs& g) { const int res = 1 << g.logW; return res <= 8 ? res * res : conv_gn_bm(g); }
@@ -582,6 +583,7 @@ int launch_gemm(const GemmArgs& g0, hipStream_t s) {
                         default: launch_tiles<CfgH4T>(&k_conv_gn2<4, true, 6, 4, 2>, g, s); break;
                     }
                 }
+                else if ((1 << g.logW) == 32 && conv_gn_bm(g) == 128) { NATINF_CG2_LAUNCH(CfgH32W, 32, true) }
                 else if ((1 << g.logW) == 32) { NATINF_CG2_LAUNCH(CfgH32, 32, false) }
                 else if (conv_gn_bm(g) == 128) { NATINF_CG2_LAUNCH(CfgH16W, 16, true) }
                 else { NATINF_CG2_LAUNCH(CfgH16, 16, false) }
@@ -1589,7 +1591,7 @@ int natinf_set_conv_gn8_tile(int one_image) {
     g_cg8_tm4 = one_image != 0; return NATINF_OK;
 }
 int natinf_set_fuse_head(int on) { g_fuse_head = on != 0; return NATINF_OK; }
-int natinf_set_conv_gn_wide(int on) { g_cg_wide = on != 0; return NATINF_OK; }
+int natinf_set_conv_gn_wide(int mask) { if (mask < 0 || mask > 3) return NATINF_EINVAL; g_cg_wide = mask; return NATINF_OK; }
 int natinf_set_conv_gn_regw(int on) {
     if (!on && !HAVE_CONV_GN_V1) return NATINF_ESTATE;      // k_conv_gn (the LDS-ring form) exists in -DNATINF_DEV builds only
     g_cg_regw = on != 0; return NATINF_OK;

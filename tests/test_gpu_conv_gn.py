@@ -26,6 +26,8 @@ def _pack(w, w1):
     (16, 2, 512, 256, 512, False, True),      # widest K: 144 + 16 K-tiles
     (16, 3, 128, 256, 0, False, False),
     (32, 2, 384, 128, 384, False, False),     # 384 channels: 12 half-chunks
+    (32, 2, 256, 256, 0, False, True),        # N = 256 at 32x32 (the 16 -> 32 up-sampling block): the 128 x 256 tile (and, forced, two 256 x 128 tiles)
+    (32, 1, 256, 256, 256, True, True),       # ... with the shortcut segment and a residual
     (8, 4, 256, 256, 0, False, True),         # 8x8 level (round 3): one whole image per 64-pixel tile, GroupNorm partials per sample
     (8, 3, 512, 256, 512, False, True),       # + the 1x1 shortcut segment
     (8, 6, 256, 256, 0, True, True),          # identity residual
@@ -68,12 +70,12 @@ def test_conv_gn_matches_torch(res, B, cin, N, c1, resid, parts):
     scd, shd, bd = (scale * -LOG2E).to(dev), (shift * -LOG2E).to(dev), bias.to(dev)           # (named: a temporary could be recycled before the launch runs)
     a1d = a1.bfloat16().to(dev).contiguous() if c1 else None
     rd = r.bfloat16().to(dev) if resid else None
-    wide = res == 16 and N % 256 == 0                      # 128-pixel x 256-channel tiles (default) -- the 256 x 128 ones are tested as well
+    wide = res in (16, 32) and N % 256 == 0                # 128-pixel x 256-channel tiles (default) -- the 256 x 128 ones are tested as well
     wf = torch.zeros_like(wd)                              # receives the fragment-major copy of the weights (k_conv_gn2)
     assert lib.natinf_set_conv_gn_regw(0) != 0          # k_conv_gn (weights through an LDS ring): -DNATINF_DEV builds only
     assert lib.natinf_set_conv_gn8_tile(0) != 0         # the two-images-per-tile form of the 8x8 level: -DNATINF_DEV builds only
     for use_wide, regw in (((1, 1), (0, 1)) if wide else ((1, 1),)):
-        lib.natinf_set_conv_gn_wide(use_wide)
+        lib.natinf_set_conv_gn_wide(3 if use_wide else 0)
         rows = res * res if res <= 8 else (128 if (wide and use_wide) else 256)      # (8x8 / 4x4: one partial row per SAMPLE)
         part = torch.zeros(M // rows, N // 4, 2, device=dev) if parts else None
         out.zero_()
@@ -82,7 +84,7 @@ def test_conv_gn_matches_torch(res, B, cin, N, c1, resid, parts):
                                            ptr(rd), out_scale, ptr(out), ptr(part), 1, stream_ptr()), "conv_gn")
             torch.cuda.synchronize()
         finally:
-            lib.natinf_set_conv_gn_wide(1)
+            lib.natinf_set_conv_gn_wide(3)
         got = out.float().cpu()
         assert torch.isfinite(got).all()
         err = ((got - ref).abs().max() / ref.abs().max()).item()
@@ -103,6 +105,8 @@ def test_ragged_channel_counts_are_refused_in_the_shipped_build():
 
 @pytest.mark.parametrize("res,B,cin,N,c1,flags", [
     (32, 2, 256, 128, 0, 1),        # Conv_0 of the 16 -> 32 up-sampling block: the patch is fetched from the 16x16 tensor
+    (32, 2, 256, 256, 0, 1),        # ... at its real width (N = 256: the 128 x 256 tile)
+    (32, 1, 256, 256, 256, 3),      # Conv_1 + shortcut of that block at N = 256
     (32, 2, 128, 128, 256, 3),      # Conv_1 + shortcut of that block: the 1x1 operand is fetched up-sampled too
     (16, 3, 256, 256, 256, 3),      # the 8 -> 16 block on the 128 x 256 tile
     (16, 2, 256, 256, 0, 1),
