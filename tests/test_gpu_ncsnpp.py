@@ -281,3 +281,26 @@ def test_workspace_too_small_is_an_error(dev, flat):
     out = torch.empty_like(x)
     rc = lib.natinf_ncsnpp_forward(eng._h, ptr(x), ptr(torch.zeros(4, device=dev)), ptr(out), 4, ptr(eng._ws), eng._ws.numel(), stream_ptr())
     assert rc == -1
+
+
+@pytest.mark.parametrize("B", [1, 3, 5, 7, 13])
+def test_odd_batches_default_plan_against_the_unfused_plan(dev, flat, B):
+    """Tails of everything that packs several samples into a tile or pairs blocks: the 4x4 level's four images per tile (batch % 4), the attention
+    kernels' XCD pairing (2 B % 16), producer-written GroupNorm tables of a partial tile -- the default plan against the plan with those fusions off."""
+    from naturaldiffusion_amd.ncsnpp import NCSNppEngine
+    from naturaldiffusion_amd._lib import lib
+    g = torch.Generator().manual_seed(100 + B)
+    x = torch.randn(B, 3, 32, 32, generator=g).to(dev)
+    labels = (torch.rand(B, generator=g) * 999).to(dev)
+    y = NCSNppEngine(flat, max_batch=B, device=dev)(x, labels).clone()
+    knobs = [lib.natinf_set_fuse_gn8, lib.natinf_set_fuse_gn4, lib.natinf_set_fuse_fin, lib.natinf_set_attn_qkv, lib.natinf_set_attn_proj]
+    try:
+        for k in knobs:
+            assert k(0) == 0
+        ref = NCSNppEngine(flat, max_batch=B, device=dev)(x, labels).clone()
+    finally:
+        for k in knobs:
+            k(1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    assert _rel(y.cpu(), ref.cpu()) < 2e-2
