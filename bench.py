@@ -317,7 +317,7 @@ def bench_cifar(args, world, rank, dev):
         ach_g = gemm_flops / (gemm_ms * 1e-3) / 1e12
         tr_gemm, tr_src_g = profiled_traffic("k_gemm")
         line["roofline_gemm"] = {
-            "kernel": "k_gemm_* (LDS-DMA implicit-GEMM tile variants: resampling-block convolutions, attention projections, NIN, linear) + k_attn256 + k_head_conv",
+            "kernel": "k_gemm_* (LDS-DMA implicit-GEMM tile variants: resampling-block convolutions, NIN, linear) + the 16x16 attention block's k_qkv256 / k_attn256<true> (HBM-bound) + k_head_conv",
             "bound": "mfma", "achieved": round(ach_g, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach_g / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": tr_gemm, "traffic_source": tr_src_g, "launches": int(gemm_n),
             "mean_launch_ms": round(gemm_ms / gemm_n, 5), "flops_per_launch": gemm_flops / gemm_n, "device_ms_total": round(gemm_ms, 3),
