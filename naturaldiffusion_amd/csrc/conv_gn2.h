@@ -58,12 +58,15 @@ template <int RES> struct PatchGeo2 { static constexpr int W = RES, WP = RES + 2
 // runs the epilogue.  The 4x4 level launches 128 tiles at B = 512 -- one block per CU on half the chip -- and a single wave per SIMD cannot cover its
 // own LDS / weight-stream latencies (tile timeline: ~930 clocks per tap for 256 clocks of MFMAs); two waves per SIMD do what the second
 // co-resident block does at the other resolutions.
-template <int RES, bool WIDE_ = false, int TM_ = 8, int NG_ = 1>
+// TN_ = 2 (RES = 4): wave tile 64 pixels x 32 channels, block tile 64 x 128 -- TWO column tiles per row tile, so that the 4x4 level launches 256 blocks (one per
+// CU) instead of 128; each block streams only its half of the weight matrix, the (small) patch is normalised by both.
+template <int RES, bool WIDE_ = false, int TM_ = 8, int NG_ = 1, int TN_ = 4>
 struct ConvGn2Cfg {
     using Geo = PatchGeo2<RES>;
     static constexpr bool WIDE = WIDE_;
-    static constexpr int WM = WIDE ? 1 : 2, WN = WIDE ? 4 : 2, TM = TM_, TN = 4, NW = 4, NG = NG_, THREADS = 256 * NG_, KT = 32;
+    static constexpr int WM = WIDE ? 1 : 2, WN = WIDE ? 4 : 2, TM = TM_, TN = TN_, NW = 4, NG = NG_, THREADS = 256 * NG_, KT = 32;
     static_assert(NG_ == 1 || (NG_ == 2 && RES == 4), "K groups: the 4x4 level only");
+    static_assert(TN_ == 4 || (TN_ == 2 && RES == 4), "32-channel wave tiles: the 4x4 level only");
     static_assert(RES == 4 ? (TM_ == 4 && WIDE_) : (TM_ == 8 || (TM_ == 4 && RES == 8 && WIDE_)), "the 4-row-tile form exists for the 8x8 and 4x4 levels only");
     static constexpr int BM_ = WM * TM * 16, BN_ = WN * TN * 16;
     static constexpr int NIMG = RES * RES >= BM_ ? 1 : BM_ / (RES * RES);   // whole images per tile (RES = 8: 2)
@@ -116,10 +119,10 @@ template <int OFF> __device__ __forceinline__ void lds_write16(unsigned addr, u3
 __device__ __forceinline__ void fresh4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 
 // EPI: the packed epilogues of gemm_dma.h (1 plain, 2 + GroupNorm partials, 5 + bf16 residual, 6 both).  g.b_frag = k_pack_frag's output.
-template <int RES, bool WIDE, int EPI, int TMV = 8, int NGV = 1>
+template <int RES, bool WIDE, int EPI, int TMV = 8, int NGV = 1, int TNV = 4>
 __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const GemmArgs g)
 {
-    using Cfg = ConvGn2Cfg<RES, WIDE, TMV, NGV>;
+    using Cfg = ConvGn2Cfg<RES, WIDE, TMV, NGV, TNV>;
     using Geo = typename Cfg::Geo;
     constexpr int BM_ = Cfg::BM_, BN_ = Cfg::BN_, NW = Cfg::NW, TM = Cfg::TM, TN = Cfg::TN, KT = Cfg::KT;
     constexpr int W = Geo::W, WS = Geo::WS, HW = RES * RES;
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
                 npk[(I) >> 1] = __builtin_bit_cast(unsigned, pr_);                                                           \
             }                                                                                                                \
         }                                                                                                                    \
-        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                                   \
+        _Pragma("unroll") for (int g_ = 0; g_ < TN; ++g_) {                                                                  \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       /* one MFMA */                                           \
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);       /* two vector instructions */                            \
         }
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
         if constexpr ((S) + 2 < TM) fs[((S) + 2) % 3] = lds_read16<AOFF((S) + 2)>(a);                                        \
         wait_lgkmcnt<((S) + 2 < TM ? 2 : TM - 1 - (S))>();                                                                    \
         EL##_PRE((EO) + (S))                                                                                                 \
-        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                                     \
+        _Pragma("unroll") for (int r_ = 0; r_ < TN; ++r_)                                                                    \
             acc[S][r_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[P][r_]), __builtin_bit_cast(bf16x8, fs[(S) % 3]), acc[S][r_], 0, 0, 0); \
         EL##_EL((EO) + (S))                                                                                                  \
         EL##_POST((EO) + (S))                                                                                                \
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
         if constexpr (TM == 8) {                                                                                              \
         NATINF_CG_STEP(a, AOFF, P, 4, EL, EO) NATINF_CG_STEP(a, AOFF, P, 5, EL, EO) NATINF_CG_STEP(a, AOFF, P, 6, EL, EO) NATINF_CG_STEP(a, AOFF, P, 7, EL, EO) }
     // the weight fragments of set P have landed (the wait in front of this): from here on they are new values to hipcc
-#define NATINF_CG_BW_READY(P) fresh4(bw[P][0], bw[P][1], bw[P][2], bw[P][3]);
+#define NATINF_CG_BW_READY(P) _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) asm volatile("" : "+v"(bw[P][j_]));
 
     // ---- prologue: this wave's table + patch pieces of half-chunk 0 and weight step 0; its pieces are normalised before the loop ----
     using std::integral_constant;

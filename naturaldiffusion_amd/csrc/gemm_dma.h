@@ -302,9 +302,9 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
             }
         }
         if constexpr (FIN) {
-            static_assert(WM == 1 && BN_ == THREADS, "one channel per thread, one wave row");
+            static_assert(WM == 1 && BN_ <= THREADS, "one channel per thread, one wave row");
             const int n = n0 + tid;
-            if (g.fin_scale && n < g.N) {
+            if (g.fin_scale && tid < BN_ && n < g.N) {
                 constexpr int HWS = BM_ / NSAMP;                       // rows of a sample
                 const int cg = g.fin_cg, qpg = cg >> 2, q0 = (n / cg) * qpg - (n0 >> 2);
                 const float inv = 1.0f / (float)(cg * HWS), ga = g.fin_gamma[n], be = g.fin_beta[n];

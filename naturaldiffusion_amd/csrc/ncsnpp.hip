@@ -215,7 +215,7 @@ using CfgR256x256 = RingCfg<2, 4, 8, 4, 4>; using CfgR256x128 = RingCfg<4, 2, 4,
 using CfgR128x128 = RingCfg<2, 2, 4, 4, 4>; using CfgR64x128 = RingCfg<2, 2, 2, 4, 4>;
 using CfgR256x128W4 = RingCfg<2, 2, 8, 4, 3>; using CfgD256x128W4 = DmaCfg<2, 2, 8, 4>;
 using CfgD512x128 = DmaCfg<4, 2, 8, 4>;
-using CfgH32 = ConvGn2Cfg<32>; using CfgH16 = ConvGn2Cfg<16>; using CfgH16W = ConvGn2Cfg<16, true>; using CfgH32W = ConvGn2Cfg<32, true>; using CfgH8T = ConvGn2Cfg<8, true, 4>; using CfgH4T = ConvGn2Cfg<4, true, 4, 2>;
+using CfgH32 = ConvGn2Cfg<32>; using CfgH16 = ConvGn2Cfg<16>; using CfgH16W = ConvGn2Cfg<16, true>; using CfgH32W = ConvGn2Cfg<32, true>; using CfgH8T = ConvGn2Cfg<8, true, 4>; using CfgH4T = ConvGn2Cfg<4, true, 4, 2, 2>;
 #ifdef NATINF_DEV
 using CfgH8W = ConvGn2Cfg<8, true>;          // 8x8: two images per 128-pixel tile (superseded by the one-image tile: 0.6 % slower per forward)
 using CfgP256x256 = PatchCfg<2, 4, 8, 4, 344>; using CfgP256x128 = PatchCfg<4, 2, 4, 4, 400>;
@@ -265,7 +265,7 @@ bool set_lds_epi_all() {
 template <int EPI>
 bool set_lds_conv_gn() {
     return set_lds<CfgH32>(&k_conv_gn2<32, false, EPI>) && set_lds<CfgH32W>(&k_conv_gn2<32, true, EPI>) && set_lds<CfgH16>(&k_conv_gn2<16, false, EPI>) && set_lds<CfgH16W>(&k_conv_gn2<16, true, EPI>) &&
-           set_lds<CfgH8T>(&k_conv_gn2<8, true, EPI, 4>) && set_lds<CfgH4T>(&k_conv_gn2<4, true, EPI, 4, 2>)
+           set_lds<CfgH8T>(&k_conv_gn2<8, true, EPI, 4>) && set_lds<CfgH4T>(&k_conv_gn2<4, true, EPI, 4, 2, 2>)
 #ifdef NATINF_DEV
            && set_lds<CfgH8W>(&k_conv_gn2<8, true, EPI>)
            && set_lds<CfgG32>(&k_conv_gn<32, false, EPI>) && set_lds<CfgG16>(&k_conv_gn<16, false, EPI>) && set_lds<CfgG16W>(&k_conv_gn<16, true, EPI>)
@@ -332,7 +332,7 @@ inline int conv_gn_bm(const GemmArgs& g) {
 }
 // rows of one GroupNorm-partial table row the launch writes (what the caller divides H*W by): a tile, or one SAMPLE of the two an 8x8 tile holds
 inline int conv_gn_part_rows(const GemmArgs& g) { const int res = 1 << g.logW; return res <= 8 ? res * res : conv_gn_bm(g); }
-inline bool conv_gn_regw(const GemmArgs& g) { return g_cg_regw && g.b_frag && g.N % (conv_gn_bm(g) <= 128 ? 256 : 128) == 0; }
+inline bool conv_gn_regw(const GemmArgs& g) { return g_cg_regw && g.b_frag && g.N % ((conv_gn_bm(g) <= 128 && (1 << g.logW) != 4) ? 256 : 128) == 0; }      // (4x4: 64 x 128 tiles)
 #ifdef NATINF_DEV
 constexpr bool HAVE_CONV_GN_V1 = true;              // k_conv_gn (weights through an LDS ring): superseded, development builds only
 #else
@@ -346,7 +346,7 @@ inline bool conv_gn_ok(const GemmArgs& g) {
     const int res = 1 << g.logW;
     if (g.logHW != 2 * g.logW || (res != 32 && res != 16 && res != 8 && res != 4) || g.N % 8) return false;
     if (res == 4 && (g.a0_C % 128 || (g.a1 && g.a1_C % 128))) return false;          // two K groups per block: an even number of half-chunks / shortcut tiles EACH
-    if (res <= 8 ? (g.M % (res * res) || g.N % 256 || g.a0_up || g.a1_up || !conv_gn_regw(g) || (g.resid && g.rowvec)) : g.M % 256 != 0) return false;      // 8x8: whole images, k_conv_gn2 only;
+    if (res <= 8 ? (g.M % (res * res) || g.N % (res == 4 ? 128 : 256) || g.a0_up || g.a1_up || !conv_gn_regw(g) || (g.resid && g.rowvec)) : g.M % 256 != 0) return false;      // 8x8: whole images, k_conv_gn2 only;
     // (its residual epilogues keep one set of column terms for both samples of a tile: no per-sample row vector there)
     if ((g.a0_up || g.a1_up || !HAVE_CONV_GN_V1) && !conv_gn_regw(g)) return false;          // up-sampled fetches: k_conv_gn2 only
     const int e = conv_gn_epi(g);
@@ -577,10 +577,10 @@ int launch_gemm(const GemmArgs& g0, hipStream_t s) {
 #endif
                 else if ((1 << g.logW) == 4) {
                     switch (e4) {
-                        case 0: launch_tiles<CfgH4T>(&k_conv_gn2<4, true, 1, 4, 2>, g, s); break;
-                        case 1: launch_tiles<CfgH4T>(&k_conv_gn2<4, true, 2, 4, 2>, g, s); break;
-                        case 2: launch_tiles<CfgH4T>(&k_conv_gn2<4, true, 5, 4, 2>, g, s); break;
-                        default: launch_tiles<CfgH4T>(&k_conv_gn2<4, true, 6, 4, 2>, g, s); break;
+                        case 0: launch_tiles<CfgH4T>(&k_conv_gn2<4, true, 1, 4, 2, 2>, g, s); break;
+                        case 1: launch_tiles<CfgH4T>(&k_conv_gn2<4, true, 2, 4, 2, 2>, g, s); break;
+                        case 2: launch_tiles<CfgH4T>(&k_conv_gn2<4, true, 5, 4, 2, 2>, g, s); break;
+                        default: launch_tiles<CfgH4T>(&k_conv_gn2<4, true, 6, 4, 2, 2>, g, s); break;
                     }
                 }
                 else if ((1 << g.logW) == 32 && conv_gn_bm(g) == 128) { NATINF_CG2_LAUNCH(CfgH32W, 32, true) }

@@ -111,8 +111,8 @@ def test_conv_gn2_k_loop_has_no_scratch_traffic(listings):
                 bad.append(ln.strip())
             elif in_loop and "v_mfma" in ln:
                 n_mfma_in_loops += 1
-        tm = int(re.search(r"k_conv_gn2ILi\d+ELb[01]ELi\d+ELi(\d+)ELi\d+EE", parts[i]).group(1))       # template arguments <RES, WIDE, EPI, TM, NG>
-        per_tap = 4 * tm                                                     # (the 64-pixel tiles of the 8x8 / 4x4 levels: four MFMA groups per tap)
+        tm, tn = (int(v) for v in re.search(r"k_conv_gn2ILi\d+ELb[01]ELi\d+ELi(\d+)ELi\d+ELi(\d+)EE", parts[i]).groups())       # template arguments <RES, WIDE, EPI, TM, NG, TN>
+        per_tap = tm * tn                                                    # MFMAs per tap and wave
         assert n_mfma_in_loops >= 2 * 9 * per_tap and not bad, (parts[i], bad[:4])
 
 
