@@ -65,6 +65,8 @@ struct ConvGn2Cfg {
     using Geo = PatchGeo2<RES>;
     static constexpr bool WIDE = WIDE_;
     static constexpr int WM = WIDE ? 1 : 2, WN = WIDE ? 4 : 2, TM = TM_, TN = TN_, NW = 4, NG = NG_, THREADS = 256 * NG_, KT = 32;
+    // (four groups -- 1,024 threads, four waves per SIMD -- were built too: the same 21 / 32 us as two at K = 2,304 / 4,608, and a parity failure at B = 512 that
+    // was not chased; the reduction below is written for any group count)
     static_assert(NG_ == 1 || (NG_ == 2 && RES == 4), "K groups: the 4x4 level only");
     static_assert(TN_ == 4 || (TN_ == 2 && RES == 4), "32-channel wave tiles: the 4x4 level only");
     static_assert(RES == 4 ? (TM_ == 4 && WIDE_) : (TM_ == 8 || (TM_ == 4 && RES == 8 && WIDE_)), "the 4-row-tile form exists for the 8x8 and 4x4 levels only");
@@ -82,13 +84,13 @@ struct ConvGn2Cfg {
     static constexpr int TILES_BYTES = 2 * PATCH_BYTES + 2 * TAB_BYTES + VOFF_BYTES;
     using Epi = EpiCfg<WM, WN, TM, TN, 81920>;
     static constexpr int EPI_BYTES = Epi::PACK_BYTES + (NIMG - 1) * WN * TN * 4 * 8;      // + the partial-sum rows of the further samples
-    static constexpr int RED_BYTES = NG > 1 ? TM * TN * 16 * 256 : 0;  // the second group's accumulators (fp32, one float4 per thread and MFMA tile)
+    static constexpr int RED_BYTES = (NG - 1) * TM * TN * 16 * 256;   // the further groups' accumulators (fp32, one float4 per thread and MFMA tile)
     static constexpr int LDS_BYTES = (NG * TILES_BYTES > EPI_BYTES ? NG * TILES_BYTES : EPI_BYTES) > RED_BYTES ? (NG * TILES_BYTES > EPI_BYTES ? NG * TILES_BYTES : EPI_BYTES) : RED_BYTES;
     static constexpr int swz_key(int xx) { return RES <= 8 ? (xx & 2) : ((xx >> 1) & 2); }
     static_assert(RES * RES % BM_ == 0 || (BM_ % (RES * RES) == 0 && WM == 1 && (NIMG == 2 || NIMG == 4) && TM % NIMG == 0), "a tile lies inside one image, or holds two / four whole images");
     static constexpr int TAPS_PER_ROUND = 8 / TM;                       // a round = eight elements per lane, one per MFMA group
     static_assert(NROUND * TAPS_PER_ROUND <= 7, "the rounds run behind taps 2..8");
-    static_assert(Epi::PACK_OK && LDS_BYTES <= (NG > 1 ? 163840 : 81920), "two blocks per CU (one with two K groups)");
+    static_assert(Epi::PACK_OK && LDS_BYTES <= (NG > 1 ? 163840 : 81920), "two blocks per CU (one with several K groups)");
 };
 
 // Weights [N][ld] bf16 in the engine's K order ((c / 64) * 9 + tap) * 64 + c % 64 (+ the c1 shortcut columns at 9 * cin) -> fragment-major
@@ -120,7 +122,7 @@ __device__ __forceinline__ void fresh4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
 
 // EPI: the packed epilogues of gemm_dma.h (1 plain, 2 + GroupNorm partials, 5 + bf16 residual, 6 both).  g.b_frag = k_pack_frag's output.
 template <int RES, bool WIDE, int EPI, int TMV = 8, int NGV = 1, int TNV = 4>
-__global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const GemmArgs g)
+__global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const GemmArgs g)      // (NGV = 4: 1,024 threads, <= 128 registers)
 {
     using Cfg = ConvGn2Cfg<RES, WIDE, TMV, NGV, TNV>;
     using Geo = typename Cfg::Geo;
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
             nmask |= (unsigned)(Cfg::swz_key(xx) >> 1) << (8 + j);
         }
     }
-    const unsigned npack = (lds_patch + wave * 1024 + lane * 16) | (nmask << 16);
+    const unsigned npack = (unsigned)(wave * 1024 + lane * 16) | (nmask << 16);      // (the address RELATIVE to the group's patch base: with four K groups the base passes 64 KiB)
     u32x4 nv = {0u, 0u, 0u, 0u}, ns0 = nv, ns1 = nv, nh0 = nv, nh1 = nv;
     unsigned npk[4] = {0u, 0u, 0u, 0u};
     float nf_even = 0.f;
@@ -315,10 +317,9 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
         asm volatile("" : "+v"(np_));                                         // (opaque: or the unpacked halves are hoisted out of the loop again)
         unsigned nb = np_ & 0xffffu;
         const unsigned nm = np_ >> 16;
-        nv = lds_read16<BUF * Cfg::PATCH_BYTES + J * NW * 1024>(nb);
+        nv = lds_read16<BUF * Cfg::PATCH_BYTES + J * NW * 1024>(nb + lds_patch);
         // the lane's row of the table: channel chunk (l & 3) ^ 2 * (bit 2 of the patch column).  Recomputed from the slot address (bits 4-9 = the lane) per
         // round: a register held across the K loop for it is the one hipcc spills (and its reload drains the weight stream)
-        nb -= lds_patch;
         // (several images per tile: the piece's image, hence its table, is wave-uniform -- pieces do not straddle images)
         const unsigned timg = NIMG > 1 ? (unsigned)((J * NW + wave) / (IMGP / 16)) * Cfg::TAB_IMG_BYTES : 0u;
         const unsigned tbase = lds_tab + timg + ((((nb >> 4) & 3u) ^ ((nm >> (7 + J)) & 2u)) << 5);
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
         unsigned np_ = npack;
         asm volatile("" : "+v"(np_));
         if (!((np_ >> (16 + J)) & 1u)) ou = u32x4{0u, 0u, 0u, 0u};
-        lds_write16<BUF * Cfg::PATCH_BYTES + J * NW * 1024>(np_ & 0xffffu, ou);
+        lds_write16<BUF * Cfg::PATCH_BYTES + J * NW * 1024>((np_ & 0xffffu) + lds_patch, ou);
     };
     // a whole round at once (prologue: no MFMAs to hide behind yet, so the eight elements are left to hipcc to interleave -- one
     // dependent unpack-fma-exp2-add-rcp-mul chain after the other costs ~70 cycles per element, 4k cycles per tile)
@@ -562,18 +563,20 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
         // the second K group hands its partial sums over (fp32, [MFMA tile][thread] float4: lane-linear 16-byte accesses) and is done;
         // S_BARRIER waits on the surviving waves only, so the first group's epilogue barriers work without it
         f32x4* red = reinterpret_cast<f32x4*>(smem) + (tid & 255);
-        if (grp == 1) {
+        if (grp > 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) red[(i * TN + j) * 256] = acc[i][j];
+                for (int j = 0; j < TN; ++j) red[((grp - 1) * TM * TN + i * TN + j) * 256] = acc[i][j];
         }
         __syncthreads();
-        if (grp == 1) return;
+        if (grp > 0) return;
+#pragma unroll 1
+        for (int gg = 0; gg < NG - 1; ++gg)              // (fixed order: groups 1, 2, ... -- deterministic; one group's values in flight at a time: 128 registers)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] += red[(i * TN + j) * 256];
+                for (int j = 0; j < TN; ++j) acc[i][j] += red[(gg * TM * TN + i * TN + j) * 256];
         __syncthreads();
     }
     // the epilogue's arguments are fetched from the kernel-argument segment HERE (conv_gn.h: kept in scalar registers across the K

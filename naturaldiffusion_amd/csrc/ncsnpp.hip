@@ -345,7 +345,7 @@ inline bool conv_gn_ok(const GemmArgs& g) {
     if (!g.gn_scale || !g.gn_shift || !g.gn_folded || g.taps != 9 || g.batch != 1 || g.a0_C % BK || (g.a1 && g.a1_C % BK)) return false;
     const int res = 1 << g.logW;
     if (g.logHW != 2 * g.logW || (res != 32 && res != 16 && res != 8 && res != 4) || g.N % 8) return false;
-    if (res == 4 && (g.a0_C % 128 || (g.a1 && g.a1_C % 128))) return false;          // two K groups per block: an even number of half-chunks / shortcut tiles EACH
+    if (res == 4 && (g.a0_C % (64 * CfgH4T::NG) || (g.a1 && g.a1_C % (64 * CfgH4T::NG)))) return false;          // two K groups per block: an even number of half-chunks / shortcut tiles EACH
     if (res <= 8 ? (g.M % (res * res) || g.N % (res == 4 ? 128 : 256) || g.a0_up || g.a1_up || !conv_gn_regw(g) || (g.resid && g.rowvec)) : g.M % 256 != 0) return false;      // 8x8: whole images, k_conv_gn2 only;
     // (its residual epilogues keep one set of column terms for both samples of a tile: no per-sample row vector there)
     if ((g.a0_up || g.a1_up || !HAVE_CONV_GN_V1) && !conv_gn_regw(g)) return false;          // up-sampled fetches: k_conv_gn2 only
