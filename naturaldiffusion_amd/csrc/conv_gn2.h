@@ -94,7 +94,7 @@ struct ConvGn2Cfg {
 };
 
 // Weights [N][ld] bf16 in the engine's K order ((c / 64) * 9 + tap) * 64 + c % 64 (+ the c1 shortcut columns at 9 * cin) -> fragment-major
-// [N / 16][NT][64 lanes][8]: K step kt = (half-chunk hc, tap t) reads columns ((hc >> 1) * 9 + t) * 64 + (hc & 1) * 32 .. + 31, the shortcut
+// [N / 16][NT][64 lanes][8] (N % 32 == 0): K step kt = (half-chunk hc, tap t) reads columns ((hc >> 1) * 9 + t) * 64 + (hc & 1) * 32 .. + 31, the shortcut
 // steps follow; lane l of a block holds row (l & 15), columns 8 * (l >> 4) .. + 7 of the step: the A operand of v_mfma_f32_16x16x32_bf16.
 __global__ __launch_bounds__(256) void k_pack_frag(const bf16* __restrict__ w, bf16* __restrict__ wf, int N, int ld, int cin, int c1)
 {
@@ -105,7 +105,9 @@ __global__ __launch_bounds__(256) void k_pack_frag(const bf16* __restrict__ w, b
     int col;
     if (kt < nk) { const int hc = kt / 9, t = kt - 9 * hc; col = ((hc >> 1) * 9 + t) * 64 + (hc & 1) * 32; }
     else col = 9 * cin + (kt - nk) * 32;
-    const uint4 v = *reinterpret_cast<const uint4*>(w + (int64_t)(nt * 16 + (lane & 15)) * ld + col + (lane >> 4) * 8);
+    // rows of an n-tile pair interleaved (gemm_dma.h, PAIR): row r of tile 2 p + h is output channel 32 p + 8 (r >> 2) + 4 h + (r & 3)
+    const int r = lane & 15, row = 32 * (nt >> 1) + 8 * (r >> 2) + 4 * (nt & 1) + (r & 3);
+    const uint4 v = *reinterpret_cast<const uint4*>(w + (int64_t)row * ld + col + (lane >> 4) * 8);
     *reinterpret_cast<uint4*>(wf + idx * 8) = v;
 }
 
@@ -597,7 +599,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
 #ifdef NATINF_DEV
     const unsigned long long dbg_t2 = cg_stamp();
 #endif
-    tile_epilogue<Cfg::WM, Cfg::WN, TM, TN, typename Cfg::Epi, EPI, NIMG, (RES <= 8)>(ge, smem, acc, m0, n0, 0, tid, lane, wm, wn);      // (two K groups: tid < 256 here)
+    tile_epilogue<Cfg::WM, Cfg::WN, TM, TN, typename Cfg::Epi, EPI, NIMG, (RES <= 8), true>(ge, smem, acc, m0, n0, 0, tid, lane, wm, wn);      // (two K groups: tid < 256 here)
 #ifdef NATINF_DEV
     if (ge.dbg_ts && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 777)) {          // development builds: tools/conv_gn_timeline.py
         // block 0: [2..4] are the epilogue's own stamps (NATINF_TS: start, slab written, copied out), [7] = the stamp in front of it

@@ -113,14 +113,19 @@ struct SlabCopy<NSW, NSW, RPS, PROW, EDGE> {
 // partials exist once per sample; gn_part rows are then indexed by (m0 / BM) * NSAMP + sample.
 // FIN (k_conv_gn2 at 8x8 / 4x4: the tile = whole samples x all BN_ = N channels): GemmArgs::fin_* -- the consumer's GroupNorm table straight from
 // the tile's own partial sums, same additions in the same order as k_gn_finalize (bit-identical tables).
-template <int WM, int WN, int TM, int TN, class Cfg, int ACT, bool GN, bool RES, bool DEQ = false, bool OUT8 = false, int NSAMP = 1, bool FIN = false>
+// PAIR (k_conv_gn2: k_pack_frag interleaves the weight rows of n-tiles 2 p, 2 p + 1 -- row r of tile 2 p + h = channel 32 p + 8 (r >> 2) + 4 h + (r & 3)): the four
+// rows 4 q + e a lane holds of both tiles are EIGHT consecutive channels 32 p + 8 q .. + 7 -- 16-byte residual loads and 16-byte slab writes instead of 8-byte ones.
+template <int WM, int WN, int TM, int TN, class Cfg, int ACT, bool GN, bool RES, bool DEQ = false, bool OUT8 = false, int NSAMP = 1, bool FIN = false, bool PAIR = false>
 __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned char* smem, f32x4 (&acc)[TM][TN],
                                                      int m0, int n0, int z, int tid, int lane, int wm, int wn)
 {
     constexpr int BN_ = WN * TN * 16, BM_ = WM * TM * 16, THREADS = WM * WN * 64, PROW = OUT8 ? BN_ + 16 : Cfg::PROW;
     static_assert(!OUT8 || (!GN && !RES && TN % 2 == 0), "fp8 output: plain column terms only");
+    static_assert(!PAIR || (TN % 2 == 0 && !OUT8 && !DEQ), "interleaved n-tile pairs: bf16 output");
     static_assert(NSAMP == 1 || ((NSAMP == 2 || NSAMP == 4) && WM == 1 && TM % NSAMP == 0 && !DEQ && !OUT8), "several samples per tile: one wave row, bf16 output");
     const int r = lane & 15, q = lane >> 4;
+    // first column, inside the wave's TN * 16, of the four consecutive columns lane group q holds of accumulator tile j
+    auto ncol = [&](int j) __attribute__((always_inline)) { return PAIR ? 32 * (j >> 1) + 8 * q + 4 * (j & 1) : 16 * j + 4 * q; };
     float dn[DEQ ? TN : 1][4], rsc[DEQ ? TM : 1], rbm[DEQ ? TM : 1];
     if constexpr (DEQ) {
 #pragma unroll
@@ -148,7 +153,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
     for (int sm = 0; sm < NCT; ++sm)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * TN * 16 + j * 16 + q * 4;
+        const int n = n0 + wn * TN * 16 + ncol(j);
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f), rv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n < g.N) {
             if (g.bias_n) b = *reinterpret_cast<const float4*>(g.bias_n + n);
@@ -161,13 +166,21 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
     // bf16 residual, fetched in the accumulator layout (8 bytes per lane: 4 columns of one row), all requests in flight at once
     uint2 rs[RES ? TM : 1][RES ? TN : 1];
     if constexpr (RES) {
-        const bf16* rb = g.resid + (int64_t)z * g.c_bs + n0 + wn * TN * 16 + q * 4;
+        const bf16* rb = g.resid + (int64_t)z * g.c_bs + n0 + wn * TN * 16;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = min(m0 + wm * TM * 16 + i * 16 + r, g.M - 1);
+            if constexpr (PAIR) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                rs[i][j] = n0 + wn * TN * 16 + j * 16 + q * 4 < g.N ? *reinterpret_cast<const uint2*>(rb + (int64_t)m * g.resid_ld + j * 16) : make_uint2(0u, 0u);
+                for (int p = 0; p < TN / 2; ++p) {                         // both tiles of a pair with one 16-byte load
+                    const uint4 v = n0 + wn * TN * 16 + ncol(2 * p) < g.N ? *reinterpret_cast<const uint4*>(rb + (int64_t)m * g.resid_ld + ncol(2 * p)) : make_uint4(0u, 0u, 0u, 0u);
+                    rs[i][2 * p] = make_uint2(v.x, v.y); rs[i][2 * p + 1] = make_uint2(v.z, v.w);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    rs[i][j] = n0 + wn * TN * 16 + ncol(j) < g.N ? *reinterpret_cast<const uint2*>(rb + (int64_t)m * g.resid_ld + ncol(j)) : make_uint2(0u, 0u);
+            }
         }
     }
     float gs[NSAMP][TN], gq[NSAMP][TN];
@@ -182,7 +195,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
             const int srow = min(m0 + (i / (TM / NSAMP)) * (BM_ / NSAMP), g.M - 1);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * TN * 16 + j * 16 + q * 4;
+                const int n = n0 + wn * TN * 16 + ncol(j);
                 lrv[j] = (g.rowvec && n < g.N) ? *reinterpret_cast<const float4*>(g.rowvec + (int64_t)(srow >> g.log_rows_per_sample) * g.rowvec_ld + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -212,7 +225,24 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
     };
     constexpr int EB = OUT8 ? 1 : 2;                   // bytes per output element
     unsigned char* wbase = smem + (wm * TM * 16 + r) * PROW + (wn * TN * 16 + q * 4) * EB;
-    if constexpr (!OUT8) {
+    if constexpr (!OUT8 && PAIR) {
+        unsigned char* wb2 = smem + (wm * TM * 16 + r) * PROW + (wn * TN * 16) * 2;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            fetch_rowvec(i);
+#pragma unroll
+            for (int p = 0; p < TN / 2; ++p) {
+                float v0[4], v1[4];
+                value(i, 2 * p, v0);
+                value(i, 2 * p + 1, v1);
+                bf16x4_t o0, o1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o0[e] = (bf16)v0[e]; o1[e] = (bf16)v1[e]; }
+                const uint2 a = __builtin_bit_cast(uint2, o0), b = __builtin_bit_cast(uint2, o1);
+                *reinterpret_cast<uint4*>(wb2 + i * 16 * PROW + ncol(2 * p) * 2) = make_uint4(a.x, a.y, b.x, b.y);
+            }
+        }
+    } else if constexpr (!OUT8) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             fetch_rowvec(i);
@@ -267,7 +297,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
 #pragma unroll
             for (int sm = 0; sm < NSAMP; ++sm)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) sred[(NSAMP > 1 ? sm : wm) * (BN_ / 4) + wn * TN * 4 + j * 4 + q] = make_float2(gs[sm][j], gq[sm][j]);
+                for (int j = 0; j < TN; ++j) sred[(NSAMP > 1 ? sm : wm) * (BN_ / 4) + wn * TN * 4 + (ncol(j) >> 2)] = make_float2(gs[sm][j], gq[sm][j]);
         }
     }
     __syncthreads();
@@ -582,7 +612,7 @@ __device__ __forceinline__ void direct_f32_epilogue(const GemmArgs& g, f32x4 (&a
 // 7 = the direct fp32 residual-stream epilogue; 8 = packed with row terms (a row bias: the V^T = W h^T + b GEMMs).  One epilogue per kernel: with both in one
 // kernel behind a run-time branch hipcc spilled inside the packed register phase (measured: isolated GEMMs +15..23 %, the
 // network 8 % SLOWER).
-template <int WM, int WN, int TM, int TN, class Cfg, int EPI, int NSAMP = 1, bool FIN = false>
+template <int WM, int WN, int TM, int TN, class Cfg, int EPI, int NSAMP = 1, bool FIN = false, bool PAIR = false>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, unsigned char* smem, f32x4 (&acc)[TM][TN],
                                               int m0, int n0, int z, int tid, int lane, int wm, int wn)
 {
@@ -591,7 +621,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, unsigned char* 
     else {
         static_assert(Cfg::PACK_OK, "packed epilogue needs the whole bf16 tile in LDS");
         NATINF_TS(2);
-        packed_tile_epilogue<WM, WN, TM, TN, Cfg, EPI == 3 ? ACT_SILU : (EPI == 4 ? ACT_GELU_TANH : ACT_NONE), EPI == 2 || EPI == 6, EPI == 5 || EPI == 6, EPI == 8, false, NSAMP, FIN && (EPI == 2 || EPI == 6)>(
+        packed_tile_epilogue<WM, WN, TM, TN, Cfg, EPI == 3 ? ACT_SILU : (EPI == 4 ? ACT_GELU_TANH : ACT_NONE), EPI == 2 || EPI == 6, EPI == 5 || EPI == 6, EPI == 8, false, NSAMP, FIN && (EPI == 2 || EPI == 6), PAIR>(
             g, smem, acc, m0, n0, z, tid, lane, wm, wn);
     }
 }

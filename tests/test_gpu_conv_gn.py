@@ -153,7 +153,7 @@ def test_up_sampling_fetch_paths_match_torch(res, B, cin, N, c1, flags):
 
 
 def test_fragment_major_weight_copy_layout():
-    """k_pack_frag (conv_gn2.h): [N/16][K steps][64 lanes][8] with lane l of K step kt holding row l & 15, columns col(kt) + 8 (l >> 4) .. + 7,
+    """k_pack_frag (conv_gn2.h): [N/16][K steps][64 lanes][8] with lane l of K step kt holding row r = l & 15 of its n-tile (= output channel 32 (nt >> 1) + 8 (r >> 2) + 4 (nt & 1) + (r & 3)), columns col(kt) + 8 (l >> 4) .. + 7,
     col(kt) = ((hc >> 1) * 9 + tap) * 64 + (hc & 1) * 32 for kt = hc * 9 + tap, then the shortcut columns -- checked element by element against
     a numpy gather of the packed matrix (the copy is what k_conv_gn2 multiplies with)."""
     from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
@@ -169,7 +169,8 @@ def test_fragment_major_weight_copy_layout():
     nk, NT = 9 * (cin // 32), 9 * (cin // 32) + c1 // 32
     col = np.array([((kt // 9 >> 1) * 9 + kt % 9) * 64 + (kt // 9 & 1) * 32 if kt < nk else 9 * cin + (kt - nk) * 32 for kt in range(NT)])
     lane = np.arange(64)
-    rows = (np.arange(N // 16)[:, None, None, None] * 16 + (lane & 15)[None, None, :, None])                          # [N/16][1][64][1]
+    nt, rr = np.arange(N // 16)[:, None, None, None], (lane & 15)[None, None, :, None]
+    rows = 32 * (nt >> 1) + 8 * (rr >> 2) + 4 * (nt & 1) + (rr & 3)                # the rows of an n-tile pair are interleaved (eight consecutive channels per accumulator lane)
     cols = col[None, :, None, None] + ((lane >> 4) * 8)[None, None, :, None] + np.arange(8)[None, None, None, :]      # [1][NT][64][8]
     want = w.view(torch.int16).numpy()[np.broadcast_to(rows, (N // 16, NT, 64, 8)), np.broadcast_to(cols, (N // 16, NT, 64, 8))]
     got = wf.cpu().view(torch.int16).numpy().reshape(N // 16, NT, 64, 8)
