@@ -91,6 +91,14 @@ __device__ __forceinline__ float dpp_row_sum(float v) {
     return v;
 }
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+// generic -> global address space: the epilogues take their pointers from a GemmArgs copy (k_conv_gn2 re-reads it from the kernel-argument segment), whose
+// provenance hipcc cannot see -- it then emits flat_load / flat_store, which go through the LDS aperture check and count on lgkmcnt as well as vmcnt
+template <class T> __device__ __forceinline__ __attribute__((address_space(1))) T* as_global(T* p) { return (__attribute__((address_space(1))) T*)p; }
+typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));       // (clang vector types: the HIP_vector_type classes cannot be read through an address-space pointer)
+typedef float gf32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 gload_u4(const void* p) { const gu32x4 t = *as_global(reinterpret_cast<const gu32x4*>(p)); return make_uint4(t[0], t[1], t[2], t[3]); }
+__device__ __forceinline__ float4 gload_f4(const void* p) { const gf32x4 t = *as_global(reinterpret_cast<const gf32x4*>(p)); return make_float4(t[0], t[1], t[2], t[3]); }
+__device__ __forceinline__ void gstore_u4(void* p, uint4 v) { *as_global(reinterpret_cast<gu32x4*>(p)) = gu32x4{v.x, v.y, v.z, v.w}; }
 // slab -> global copy of sweeps SW .. NSW-1: all LDS reads first, then the stores (template recursion instead of an array of
 // kept values: hipcc left a 16-entry uint4 array in scratch memory here)
 template <int SW, int NSW, int RPS, int PROW, bool EDGE>
@@ -99,7 +107,7 @@ struct SlabCopy {
     static __device__ __forceinline__ void run(const unsigned char* src, T* dst, int64_t ld, int m, int M) {
         const uint4 v = *reinterpret_cast<const uint4*>(src + SW * RPS * PROW);
         SlabCopy<SW + 1, NSW, RPS, PROW, EDGE>::run(src, dst, ld, m, M);
-        if (!EDGE || m + SW * RPS < M) *reinterpret_cast<uint4*>(dst + (int64_t)(SW * RPS) * ld) = v;
+        if (!EDGE || m + SW * RPS < M) gstore_u4(dst + (int64_t)(SW * RPS) * ld, v);
     }
 };
 template <int NSW, int RPS, int PROW, bool EDGE>
@@ -156,10 +164,10 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
         const int n = n0 + wn * TN * 16 + ncol(j);
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f), rv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n < g.N) {
-            if (g.bias_n) b = *reinterpret_cast<const float4*>(g.bias_n + n);
+            if (g.bias_n) b = gload_f4(g.bias_n + n);
             // (NSAMP > 1: the further samples' rows; a partial last tile reads the last real sample's again -- those rows are not stored)
             const int srow = NSAMP > 1 ? min(m0 + sm * (BM_ / NSAMP), g.M - 1) : m0;
-            if (g.rowvec && !LAZY_RV) rv = *reinterpret_cast<const float4*>(g.rowvec + (int64_t)((srow >> g.log_rows_per_sample) + z * g.z_samples) * g.rowvec_ld + n);
+            if (g.rowvec && !LAZY_RV) rv = gload_f4(g.rowvec + (int64_t)((srow >> g.log_rows_per_sample) + z * g.z_samples) * g.rowvec_ld + n);
         }
         ct[sm][j][0] = b.x + rv.x; ct[sm][j][1] = b.y + rv.y; ct[sm][j][2] = b.z + rv.z; ct[sm][j][3] = b.w + rv.w;
     }
@@ -173,7 +181,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
             if constexpr (PAIR) {
 #pragma unroll
                 for (int p = 0; p < TN / 2; ++p) {                         // both tiles of a pair with one 16-byte load
-                    const uint4 v = n0 + wn * TN * 16 + ncol(2 * p) < g.N ? *reinterpret_cast<const uint4*>(rb + (int64_t)m * g.resid_ld + ncol(2 * p)) : make_uint4(0u, 0u, 0u, 0u);
+                    const uint4 v = n0 + wn * TN * 16 + ncol(2 * p) < g.N ? gload_u4(rb + (int64_t)m * g.resid_ld + ncol(2 * p)) : make_uint4(0u, 0u, 0u, 0u);
                     rs[i][2 * p] = make_uint2(v.x, v.y); rs[i][2 * p + 1] = make_uint2(v.z, v.w);
                 }
             } else {
@@ -569,7 +577,7 @@ __device__ __forceinline__ void direct_f32_epilogue(const GemmArgs& g, f32x4 (&a
         n_ok[j] = n < g.N;
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f), rv = make_float4(0.f, 0.f, 0.f, 0.f), gv = make_float4(1.f, 1.f, 1.f, 1.f);
         if (n_ok[j]) {
-            if (g.bias_n) b = *reinterpret_cast<const float4*>(g.bias_n + n);
+            if (g.bias_n) b = gload_f4(g.bias_n + n);
             if (g.rowvec) rv = *reinterpret_cast<const float4*>(g.rowvec + sample * g.rowvec_ld + n);
             if (g.gate) gv = *reinterpret_cast<const float4*>(g.gate + sample * g.gate_ld + n);
         }
