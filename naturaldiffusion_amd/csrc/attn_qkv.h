@@ -3,7 +3,7 @@
 //
 // Until round 3 (late) this was three launches, every one bound by HBM: k_gn_apply (x -> h: 67 + 67 MB at B = 512, 35 us), the q | k GEMM (h -> [q | k]:
 // 67 + 134 MB, 66 us) and the batched V^T GEMM (h -> V^T: 67 + 67 MB, 34 us).  Here x is read once and h never exists:
-//   * a block = 128 tokens of one sample (4 waves x 32 tokens; grid 2 B); a lane loads its wave's x fragments -- token 16 g + r, channels
+//   * a block = the 256 tokens of one sample (8 waves x 32 tokens; grid B); a lane loads its wave's x fragments -- token 16 g + r, channels
 //     32 kc + 8 q .. + 7 -- straight into the MFMA operand layout, normalises them in registers (x * scale + shift with the sample's table, rounded to
 //     bf16 as k_gn_apply rounds h) and keeps all 256 channels of its 32 tokens as sixteen operand registers sets (64 VGPRs);
 //   * the three weight matrices arrive fragment-major (k_pack_qkv_w: [48 n-tiles][8 K steps][64 lanes][8], 384 KB, L2-resident) in 24 tiles of 16 KB
@@ -11,10 +11,11 @@
 //   * q | k tiles: out^T = W h^T (weights as the A operand) -- a lane ends up with four consecutive output channels of one token: 8-byte stores into
 //     [q | k] (row-major, what k_attn256 reads); v tiles: the SAME registers as the A operand and the weights as B -- a lane ends up with four
 //     consecutive TOKENS of one channel: 8-byte stores into V^T ([B][256 channels][256 tokens]).  Biases: per column for q | k, per row for V^T.
-// 768 MFMAs per wave (12 us of matrix time per CU) under 67 MB in, 201 MB out: four blocks per CU, 126 registers, 82 us per launch at B = 512 (35 + 66 + 34 us
+// 768 MFMAs per wave (12 us of matrix time per CU) under 67 MB in, 201 MB out: two 8-wave blocks per CU, 126 registers, 75 us per launch at B = 512 (35 + 66 + 34 us
 // for the three launches it replaces), output bit-identical to theirs.  What the first forms taught (105 -> 100 -> 92 -> 82 us): 32-KB tiles at two blocks
 // per CU left the next tile's DMA exposed; a per-n-tile bias LOAD inside the loop made hipcc drain the DMA and the previous stores (vmcnt(0)) at every
-// n-tile; 8-byte stores (32 contiguous bytes per row and instruction) cost 10 us against 16-byte ones (64).
+// n-tile; 8-byte stores (32 contiguous bytes per row and instruction) cost 10 us against 16-byte ones (64).  One sample per block (8 waves, two blocks
+// per CU) instead of half a sample: the 384 KB of weights cross L2 -> LDS once per sample -- 197 MB per launch instead of 393 (more than the HBM traffic): 82 -> 75 us.
 #pragma once
 #include "ncsnpp_kernels.h"
 
@@ -44,8 +45,8 @@ __global__ __launch_bounds__(256) void k_pack_qkv_w(const float* __restrict__ w0
 }
 
 // x: [B*256][x_ld] bf16 (raw block input); gsc / gsh: GroupNorm (scale | shift) tables [B][256] fp32; wf: k_pack_qkv_w's output; bqk: [512] (q then k), bv: [256];
-// qk: [B*256][512]; vT: [B][256][256].  grid = 2 B, 256 threads, QKV_LDS_BYTES.
-__global__ __launch_bounds__(256, 4) void k_qkv256(const bf16* __restrict__ x, int x_ld, const float* __restrict__ gsc, const float* __restrict__ gsh,
+// qk: [B*256][512]; vT: [B][256][256].  grid = B, 512 threads, QKV_LDS_BYTES.
+__global__ __launch_bounds__(512, 2) void k_qkv256(const bf16* __restrict__ x, int x_ld, const float* __restrict__ gsc, const float* __restrict__ gsh,
                                                   const bf16* __restrict__ wf, const float* __restrict__ bqk, const float* __restrict__ bv,
                                                   bf16* __restrict__ qk, bf16* __restrict__ vT)
 {
@@ -55,8 +56,8 @@ __global__ __launch_bounds__(256, 4) void k_qkv256(const bf16* __restrict__ x, i
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x >> 1, half = blockIdx.x & 1;
-    const int tok0 = half * 128 + wave * 32;                     // the wave's first token inside the sample
+    const int b = blockIdx.x;                                    // a block = one sample: 8 waves x 32 tokens (the weight tiles are streamed once per sample, not per half)
+    const int tok0 = wave * 32;                                  // the wave's first token inside the sample
 
     auto issue = [&](int i) __attribute__((always_inline)) {     // weight tile i: n-tiles 2 i, 2 i + 1, all eight K steps
         unsigned char* st = smem + (i & 1) * QKV_STAGE;
@@ -64,8 +65,8 @@ __global__ __launch_bounds__(256, 4) void k_qkv256(const bf16* __restrict__ x, i
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
         const bf16* base = wf + (int64_t)i * (QKV_STAGE / 2);
 #pragma unroll
-        for (int j = 0; j < QKV_STAGE / 4096; ++j) {
-            const int p = wave * (QKV_STAGE / 4096) + j;
+        for (int j = 0; j < QKV_STAGE / 8192; ++j) {
+            const int p = wave * (QKV_STAGE / 8192) + j;
             __builtin_amdgcn_global_load_lds(base + p * 512 + l * 8, (lds_void*)(st + p * 1024), 16, 0, 0);
         }
     };

@@ -846,7 +846,7 @@ struct Builder {
             const int64_t sc_ = sc, sh_ = sh;
             op(CLS_GEMM, [=](const Ctx& c) {
                 if (g_record) return;
-                hipLaunchKernelGGL(k_qkv256, dim3((unsigned)(2 * c.B)), dim3(256), QKV_LDS_BYTES, c.stream, (const bf16*)c.act(x), x.ld, c.at<float>(sc_), c.at<float>(sh_),
+                hipLaunchKernelGGL(k_qkv256, dim3((unsigned)c.B), dim3(512), QKV_LDS_BYTES, c.stream, (const bf16*)c.act(x), x.ld, c.at<float>(sc_), c.at<float>(sh_),
                                    c.w<bf16>(wqkvf), c.w<float>(bqk), c.w<float>(bv), c.at<bf16>(qk), c.at<bf16>(vT));
             });
         }

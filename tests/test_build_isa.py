@@ -200,5 +200,5 @@ def test_qkv256_loop_has_no_ordinary_global_load(listings):
                 loads.append(t)                                              # (anything narrower than 16 bytes)
             elif re.match(r"s_waitcnt.*vmcnt\(0\)", t):
                 drains.append(t)
-    assert dma >= 4 and stores >= 4 and not loads, (dma, stores, loads[:3])
+    assert dma >= 2 and stores >= 4 and not loads, (dma, stores, loads[:3])
     assert len(drains) <= 1, drains                                           # (the t == 0 branch of the tile wait)
