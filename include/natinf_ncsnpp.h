@@ -159,6 +159,9 @@ int natinf_set_attn256(int on);
 /* 1 (default; read when a plan is built): k_attn256 also applies the attention block's output projection, skip connection and rescale and writes the
  * GroupNorm partials of the block's output (the O tensor is never stored); 0: a separate GEMM launch for the projection. */
 int natinf_set_attn_proj(int on);
+/* 1 (default; read at launch): the projection-fused attention kernel runs one 8-wave block per sample (each K / V^T / W3 tile crosses L2 -> LDS once per
+ * sample); 0: two 4-wave blocks of 128 queries per sample, two blocks per CU. */
+int natinf_set_attn_waves8(int on);
 /* 1 (default; read when a plan is built): GroupNorm-apply and the q | k | v projections of the 16x16 attention block run as ONE launch (k_qkv256:
  * the block input is read once, the normalised tensor is never stored); 0: k_gn_apply + the q | k GEMM + the batched V^T GEMM. */
 int natinf_set_attn_qkv(int on);

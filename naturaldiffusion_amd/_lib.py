@@ -68,6 +68,7 @@ SIGNATURES = {
     "natinf_set_fuse_gn4": (C.c_int, [_i32]),
     "natinf_set_fuse_fin": (C.c_int, [_i32]),
     "natinf_set_attn_proj": (C.c_int, [_i32]),
+    "natinf_set_attn_waves8": (C.c_int, [_i32]),
     "natinf_set_attn_qkv": (C.c_int, [_i32]),
     "natinf_set_conv_gn_warm": (C.c_int, [_i32]),
     "natinf_set_attn256": (C.c_int, [_i32]),

@@ -45,8 +45,10 @@ __global__ __launch_bounds__(256) void k_pack_attn_w3(const float* __restrict__ 
 }
 
 // qk: [B*256][qk_ld] bf16, q at column 0, k at column k_off; vT: [B][256 channels][256 tokens]; o: [B*256][o_ld].  grid = 2 B, 256 threads.
-template <bool PROJ>
-__global__ __launch_bounds__(256, 2) void k_attn256(const bf16* __restrict__ qk, int qk_ld, int k_off, const bf16* __restrict__ vT,
+// NWV = 8 (the PROJ form's launch): ONE sample per block, 8 waves x 32 queries, one block per CU -- every K / V^T / W3 tile crosses L2 -> LDS once per sample
+// instead of once per half (393 -> 197 MB per launch at B = 512, more than the kernel's HBM traffic); NWV = 4: two blocks of 128 queries per sample.
+template <bool PROJ, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn256(const bf16* __restrict__ qk, int qk_ld, int k_off, const bf16* __restrict__ vT,
                                                     bf16* __restrict__ o, int o_ld, float scale, const bf16* __restrict__ w3f, const float* __restrict__ b3,
                                                     const bf16* __restrict__ resid, int resid_ld, float out_scale, float2* __restrict__ gn_part, int gn_quads)
 {
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(256, 2) void k_attn256(const bf16* __restrict__ qk,
     // same wave of blocks -- take the two query halves of one sample, so the second read hits that XCD's L2 (PMC, round 3: 336 MB fetched per launch at
     // B = 512 against 201 MB of operands with the halves on neighbouring ids = different XCDs).  A tail of < 16 blocks keeps the plain order.
     const int bid = blockIdx.x, full = (int)gridDim.x & ~15;
-    const int b = bid < full ? ((bid >> 4) << 3) + (bid & 7) : bid >> 1, qhalf = bid < full ? (bid >> 3) & 1 : bid & 1;
+    const int b = NWV == 8 ? bid : (bid < full ? ((bid >> 4) << 3) + (bid & 7) : bid >> 1), qhalf = NWV == 8 ? 0 : (bid < full ? (bid >> 3) & 1 : bid & 1);
+    constexpr int NP = 32 / NWV;                          // 1-KiB DMA pieces per wave and 32-KB tile
     const bf16* qbase = qk + (int64_t)b * T * qk_ld;
     const bf16* kbase = qbase + k_off;
     const bf16* vbase = vT + (int64_t)b * A256_D * T;
@@ -73,23 +76,23 @@ __global__ __launch_bounds__(256, 2) void k_attn256(const bf16* __restrict__ qk,
         if (PROJ && i >= 2 * NKT) {                       // W3 tile i - 8: n-tiles 4 (i - 8) .. + 3, all eight K steps: 32 fragment blocks of 1 KiB, lane-linear
             const bf16* base = w3f + (int64_t)(i - 2 * NKT) * (A256_STAGE / 2);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int p = wave * 8 + j;
+            for (int j = 0; j < NP; ++j) {
+                const int p = wave * NP + j;
                 __builtin_amdgcn_global_load_lds(base + p * 512 + l * 8, (lds_void*)(st + p * 1024), 16, 0, 0);
             }
         } else if (i < NKT) {
             const bf16* base = kbase + (int64_t)(i * KT) * qk_ld;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int p = wave * 8 + j, row = 2 * p + (l >> 5), ch = l & 31;
+            for (int j = 0; j < NP; ++j) {
+                const int p = wave * NP + j, row = 2 * p + (l >> 5), ch = l & 31;
                 const int h = (row & 3) | (((row >> 3) & 3) << 2);
                 __builtin_amdgcn_global_load_lds(base + row * qk_ld + ((ch ^ h) << 3), (lds_void*)(st + p * 1024), 16, 0, 0);
             }
         } else {
             const bf16* base = vbase + (i - NKT) * KT;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int p = wave * 8 + j, d = 8 * p + (l >> 3), ch = l & 7;
+            for (int j = 0; j < NP; ++j) {
+                const int p = wave * NP + j, d = 8 * p + (l >> 3), ch = l & 7;
                 __builtin_amdgcn_global_load_lds(base + d * T + ((ch ^ ((d >> 1) & 7)) << 3), (lds_void*)(st + p * 1024), 16, 0, 0);
             }
         }
@@ -242,8 +245,8 @@ __global__ __launch_bounds__(256, 2) void k_attn256(const bf16* __restrict__ qk,
             if (tid < 64) {
                 float s = 0.f, ss = 0.f;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) { s += sred[w * 64 + tid].x; ss += sred[w * 64 + tid].y; }
-                gn_part[(int64_t)blockIdx_pair(b, qhalf) * gn_quads + tid] = make_float2(s, ss);
+                for (int w = 0; w < NWV; ++w) { s += sred[w * 64 + tid].x; ss += sred[w * 64 + tid].y; }
+                gn_part[(int64_t)(NWV == 8 ? b : blockIdx_pair(b, qhalf)) * gn_quads + tid] = make_float2(s, ss);      // (NWV = 8: one partial row per sample)
             }
         }
         return;

@@ -224,6 +224,7 @@ using CfgG32 = ConvGnCfg<32>; using CfgG16 = ConvGnCfg<16>; using CfgG16W = Conv
 int g_fuse_head = 1;               // natinf_set_fuse_head (read when a plan is BUILT): GroupNorm + SiLU + the 128 -> 3 output convolution as ONE launch (head_conv.h)
 int g_cg8_tm4 = 1;                 // natinf_set_conv_gn8_tile: 1 = 8x8 level on 64-pixel x 256-channel tiles (one image per tile, two blocks per CU), 0 = 128 x 256 (two images per tile; -DNATINF_DEV builds)
 int g_attn_qkv = 1;                // natinf_set_attn_qkv (read when a plan is BUILT): GroupNorm-apply + the q | k | v projections of the 16x16 attention as ONE launch (attn_qkv.h)
+int g_attn_w8 = 1;                 // natinf_set_attn_waves8: k_attn256<true> as one 8-wave block per sample (1) or two 4-wave blocks (0)
 int g_attn_proj = 1;               // natinf_set_attn_proj (read when a plan is BUILT): the 16x16 attention's output projection + skip + GroupNorm partials inside k_attn256
 int g_attn256 = 1;                 // natinf_set_attn256: 1 = k_attn256 (K / V^T streamed through a two-stage LDS ring, two blocks per CU), 0 = k_attn_fused<8,16,true>
 int g_fuse_gn8 = 1;                // natinf_set_fuse_gn8 (read when a plan is BUILT): the 8x8 level on the fused kernel too (two images per 128-pixel tile)
@@ -300,6 +301,7 @@ bool configure_gemm_kernels() {
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_qkv256), hipFuncAttributeMaxDynamicSharedMemorySize, QKV_LDS_BYTES) == hipSuccess &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<false>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<true>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
          set_lds<AttnCfg<2, 4>>(&k_attn_fused<2, 4>) && set_lds<AttnCfg<3, 6>>(&k_attn_fused<3, 6>) &&
          set_lds<AttnCfg<3, 5>>(&k_attn_fused<3, 5>) &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess;
@@ -885,10 +887,17 @@ struct Builder {
             op(CLS_GEMM, [=](const Ctx& c) {
                 if (g_record) return;                    // natinf_ncsnpp_describe_gemms: GEMM launches only, nothing touches memory
                 if (proj) {
+                    if (g_attn_w8) {
+                        hipLaunchKernelGGL((k_attn256<true, 8>), dim3((unsigned)c.B), dim3(512), A256_LDS_BYTES, c.stream, c.at<bf16>(qk), 2 * C, C, c.at<bf16>(vT), c.act(out), out.ld,
+                                           1.0f / sqrtf((float)C), c.w<bf16>(w3f), c.w<float>(b3), (const bf16*)c.act(x), x.ld, rs_attn,
+                                           po_attn.valid ? c.at<float2>(po_attn.off) : (float2*)nullptr, po_attn.quads);
+                        if (po_attn.valid) c.part_bm[po_attn.id] = 256;
+                    } else {
                     hipLaunchKernelGGL(k_attn256<true>, dim3((unsigned)(2 * c.B)), dim3(256), A256_LDS_BYTES, c.stream, c.at<bf16>(qk), 2 * C, C, c.at<bf16>(vT), c.act(out), out.ld,
                                        1.0f / sqrtf((float)C), c.w<bf16>(w3f), c.w<float>(b3), (const bf16*)c.act(x), x.ld, rs_attn,
                                        po_attn.valid ? c.at<float2>(po_attn.off) : (float2*)nullptr, po_attn.quads);
                     if (po_attn.valid) c.part_bm[po_attn.id] = 128;
+                    }
                 }
                 else if (g_attn256)
                     hipLaunchKernelGGL(k_attn256<false>, dim3((unsigned)(2 * c.B)), dim3(256), A256_LDS_BYTES, c.stream, c.at<bf16>(qk), 2 * C, C, c.at<bf16>(vT), c.act(O), C,
@@ -1581,6 +1590,7 @@ int natinf_set_attn256(int on) {
 }
 int natinf_set_conv_gn_warm(int mask) { if (mask < 0 || mask > 15) return NATINF_EINVAL; g_cg_warm = mask; return NATINF_OK; }
 int natinf_set_attn_qkv(int on) { g_attn_qkv = on != 0; return NATINF_OK; }
+int natinf_set_attn_waves8(int on) { g_attn_w8 = on != 0; return NATINF_OK; }
 int natinf_set_attn_proj(int on) { g_attn_proj = on != 0; return NATINF_OK; }
 int natinf_set_fuse_fin(int on) { g_fuse_fin = on != 0; return NATINF_OK; }
 int natinf_set_fuse_gn4(int on) { g_fuse_gn4 = on != 0; return NATINF_OK; }
