@@ -148,7 +148,7 @@ int natinf_set_fuse_gn4(int on);
 /* 1 (default; read when a plan is built): at 8x8 / 4x4, where a tile of the fused convolution holds whole samples and every output channel, its
  * epilogue writes the GroupNorm (scale | shift) table of the tensor's consumer itself; 0: a k_gn_finalize launch per table, as at 16x16 / 32x32. */
 int natinf_set_fuse_fin(int on);
-/* Bit mask by resolution (1: 4x4, 2: 8x8, 4: 16x16, 8: 32x32; read at launch) of the fused-convolution launches whose first blocks request the
+/* Bit mask by resolution (1: 4x4, 2: 8x8; bits 4 / 8 -- 16x16 / 32x32 -- are accepted and ignored: measured +-0 there, compiled out; read at launch) of the fused-convolution launches whose first blocks request the
  * whole weight matrix once at kernel start, so that the K loop's one-tap-ahead weight stream hits L2 inside a forward pass (where every layer's
  * weights are cold).  NATINF_EINVAL outside 0..15. */
 int natinf_set_conv_gn_warm(int mask);

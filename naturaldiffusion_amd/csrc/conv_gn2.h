@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
     // (In FRONT of the first patch / weight requests: behind them, with their asm destination registers already "defined", the loop below raised
     // the pressure enough in the 32x32 instantiation for hipcc to spill weight registers whose loads were still in flight.)
     unsigned warm_junk = 0;                                               // ONE destination register for all of them ("+v": it stays allocated from the first request to the wait below)
-    if (g.w_warm) {
+    if (RES <= 8 && g.w_warm) {                                            // (32x32 / 16x16: measured +-0 -- later rounds of blocks hide the first one's misses -- and one register the 256-register instantiations do not have)
         const int jx = (int)blockIdx.x >> 3;
         const int nbx = min(((int)gridDim.x + 7 - ((int)blockIdx.x & 7)) >> 3, 16);
         if (jx < nbx) {
@@ -599,7 +599,12 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
 #ifdef NATINF_DEV
     const unsigned long long dbg_t2 = cg_stamp();
 #endif
-    tile_epilogue<Cfg::WM, Cfg::WN, TM, TN, typename Cfg::Epi, EPI, NIMG, (RES <= 8), true>(ge, smem, acc, m0, n0, 0, tid, lane, wm, wn);      // (two K groups: tid < 256 here)
+    // (thread / lane id recomputed: the prologue's copies, kept alive across the K loops for the epilogue alone, are among the values hipcc spills in the
+    // 256-register instantiations -- and a kernel with ANY scratch use starts ~2 us later in the stream than one without)
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int tid_e = wave_all * 64 + lane_e;
+    tile_epilogue<Cfg::WM, Cfg::WN, TM, TN, typename Cfg::Epi, EPI, NIMG, (RES <= 8), true>(ge, smem, acc, m0, n0, 0, tid_e, lane_e, wm, wn);      // (two K groups: tid < 256 here)
 #ifdef NATINF_DEV
     if (ge.dbg_ts && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 777)) {          // development builds: tools/conv_gn_timeline.py
         // block 0: [2..4] are the epilogue's own stamps (NATINF_TS: start, slab written, copied out), [7] = the stamp in front of it

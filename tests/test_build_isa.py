@@ -75,7 +75,8 @@ HOT = [  # substrings of the demangled names of the kernels the bench lines are 
     "k_gemm_dma<2, 4, 8, 4, 6, 2>", "k_gemm_dma<4, 2, 8, 4, 6, 2>", "k_gemm_dma<2, 4, 8, 4, 6, 6>", "k_gemm_dma<4, 2, 8, 4, 6, 6>",
     "k_gemm_dma<2, 4, 8, 4, 6, 7>", "k_gemm_dma<2, 4, 8, 4, 6, 1>", "k_gemm_dma<2, 4, 8, 4, 6, 4>",
     "k_gemm_dma<2, 2, 4, 4, 2, 0>", "k_gemm_dma<2, 2, 4, 4, 2, 1>", "k_gemm_ring<2, 2, 2, 4, 4, 0>", "k_gemm_ring<2, 2, 8, 4, 3, 1>",
-    "k_attn256<false", "k_attn256<true", "k_qkv256", "k_flash_attn64", "k_gn_apply", "k_ln_modulate",
+    "k_attn256<false", "k_attn256<true", "k_qkv256", "k_flash_attn64", "k_gn_apply", "k_ln_modulate", "k_head_conv",
+    "k_conv_gn2<",                     # every instantiation of the dominant kernel (spill-free since the end of round 3: the epilogue recomputes its lane / thread id)
 ]
 
 
