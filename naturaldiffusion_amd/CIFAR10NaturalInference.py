@@ -23,13 +23,13 @@ from .sampler import CifarNI, vp_std_f32
 root_path = Path(__file__).resolve().parent.parent
 
 
-def _to_pixel(x: torch.Tensor, centered: int) -> torch.Tensor:
+def _to_pixel(x: torch.Tensor, centered: int, to_cpu: bool = True) -> torch.Tensor:
     _lib.require_gpu()
     x = x.contiguous()
     B, C, H, W = x.shape
     out = torch.empty((B, H, W, C), dtype=torch.uint8, device=x.device)
     check(lib.natinf_to_pixel_u8(ptr(x), ptr(out), B, C, H, W, centered, stream_ptr()), "natinf_to_pixel_u8")
-    return out.cpu()
+    return out.cpu() if to_cpu else out            # (the copy to the host blocks: the batch pipeline of natural_inference_tx copies at the end)
 
 
 def to_pixel(batch: torch.Tensor) -> torch.Tensor:
@@ -186,10 +186,17 @@ def natural_inference_tx(batch_size: int = 500,
                          ckpt_filename: Optional[str] = None,
                          weight_path: Optional[str] = None,
                          sample_count: int = 50 * 1000, seed: int = 888, device: str = "cuda:0",
-                         compute_fid: bool = True, flat_params: Optional[torch.Tensor] = None):
+                         compute_fid: bool = True, flat_params: Optional[torch.Tensor] = None, streams: int = 1):
     """Reference :242-317: generate ``sample_count`` CIFAR10 images with the NI matrix at ``weight_path``
     and score them.  ``flat_params`` lets a caller supply weights directly (engine order) instead of the
-    score_sde checkpoint."""
+    score_sde checkpoint.
+
+    ``streams`` (default 1 = the reference's order, :287-309): the batches are independent trajectories; with ``streams=2`` consecutive
+    batches go to two HIP streams (one engine handle + history buffer each), so that the under-occupied launches of one batch -- the 4x4
+    level, the per-sample GroupNorm tables, every launch's last round of blocks -- run under the other batch's convolutions: -6.6 % per
+    batch at 512 images on one MI355X.  NOT the default: the noise is drawn in the reference's order and every batch runs the same launches,
+    but with two engines in flight the images are reproducible only to bf16 rounding noise, not bit for bit (whole-image one-ulp differences
+    of GroupNorm statistics that one engine alone, or one engine beside any other GPU work, never shows: DESIGN.md section 5; unexplained)."""
     from .ncsnpp import NCSNppEngine, load_score_sde_checkpoint
     ckpt_filename = ckpt_filename or str(root_path / "deps/score_sde_pytorch/checkpoint_8.pth")
     weight_path = weight_path or str(root_path / "weights/step_5_weight_00.npz")
@@ -199,18 +206,34 @@ def natural_inference_tx(batch_size: int = 500,
     C, B, node = load_coeff_npz(weight_path)
     print(C / np.diag(C)[:, None])
     print(weight_path)
-    engine = NCSNppEngine(flat_params, max_batch=batch_size, device=device)
     bz = batch_size
     num = int(np.ceil(sample_count / bz))
-    ni = CifarNI(C, B, node, bz * 3 * 32 * 32, device=device)
+    n_str = max(1, min(int(streams), num))
+    side = [torch.cuda.Stream(device=device) for _ in range(n_str)] if n_str > 1 else [None]
+    engines, nis = [], []
+    for st in side:                                       # every lane's buffers are allocated (and its weights packed) on the stream that will use them
+        with torch.cuda.stream(st):
+            engines.append(NCSNppEngine(flat_params, max_batch=batch_size, device=device))
+            nis.append(CifarNI(C, B, node, bz * 3 * 32 * 32, device=device))
+    torch.cuda.synchronize(torch.device(device))
     torch.manual_seed(seed)
     all_batch = []
+    main = torch.cuda.current_stream(torch.device(device))
     for ii in range(num):
         print("processing", ii)
         noise = torch.randn(bz, 3, 32, 32, dtype=torch.float32, device=device)
-        out = ni.run(engine, noise)
-        all_batch.append(to_pixel_from_centered(out))
-    all_batch = torch.concatenate(all_batch)
+        k = ii % n_str
+        if side[k] is None:
+            all_batch.append(to_pixel_from_centered(nis[k].run(engines[k], noise)))
+            continue
+        side[k].wait_stream(main)                        # the noise was drawn on the caller's stream
+        noise.record_stream(side[k])
+        with torch.cuda.stream(side[k]):
+            all_batch.append(_to_pixel(nis[k].run(engines[k], noise), 1, to_cpu=False))      # uint8 on the device: nothing here waits for the GPU
+    for st in side:
+        if st is not None:
+            main.wait_stream(st)
+    all_batch = torch.concatenate([t.cpu() for t in all_batch])
     if not compute_fid:
         return all_batch
     try:

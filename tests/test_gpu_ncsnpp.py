@@ -304,3 +304,17 @@ def test_odd_batches_default_plan_against_the_unfused_plan(dev, flat, B):
     torch.cuda.synchronize()
     assert torch.isfinite(y).all()
     assert _rel(y.cpu(), ref.cpu()) < 2e-2
+
+
+def test_natural_inference_tx_two_stream_pipeline(dev, flat, repo_root):
+    """CIFAR10NaturalInference.natural_inference_tx(streams=2): consecutive batches on two HIP streams (two engine handles) against the reference's
+    one-after-the-other order (the default).  Same noise order, same launches per batch -- but two engines in flight perturb whole-image GroupNorm statistics
+    by an ulp now and then, which this synthetic random-weight network amplifies: the images agree to rounding noise, not bit for bit.
+    5 batches of 8 (an odd count: the streams end unevenly); two single-stream runs must be identical."""
+    from naturaldiffusion_amd import CIFAR10NaturalInference as M
+    w = str(repo_root / "weights" / "step_5_weight_00.npz")
+    run = lambda s: M.natural_inference_tx(batch_size=8, weight_path=w, sample_count=40, seed=7, device=dev, compute_fid=False, flat_params=flat, streams=s)
+    a, a2, b = run(1), run(1), run(2)
+    assert a.shape == (40, 32, 32, 3) and a.dtype == torch.uint8 and torch.equal(a, a2)
+    d = (a.int() - b.int()).abs().float()
+    assert b.shape == a.shape and float(d.mean()) < 0.5 and float((d > 2).float().mean()) < 0.02, (float(d.mean()), float((d > 2).float().mean()))
