@@ -54,6 +54,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn256(const bf
 {
     constexpr int T = A256_T, KT = A256_KT, NKT = T / KT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

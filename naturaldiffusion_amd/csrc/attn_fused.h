@@ -37,6 +37,7 @@ __global__ __launch_bounds__(512) void k_attn_fused(const bf16* __restrict__ qk,
     using Cfg = AttnCfg<NQK, ND, TWO_PHASE>;
     constexpr int T = Cfg::T, KSTR = Cfg::KSTR, VSTR = Cfg::VSTR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
     unsigned char* sK = smem;
     unsigned char* sV = TWO_PHASE ? smem : smem + T * KSTR;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;

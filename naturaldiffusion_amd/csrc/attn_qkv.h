@@ -52,6 +52,7 @@ __global__ __launch_bounds__(512, 2) void k_qkv256(const bf16* __restrict__ x, i
 {
     constexpr int T = 256, C = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;

@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
     constexpr int W = Geo::W, WP = Geo::WP, WS = Geo::WS, HW = RES * RES;
     constexpr int PB = Cfg::PB, PPW = Cfg::PPW, PSW = Cfg::PSW, AUXP = Cfg::AUXP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
     unsigned char* const sPatch = smem;                                   // [2][PATCH_BYTES]
     unsigned char* const sB = smem + 2 * Cfg::PATCH_BYTES;                // [NSB][BT_BYTES]
     unsigned char* const sTab = sB + NSB * Cfg::BT_BYTES;                 // [2][scale 32 | shift 32] fp32

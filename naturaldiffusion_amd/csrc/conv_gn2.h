@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_pack_frag(const bf16* __restrict__ w, b
 // (functions, not asm statements inside the kernel's generic lambdas: clang rejects asm operands that name captured variables there)
 __device__ __forceinline__ u32x4 gload16(unsigned voff, const void* sbase) {
     u32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile(NATINF_PAD_PRE "global_load_dwordx4 %0, %1, %2" NATINF_PAD_POST : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
     return v;
 }
 template <int OFF> __device__ __forceinline__ void lds_write16(unsigned addr, u32x4 v) {
@@ -122,7 +122,7 @@ template <int OFF> __device__ __forceinline__ void lds_write16(unsigned addr, u3
     // instructions it can see -- not inside inline asm).  Without it the write could pick up the OLD contents of the last register norm_store's v_cndmask
     // had just written: a stale 16-byte slot of the normalised patch, whenever the two instructions issued back to back -- which depends on what else is
     // resident on the SIMD (found as run-to-run differences of a whole image's GroupNorm statistics when two engines ran concurrently on two streams).
-    asm volatile("s_nop 0\n\tds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(OFF) : "memory");
+    asm volatile(NATINF_PAD_PRE "s_nop 0\n\tds_write_b128 %0, %1 offset:%2" NATINF_PAD_POST :: "v"(addr), "v"(v), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void fresh4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
     constexpr int W = Geo::W, WS = Geo::WS, HW = RES * RES;
     constexpr int PSW = Cfg::PSW, NROUND = Cfg::NROUND, NPIECE = Cfg::NPIECE, NFULL = Cfg::NFULL, NIMG = Cfg::NIMG, IMGP = Cfg::IMGP, NG = Cfg::NG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
     // LDS: [2][PATCH_BYTES] patch buffers, then [2][scale 32 | shift 32] fp32 tables (the epilogue reuses all of it as its slab)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
     // why: hipcc drains vmcnt in front of any LDS access it can see while an LDS-DMA is in flight).
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     auto glds16 = [](unsigned voff, const void* sbase, unsigned lds_dst) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+        asm volatile(NATINF_PAD_PRE "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" NATINF_PAD_POST :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
     };
     // (LDS byte addresses straight from the array: a cast of a generic pointer carries a null check against the shared aperture, which
     // hipcc has mis-selected into a vector compare on an SGPR-only operand in some variants of this kernel)
@@ -201,15 +202,15 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
             for (int im = 0; im < NIMG; ++im) {
                 const unsigned dst = lds_tab + buf * Cfg::TAB_BYTES + im * Cfg::TAB_IMG_BYTES;
                 const int64_t io = (int64_t)min(im, nval - 1) * g.gn_ld;
-                if (l < 32) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(toff), "s"(gsc + io + hc * KT), "s"(dst) : "memory", "m0");
-                else        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(toff), "s"(gsh + io + hc * KT), "s"(dst) : "memory", "m0");
+                if (l < 32) asm volatile(NATINF_PAD_PRE "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" NATINF_PAD_POST :: "v"(toff), "s"(gsc + io + hc * KT), "s"(dst) : "memory", "m0");
+                else        asm volatile(NATINF_PAD_PRE "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" NATINF_PAD_POST :: "v"(toff), "s"(gsh + io + hc * KT), "s"(dst) : "memory", "m0");
             }
         }
         const bf16* base = img + hc * KT;
         if constexpr (!FIRST) {
             unsigned vo[NROUND];
 #pragma unroll
-            for (int j = 0; j < NROUND; ++j) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(vo[j]) : "v"(lds_voff), "n"(j * 1024) : "memory");
+            for (int j = 0; j < NROUND; ++j) asm volatile(NATINF_PAD_PRE "ds_read_b32 %0, %1 offset:%2" NATINF_PAD_POST : "=v"(vo[j]) : "v"(lds_voff), "n"(j * 1024) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // (tap 0, behind the hand-off barrier: no other LDS read of this wave is in flight)
 #pragma unroll
             for (int j = 0; j < NROUND; ++j) {
@@ -236,13 +237,13 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
                 const int y = min(max(yy - 1, 0), RES - 1), x = min(max(xx - 1, 0), RES - 1);
                 const unsigned vo = (unsigned)((min(im, nval - 1) * HW + y * W + x) * g.a0_ld + ((pslot ^ Cfg::swz_key(xx)) << 3)) * 2u;
                 glds16(vo, base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
-                asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(lds_voff), "v"(vo), "n"(j * 1024) : "memory");
+                asm volatile(NATINF_PAD_PRE "ds_write_b32 %0, %1 offset:%2" NATINF_PAD_POST :: "v"(lds_voff), "v"(vo), "n"(j * 1024) : "memory");
             } else {
                 const int yy = pp / WS, xx = pp - yy * WS;
                 const int y = min(max(y0 - 1 + yy, 0), RES - 1), x = min(max(xx - 1, 0), RES - 1);      // halo / pad: any readable pixel
                 const unsigned vo = (unsigned)(((y >> ush) * (W >> ush) + (x >> ush)) * g.a0_ld + ((pslot ^ Cfg::swz_key(xx)) << 3)) * 2u;
                 glds16(vo, base, lds_patch + buf * Cfg::PATCH_BYTES + q * 1024);
-                asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(lds_voff), "v"(vo), "n"(j * 1024) : "memory");
+                asm volatile(NATINF_PAD_PRE "ds_write_b32 %0, %1 offset:%2" NATINF_PAD_POST :: "v"(lds_voff), "v"(vo), "n"(j * 1024) : "memory");
             }
         }
     };

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_conv_patch(const GemmArgs g
     using Cfg = PatchCfg<WM, WN, TM, TN, PMAX>;
     constexpr int BM_ = Cfg::BM_, BN_ = Cfg::BN_, NW = Cfg::NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
     unsigned char* sPatch = smem;                                  // [2][PATCH_BYTES]
     unsigned char* sB = smem + 2 * Cfg::PATCH_BYTES;               // [2][BT_BYTES]
     const int tid = threadIdx.x, lane = tid & 63;

@@ -61,6 +61,7 @@ struct FlashArgs {
 __global__ __launch_bounds__(256, 2) void k_flash_attn64(const FlashArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -44,6 +44,7 @@ template <int FLAGS>      // tuning: bit 0 = no s_setprio around the MFMA cluste
 __global__ __launch_bounds__(512) void k_gemm_8ph(const GemmArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     const int tid = threadIdx.x, lane = tid & 63;

@@ -84,10 +84,21 @@ struct DmaCfg {
 // sweeps 11.6k + stores 2.8k = 19.5k per tile against 3.7k per 64-wide K-tile of main loop; tools/tile_timeline.py.)
 // sum over the 16 lanes of a DPP row, left in every lane of the row: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
 __device__ __forceinline__ float dpp_row_sum(float v) {
+    // The opaque statements keep every stage a scalar `v_add_f32_dpp`.  Without them the SLP vectoriser pairs a (sum, sum of squares) couple into
+    // `v_pk_add_f32` fed by `v_mov_b32_dpp` copies, and a DPP source then reads a packed-fp32 result two or three instructions after it issued.
+    // hipcc keeps its two wait states for that (VALU write -> DPP read), but the packed add takes two passes over the wave: whenever a wave of
+    // ANOTHER kernel shared the SIMD (two engines on two HIP streams), lanes 48-63 of the DPP source were still the old value -- one partial sum of
+    // one tile off by 10-50 %, a whole image's GroupNorm statistics slightly off, run-to-run.  Alone on its SIMD the kernel never showed it.
+    // (tools/debug_det5.py reproduces it on a single launch; tools/scan_pk_hazard.py looks for the shape in the assembly)
+    asm volatile("" : "+v"(v));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    asm volatile("" : "+v"(v));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    asm volatile("" : "+v"(v));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    asm volatile("" : "+v"(v));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    asm volatile("" : "+v"(v));
     return v;
 }
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
@@ -642,7 +653,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, unsigned char* 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int OFF> __device__ __forceinline__ u32x4 lds_read16(unsigned addr) {
     u32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    asm volatile(NATINF_PAD_PRE "ds_read_b128 %0, %1 offset:%2" NATINF_PAD_POST : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     return v;
 }
 template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
@@ -693,6 +704,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_dma(const GemmArgs g)
     using Cfg = DmaCfg<WM, WN, TM, TN>;
     constexpr int BM_ = Cfg::BM_, BN_ = Cfg::BN_, THREADS = Cfg::THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -867,6 +879,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_ring(const GemmArgs g)
     using Cfg = RingCfg<WM, WN, TM, TN, NS>;
     constexpr int BM_ = Cfg::BM_, BN_ = Cfg::BN_, BKR = Cfg::BKR, ROW = 32;      // ROW: bf16 per LDS row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -1005,6 +1018,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
                                                        bf16* __restrict__ c, int c_ld, float2* __restrict__ gn_part, int gn_quads)
 {
     __shared__ float2 red[512];                              // [row lane][quad], 256 / cpr row lanes x 2 * cpr quads = 512 entries
+    lds_poison();
     const int cpr = N >> 3, tid = threadIdx.x;               // host guarantees 256 % cpr == 0
     const int cx = tid % cpr, ry = tid / cpr, rp = 256 / cpr, n = cx * 8;
     float bn[8];

@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256, 3) void k_head_conv(const bf16* __restrict__ x
     using Cfg = HeadConvCfg;
     constexpr int RES = Cfg::RES, C = Cfg::C, ROWS = Cfg::ROWS, PW = Cfg::PW, PSTR = Cfg::PSTR, NPIX = Cfg::NPIX;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
     unsigned char* const patch = smem;
     float* const tab = reinterpret_cast<float*>(smem + NPIX * PSTR);           // [scale 64 | shift 64] of the current half
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -23,6 +23,31 @@ typedef __bf16 bf16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Debug build (-DNATINF_ASM_PAD): wait states in front of and behind every hand-written memory instruction.  Padding cannot change a
+// result unless a hazard the hardware does not interlock (and hipcc cannot see inside inline asm) is being hit.
+#ifdef NATINF_ASM_PAD
+#define NATINF_PAD_PRE "s_nop 7\n\ts_nop 7\n\t"
+#define NATINF_PAD_POST "\n\ts_nop 7\n\ts_nop 7"
+#else
+#define NATINF_PAD_PRE ""
+#define NATINF_PAD_POST ""
+#endif
+
+// Debug build (-DNATINF_LDS_POISON): every kernel first fills the whole 160-KiB LDS address range of its workgroup with NaN
+// patterns (writes past the allocation are dropped by the hardware), so that a read of LDS the block has not written itself
+// -- whatever the previous workgroup on that compute unit left there -- shows up as NaN in the parity tests.
+__device__ __forceinline__ void lds_poison()
+{
+#ifdef NATINF_LDS_POISON
+    typedef uint32_t poison_u4 __attribute__((ext_vector_type(4)));
+    const poison_u4 v = {0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};
+    for (uint32_t a = threadIdx.x * 16; a < 163840u; a += blockDim.x * 16)
+        asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(v) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+#endif
+}
+
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int LDS_ROW = BK;                           // 64 bf16 = 128 B rows, chunk-swizzled
 constexpr int TILE_ELEMS = BM * LDS_ROW;              // per operand per buffer
@@ -269,6 +294,7 @@ __device__ __forceinline__ uint4 ld_or_zero(const bf16* p, bool ok) {
 __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const GemmArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
     bf16* sA = reinterpret_cast<bf16*>(smem);
     bf16* sB = sA + 2 * TILE_ELEMS;
 
@@ -399,6 +425,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(const bf16* __restrict__ x, in
 {
     __shared__ float s_part[2][16 * 128 + 64];     // [sum|sq][lane * C + c]; lanes*C <= 2048 for every C in use
     __shared__ float s_sum[512], s_sq[512], s_mean[32], s_rstd[32];
+    lds_poison();
     const int tid = threadIdx.x, b = blockIdx.x;
     const int cpp = C >> 3;                        // 16-byte chunks per pixel
     const int lanes = 256 / cpp;                   // pixel lanes (16 / 8 / 5 / 4 for C = 128 / 256 / 384 / 512)
@@ -457,6 +484,7 @@ __global__ __launch_bounds__(256) void k_gn_finalize(const float2* __restrict__ 
     // then sums its group's quads itself (<= 4 LDS reads) instead of waiting for a 32-thread middle phase behind a second barrier.  Same
     // additions in the same order as the three-phase form it replaces: bit-identical tables (5.2 -> ~3.5 us per launch, 68 launches per forward).
     __shared__ float2 s_p[128];
+    lds_poison();
     const int tid = threadIdx.x, b = blockIdx.x, nq = quads0 + quads1;
     float ga[2] = {0.f, 0.f}, be[2] = {0.f, 0.f};
 #pragma unroll
