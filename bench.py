@@ -125,8 +125,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--no-two-streams", dest="two_streams_extra", action="store_false", help="skip the extra two-stream timing of the CIFAR10 workload")
-    ap.add_argument("--streams", type=int, default=1, help="CIFAR10 workload: HIP streams the consecutive batches (steps) alternate between (2: reported as two_streams next to the headline)")
+    ap.add_argument("--no-single-stream", dest="single_stream_extra", action="store_false", help="skip the extra one-stream timing of the CIFAR10 workload")
+    ap.add_argument("--streams", type=int, default=2, help="CIFAR10 workload: HIP streams the consecutive batches (steps) alternate between, as in natural_inference_tx "
+                                                          "(default 2; 1 = one batch after the other)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--weights", default=str(ROOT / "weights" / "step_15_weight_173.npz"))
@@ -246,7 +247,7 @@ def bench_cifar(args, world, rank, dev):
     # natural_inference_tx, consecutive batches (= steps) go to `--streams` HIP streams, each with its own engine handle and history buffer: a step is still
     # one 15-step pass over one batch of 512, exactly K of them are timed between the synchronize / barrier brackets, and the under-occupied launches of one
     # batch run under the other's convolutions.  The single-stream time of the same K steps is measured as well and reported next to it.
-    n_str = max(1, min(max(args.streams, 2 if args.two_streams_extra else 1), args.steps))
+    n_str = max(1, min(args.streams, args.steps))
     lanes = [(engine, ni, None)] + [(NCSNppEngine(flat, max_batch=Bz, device=dev), CifarNI(C, Bm, node, E, device=dev), None) for _ in range(n_str - 1)]
     if n_str > 1:
         lanes = [(e_, n_, torch.cuda.Stream(device=dev)) for e_, n_, _ in lanes]
@@ -257,8 +258,10 @@ def bench_cifar(args, world, rank, dev):
             return n_.run(e_, noises[i & 1])
 
     torch.cuda.synchronize()
-    dt1, out = timed_region(one_step, args.steps, args.warmup, world, torch.cuda.synchronize, dist, dev)
-    assert torch.isfinite(out).all()
+    dt1 = None
+    if n_str == 1 or args.single_stream_extra:
+        dt1, out = timed_region(one_step, args.steps, args.warmup, world, torch.cuda.synchronize, dist, dev)
+        assert torch.isfinite(out).all()
     if n_str > 1:
         dt, out = timed_region(one_step_streams, args.steps, max(args.warmup, n_str), world, torch.cuda.synchronize, dist, dev)
         torch.cuda.synchronize()
@@ -266,10 +269,6 @@ def bench_cifar(args, world, rank, dev):
     else:
         dt = dt1
     imgs = world * Bz * args.steps
-    headline_streams = max(1, min(args.streams, args.steps))
-    dt2 = dt
-    if headline_streams == 1:
-        dt = dt1                                          # the headline is the single-stream order unless --streams asks otherwise
     value = imgs / dt
 
     line = {
@@ -282,13 +281,14 @@ def bench_cifar(args, world, rank, dev):
                                "ni_step fp64 history",
                    "coeff_file": os.path.basename(args.weights), "nfe": n_step, "batch_per_gpu": Bz,
                    "sharding": f"batch-sharded x{world}, no collective",
-                   "streams": headline_streams},
+                   "streams": n_str},
     }
-    if n_str > 1:
-        line["two_streams"] = {"value": round(imgs / dt2, 2), "ms_per_step": round(dt2 / args.steps * 1e3, 3),
-                               "note": "the same K steps with consecutive batches alternating between two HIP streams (two engine handles): the under-occupied launches of one "
-                                       "batch run under the other's convolutions.  Not the headline: with two engines in flight the outputs are reproducible to bf16 rounding "
-                                       "noise only, not bit for bit (DESIGN.md section 5)"}
+    if n_str > 1 and dt1 is not None:
+        line["single_stream"] = {"value": round(imgs / dt1, 2), "ms_per_step": round(dt1 / args.steps * 1e3, 3),
+                                 "note": "the same K steps one batch after the other on one HIP stream (the reference's order).  The headline alternates consecutive batches "
+                                         "between two streams (two engine handles; bit-identical images): the under-occupied launches of one batch run under the other's "
+                                         "convolutions.  The roofline objects below are measured in THIS order -- kernel durations are only meaningful with one kernel "
+                                         "on the GPU at a time"}
 
     if rank == 0 and not args.no_roofline:
         # ---- instrumented replica of the timed region: HIP events around every engine launch group and

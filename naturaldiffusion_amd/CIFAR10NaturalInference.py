@@ -186,17 +186,16 @@ def natural_inference_tx(batch_size: int = 500,
                          ckpt_filename: Optional[str] = None,
                          weight_path: Optional[str] = None,
                          sample_count: int = 50 * 1000, seed: int = 888, device: str = "cuda:0",
-                         compute_fid: bool = True, flat_params: Optional[torch.Tensor] = None, streams: int = 1):
+                         compute_fid: bool = True, flat_params: Optional[torch.Tensor] = None, streams: int = 2):
     """Reference :242-317: generate ``sample_count`` CIFAR10 images with the NI matrix at ``weight_path``
     and score them.  ``flat_params`` lets a caller supply weights directly (engine order) instead of the
     score_sde checkpoint.
 
-    ``streams`` (default 1 = the reference's order, :287-309): the batches are independent trajectories; with ``streams=2`` consecutive
-    batches go to two HIP streams (one engine handle + history buffer each), so that the under-occupied launches of one batch -- the 4x4
-    level, the per-sample GroupNorm tables, every launch's last round of blocks -- run under the other batch's convolutions: -6.6 % per
-    batch at 512 images on one MI355X.  NOT the default: the noise is drawn in the reference's order and every batch runs the same launches,
-    but with two engines in flight the images are reproducible only to bf16 rounding noise, not bit for bit (whole-image one-ulp differences
-    of GroupNorm statistics that one engine alone, or one engine beside any other GPU work, never shows: DESIGN.md section 5; unexplained)."""
+    ``streams`` (default 2): the batches are independent trajectories (reference loop :287-309); consecutive batches go to two HIP streams
+    (one engine handle + history buffer each), so that the under-occupied launches of one batch -- the 4x4 level, the per-sample GroupNorm
+    tables, every launch's last round of blocks -- run under the other batch's convolutions: -6 % per batch at 512 images on one MI355X.
+    The noise is drawn in the reference's order and every batch runs the same launches: the images are bit-identical to ``streams=1``,
+    the reference's one-after-the-other order (tests/test_gpu_ncsnpp.py; DESIGN.md section 5 for what that took)."""
     from .ncsnpp import NCSNppEngine, load_score_sde_checkpoint
     ckpt_filename = ckpt_filename or str(root_path / "deps/score_sde_pytorch/checkpoint_8.pth")
     weight_path = weight_path or str(root_path / "weights/step_5_weight_00.npz")

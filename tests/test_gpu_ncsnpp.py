@@ -307,14 +307,37 @@ def test_odd_batches_default_plan_against_the_unfused_plan(dev, flat, B):
 
 
 def test_natural_inference_tx_two_stream_pipeline(dev, flat, repo_root):
-    """CIFAR10NaturalInference.natural_inference_tx(streams=2): consecutive batches on two HIP streams (two engine handles) against the reference's
-    one-after-the-other order (the default).  Same noise order, same launches per batch -- but two engines in flight perturb whole-image GroupNorm statistics
-    by an ulp now and then, which this synthetic random-weight network amplifies: the images agree to rounding noise, not bit for bit.
-    5 batches of 8 (an odd count: the streams end unevenly); two single-stream runs must be identical."""
+    """CIFAR10NaturalInference.natural_inference_tx(streams=2, the default): consecutive batches on two HIP streams (two engine handles) against the
+    reference's one-after-the-other order.  Same noise order, same launches per batch: bit-identical images, run after run (it was not, until the DPP
+    reduction of the GroupNorm partial sums stopped reading packed-fp32 results: DESIGN.md section 5).  5 batches of 8: the streams end unevenly."""
     from naturaldiffusion_amd import CIFAR10NaturalInference as M
     w = str(repo_root / "weights" / "step_5_weight_00.npz")
     run = lambda s: M.natural_inference_tx(batch_size=8, weight_path=w, sample_count=40, seed=7, device=dev, compute_fid=False, flat_params=flat, streams=s)
-    a, a2, b = run(1), run(1), run(2)
-    assert a.shape == (40, 32, 32, 3) and a.dtype == torch.uint8 and torch.equal(a, a2)
-    d = (a.int() - b.int()).abs().float()
-    assert b.shape == a.shape and float(d.mean()) < 0.5 and float((d > 2).float().mean()) < 0.02, (float(d.mean()), float((d > 2).float().mean()))
+    a, b = run(1), run(2)
+    assert a.shape == (40, 32, 32, 3) and a.dtype == torch.uint8
+    for _ in range(3):
+        assert torch.equal(run(2), a)
+    assert torch.equal(b, a)
+
+
+def test_two_engines_on_two_streams_are_bit_reproducible(dev, flat):
+    """Two engine handles running concurrently on two HIP streams, 64 images each: every forward equals the one computed alone.  (The failure this guards
+    against needed a wave of another kernel on the same SIMD: 30-40 of 40 such forwards differed in a whole image's GroupNorm statistics.)"""
+    from naturaldiffusion_amd.ncsnpp import NCSNppEngine
+    B = 64
+    e1, e2 = NCSNppEngine(flat, max_batch=B, device=dev), NCSNppEngine(flat, max_batch=B, device=dev)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x1, x2 = torch.randn(B, 3, 32, 32, generator=g).to(dev), torch.randn(B, 3, 32, 32, generator=g).to(dev)
+    t = (torch.rand(B, generator=g) * 999).to(dev)
+    r1, r2 = e1(x1, t).clone(), e2(x2, t).clone()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    bad = 0
+    for _ in range(20):
+        with torch.cuda.stream(s2):
+            o2 = e2(x2, t)
+        with torch.cuda.stream(s1):
+            o1 = e1(x1, t)
+        torch.cuda.synchronize()
+        bad += int(not torch.equal(o1, r1)) + int(not torch.equal(o2, r2))
+    assert bad == 0, bad
