@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
         u32x4 ou = {npk[0], npk[1], npk[2], npk[3]};
         if ((int)npa >= 0) ou = u32x4{0u, 0u, 0u, 0u};
         const unsigned pa = npa & 0x7fffffffu;
-        asm volatile("s_nop 0\n\tds_write_b128 %0, %1" :: "v"(pa), "v"(ou) : "memory");      // (one wait state between the VALU write of the data and a > 64-bit DS write: conv_gn2.h)
+        asm volatile("ds_write_b128 %0, %1" :: "v"(pa), "v"(ou) : "memory");
     };
     auto norm_round = [&](int j, int buf) __attribute__((always_inline)) {   // a whole slice at once (prologue)
         norm_load(j, buf);

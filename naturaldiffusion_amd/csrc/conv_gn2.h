@@ -118,11 +118,7 @@ __device__ __forceinline__ u32x4 gload16(unsigned voff, const void* sbase) {
     return v;
 }
 template <int OFF> __device__ __forceinline__ void lds_write16(unsigned addr, u32x4 v) {
-    // s_nop 0: a DS write of more than 64 bits needs ONE wait state after a VALU write of its data registers (LLVM's hazard recognizer inserts it for the
-    // instructions it can see -- not inside inline asm).  Without it the write could pick up the OLD contents of the last register norm_store's v_cndmask
-    // had just written: a stale 16-byte slot of the normalised patch, whenever the two instructions issued back to back -- which depends on what else is
-    // resident on the SIMD (found as run-to-run differences of a whole image's GroupNorm statistics when two engines ran concurrently on two streams).
-    asm volatile(NATINF_PAD_PRE "s_nop 0\n\tds_write_b128 %0, %1 offset:%2" NATINF_PAD_POST :: "v"(addr), "v"(v), "n"(OFF) : "memory");
+    asm volatile(NATINF_PAD_PRE "ds_write_b128 %0, %1 offset:%2" NATINF_PAD_POST :: "v"(addr), "v"(v), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void fresh4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 

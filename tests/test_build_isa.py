@@ -203,3 +203,18 @@ def test_qkv256_loop_has_no_ordinary_global_load(listings):
                 drains.append(t)
     assert dma >= 2 and stores >= 4 and not loads, (dma, stores, loads[:3])
     assert len(drains) <= 1, drains                                           # (the t == 0 branch of the tile wait)
+
+
+def test_no_dpp_source_reads_a_packed_fp32_result(listings):
+    """A DPP (or lane-read) source operand that a `v_pk_*_f32` instruction wrote at most eight instructions earlier.  hipcc's two wait states between a VALU
+    write and a DPP read do not cover a two-pass packed instruction once a wave of another kernel shares the SIMD: lanes 48-63 then read the old value
+    (found as non-reproducible GroupNorm partial sums with two engines on two HIP streams: DESIGN.md section 5; `dpp_row_sum` in gemm_dma.h keeps the
+    vectoriser from producing the shape).  No kernel of the library may contain it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("scan_pk_hazard", Path(__file__).resolve().parent.parent / "tools" / "scan_pk_hazard.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for stem in ("ni_step", "ncsnpp"):
+        hits = mod.scan(str(BUILD / f"{stem}-hip-amdgcn-amd-amdhsa-gfx950.s"), 8)
+        bad = {k: v[:2] for k, v in hits.items() if k[1] in ("dpp", "lane")}
+        assert not bad, bad

@@ -10,5 +10,5 @@ CMD="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $CMD > $O.stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $CMD > $O.fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $CMD > $O.write.log 2>&1
-python3 $R/bench.py --steps 3 --warmup 1 > $O.bench.json 2> $O.bench.err
+python3 $R/bench.py > $O.bench.json 2> $O.bench.err
 tail -1 $O.bench.json | cut -c1-400

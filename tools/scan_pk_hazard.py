@@ -6,45 +6,54 @@ result -- the shape hipcc gave the GroupNorm partial sums once the SLP vectorise
 in lanes 48-63 whenever a wave of another kernel shared the SIMD (two engines on two streams); alone on its SIMD it never did.
 hipcc keeps two wait states between a VALU write and a DPP read, whatever the writer is.
 
-usage: scan_pk_hazard.py file.s [max distance, default 6]"""
+usage: scan_pk_hazard.py file.s [max distance, default 6]   (tests/test_build_isa.py imports scan())"""
 import re, sys
-path = sys.argv[1]; maxd = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+
+
 def regs(tok):
     out = set()
     for m in re.finditer(r'\bv\[(\d+):(\d+)\]', tok): out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
     for m in re.finditer(r'\bv(\d+)\b', tok): out.add(int(m.group(1)))
     return out
-cur = None; window = []; hits = {}
-for ln in open(path):
-    m = re.match(r'^(_Z\w+):', ln)
-    if m: cur = m.group(1); window = []; continue
-    l = ln.strip()
-    if not l or l[0] in '.;' or l.endswith(':') or cur is None: continue
-    op, _, rest = l.partition(' ')
-    ops = [o.strip() for o in rest.split(',')]
-    if op.startswith('s_nop'): window = [(w, d, age + int(rest.split()[0]) + 1) for (w, d, age) in window]
-    else: window = [(w, d, age + 1) for (w, d, age) in window]
-    window = [(w, d, age) for (w, d, age) in window if age <= maxd]
-    kind = None; src = set()
-    if '_dpp' in op: kind = 'dpp'; src = regs(','.join(ops[1:]))
-    elif op.startswith(('ds_write_b128', 'ds_write_b96', 'global_store_dwordx4', 'global_store_dwordx3', 'buffer_store_dwordx4', 'buffer_store_dwordx3')):
-        kind = 'wide'; src = regs(rest)      # (a > 64-bit store's data: one wait state after a VALU write, by hipcc's rule)
-    elif op.startswith(('ds_write', 'ds_bpermute', 'ds_permute', 'ds_swizzle')): kind = 'lds'; src = regs(rest)
-    elif op.startswith(('global_store', 'buffer_store', 'flat_store', 'scratch_store', 'global_atomic')): kind = 'store'; src = regs(rest)
-    elif op.startswith(('v_readlane', 'v_readfirstlane', 'v_permlane')): kind = 'lane'; src = regs(','.join(ops[1:]))
-    if kind:
-        for (w, d, age) in window:
-            if d & src: hits.setdefault((cur, kind), []).append((age - 1, w, l))
-    if op.startswith('v_pk_') and op.endswith('_f32'):
-        window.append((l, regs(ops[0]), 0))
-    else:
-        dst = regs(ops[0]) if op.startswith('v_') else set()
-        window = [(w, d - dst, age) for (w, d, age) in window]     # overwritten since
-tot = {}
-for (fn, kind), hs in sorted(hits.items()):
-    tot[kind] = tot.get(kind, 0) + len(hs)
-    dmin = min(h[0] for h in hs)
-    print(f"{kind:5s} {len(hs):4d} hits, closest {dmin} instruction(s) between: {fn[:110]}")
-    if kind in ('dpp', 'lane', 'wide'):
-        for h in hs[:2]: print(f"        {h[1]}  ->  {h[2]}   ({h[0]} between)")
-print("totals:", tot)
+
+
+def scan(path, maxd=6):
+    """{(kernel, kind): [(instructions between, producer, consumer), ...]}; kind: dpp | lane | wide | lds | store."""
+    cur = None; window = []; hits = {}
+    for ln in open(path):
+        m = re.match(r'^(_Z\w+):', ln)
+        if m: cur = m.group(1); window = []; continue
+        l = ln.strip()
+        if not l or l[0] in '.;' or l.endswith(':') or cur is None: continue
+        op, _, rest = l.partition(' ')
+        ops = [o.strip() for o in rest.split(',')]
+        if op.startswith('s_nop'): window = [(w, d, age + int(rest.split()[0]) + 1) for (w, d, age) in window]
+        else: window = [(w, d, age + 1) for (w, d, age) in window]
+        window = [(w, d, age) for (w, d, age) in window if age <= maxd + 1]
+        kind = None; src = set()
+        if '_dpp' in op: kind = 'dpp'; src = regs(','.join(ops[1:]))
+        elif op.startswith(('ds_write_b128', 'ds_write_b96', 'global_store_dwordx4', 'global_store_dwordx3', 'buffer_store_dwordx4', 'buffer_store_dwordx3')):
+            kind = 'wide'; src = regs(rest)      # (a > 64-bit store's data)
+        elif op.startswith(('ds_write', 'ds_bpermute', 'ds_permute', 'ds_swizzle')): kind = 'lds'; src = regs(rest)
+        elif op.startswith(('global_store', 'buffer_store', 'flat_store', 'scratch_store', 'global_atomic')): kind = 'store'; src = regs(rest)
+        elif op.startswith(('v_readlane', 'v_readfirstlane', 'v_permlane')): kind = 'lane'; src = regs(','.join(ops[1:]))
+        if kind:
+            for (w, d, age) in window:
+                if d & src: hits.setdefault((cur, kind), []).append((age - 1, w, l))
+        if op.startswith('v_pk_') and op.endswith('_f32'):
+            window.append((l, regs(ops[0]), 0))
+        else:
+            dst = regs(ops[0]) if op.startswith('v_') else set()
+            window = [(w, d - dst, age) for (w, d, age) in window]     # overwritten since
+    return hits
+
+
+if __name__ == "__main__":
+    hits = scan(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 6)
+    tot = {}
+    for (fn, kind), hs in sorted(hits.items()):
+        tot[kind] = tot.get(kind, 0) + len(hs)
+        print(f"{kind:5s} {len(hs):4d} hits, closest {min(h[0] for h in hs)} instruction(s) between: {fn[:110]}")
+        if kind in ('dpp', 'lane'):
+            for h in hs[:2]: print(f"        {h[1]}  ->  {h[2]}   ({h[0]} between)")
+    print("totals:", tot)
