@@ -218,3 +218,20 @@ def test_no_dpp_source_reads_a_packed_fp32_result(listings):
         hits = mod.scan(str(BUILD / f"{stem}-hip-amdgcn-amd-amdhsa-gfx950.s"), 8)
         bad = {k: v[:2] for k, v in hits.items() if k[1] in ("dpp", "lane")}
         assert not bad, bad
+
+
+def test_packed_fp32_scanner_recognises_the_shape(tmp_path):
+    """The scanner itself, on the two forms of one reduction stage: hipcc's packed form of round 3 (a hit) and the scalar form `dpp_row_sum` now compiles to (none)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("scan_pk_hazard", Path(__file__).resolve().parent.parent / "tools" / "scan_pk_hazard.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = tmp_path / "bad.s"
+    bad.write_text("_Zbad:\n\tv_pk_add_f32 v[18:19], v[26:27], v[18:19]\n\tv_pk_add_f32 v[8:9], v[12:13], v[8:9]\n\tv_pk_add_f32 v[14:15], v[14:15], v[16:17]\n"
+                   "\tv_pk_add_f32 v[0:1], v[2:3], v[0:1]\n\tv_mov_b32_dpp v26, v18 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_endpgm\n")
+    hits = mod.scan(str(bad), 8)
+    assert [(h[0], h[2].split()[0]) for h in hits[("_Zbad", "dpp")]] == [(3, "v_mov_b32_dpp")]
+    good = tmp_path / "good.s"
+    good.write_text("_Zgood:\n\tv_add_f32_e32 v2, v2, v3\n\tv_add_f32_dpp v0, v36, v36 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+                    "\tv_pk_mul_f32 v[6:7], v[6:7], v[8:9]\n\tv_mov_b32_e32 v6, v1\n\tv_add_f32_dpp v1, v6, v6 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_endpgm\n")
+    assert not {k: v for k, v in mod.scan(str(good), 8).items() if k[1] in ("dpp", "lane")}      # (v6 was overwritten by a plain move in between)
