@@ -1,3 +1,5 @@
+"""Two engines on two HIP streams (the victim keeps its activations): per-module taps against the solo run -- which module differs first, in how many
+elements and pixels of which image.  (First tool of the hunt in DESIGN.md section 5; with the fixed dpp_row_sum it prints nothing.)"""
 import sys, torch
 sys.path.insert(0, "/root/repo")
 from naturaldiffusion_amd._lib import lib

@@ -1,3 +1,5 @@
+"""Two-engine reproducibility counter against an arbitrary checkout (argv[1] = repository root to import from): used to show that the session-start build
+had the same non-reproducibility."""
 import sys, torch
 root = sys.argv[1]
 sys.path.insert(0, root)

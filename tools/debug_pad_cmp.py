@@ -1,3 +1,4 @@
+"""Compare the two files tools/debug_pad.py wrote (default and -DNATINF_ASM_PAD builds): outputs and per-module taps bit for bit."""
 import sys, torch
 sys.path.insert(0, "/root/repo")
 from naturaldiffusion_amd.ncsnpp import module_table
