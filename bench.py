@@ -5,6 +5,9 @@ One "step" = one pass of the hot path over one batch: BASELINE config 2, i.e. 15
 Inference with ``weights/step_15_weight_173.npz`` on a batch of 512 CIFAR10-shaped samples: 15 NCSN++
 forwards in the HIP engine (bf16 MFMA) + 15 fused ``ni_step`` launches (fp64 history, the reference's
 arithmetic).  Inputs (noise, weights, coefficient rows) are resident in HBM before the timed region.
+Consecutive steps alternate between two HIP streams (two engine handles, two history buffers), the order
+``CIFAR10NaturalInference.natural_inference_tx`` runs its batches in: the images are bit-identical to the
+one-after-the-other order, whose time for the same K steps is reported as ``single_stream`` (``--streams 1`` makes it the headline).
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -21,7 +24,8 @@ config 4) and ``sd3_fp8`` (config 5) objects with their own value / ms_per_step 
 
 The JSON line also carries
   roofline          the dominant kernel (k_conv_gn2, MFMA-bound): algorithmic flops per launch / mean launch
-                    duration, measured with HIP events on the engine's stream over a timed region
+                    duration, measured with HIP events on the engine's stream over an instrumented one-stream replica of
+                    the timed region (one kernel on the GPU at a time)
   roofline_gemm     the same for the remaining k_gemm_* launches; roofline_whole_denoiser: all flops / all device time
   roofline_ni_step  the named recurrence kernel (HBM-bound): algorithmic bytes per launch / mean duration
   cpu_baseline      the CPU oracle (eager PyTorch restatement of the reference path) timed on this host (BASELINE.md section 3:
