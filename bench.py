@@ -128,7 +128,7 @@ def timed_region(one_step, steps, warmup, world, sync, dist, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--no-single-stream", dest="single_stream_extra", action="store_false", help="skip the extra one-stream timing of the CIFAR10 workload")
     ap.add_argument("--streams", type=int, default=2, help="CIFAR10 workload: HIP streams the consecutive batches (steps) alternate between, as in natural_inference_tx "
                                                           "(default 2; 1 = one batch after the other)")
