@@ -23,6 +23,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_fp8(const GemmArgs g)
     using Cfg = DmaCfg<2, 4, 8, 4>;
     constexpr int WN = 4, TM = 8, TN = 4, BM_ = 256, BN_ = 256, BKB = 128;       // BKB: K bytes (= elements) per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
