@@ -1,36 +1,70 @@
 #!/usr/bin/env python3
 """bench.py -- images/sec of N-step Natural Inference on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one batch: BASELINE config 2, i.e. 15-step Natural
-Inference with ``weights/step_15_weight_173.npz`` on a batch of 512 CIFAR10-shaped samples: 15 NCSN++
-forwards in the HIP engine (bf16 MFMA) + 15 fused ``ni_step`` launches (fp64 history, the reference's
-arithmetic).  Inputs (noise, weights, coefficient rows) are resident in HBM before the timed region.
-Consecutive steps alternate between two HIP streams (two engine handles, two history buffers), the order
-``CIFAR10NaturalInference.natural_inference_tx`` runs its batches in: the images are bit-identical to the
-one-after-the-other order, whose time for the same K steps is reported as ``single_stream`` (``--streams 1`` makes it the headline).
+    python bench.py --gpus N --steps K --warmup W [--workload cifar10|sd3|fid50k|validate]
 
-    python bench.py --gpus N --steps K --warmup W
+The JSON line carries NUMBERS and short identifiers only (the whole line stays under 3 KB so that it survives any log tail);
+what every field means is written HERE.
 
-Multi-GPU: generation batches are independent, so rank r simply runs its own batches (weak scaling, no
-collective on the data path); timing is barrier + synchronize on both sides and the max over ranks.  One
-process per GPU: under ``torch.distributed.run`` (WORLD_SIZE set) this process IS a rank; a bare
-``python bench.py --gpus N`` starts the N ranks itself (``launch_ranks``: a child ``torch.distributed.run``,
-started before this process has touched the GPU -- the reference uses every visible GPU from one command,
-deps/score_sde_pytorch/models/utils.py:93) and relays rank 0's JSON line.
+Top level (default workload = BASELINE config 2).  One "step" = one pass of the hot path over one batch: 15-step Natural
+Inference with ``weights/step_15_weight_173.npz`` on 512 CIFAR10-shaped samples = 15 NCSN++ forwards in the HIP engine (bf16
+MFMA operands, fp32 accumulate) + 15 fused ``ni_step`` launches (fp64 history, the reference's arithmetic).  Inputs (noise,
+weights, coefficient rows) are resident in HBM before the timed region.  ``value`` is TWO-STREAM THROUGHPUT: consecutive steps
+alternate between two HIP streams (two engine handles sharing one copy of the packed weights, two history buffers) -- the order
+``CIFAR10NaturalInference.natural_inference_tx`` / ``generate_sharded`` run their batches in; the images are bit-identical to the
+one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
+  single_stream     {value, ms_per_step}: the same K steps one batch after the other on ONE stream (the reference's order; the
+                    like-for-like number for rounds 1-2, whose headline was this).  ``--streams 1`` makes it the headline.
+  sd3, sd3_fp8      BASELINE configs 4 / 5 (``--workload sd3 [--fp8]`` alone): 28-step SD3-form NI at 1024x1024, 4 images x CFG per
+                    GPU = ONE batched MMDiT forward of 8 sequences (4,096 image + 333 text tokens) per step + one fused
+                    ``natinf_step_f16chain`` launch; a step = one 4-image batch through all 28 steps; SD3-medium-shaped synthetic
+                    weights (2.03 B parameters).  fp8 = e4m3 operands (v_mfma_f32_16x16x128_f8f6f4) for the image-stream q|k, v, fc1,
+                    fc2 GEMMs, bf16 elsewhere.  Fields: value (images/s), ms_per_step, frac (all 2*MAC flops of the forward / wall time
+                    / 2,500 TFLOP/s), attn {k_flash_attn64 timed IN the engine: HIP events around each launch of one 28-step batch: ms,
+                    TFLOP/s, frac of the bf16 peak; iso_ms = the same kernel in a back-to-back loop, which this power-capped part clocks
+                    lower}, gemm {per image-stream projection shape (M = 32,768): TFLOP/s and frac of ITS operand type's dense peak
+                    (bf16 2,500 / fp8 5,000); frac = sum(flops_i / peak_i) / sum(time_i)}, cpu (the MMDiT oracle on one sequence through 2
+                    of 24 blocks, extrapolated: images/s), acc (28-step NI through a 4-block / 256-wide MMDiT: relative RMS of the final
+                    latents vs the fp32 oracle -- PARITY UNPINNED, the oracle restates the published architecture).
+  fid50k            BASELINE config 3 (``--workload fid50k`` alone): the 50,000-image FID job of reference
+                    src/CIFAR10NaturalInference.py:281-312 for BOTH coefficient-matrix equivalents -- DPM-Solver++(2S)
+                    (results/dpmsolverpp/dpmsolverpp2s_018.npz) and DDIM on the continuous VP grid (coeffgen.ddim_vp_continuous over
+                    linspace(1, 1e-3, 19)), 18 NFE each.  This rank generates ITS share (global indices rank, rank + W, ...; batches of
+                    512 + one ragged batch) with ``generate_sharded`` (two lanes, Philox noise by global index, uint8 images kept on
+                    the device), scores it with the Inception-V3 pool3 engine in the reference's batches of 50, and
+                    ``calc_fid_sharded`` sums (n, sum, outer-product sum) over ranks with ONE all-reduce and evaluates the Frechet
+                    distance (scipy sqrtm on the host, as pytorch_fid does).  With ONE GPU the default share is rank 0 of 8
+                    (``share_of``: 6,250 images; ``--fid-share-of 1`` runs all 50,000).  value = images generated AND scored per second
+                    over all ranks, both matrices; s = wall seconds {gen, inception, allreduce, frechet} summed over the two matrices;
+                    gen_rate = images/s of generation alone; inc_rate = Inception images/s.  The checkpoint, the Inception weights and
+                    cifar10_mu_sigma.npz are downloads: without them synthetic weights / (0, I) reference statistics stand in and
+                    fid = "blocked"; d_matrices = Frechet distance between the two matrices' image statistics (same network, same
+                    noise: a sanity figure that needs no asset).
+  validate          SURVEY 8f N2 + N4 (``--workload validate`` alone): ``ValidateNaturalInference.natural_inference("ddim", 24)`` --
+                    DiT-XL/2 engine, 8 class-conditional latents, CFG 4 (two forwards per step), 24 steps, one fused
+                    ``natinf_step_f32prod`` launch per step -- then the AutoencoderKL decoder engine (8 x 256x256 images) and the PNG
+                    row.  value = images/s; dit_ms = mean DiT forward (B = 8); vae_ms = decode of the 8 latents; synthetic weights.
+  roofline          the dominant kernel, ``k_conv_gn2`` at 32x32 / 16x16 (3x3 convolution with GroupNorm-apply + SiLU fused into its
+                    operand path; MFMA-bound): achieved = algorithmic flops per launch (2*M*N*K of the launches, from the engine's own
+                    launch table) / mean launch duration, measured with HIP events on the engine's stream over an instrumented ONE-stream
+                    replica of the timed region (one kernel on the GPU at a time); traffic = HBM bytes per launch from the newest
+                    committed rocprofv3 PMC summary (profiles/rNN/*_hbm_traffic.json: bench.py cannot run rocprofv3 on itself);
+                    share = its part of the engine's device time.
+  roofline_conv_gn8 the same kernel's 8x8 / 4x4 instantiations; roofline_gemm: every other matmul-shaped launch (k_gemm_*, the 16x16
+                    attention block's k_qkv256 / k_attn256, k_head_conv); roofline_whole_denoiser: all flops / all device time.
+  roofline_ni_step  ``k_step_f64hist`` (HBM-bound): algorithmic bytes per launch / mean launch duration.
+  cpu_baseline      the CPU oracle (eager-PyTorch restatement of the reference path: fp32 NCSN++ + fp64 recurrence) on this host:
+                    64 images x 15 steps; ``config1`` = BASELINE config 1 (8 images x 5 steps) images/s; threads = min(32, physical):
+                    more are slower at this size.
+  accuracy          final x of the 64 cpu_baseline images, HIP bf16 engine vs fp32 oracle on identical noise: relative RMS, mean
+                    |delta| in uint8 steps.  (The synthetic network is not a denoiser: tests/test_gpu_accuracy.py has the image-level
+                    figures with a well-conditioned one.)  fid: blocked on checkpoint_8.pth / Inception weights / cifar10_mu_sigma.npz.
 
-The default line carries all three north-star workloads: the CIFAR10 metric at top level plus ``sd3`` (BASELINE
-config 4) and ``sd3_fp8`` (config 5) objects with their own value / ms_per_step / rooflines / cpu_baseline
-(``--no-sd3`` skips them; ``--workload sd3 [--fp8]`` runs one of them alone as the top-level line).
-
-The JSON line also carries
-  roofline          the dominant kernel (k_conv_gn2, MFMA-bound): algorithmic flops per launch / mean launch
-                    duration, measured with HIP events on the engine's stream over an instrumented one-stream replica of
-                    the timed region (one kernel on the GPU at a time)
-  roofline_gemm     the same for the remaining k_gemm_* launches; roofline_whole_denoiser: all flops / all device time
-  roofline_ni_step  the named recurrence kernel (HBM-bound): algorithmic bytes per launch / mean duration
-  cpu_baseline      the CPU oracle (eager PyTorch restatement of the reference path) timed on this host (BASELINE.md section 3:
-                    config 1 and a B=64 15-step point, denoiser / combine split)
-  accuracy          image-level difference of the bf16 engine's 15-step samples from the fp32 oracle's on identical noise
+Multi-GPU: generation batches are independent, so rank r runs its own batches (weak scaling, no collective on the data path;
+fid50k: one all-reduce of statistics at the end); timing is barrier + synchronize on both sides and the max over ranks.  One process
+per GPU: under ``torch.distributed.run`` (WORLD_SIZE set) this process IS a rank; a bare ``python bench.py --gpus N`` starts the N
+ranks itself (``launch_ranks``, before this process touches a GPU) and relays rank 0's line.  With N > 1 only rank 0 runs the
+instrumented replica / CPU legs, and the SD3 / validate sub-objects are left to ``--workload`` runs (the line then carries fid50k).
 """
 import argparse
 import json
@@ -43,8 +77,15 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_FP8_PEAK_TFLOPS = 5000.0
 HBM_PEAK_GBS = 8000.0                # HBM3E spec, same guide
 GFLOP_PER_IMAGE_FORWARD = 21.69307136  # 2*MAC of conv/linear/attention matmuls (oracle.flops_per_image)
+INCEPTION_GFLOP_PER_IMAGE = 11.42      # pool3 path at 299x299
+
+
+def r4(x):
+    """4 significant digits: the line is numbers, keep them short"""
+    return None if x is None else float(f"{float(x):.4g}")
 
 
 def ni_step_bytes_per_element(C, s_x=4, s_h=8):
@@ -64,14 +105,14 @@ def profiled_traffic(match, exclude=None):
     tools/summarize_profile.py).  bench.py cannot run rocprofv3 itself; returns None when no summary exists."""
     files = sorted(ROOT.glob("profiles/r*/*_hbm_traffic.json"))
     if not files:
-        return None, None
+        return None
     tab = json.loads(files[-1].read_text())
     excl = (exclude,) if isinstance(exclude, str) else tuple(exclude or ())
     rows = [v for k, v in tab.items() if match in k and not any(e in k for e in excl)]
     n = sum(v["launches"] for v in rows)
     if not n:
-        return None, None
-    return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in rows) / n, str(files[-1].relative_to(ROOT))
+        return None
+    return r4(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in rows) / n)
 
 
 def launch_ranks(args):
@@ -101,7 +142,8 @@ def launch_ranks(args):
 
 
 def timed_region(one_step, steps, warmup, world, sync, dist, dev):
-    """W untimed steps, then exactly K steps between (synchronize, barrier, synchronize) brackets; returns the max over ranks (s)."""
+    """W untimed steps, then exactly K steps between (synchronize, barrier, synchronize) brackets; returns the max over ranks (s)
+    and the outputs of the LAST TWO steps (one per lane of a two-stream run)."""
     import torch
 
     def barrier():
@@ -109,38 +151,41 @@ def timed_region(one_step, steps, warmup, world, sync, dist, dev):
         if world > 1:
             dist.barrier()
         sync()
-    out = None
+    outs = []
     for i in range(warmup):
         one_step(i)
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
-        out = one_step(i)
+        outs = (outs + [one_step(i)])[-2:]
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
-    return dt, out
+    return dt, outs
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 8 for cifar10, 2 for sd3, 1 for fid50k, 3 for validate)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 1; 0 for fid50k)")
     ap.add_argument("--no-single-stream", dest="single_stream_extra", action="store_false", help="skip the extra one-stream timing of the CIFAR10 workload")
-    ap.add_argument("--streams", type=int, default=2, help="CIFAR10 workload: HIP streams the consecutive batches (steps) alternate between, as in natural_inference_tx "
-                                                          "(default 2; 1 = one batch after the other)")
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=2, help="CIFAR10 / fid50k: HIP streams the consecutive batches alternate between (default 2; 1 = one batch after the other)")
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--weights", default=str(ROOT / "weights" / "step_15_weight_173.npz"))
-    ap.add_argument("--workload", choices=["cifar10", "sd3", "selftest"], default="cifar10",
-                    help="cifar10 = the BASELINE.json metric (default; its line also carries the sd3 / sd3_fp8 objects); sd3 = config 4 alone "
-                         "(SD3 1024x1024 28-step NI, MMDiT bf16); selftest = the launcher / rendezvous / timing skeleton without kernels (CPU, gloo)")
+    ap.add_argument("--workload", choices=["cifar10", "sd3", "fid50k", "validate", "selftest"], default="cifar10",
+                    help="cifar10 = the BASELINE.json metric (default; its line also carries sd3 / sd3_fp8 / fid50k / validate objects); the others alone "
+                         "as the top-level line; selftest = the launcher / rendezvous / timing skeleton without kernels (CPU, gloo)")
     ap.add_argument("--fp8", action="store_true", help="with --workload sd3: BASELINE config 5 (sharp-variant weights, fp8 e4m3 GEMM operands)")
     ap.add_argument("--no-sd3", action="store_true", help="default workload: leave out the sd3 / sd3_fp8 objects")
+    ap.add_argument("--no-fid50k", action="store_true", help="default workload: leave out the fid50k object")
+    ap.add_argument("--no-validate", action="store_true", help="default workload: leave out the validate object")
     ap.add_argument("--sd3-steps", type=int, default=2, help="timed 4-image batches of each SD3 configuration inside the default line")
+    ap.add_argument("--fid-samples", type=int, default=50000, help="fid50k: images of the whole job (reference: 50,000)")
+    ap.add_argument("--fid-share-of", type=int, default=0, help="fid50k on ONE GPU: run rank 0's share of a job sharded this many ways (default 8; 1 = the whole job)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process-group backend (gloo: the selftest workload on CPU)")
     ap.add_argument("--same-device", action="store_true",
                     help="functional test of the N > 1 path on a ONE-GPU box: every rank uses cuda:0 (gloo backend only: RCCL refuses two ranks on one device)")
@@ -148,11 +193,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the event-instrumented replica (for rocprof runs)")
     args = ap.parse_args()
+    dflt = {"cifar10": (8, 1), "sd3": (2, 1), "fid50k": (1, 0), "validate": (3, 1), "selftest": (8, 1)}[args.workload]
+    args.steps = dflt[0] if args.steps is None else args.steps
+    args.warmup = dflt[1] if args.warmup is None else args.warmup
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)              # before anything here imports torch or touches a GPU
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -176,25 +223,43 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    import gc
+
+    def release():
+        gc.collect(); torch.cuda.empty_cache()
+
     if args.workload == "sd3":
         line = bench_sd3(args, world, rank, dev, fp8=args.fp8, steps=args.steps, warmup=args.warmup)
+    elif args.workload == "fid50k":
+        line = bench_fid50k(args, world, rank, dev, steps=args.steps, warmup=args.warmup)
+    elif args.workload == "validate":
+        line = bench_validate(args, world, rank, dev, steps=args.steps, warmup=args.warmup)
     else:
         line = bench_cifar(args, world, rank, dev)
-        if not args.no_sd3:
-            # configs 4 / 5 in the same line: every rank runs them (they shard like the CIFAR10 batches), rank 0 reports
-            import gc
-            gc.collect(); torch.cuda.empty_cache()
+        tail = {k: line.pop(k) for k in list(line) if k.startswith(("config", "roofline", "cpu_baseline", "accuracy"))}
+        strip = ("metric", "unit", "n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "config", "warmup")
+        release()
+        if not args.no_sd3 and world == 1:
+            # configs 4 / 5 in the same line (one GPU: with N > 1 they are `--workload sd3 [--fp8]` runs -- every rank would repeat them)
             from naturaldiffusion_amd.mmdit import SD3_MEDIUM
             from naturaldiffusion_amd.synth import synthetic_mmdit_flat
             flat = synthetic_mmdit_flat(grid=64, seed=0, **SD3_MEDIUM)
             for key, fp8 in (("sd3", False), ("sd3_fp8", True)):
                 sub = bench_sd3(args, world, rank, dev, fp8=fp8, steps=args.sd3_steps, warmup=1, flat=flat)
-                for drop in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data"):
-                    sub.pop(drop, None)
-                line[key] = sub
-                gc.collect(); torch.cuda.empty_cache()
+                line[key] = {k: v for k, v in sub.items() if k not in strip and k != "dtype"}
+                release()
+            del flat
+        if not args.no_fid50k:
+            sub = bench_fid50k(args, world, rank, dev, steps=1, warmup=0)
+            line["fid50k"] = {k: v for k, v in sub.items() if k not in strip and k not in ("dtype", "cpu_baseline", "roofline")}
+            release()
+        if not args.no_validate and world == 1:
+            sub = bench_validate(args, world, rank, dev, steps=3, warmup=1)
+            line["validate"] = {k: v for k, v in sub.items() if k not in strip and k not in ("dtype", "cpu_baseline", "roofline")}
+            release()
+        line.update(tail)
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line, separators=(",", ":")), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -210,7 +275,7 @@ def bench_selftest(args, world, rank):
     if rank == args.selftest_fail_rank:
         raise SystemExit(3)
     a = torch.ones(64, 64)
-    dt, out = timed_region(lambda i: (a @ a).sum() + rank, args.steps, args.warmup, world, lambda: None, dist, torch.device("cpu"))
+    dt, _ = timed_region(lambda i: (a @ a).sum() + rank, args.steps, args.warmup, world, lambda: None, dist, torch.device("cpu"))
     tot = torch.tensor([float(rank + 1)])
     if world > 1:
         dist.all_reduce(tot)
@@ -247,12 +312,11 @@ def bench_cifar(args, world, rank, dev):
     def one_step(i):
         return ni.run(engine, noises[i & 1])
 
-    # The job is a sequence of independent batches (50,000 images = ranks x batches of 512; reference loop CIFAR10NaturalInference.py:287-309).  As in
-    # natural_inference_tx, consecutive batches (= steps) go to `--streams` HIP streams, each with its own engine handle and history buffer: a step is still
-    # one 15-step pass over one batch of 512, exactly K of them are timed between the synchronize / barrier brackets, and the under-occupied launches of one
-    # batch run under the other's convolutions.  The single-stream time of the same K steps is measured as well and reported next to it.
+    # The job is a sequence of independent batches (reference loop CIFAR10NaturalInference.py:287-309).  As in natural_inference_tx /
+    # generate_sharded, consecutive batches (= steps) go to `--streams` HIP streams, each with its own engine handle (cloned: shared
+    # packed weights) and history buffer: a step is still one 15-step pass over one batch of 512, exactly K of them are timed.
     n_str = max(1, min(args.streams, args.steps))
-    lanes = [(engine, ni, None)] + [(NCSNppEngine(flat, max_batch=Bz, device=dev), CifarNI(C, Bm, node, E, device=dev), None) for _ in range(n_str - 1)]
+    lanes = [(engine, ni, None)] + [(engine.clone(), CifarNI(C, Bm, node, E, device=dev), None) for _ in range(n_str - 1)]
     if n_str > 1:
         lanes = [(e_, n_, torch.cuda.Stream(device=dev)) for e_, n_, _ in lanes]
 
@@ -268,39 +332,28 @@ def bench_cifar(args, world, rank, dev):
     torch.cuda.synchronize()
     dt1 = None
     if n_str == 1 or args.single_stream_extra:
-        dt1, out = timed_region(one_step, args.steps, args.warmup, world, torch.cuda.synchronize, dist, dev)
-        assert torch.isfinite(out).all()
+        dt1, outs = timed_region(one_step, args.steps, args.warmup, world, torch.cuda.synchronize, dist, dev)
+        assert all(torch.isfinite(o).all() for o in outs)
     if n_str > 1:
-        dt, out = timed_region(one_step_streams, args.steps, args.warmup, world, torch.cuda.synchronize, dist, dev)
+        dt, outs = timed_region(one_step_streams, args.steps, max(args.warmup, n_str), world, torch.cuda.synchronize, dist, dev)   # every lane warmed
         torch.cuda.synchronize()
-        assert torch.isfinite(out).all()
+        assert all(torch.isfinite(o).all() for o in outs)                  # the last step of BOTH lanes
     else:
         dt = dt1
     imgs = world * Bz * args.steps
-    value = imgs / dt
-
     line = {
-        "metric": "images/sec at 15-step Natural Inference (CIFAR10 32x32, NCSN++)",
-        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": "images/sec at 15-step Natural Inference (CIFAR10 32x32, NCSN++)" + (", two-stream throughput" if n_str > 1 else ""),
+        "value": round(imgs / dt, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "CIFAR10 Natural Inference 15-step (step_15_weight_173.npz), batch=512 per GPU, "
-                               "NCSN++ (cifar10_ddpmpp_continuous, 61.8M params, synthetic weights) bf16 MFMA / fp32 acc, "
-                               "ni_step fp64 history",
-                   "coeff_file": os.path.basename(args.weights), "nfe": n_step, "batch_per_gpu": Bz,
-                   "sharding": f"batch-sharded x{world}, no collective",
-                   "streams": n_str},
     }
     if n_str > 1 and dt1 is not None:
-        line["single_stream"] = {"value": round(imgs / dt1, 2), "ms_per_step": round(dt1 / args.steps * 1e3, 3),
-                                 "note": "the same K steps one batch after the other on one HIP stream (the reference's order).  The headline alternates consecutive batches "
-                                         "between two streams (two engine handles; bit-identical images): the under-occupied launches of one batch run under the other's "
-                                         "convolutions.  The roofline objects below are measured in THIS order -- kernel durations are only meaningful with one kernel "
-                                         "on the GPU at a time"}
+        line["single_stream"] = {"value": round(imgs / dt1, 2), "ms_per_step": round(dt1 / args.steps * 1e3, 3)}
+    line["config"] = {"workload": f"CIFAR10 NI 15-step {os.path.basename(args.weights)} B={Bz}/GPU NCSN++ 61.8M bf16 MFMA, ni_step fp64 history",
+                      "nfe": n_step, "batch_per_gpu": Bz, "streams": n_str, "sharding": f"batch x{world}, no collective"}
 
     if rank == 0 and not args.no_roofline:
-        # ---- instrumented replica of the timed region: HIP events around every engine launch group and
-        # ---- every ni_step launch (same stream)
+        # ---- instrumented replica of the timed region: HIP events around every engine launch group and every ni_step launch (same stream)
         engine.profile(True)
         ev = []
         orig_step = ni.step
@@ -314,11 +367,9 @@ def bench_cifar(args, world, rank, dev):
             return r
         ni.step = timed_step
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
         for i in range(args.steps):
             one_step(i)
         torch.cuda.synchronize()
-        dt_inst = time.perf_counter() - t1
         prof = engine.profile_read()
         engine.profile(False)
         ni.step = orig_step
@@ -332,59 +383,35 @@ def bench_cifar(args, world, rank, dev):
         rows = engine.describe_gemms(Bz)
         fl = lambda r: 2.0 * r[0] * r[1] * (r[2] + r[3]) * r[5]
         is8 = lambda r: r[0] in (Bz * 64, Bz * 16)                                # the 8x8 and 4x4 levels: 64 / 16 pixels per image
-        cg_rows = [r for r in rows if r[6].startswith("conv_gn") and not is8(r)]
-        c8_rows = [r for r in rows if r[6].startswith("conv_gn") and is8(r)]
-        cg_flops = sum(fl(r) for r in cg_rows) * fwd
-        c8_flops = sum(fl(r) for r in c8_rows) * fwd
+        cg_flops = sum(fl(r) for r in rows if r[6].startswith("conv_gn") and not is8(r)) * fwd
+        c8_flops = sum(fl(r) for r in rows if r[6].startswith("conv_gn") and is8(r)) * fwd
         gemm_flops = GFLOP_PER_IMAGE_FORWARD * 1e9 * Bz * fwd - cg_flops - c8_flops          # the rest: the k_gemm_* launches, the fused attention, the head
         all_ms = cg_ms + c8_ms + gemm_ms + other_ms
         ach = cg_flops / (cg_ms * 1e-3) / 1e12
-        tr_cg, tr_src = profiled_traffic("k_conv_gn", exclude=("k_conv_gn2<8", "k_conv_gn2<4"))
-        line["roofline"] = {
-            "kernel": "k_conv_gn2<32 | 16, ...> (3x3 convolution with GroupNorm-apply + SiLU fused into its operand path, weights streamed through registers; the 32x32 and "
-                      f"16x16 levels: the dominant kernel, {100 * cg_ms / all_ms:.0f} % of the engine's device time; its 8x8 / 4x4 instantiations: roofline_conv_gn8)", "bound": "mfma",
-            "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-            "traffic": tr_cg, "traffic_source": tr_src, "traffic_note": "HBM bytes per launch from the committed rocprofv3 PMC summary named in traffic_source (the same launches), not measured by this run",
-            "launches": int(cg_n), "mean_launch_ms": round(cg_ms / cg_n, 5),
-            "flops_per_launch": cg_flops / cg_n, "device_ms_total": round(cg_ms, 3),
-            "ms_per_step_instrumented": round(dt_inst / args.steps * 1e3, 3),
-        }
+        line["roofline"] = {"kernel": "k_conv_gn2<32|16>", "bound": "mfma", "achieved": r4(ach), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": r4(ach / MFMA_BF16_PEAK_TFLOPS), "traffic": profiled_traffic("k_conv_gn", exclude=("k_conv_gn2<8", "k_conv_gn2<4")),
+                            "launches": int(cg_n), "mean_launch_ms": r4(cg_ms / cg_n), "flops_per_launch": r4(cg_flops / cg_n), "share": r4(cg_ms / all_ms)}
         if c8_n:
             ach8 = c8_flops / (c8_ms * 1e-3) / 1e12
-            line["roofline_conv_gn8"] = {
-                "kernel": "k_conv_gn2<8 | 4, true, ..., 4> (the same fused kernel on the 8x8 and 4x4 levels: 64-pixel x 256-channel tiles = one 8x8 image, two blocks per CU / "
-                          f"four 4x4 images, two K groups of four waves per block, 128 tiles at B = 512; {100 * c8_ms / all_ms:.0f} % of the engine's device time)", "bound": "mfma", "achieved": round(ach8, 2),
-                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach8 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "launches": int(c8_n),
-                "mean_launch_ms": round(c8_ms / c8_n, 5), "flops_per_launch": c8_flops / c8_n, "device_ms_total": round(c8_ms, 3)}
+            line["roofline_conv_gn8"] = {"kernel": "k_conv_gn2<8|4>", "achieved": r4(ach8), "frac": r4(ach8 / MFMA_BF16_PEAK_TFLOPS), "launches": int(c8_n),
+                                         "mean_launch_ms": r4(c8_ms / c8_n), "share": r4(c8_ms / all_ms)}
         ach_g = gemm_flops / (gemm_ms * 1e-3) / 1e12
-        tr_gemm, tr_src_g = profiled_traffic("k_gemm")
-        line["roofline_gemm"] = {
-            "kernel": "k_gemm_* (LDS-DMA implicit-GEMM tile variants: resampling-block convolutions, NIN, linear) + the 16x16 attention block's k_qkv256 / k_attn256<true> (HBM-bound) + k_head_conv",
-            "bound": "mfma", "achieved": round(ach_g, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach_g / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": tr_gemm, "traffic_source": tr_src_g, "launches": int(gemm_n),
-            "mean_launch_ms": round(gemm_ms / gemm_n, 5), "flops_per_launch": gemm_flops / gemm_n, "device_ms_total": round(gemm_ms, 3),
-            "other_kernels_device_ms": round(other_ms, 3), "other_launches": int(other_n),
-        }
-        line["roofline_whole_denoiser"] = {
-            "bound": "mfma", "achieved": round((cg_flops + c8_flops + gemm_flops) / (all_ms * 1e-3) / 1e12, 2),
-            "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round((cg_flops + c8_flops + gemm_flops) / (all_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-            "note": "all matmul flops of the forward / device time of ALL its kernels (normalisation, statistics, softmax included)"}
+        line["roofline_gemm"] = {"kernel": "k_gemm_*+k_qkv256+k_attn256+k_head_conv", "achieved": r4(ach_g), "frac": r4(ach_g / MFMA_BF16_PEAK_TFLOPS),
+                                 "launches": int(gemm_n), "mean_launch_ms": r4(gemm_ms / gemm_n), "share": r4(gemm_ms / all_ms),
+                                 "other_share": r4(other_ms / all_ms), "other_launches": int(other_n)}
+        whole = (cg_flops + c8_flops + gemm_flops) / (all_ms * 1e-3) / 1e12
+        line["roofline_whole_denoiser"] = {"achieved": r4(whole), "frac": r4(whole / MFMA_BF16_PEAK_TFLOPS)}
         bpe = ni_step_bytes_per_element(C)
         tot_ms = sum(a0.elapsed_time(a1) for _, a0, a1 in ev)
         tot_bytes = sum(bpe[k] * E for k, _, _ in ev)
         ach_gbs = tot_bytes / (tot_ms * 1e-3) / 1e9
-        tr_ni, tr_src = profiled_traffic("k_step_f64hist")
-        line["roofline_ni_step"] = {
-            "kernel": "k_step_f64hist", "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(ach_gbs / HBM_PEAK_GBS, 4), "traffic": tr_ni, "traffic_source": tr_src,
-            "launches": len(ev), "mean_launch_ms": round(tot_ms / len(ev), 5),
-            "bytes_per_launch": tot_bytes / len(ev), "bytes_per_element_by_step": bpe,
-        }
+        line["roofline_ni_step"] = {"kernel": "k_step_f64hist", "bound": "hbm", "achieved": r4(ach_gbs), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": r4(ach_gbs / HBM_PEAK_GBS), "traffic": profiled_traffic("k_step_f64hist"), "launches": len(ev),
+                                    "mean_launch_ms": r4(tot_ms / len(ev)), "bytes_per_launch": r4(tot_bytes / len(ev))}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the oracle (eager-PyTorch restatement of the reference path, fp32 NCSN++ +
-        # ---- fp64 recurrence) on this host's cores; two bounded points, each split into denoiser and combine time
+        # ---- fp64 recurrence) on this host's cores; two bounded points
         from oracle import ni_oracle as O, ncsnpp_oracle as N
         from naturaldiffusion_amd.synth import synthetic_state_dict
         try:
@@ -416,36 +443,23 @@ def bench_cifar(args, world, rank, dev):
             tc = time.perf_counter()
             xs = O.cifar_ni_trajectory(timed_model, z, Cc, Bc, nodec)
             dc = time.perf_counter() - tc
-            points.append({"coeff_file": wname, "images": nb, "nfe": int(nodec.shape[0] - 1), "seconds": round(dc, 2),
-                           "images_per_s": round(nb / dc, 4), "denoiser_s": round(spent["t"], 2), "combine_s": round(dc - spent["t"], 3)})
+            points.append({"images": nb, "nfe": int(nodec.shape[0] - 1), "seconds": dc, "images_per_s": nb / dc, "denoiser_s": spent["t"]})
             if nb == 64:
                 final64, z64 = xs[-1], z
-        main_pt = points[-1]
-        line["cpu_baseline"] = {"value": main_pt["images_per_s"], "unit": "images/s", "cores": threads, "kind": "port",
-                                "sample": f"{main_pt['images']} images x {main_pt['nfe']} steps, same coefficient file and synthetic weights "
-                                          f"(fp32 NCSN++ oracle + fp64 recurrence), {main_pt['seconds']} s "
-                                          f"({main_pt['denoiser_s']} s denoiser + {main_pt['combine_s']} s combine); host: {physical} physical / "
-                                          f"{os.cpu_count()} logical CPUs, {threads} threads (see bench.py: more threads are slower at this size)",
-                                "physical_cores": physical, "points": points}
+        mp = points[-1]
+        line["cpu_baseline"] = {"value": r4(mp["images_per_s"]), "unit": "images/s", "cores": threads, "kind": "port",
+                                "sample": f"{mp['images']} img x {mp['nfe']} steps oracle fp32+fp64 {mp['seconds']:.1f}s (denoiser {mp['denoiser_s']:.1f}s)",
+                                "physical_cores": physical, "config1": r4(points[0]["images_per_s"])}
         # ---- accuracy of the bf16 engine at the image level (stand-in for the FID delta, which is blocked on assets): the same
         # ---- 64 noise tensors through the HIP path, against the fp32 / fp64 oracle trajectory just computed
         if final64 is not None and os.path.basename(args.weights) == "step_15_weight_173.npz":
             eng64 = NCSNppEngine(synthetic_flat_params(0), max_batch=64, device=dev)
             got = CifarNI(C, Bm, node, 64 * 3 * 32 * 32, device=dev).run(eng64, z64.to(dev)).cpu()
-            d = (got - final64).abs()
             pg, pr = O.to_pixel(got).to(torch.int16), O.to_pixel(final64).to(torch.int16)
-            pd = (pg - pr).abs()
             rms = lambda t: float((t.double() ** 2).mean().sqrt())
-            line["accuracy"] = {"what": "final x of 15-step NI (step_15_weight_173), the 64 images of the cpu_baseline sample, HIP bf16 engine vs the fp32 "
-                                        "oracle on identical noise.  The synthetic network is not a denoiser (|x| reaches 1e3), so the numbers are relative; "
-                                        "tests/test_gpu_accuracy.py has the image-level figures with a well-conditioned denoiser (256 images: mean |dx| "
-                                        "0.0075, 0.67 uint8 steps per pixel) and shows the error equals that of an fp32-accumulate model with bf16 operands",
-                                "rel_rms": round(rms(got - final64) / rms(final64), 5), "rel_max": round(float(d.max() / final64.abs().max()), 5),
-                                "x_abs_max": round(float(final64.abs().max()), 1), "uint8_pixels_differing": round(float((pd > 0).float().mean()), 4),
-                                "uint8_mean_abs_diff": round(float(pd.float().mean()), 4),
-                                "fid": "blocked: checkpoint_8.pth / Inception weights / cifar10_mu_sigma.npz absent"}
-
-    del engine, ni
+            line["accuracy"] = {"rel_rms": r4(rms(got - final64) / rms(final64)), "uint8_mean_abs_diff": r4(float((pg - pr).abs().float().mean())),
+                                "fid": "blocked"}
+    del engine, ni, lanes
     return line
 
 
@@ -455,7 +469,6 @@ def sd3_reduced_depth_accuracy(dev, weights_csv="sd3_step_28_weight_sharp.csv", 
     coefficient file -- final latents of the HIP engine with bf16 operands and with NATINF_MMDIT_FP8 against oracle/mmdit_oracle.py
     (fp32; PARITY UNPINNED) + the oracle's restatement of the loop (src/SD3NaturalInference.py:198-223) on identical noise.
     Checker code: only bench.py's accuracy leg and tests/ call this."""
-    import numpy as np
     import torch
     from oracle import mmdit_oracle as MO, ni_oracle as O
     from naturaldiffusion_amd.coeff import load_sd3_csv
@@ -493,17 +506,11 @@ def sd3_reduced_depth_accuracy(dev, weights_csv="sd3_step_28_weight_sharp.csv", 
         out[name] = {"rel_rms": round(float((d ** 2).mean().sqrt() / (ref ** 2).mean().sqrt()), 5), "rel_max": round(float(d.abs().max() / ref.abs().max()), 5),
                      "mean_abs": round(float(d.abs().mean()), 5), "finite": bool(torch.isfinite(got).all())}
         del eng
-    out["what"] = (f"final latents of 28-step SD3-form NI ({weights_csv}, CFG 7, {n} images, 32x32x16 latents) through a 4-block / 256-wide MMDiT: HIP engine "
-                   "(bf16 operands | fp8 e4m3 image-stream GEMM operands) vs the fp32 oracle + oracle loop on identical noise; latents rms "
-                   f"{float((ref ** 2).mean().sqrt()):.3f}, max {float(ref.abs().max()):.3f}")
     return out
 
 
 def bench_sd3(args, world, rank, dev, fp8=False, steps=2, warmup=1, flat=None):
-    """BASELINE config 4: SD3NaturalInference 28-step (weights/sd3_step_28_weight.csv), 1024x1024 (latents
-    [4,16,128,128] fp16), CFG 7 -> per step ONE batched MMDiT forward of 8 sequences (4,096 image + 333 text tokens) +
-    one fused natinf_step_f16chain launch.  A "step" of this bench = one 4-image batch through all 28 steps.
-    SD3-medium-shaped synthetic weights and synthetic text embeddings (the checkpoint / text encoders are downloads)."""
+    """BASELINE config 4 / 5 (see the module docstring)."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -537,8 +544,8 @@ def bench_sd3(args, world, rank, dev, fp8=False, steps=2, warmup=1, flat=None):
             mean, x = ni.step(k, x, v[:n].reshape(-1), v[n:].reshape(-1), zflat, want_next=k + 1 < nstep)
         return mean
 
-    dt, out = timed_region(lambda i: one_step(), steps, warmup, world, torch.cuda.synchronize, dist, dev)
-    assert torch.isfinite(out.float()).all()
+    dt, outs = timed_region(lambda i: one_step(), steps, warmup, world, torch.cuda.synchronize, dist, dev)
+    assert torch.isfinite(outs[-1].float()).all()
     D, L, tx = 1536, 24, 4096
     T = tx + tc
     flops_fwd_seq = L * (2.0 * T * 3 * D * D + 4.0 * T * T * D + 2.0 * T * D * D + 2.0 * T * 8 * D * D) - 2.0 * tc * 9 * D * D + 2.0 * tc * 4096 * D
@@ -546,15 +553,13 @@ def bench_sd3(args, world, rank, dev, fp8=False, steps=2, warmup=1, flat=None):
     line = {"metric": "images/sec at 28-step Natural Inference (SD3 1024x1024, MMDiT)", "value": round(world * n * steps / dt, 4),
             "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8+bf16" if fp8 else "bf16", "data": "synthetic",
-            "config": {"workload": f"SD3 Natural Inference 28-step ({wname}), 4 images x CFG per GPU = 8 sequences of 4096+333 "
-                                   "tokens per forward, SD3-medium-shaped MMDiT (2.03 B params, synthetic weights) "
-                                   + ("fp8 e4m3 operands for the image-stream q|k, v, fc1 GEMMs, bf16 elsewhere, fp32 acc, " if fp8 else "bf16 MFMA / fp32 acc, ")
-                                   + "ni_step fp16 chain", "nfe": 2 * nstep, "images_per_gpu": n, "sharding": f"batch-sharded x{world}, no collective"},
-            "roofline": {"kernel": "whole forward (k_gemm_dma / k_gemm_fp8 + k_flash_attn64), 2*MAC flops / wall time; peak = dense bf16", "bound": "mfma", "achieved": round(tf, 1),
-                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}}
+            "frac": r4(tf / MFMA_BF16_PEAK_TFLOPS),
+            "config": {"workload": f"SD3 NI 28-step {wname} 1024x1024, 4 img x CFG/GPU = 8 seq x (4096+333) tokens, MMDiT 2.03B " + ("fp8 e4m3 + bf16" if fp8 else "bf16"),
+                       "nfe": 2 * nstep, "images_per_gpu": n, "sharding": f"batch x{world}, no collective"},
+            "roofline": {"kernel": "whole forward", "bound": "mfma", "achieved": r4(tf), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": r4(tf / MFMA_BF16_PEAK_TFLOPS), "traffic": None}}
     if rank == 0 and not args.no_roofline:
         # ---- per-kernel rooflines, measured live with HIP events on the kernels' own ABI entry points at the engine's shapes
-        # ---- (the engine has no per-launch hook; these are the same kernels, same shapes, same process)
         from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
         ev = lambda: torch.cuda.Event(enable_timing=True)
 
@@ -572,10 +577,7 @@ def bench_sd3(args, world, rank, dev, fp8=False, steps=2, warmup=1, flat=None):
         o = torch.empty(Bs, Tp, D, device=dev, dtype=torch.bfloat16)
         t_fa_iso = timed(lambda: check(lib.natinf_attention_hd64_bf16(ptr(q), ptr(q) + 2 * D, 2 * D, Tp * 2 * D, ptr(vT), ptr(o), D, Tp * D, Bs, H, Tp, T, 0.125,
                                                                        stream_ptr()), "attention"))
-        # the same kernel where it actually runs: one more 28-step batch with an event pair around every k_flash_attn64 launch of the
-        # engine (natinf_attention_profile).  Round 2 quoted the isolated back-to-back loop above (1.44 ms) next to rocprof's in-engine
-        # average (1.15 ms): both were right -- a loop of nothing but this kernel draws more power than the GEMM / attention mix of a
-        # forward and gets a lower clock on this power-capped part (rocprofv3 shows the same 1.2 vs 1.4-1.5 ms split, profiles/r03)
+        # the same kernel where it actually runs: one more 28-step batch with an event pair around every k_flash_attn64 launch of the engine
         import ctypes
         check(lib.natinf_attention_profile(1), "attention_profile")
         one_step(); torch.cuda.synchronize()
@@ -584,42 +586,30 @@ def bench_sd3(args, world, rank, dev, fp8=False, steps=2, warmup=1, flat=None):
         check(lib.natinf_attention_profile(0), "attention_profile")
         t_fa = ms_tot.value / max(1, n_l.value) * 1e-3
         fa_flops = 4.0 * T * T * 64 * H * Bs
-        line["roofline"] = {"kernel": "k_flash_attn64 (joint attention, 8 sequences x 24 heads x 4,429 keys, head_dim 64), timed in the engine: HIP events "
-                                      "around each of its launches in one 28-step batch", "bound": "mfma",
-                            "achieved": round(fa_flops / t_fa / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(fa_flops / t_fa / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                            "mean_launch_ms": round(t_fa * 1e3, 4), "launches": int(n_l.value), "flops_per_launch": fa_flops,
-                            "isolated_loop_ms": round(t_fa_iso * 1e3, 4), "launches_per_image_batch": L * nstep,
-                            "share_of_forward_flops": round(L * fa_flops / (flops_fwd_seq * Bs), 3)}
+        line["roofline"] = {"kernel": "k_flash_attn64", "bound": "mfma", "achieved": r4(fa_flops / t_fa / 1e12), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": r4(fa_flops / t_fa / 1e12 / MFMA_BF16_PEAK_TFLOPS), "traffic": None, "mean_launch_ms": r4(t_fa * 1e3), "launches": int(n_l.value),
+                            "flops_per_launch": r4(fa_flops), "iso_ms": r4(t_fa_iso * 1e3), "flop_share": r4(L * fa_flops / (flops_fwd_seq * Bs))}
         M = Bs * tx
-        shapes = [("q|k", 2 * D, D), ("v^T / out", D, D), ("fc1", 4 * D, D), ("fc2", D, 4 * D)]
+        shapes = [("qk", 2 * D, D), ("v_out", D, D), ("fc1", 4 * D, D), ("fc2", D, 4 * D)]
         tot_t, tot_f, tot_ideal, per = 0.0, 0.0, 0.0, {}
         for name, N_, K_ in shapes:
-            if fp8 and name != "v^T / out":
+            if fp8 and name != "v_out":
                 a8 = torch.randint(0, 255, (M, K_), device=dev, dtype=torch.uint8); b8 = torch.randint(0, 255, (N_, K_), device=dev, dtype=torch.uint8)
                 a8 &= 0x77; b8 &= 0x77                                                 # finite e4m3 patterns
                 sa, sb = torch.ones(M, device=dev), torch.ones(N_, device=dev)
                 c = torch.empty(M, N_, device=dev, dtype=torch.bfloat16)
                 t_ = timed(lambda: check(lib.natinf_debug_gemm_fp8(M, N_, K_, ptr(a8), ptr(sa), None, ptr(b8), ptr(sb), None, ptr(c), None, 0, 1, stream_ptr()), "gemm_fp8"))
-                kind = "fp8"
+                pk_ = MFMA_FP8_PEAK_TFLOPS
             else:
                 a = torch.randn(M, K_, device=dev).bfloat16(); b = torch.randn(N_, K_, device=dev).bfloat16()
                 c = torch.empty(M, N_, device=dev, dtype=torch.bfloat16)
                 t_ = timed(lambda: check(lib.natinf_debug_gemm(0, M, N_, K_, 0, 1, 0, 1, ptr(a), None, ptr(b), None, ptr(c), 0, 1.0, 1, stream_ptr()), "gemm"))
-                kind = "bf16"
+                pk_ = MFMA_BF16_PEAK_TFLOPS
             f_ = 2.0 * M * N_ * K_
-            pk_ = 5000.0 if kind == "fp8" else MFMA_BF16_PEAK_TFLOPS
-            per[name] = {"M": M, "N": N_, "K": K_, "operands": kind, "ms": round(t_ * 1e3, 4), "TFLOP/s": round(f_ / t_ / 1e12, 1),
-                         "peak": pk_, "frac": round(f_ / t_ / 1e12 / pk_, 4)}
+            per[name] = [r4(f_ / t_ / 1e12), r4(f_ / t_ / 1e12 / pk_)]             # [TFLOP/s, fraction of the operand type's dense peak]
             tot_t += t_; tot_f += f_; tot_ideal += f_ / (pk_ * 1e12)
-        # one fraction over mixed operand types: the time the dense peaks of each shape's own operand type would need / the time taken
-        line["roofline_gemm"] = {"kernel": ("k_gemm_fp8 (image-stream q|k, fc1, fc2: e4m3 operands, v_mfma_f32_16x16x128_f8f6f4; peak 5,000) + k_gemm_dma (v^T / out: bf16; peak 2,500)" if fp8
-                                            else "k_gemm_dma<2,4,8,4> 256x256 LDS-DMA tiles") + ", image-stream projections of one block",
-                                 "bound": "mfma", "achieved": round(tot_f / tot_t / 1e12, 1), "peak": round(tot_f / tot_ideal / 1e12, 1), "unit": "TFLOP/s",
-                                 "frac": round(tot_ideal / tot_t, 4), "traffic": None, "shapes": per,
-                                 "note": "peak = flop-weighted dense peak of the shapes' operand types; frac = sum(flops_i / peak_i) / sum(time_i)"}
-        line["roofline_whole_forward"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                          "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "note": "2*MAC flops of all matmuls / wall time of the bench (dense bf16 peak)"}
+        line["roofline_gemm"] = {"kernel": "k_gemm_fp8+k_gemm_dma" if fp8 else "k_gemm_dma", "achieved": r4(tot_f / tot_t / 1e12), "peak": r4(tot_f / tot_ideal / 1e12),
+                                 "frac": r4(tot_ideal / tot_t), "shapes": per}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the MMDiT oracle (fp32, eager PyTorch) on ONE sequence through TWO blocks at full width, extrapolated to the
         # ---- 24 blocks x 2 sequences (CFG) x 28 steps of an image -- a full forward on the CPU would take minutes
@@ -635,14 +625,174 @@ def bench_sd3(args, world, rank, dev, fp8=False, steps=2, warmup=1, flat=None):
         MO.forward(Po, xo, to_, eo, po)
         d2 = time.perf_counter() - tcpu
         per_image_s = d2 / 2 * L * 2 * nstep
-        line["cpu_baseline"] = {"value": round(1.0 / per_image_s, 6), "unit": "images/s", "cores": threads, "kind": "port",
-                                "sample": f"oracle/mmdit_oracle.py (fp32): one sequence (4096+333 tokens) through 2 of the 24 blocks in {d2:.1f} s, "
-                                          f"extrapolated x{L // 2} blocks x 2 sequences (CFG) x {nstep} steps = {per_image_s:.0f} s per image; host has {os.cpu_count()} logical CPUs"}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = {"value": r4(1.0 / per_image_s), "unit": "images/s", "cores": threads, "kind": "port",
+                                "sample": f"mmdit oracle fp32: 1 seq x 2 of 24 blocks {d2:.1f}s, extrapolated to {per_image_s:.0f}s/image"}
         del eng
-        line["accuracy"] = sd3_reduced_depth_accuracy(dev, wname)
+        acc = sd3_reduced_depth_accuracy(dev, wname)
+        line["acc"] = {"bf16_rel_rms": acc["bf16"]["rel_rms"], "fp8_rel_rms": acc["fp8"]["rel_rms"], "pinned": False}
         eng = None
     del eng, ni
+    return line
+
+
+def bench_fid50k(args, world, rank, dev, steps=1, warmup=0):
+    """BASELINE config 3 (see the module docstring): generate_sharded + Inception pool3 engine + calc_fid_sharded, both matrices."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from naturaldiffusion_amd import _lib, coeffgen
+    from naturaldiffusion_amd import CIFAR10NaturalInference as M
+    from naturaldiffusion_amd.coeff import load_coeff_npz
+    from naturaldiffusion_amd.fid_stats import ActivationStats, frechet_distance
+    from naturaldiffusion_amd.inception import InceptionEngine, load_fid_inception_weights
+    from naturaldiffusion_amd.ncsnpp import NCSNppEngine, load_score_sde_checkpoint
+    from naturaldiffusion_amd.synth import synthetic_flat_params, synthetic_inception_flat
+    _lib.require_gpu()
+    total = int(args.fid_samples)
+    share_of = world if world > 1 else (args.fid_share_of or 8)           # one GPU: rank 0's share of an 8-way job unless told otherwise
+    vrank = rank if world > 1 else 0
+    ckpt = ROOT / "deps/score_sde_pytorch/checkpoint_8.pth"
+    ref_path = ROOT / "weights/cifar10_mu_sigma.npz"
+    inc_path = M.inception_weights_path()
+    blocked = [n for n, p in (("checkpoint_8.pth", ckpt), ("inception weights", inc_path), ("cifar10_mu_sigma.npz", ref_path)) if not Path(p).exists()]
+    flat = load_score_sde_checkpoint(str(ckpt)) if ckpt.exists() else synthetic_flat_params(0)
+    engine = NCSNppEngine(flat, max_batch=args.batch, device=dev)
+    lanes = [engine] + [engine.clone() for _ in range(max(1, args.streams) - 1)]
+    inception = InceptionEngine(load_fid_inception_weights(inc_path) if Path(inc_path).exists() else synthetic_inception_flat(0), max_batch=50, device=dev)
+    ref = (str(ref_path) if ref_path.exists() else (np.zeros(2048), np.eye(2048)))
+    mats = [("dpmsolverpp2s_018", load_coeff_npz(ROOT / "results/dpmsolverpp/dpmsolverpp2s_018.npz")),
+            ("ddim_vp_018", coeffgen.ddim_vp_continuous(np.linspace(1.0, 1e-3, 19)))]
+    for e_ in lanes:                                                       # set-up, not a step: code objects load, workspaces are touched
+        e_(torch.zeros(2, 3, 32, 32, device=dev), torch.full((2,), 500.0, device=dev))
+    inception(torch.zeros(2, 32, 32, 3, dtype=torch.uint8, device=dev))
+    torch.cuda.synchronize()
+    acc = {"gen": 0.0, "inception": 0.0, "allreduce": 0.0, "frechet": 0.0}
+    res = {}
+
+    def one_step(i):
+        for name, coeff in mats:
+            t0 = time.perf_counter()
+            imgs, idx = M.generate_sharded(lanes, None, total, args.batch, rank=vrank, world=share_of, seed=888, device=dev, to_cpu=False, coeff=coeff)
+            torch.cuda.synchronize()
+            acc["gen"] += time.perf_counter() - t0
+            tm = {}
+            fid = M.calc_fid_sharded(imgs, ref, dev, model=inception, timings=tm)
+            for k in ("inception", "allreduce", "frechet"):
+                acc[k] += tm[k + "_s"]
+            res[name] = {"fid": fid, "images_local": int(imgs.shape[0]), "images_all": tm["images_all_ranks"], "imgs": imgs}
+        return res
+
+    dt, _ = timed_region(one_step, steps, warmup, world, torch.cuda.synchronize, dist, dev)
+    n_local = res[mats[0][0]]["images_local"]
+    n_all = res[mats[0][0]]["images_all"]
+    runs = steps + warmup
+    per = {k: v / runs for k, v in acc.items()}                           # per pass over both matrices
+    line = {"metric": "images/sec generated and FID-scored (CIFAR10 50k-image FID job, DPM-Solver++(2S) and DDIM coefficient matrices, 18 NFE)",
+            "value": round(len(mats) * n_all * steps / dt, 2), "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(dt / steps * 1e3, 1), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "images": n_local, "share_of": share_of, "batches": int(np.ceil(n_local / args.batch)), "last_batch": n_local - (int(np.ceil(n_local / args.batch)) - 1) * args.batch,
+            "s": {k: r4(v) for k, v in per.items()}, "gen_rate": r4(len(mats) * n_local / per["gen"]), "inc_rate": r4(len(mats) * n_local / per["inception"]),
+            "fid": ("blocked" if blocked else {k: r4(v["fid"]) for k, v in res.items()}),
+            "config": {"workload": f"CIFAR10 FID job {total} images / {share_of} shares, dpmsolverpp2s_018.npz + coeffgen.ddim_vp_continuous(19 nodes), B={args.batch}, "
+                                   "Inception pool3 engine in 50s, one statistics all-reduce", "nfe": 18, "streams": len(lanes), "sharding": f"batch x{share_of}"}}
+    if blocked:
+        line["frechet_vs_synthetic_ref"] = {k: r4(v["fid"]) for k, v in res.items()}
+    # untimed sanity figure that needs no asset: the two matrices integrate the same ODE from the same noise with the same network, so their image
+    # statistics must be close (statistics of THIS rank's images)
+    if rank == 0:
+        st = []
+        for name, _ in mats:
+            s_ = ActivationStats(2048, device=dev)
+            im = res[name]["imgs"]
+            for i in range(0, len(im), 50):
+                s_.update(inception(im[i:i + 50]))
+            st.append(s_.mean_cov())
+        line["d_matrices"] = r4(frechet_distance(st[0][0], st[0][1], st[1][0], st[1][1]))
+        inc_tf = INCEPTION_GFLOP_PER_IMAGE * 1e9 * len(mats) * n_local / per["inception"] / 1e12
+        line["roofline"] = {"kernel": "inception pool3 engine (im2col + k_gemm_*, hi+lo filter terms)", "bound": "mfma", "achieved": r4(inc_tf), "peak": MFMA_BF16_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": r4(inc_tf / MFMA_BF16_PEAK_TFLOPS), "traffic": None}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "fid50k":
+        # bounded CPU sample of the same job: 16 images x 18 steps through the oracle denoiser + recurrence, then the Inception oracle on them
+        from oracle import ni_oracle as O, ncsnpp_oracle as N, inception_oracle as IO
+        from naturaldiffusion_amd.synth import synthetic_state_dict
+        threads = max(1, min(32, torch.get_num_threads()))
+        torch.set_num_threads(threads)
+        model = N.model_fn_from_params(synthetic_state_dict(0))
+        z = torch.randn(16, 3, 32, 32, generator=torch.Generator().manual_seed(888))
+        t0 = time.perf_counter()
+        x = O.cifar_ni_trajectory(model, z, *mats[0][1])[-1]
+        IO.forward(IO.make_params(0), O.to_pixel((x + 1) / 2).permute(0, 3, 1, 2).float() / 255)
+        dc = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": r4(16 / dc), "unit": "images/s", "cores": threads, "kind": "port",
+                                "sample": f"16 img x 18 steps oracle NCSN++ fp32 + fp64 recurrence + Inception oracle, {dc:.1f}s"}
+    del engine, lanes, inception, res
+    return line
+
+
+def bench_validate(args, world, rank, dev, steps=3, warmup=1):
+    """SURVEY 8f N2 + N4 (see the module docstring): ValidateNaturalInference.natural_inference("ddim", 24) on the DiT-XL/2 engine + VAE decode."""
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    from naturaldiffusion_amd import _lib
+    from naturaldiffusion_amd import ValidateNaturalInference as V
+    from naturaldiffusion_amd.dit import DiTEngine, flatten_state_dict, XL2
+    from naturaldiffusion_amd.synth import synthetic_dit_state_dict, synthetic_vae_flat
+    from naturaldiffusion_amd.vae import VAEDecoder
+    _lib.require_gpu()
+    n, nstep = 8, 24
+    V.device = str(dev)
+    dit = DiTEngine(flatten_state_dict(synthetic_dit_state_dict(XL2["depth"], XL2["hidden"], seed=0), XL2["depth"], XL2["hidden"]), n, device=dev, **XL2)
+    vae = VAEDecoder(synthetic_vae_flat(4), max_batch=n, latent_ch=4, latent_res=32, device=dev)
+    outdir = Path(tempfile.mkdtemp(prefix="natinf_validate_"))
+    t_acc = {"dit": 0.0, "dit_n": 0, "vae": 0.0, "vae_n": 0}
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    class TimedDiT:
+        def forward(self, z, t, y):
+            a, b = ev(), ev()
+            a.record(); out = dit(z, t, y); b.record()
+            t_acc.setdefault("ev", []).append((a, b))
+            return out
+
+    def decode(latents, path):
+        a, b = ev(), ev()
+        a.record(); img = vae(latents); b.record()
+        t_acc.setdefault("evv", []).append((a, b))
+        V.save_image_grid(img, outdir / Path(path).name)
+        return img
+    V.denoiser_factory, V.decoder_factory = (lambda: TimedDiT()), (lambda: decode)
+    try:
+        dt, outs = timed_region(lambda i: V.natural_inference("ddim", nstep), steps, warmup, world, torch.cuda.synchronize, dist, dev)
+    finally:
+        V.denoiser_factory = V.decoder_factory = None
+    assert torch.isfinite(outs[-1]).all()
+    dit_ms = sum(a.elapsed_time(b) for a, b in t_acc["ev"]) / len(t_acc["ev"])
+    vae_ms = sum(a.elapsed_time(b) for a, b in t_acc["evv"]) / len(t_acc["evv"])
+    dit_fl = XL2["depth"] * 256 * (24 * XL2["hidden"] ** 2 + 4 * 256 * XL2["hidden"]) * n            # 2*MAC per forward of 8 images (tools/bench_dit.py)
+    line = {"metric": "images/sec at 24-step Natural Inference (DiT-XL/2 256x256, CFG 4, DDIM matrix) incl. VAE decode",
+            "value": round(world * n * steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(dt / steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "dit_ms": r4(dit_ms), "dit_forwards": 2 * nstep, "vae_ms": r4(vae_ms),
+            "config": {"workload": "ValidateNaturalInference.natural_inference('ddim', 24): DiT-XL/2 engine B=8, CFG 4 (2 forwards / step), natinf_step_f32prod, "
+                                   "AutoencoderKL decoder engine 8 x 256x256 + PNG row", "nfe": 2 * nstep, "images_per_gpu": n},
+            "roofline": {"kernel": "DiT-XL/2 forward B=8 (k_gemm_* + k_attn_fused)", "bound": "mfma", "achieved": r4(dit_fl / (dit_ms * 1e-3) / 1e12),
+                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": r4(dit_fl / (dit_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS), "traffic": None}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "validate":
+        from oracle import dit_oracle as DO
+        threads = max(1, min(32, torch.get_num_threads()))
+        torch.set_num_threads(threads)
+        P = DO.make_params(4, XL2["hidden"], seed=3)                       # 4 of 28 blocks at full width, extrapolated
+        g = torch.Generator().manual_seed(5)
+        x, t, y = torch.randn(n, 4, 32, 32, generator=g), torch.full((n,), 500.0), torch.zeros(n, dtype=torch.long)
+        t0 = time.perf_counter()
+        DO.forward(P, x, t, y, XL2["heads"])
+        d4 = time.perf_counter() - t0
+        per_batch = d4 / 4 * XL2["depth"] * 2 * nstep
+        line["cpu_baseline"] = {"value": r4(n / per_batch), "unit": "images/s", "cores": threads, "kind": "port",
+                                "sample": f"dit oracle fp32: B=8 through 4 of 28 blocks {d4:.1f}s, extrapolated to {per_batch:.0f}s per 8 images (no VAE)"}
+    del dit, vae
     return line
 
 

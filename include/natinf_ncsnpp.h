@@ -37,9 +37,12 @@ typedef struct natinf_ncsnpp* natinf_ncsnpp_t;
  * reference's docstring names (src/CIFAR10NaturalInference.py:416).  Sizes of such a handle: natinf_ncsnpp_handle_param_count / _packed_bytes. */
 #define NATINF_NCSNPP_DDPM 2
 
-/* Number of fp32 parameters (61,804,419) in the flat order documented at natinf_ncsnpp_load. */
+/* Number of fp32 parameters (61,804,419) of the NCSN++ plan, in the flat order documented at natinf_ncsnpp_load. */
 int64_t natinf_ncsnpp_param_count(void);
-/* Bytes of device memory for the packed (bf16, GEMM-ready) weights + fp32 biases / affine terms. */
+/* Bytes of device memory for the packed (bf16, GEMM-ready) weights + fp32 biases / affine terms: the LARGEST NCSN++ plan (every
+ * plan-build-time fusion on), whatever the natinf_set_* switches are when this is first asked -- a buffer of this size fits every
+ * NCSN++ plan.  Both handle-less queries answer for NCSN++ only; prefer the natinf_ncsnpp_handle_* forms (exact for THIS handle,
+ * and the only ones that know the `ddpm` network). */
 int64_t natinf_ncsnpp_packed_bytes(void);
 int64_t natinf_ncsnpp_handle_param_count(natinf_ncsnpp_t h);      /* of THIS handle's network (NCSN++ or `ddpm`) */
 int64_t natinf_ncsnpp_handle_packed_bytes(natinf_ncsnpp_t h);
@@ -61,6 +64,12 @@ int natinf_ncsnpp_describe(natinf_ncsnpp_t h, char* buf, int cap);
  * `packed` must stay alive and untouched for the life of the handle's forwards. */
 int natinf_ncsnpp_load(natinf_ncsnpp_t h, const float* params_f32, int64_t n_params,
                        void* packed, int64_t packed_bytes, natinf_stream_t stream);
+
+/* A second handle of the same network (same flags, built under the same natinf_set_* switches) adopts the packed weights `loaded` was
+ * loaded with instead of packing its own copy: the packed buffer is read-only during forwards, so one copy serves any number of handles
+ * (one handle per HIP stream: a handle's launch plan writes one workspace at a time).  The buffer must outlive both handles' forwards.
+ * NATINF_ESTATE if `loaded` has no weights yet, NATINF_EINVAL if the two plans do not address the buffer identically. */
+int natinf_ncsnpp_share(natinf_ncsnpp_t h, natinf_ncsnpp_t loaded);
 
 /* out = model(x, labels): x, out [B,3,32,32] fp32 NCHW; labels [B] fp32 (= t*999). */
 int natinf_ncsnpp_forward(natinf_ncsnpp_t h, const float* x, const float* labels, float* out, int B,

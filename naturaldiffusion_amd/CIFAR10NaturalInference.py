@@ -93,27 +93,99 @@ def philox_noise(indices, shape_per_image, seed: int, device="cuda:0") -> torch.
     return out
 
 
+class BatchLanes:
+    """The batch pipeline of ``natural_inference_tx`` / ``generate_sharded``: the batches of a generation job are independent
+    trajectories (reference loop :287-309), so consecutive batches go to ``len(models)`` lanes -- one HIP stream, one denoiser handle and
+    one set of history slabs each -- and the under-occupied launches of one batch run under the other's convolutions.
+    A batch is enqueued end to end (noise, 15-18 forwards + ni_step launches, ``to_pixel``) without the host waiting for the GPU; the uint8
+    images stay on the device until ``finish``; at most ``depth`` batches per lane are enqueued ahead of the GPU."""
+
+    def __init__(self, models, C, B, node, device, depth: int = 2):
+        _lib.require_gpu()
+        self.device = torch.device(device)
+        self.coeff = (C, B, node)
+        self.models = list(models)
+        multi = len(self.models) > 1
+        self.streams = [torch.cuda.Stream(device=self.device) if multi else None for _ in self.models]
+        self.samplers = [dict() for _ in self.models]                   # per lane: batch size -> CifarNI (a ragged last batch gets its own slabs)
+        self.pending = [[] for _ in self.models]
+        self.depth = int(depth)
+        self.count = 0
+        self.out = []
+
+    def _sampler(self, k: int, n: int) -> CifarNI:
+        if n not in self.samplers[k]:
+            self.samplers[k][n] = CifarNI(*self.coeff, n * 3 * 32 * 32, device=self.device)
+        return self.samplers[k][n]
+
+    def submit(self, n: int, noise=None, noise_fn=None) -> torch.Tensor:
+        """One batch of ``n`` images: ``noise`` (drawn on the CALLER's current stream) or ``noise_fn()`` (called on the lane's stream).
+        Returns the uint8 [n, 32, 32, 3] DEVICE tensor the lane will fill."""
+        k = self.count % len(self.models)
+        self.count += 1
+        st = self.streams[k]
+        if len(self.pending[k]) >= self.depth:                          # bound the host's run-ahead (and the noise tensors in flight)
+            self.pending[k].pop(0).synchronize()
+        with torch.cuda.device(self.device):
+            if st is not None and noise is not None:
+                st.wait_stream(torch.cuda.current_stream())
+                noise.record_stream(st)
+            with torch.cuda.stream(st):
+                ni = self._sampler(k, n)                                # (first use allocates on the lane's stream)
+                z = noise if noise is not None else noise_fn()
+                pix = _to_pixel(ni.run(self.models[k], z), 1, to_cpu=False)
+                ev = torch.cuda.Event()
+                ev.record()
+        self.pending[k].append(ev)
+        self.out.append(pix)
+        return pix
+
+    def finish(self):
+        """Wait for every lane (the caller's stream then sees the images); returns the list of per-batch uint8 device tensors."""
+        with torch.cuda.device(self.device):
+            main = torch.cuda.current_stream()
+            for st in self.streams:
+                if st is not None:
+                    main.wait_stream(st)
+        self.pending = [[] for _ in self.models]
+        out, self.out = self.out, []
+        return out
+
+
+def _lane_models(model_fn, streams: int, n_batches: int):
+    """One denoiser per lane.  An ``NCSNppEngine`` is cloned (own launch plan + workspace, shared packed weights); a sequence of callables
+    is taken as given (one lane each); any other callable owns state we cannot duplicate, so it gets one lane."""
+    from .ncsnpp import NCSNppEngine
+    if isinstance(model_fn, (list, tuple)):
+        return list(model_fn)
+    n = max(1, min(int(streams), n_batches))
+    if isinstance(model_fn, NCSNppEngine):
+        return [model_fn] + [model_fn.clone() for _ in range(n - 1)]
+    return [model_fn]
+
+
 @torch.no_grad()
-def generate_sharded(model_fn: Callable, weight_path, sample_count: int, batch_size: int, rank: int = 0, world: int = 1,
-                     seed: int = 888, device="cuda:0"):
+def generate_sharded(model_fn, weight_path, sample_count: int, batch_size: int, rank: int = 0, world: int = 1,
+                     seed: int = 888, device="cuda:0", streams: int = 2, to_cpu: bool = True, coeff=None):
     """Batch-sharded generation (BASELINE config 3): this rank generates the images whose
-    global index is rank, rank+world, ... in batches of ``batch_size`` -- no collective on the data path.
-    Returns (uint8 images [n_local, 32, 32, 3] on the CPU, their global indices)."""
+    global index is rank, rank+world, ... in batches of ``batch_size`` -- no collective on the data path -- on the two-lane pipeline
+    of ``natural_inference_tx`` (``BatchLanes``): Philox noise keyed by the GLOBAL image index drawn on the lane's own stream, uint8 images
+    kept on the device, one copy to the host at the end (none with ``to_cpu=False``: ``calc_fid_sharded`` scores device tensors).
+    ``model_fn``: an ``NCSNppEngine`` (cloned per lane), a sequence of callables (one lane each) or one callable (one lane).
+    ``coeff``: (C, B, node_coeff) instead of a file (matrices from ``coeffgen``).
+    Returns (uint8 images [n_local, 32, 32, 3], their global indices [n_local] int64 on the CPU)."""
     from .shard import rank_batches
-    C, B, node = load_coeff_npz(weight_path)
-    samplers = {}
-    imgs, idxs = [], []
-    for batch in rank_batches(sample_count, batch_size, rank, world):
-        n = len(batch)
-        if n not in samplers:                                   # the ragged last batch gets its own slabs
-            samplers[n] = CifarNI(C, B, node, n * 3 * 32 * 32, device=device)
-        noise = philox_noise(batch, (3, 32, 32), seed, device)
-        out = samplers[n].run(model_fn, noise)
-        imgs.append(to_pixel_from_centered(out))
-        idxs.append(torch.tensor(batch, dtype=torch.int64))
-    if not imgs:
-        return torch.empty((0, 32, 32, 3), dtype=torch.uint8), torch.empty(0, dtype=torch.int64)
-    return torch.cat(imgs), torch.cat(idxs)
+    C, B, node = coeff if coeff is not None else load_coeff_npz(weight_path)
+    batches = list(rank_batches(sample_count, batch_size, rank, world))
+    dev = torch.device(device)
+    if not batches:
+        return torch.empty((0, 32, 32, 3), dtype=torch.uint8, device="cpu" if to_cpu else dev), torch.empty(0, dtype=torch.int64)
+    lanes = BatchLanes(_lane_models(model_fn, streams, len(batches)), C, B, node, dev)
+    for batch in batches:
+        lanes.submit(len(batch), noise_fn=lambda b=batch: philox_noise(b, (3, 32, 32), seed, dev))
+    imgs = torch.cat(lanes.finish())
+    idxs = torch.cat([torch.tensor(b, dtype=torch.int64) for b in batches])
+    return (imgs.cpu() if to_cpu else imgs), idxs
 
 
 INCEPTION_WEIGHTS = "pt_inception-2015-12-05-6726825d.pth"      # what pytorch_fid downloads on first use (FID_WEIGHTS_URL)
@@ -156,29 +228,59 @@ def calc_fid(imgs, ref_path, device, model=None):
     """Reference :73-86 (InceptionV3 pool3 + Frechet distance).  Needs the Inception weights and the ``cifar10_mu_sigma.npz``
     statistics, neither of which ships with the reference."""
     from .fid_stats import frechet_distance
-    if not os.path.exists(ref_path):
-        raise FileNotFoundError(f"fid: blocked -- {ref_path} (CIFAR10 Inception statistics) is missing")
+    ref_mu, ref_sigma = _ref_statistics(ref_path)
     model = model or fid_inception(device, tuple(imgs.shape[1:3]))
     act = get_activation(imgs, model, 2048, device)
     mu, sigma = np.mean(act, axis=0), np.cov(act, rowvar=False)
-    ref = np.load(ref_path)
-    return frechet_distance(ref["mu"], ref["sigma"], mu, sigma)
+    return frechet_distance(ref_mu, ref_sigma, mu, sigma)
 
 
-def calc_fid_sharded(imgs, ref_path, device, group=None, model=None):
-    """``calc_fid`` for a batch-sharded run: every rank scores ITS images, the (count, sum, outer-product sum) statistics
-    are summed over ranks with one all-reduce (fid_stats.ActivationStats), and every rank returns the same FID."""
+def _ref_statistics(ref):
+    """``ref``: path of a ``cifar10_mu_sigma.npz``-style file (keys mu, sigma) or a (mu, sigma) pair."""
+    if isinstance(ref, (tuple, list)):
+        return np.asarray(ref[0]), np.asarray(ref[1])
+    if not os.path.exists(ref):
+        raise FileNotFoundError(f"fid: blocked -- {ref} (CIFAR10 Inception statistics) is missing")
+    f = np.load(ref)
+    return f["mu"], f["sigma"]
+
+
+def calc_fid_sharded(imgs, ref_path, device, group=None, model=None, timings: Optional[dict] = None):
+    """``calc_fid`` for a batch-sharded run: every rank scores ITS images (uint8 [n_local, H, W, 3], on the device or the host) in the
+    reference's batches of 50, the (count, sum, outer-product sum) statistics are summed over ranks with ONE all-reduce (33.6 MB of fp64,
+    fid_stats.ActivationStats) instead of gathering images or activations, and every rank returns the same FID.  ``timings`` (optional
+    dict) receives the wall seconds of the three parts: inception_s, allreduce_s, frechet_s."""
+    import time
     from .fid_stats import ActivationStats, frechet_distance
-    if not os.path.exists(ref_path):
-        raise FileNotFoundError(f"fid: blocked -- {ref_path} (CIFAR10 Inception statistics) is missing")
+    ref_mu, ref_sigma = _ref_statistics(ref_path)
     model = model or fid_inception(device, tuple(imgs.shape[1:3]))
+    dev = torch.device(device)
+    sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)
+    t0 = time.perf_counter()
     st = ActivationStats(2048, device=device)
     for i in range(0, len(imgs), 50):
         st.update(model(imgs[i:i + 50]))
+    sync()
+    t1 = time.perf_counter()
     st.all_reduce(group)
+    sync()
+    t2 = time.perf_counter()
     mu, cov = st.mean_cov()
-    ref = np.load(ref_path)
-    return frechet_distance(ref["mu"], ref["sigma"], mu, cov)
+    fid = frechet_distance(ref_mu, ref_sigma, mu, cov)
+    if timings is not None:
+        timings.update(inception_s=t1 - t0, allreduce_s=t2 - t1, frechet_s=time.perf_counter() - t2, images_all_ranks=int(float(st.n)))
+    return fid
+
+
+class FidBlocked:
+    """What ``natural_inference_tx(compute_fid=True)`` returns when the FID assets (Inception weights, ``cifar10_mu_sigma.npz``) are absent:
+    the images it generated and the reason -- distinguishable from both a FID value (float) and the ``compute_fid=False`` result (a tensor)."""
+
+    def __init__(self, images: torch.Tensor, reason: str):
+        self.images, self.reason = images, reason
+
+    def __repr__(self):
+        return f"FidBlocked({tuple(self.images.shape)}, {self.reason!r})"
 
 
 @torch.no_grad()
@@ -207,39 +309,22 @@ def natural_inference_tx(batch_size: int = 500,
     print(weight_path)
     bz = batch_size
     num = int(np.ceil(sample_count / bz))
-    n_str = max(1, min(int(streams), num))
-    side = [torch.cuda.Stream(device=device) for _ in range(n_str)] if n_str > 1 else [None]
-    engines, nis = [], []
-    for st in side:                                       # every lane's buffers are allocated (and its weights packed) on the stream that will use them
-        with torch.cuda.stream(st):
-            engines.append(NCSNppEngine(flat_params, max_batch=batch_size, device=device))
-            nis.append(CifarNI(C, B, node, bz * 3 * 32 * 32, device=device))
+    engine = NCSNppEngine(flat_params, max_batch=batch_size, device=device)
+    lanes = BatchLanes(_lane_models(engine, streams, num), C, B, node, device)       # the second lane shares the first's packed weights
     torch.cuda.synchronize(torch.device(device))
     torch.manual_seed(seed)
-    all_batch = []
-    main = torch.cuda.current_stream(torch.device(device))
     for ii in range(num):
         print("processing", ii)
-        noise = torch.randn(bz, 3, 32, 32, dtype=torch.float32, device=device)
-        k = ii % n_str
-        if side[k] is None:
-            all_batch.append(to_pixel_from_centered(nis[k].run(engines[k], noise)))
-            continue
-        side[k].wait_stream(main)                        # the noise was drawn on the caller's stream
-        noise.record_stream(side[k])
-        with torch.cuda.stream(side[k]):
-            all_batch.append(_to_pixel(nis[k].run(engines[k], noise), 1, to_cpu=False))      # uint8 on the device: nothing here waits for the GPU
-    for st in side:
-        if st is not None:
-            main.wait_stream(st)
-    all_batch = torch.concatenate([t.cpu() for t in all_batch])
+        noise = torch.randn(bz, 3, 32, 32, dtype=torch.float32, device=device)      # the reference's stream of normals, in its order (:290)
+        lanes.submit(bz, noise=noise)
+    all_batch = torch.concatenate(lanes.finish()).cpu()                                # ONE copy to the host, after the last batch
     if not compute_fid:
         return all_batch
     try:
         fid_value = calc_fid(all_batch, root_path / "weights/cifar10_mu_sigma.npz", device)
     except FileNotFoundError as e:                          # the assets are downloads: say so, keep the images
         print(e)
-        return all_batch
+        return FidBlocked(all_batch, str(e))
     print(fid_value)
     print(weight_path)
     print(C / np.diag(C)[:, None])

@@ -48,6 +48,7 @@ SIGNATURES = {
     "natinf_ncsnpp_describe": (C.c_int, [_p, C.c_char_p, _i32]),
     "natinf_ncsnpp_destroy": (C.c_int, [_p]),
     "natinf_ncsnpp_load": (C.c_int, [_p, _p, _i64, _p, _i64, _p]),
+    "natinf_ncsnpp_share": (C.c_int, [_p, _p]),
     "natinf_ncsnpp_forward": (C.c_int, [_p, _p, _p, _p, _i32, _p, _i64, _p]),
     "natinf_ncsnpp_debug_tap": (C.c_int, [_p, _i32, _p, _i64, _p]),
     "natinf_ncsnpp_describe_gemms": (C.c_int, [_p, _i32, C.c_char_p, _i32]),

@@ -1355,10 +1355,12 @@ natinf_ncsnpp* make_engine(int flags) {
 // A/B knobs are set to when they are first asked -- a packed buffer of that size fits every plan.
 const natinf_ncsnpp& reference_engine() {
     static natinf_ncsnpp* e = [] {
-        const int fg = g_fuse_gn, fu = g_fuse_up, fh = g_fuse_head, f8 = g_fuse_gn8;
-        g_fuse_gn = 1; g_fuse_up = 1; g_fuse_head = 1; g_fuse_gn8 = 1;
+        // every knob that is read when a plan is BUILT and adds a repacked weight copy or a table: saved, forced on, restored
+        int* knobs[] = {&g_fuse_gn, &g_fuse_up, &g_fuse_head, &g_fuse_gn8, &g_fuse_gn4, &g_fuse_fin, &g_attn_qkv, &g_attn_proj, &g_attn256};
+        int saved[sizeof(knobs) / sizeof(knobs[0])];
+        for (size_t i = 0; i < sizeof(knobs) / sizeof(knobs[0]); ++i) { saved[i] = *knobs[i]; *knobs[i] = 1; }
         natinf_ncsnpp* r = make_engine(0);
-        g_fuse_gn = fg; g_fuse_up = fu; g_fuse_head = fh; g_fuse_gn8 = f8;
+        for (size_t i = 0; i < sizeof(knobs) / sizeof(knobs[0]); ++i) *knobs[i] = saved[i];
         return r;
     }();
     return *e;
@@ -1416,6 +1418,17 @@ int natinf_ncsnpp_load(natinf_ncsnpp_t h, const float* params_f32, int64_t n_par
     for (const auto& f : h->packs) f(p);
     h->packed = reinterpret_cast<const unsigned char*>(packed);
     return hipGetLastError() == hipSuccess ? NATINF_OK : NATINF_ELAUNCH;
+}
+
+int natinf_ncsnpp_share(natinf_ncsnpp_t h, natinf_ncsnpp_t loaded) {
+    if (!h || !loaded || h == loaded) return NATINF_EINVAL;
+    if (!loaded->packed) return NATINF_ESTATE;
+    // same network, same plan-build-time switches: the two plans address the packed buffer identically
+    if ((h->flags & NATINF_NCSNPP_DDPM) != (loaded->flags & NATINF_NCSNPP_DDPM) || h->n_params != loaded->n_params || h->packed_bytes != loaded->packed_bytes ||
+        h->packs.size() != loaded->packs.size())
+        return NATINF_EINVAL;
+    h->packed = loaded->packed;
+    return NATINF_OK;
 }
 
 int natinf_ncsnpp_forward(natinf_ncsnpp_t h, const float* x, const float* labels, float* out, int B, void* workspace,

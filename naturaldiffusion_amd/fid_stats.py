@@ -31,11 +31,18 @@ class ActivationStats:
         self.s2 += a.t() @ a
 
     def all_reduce(self, group=None) -> None:
-        """sum the statistics of all ranks in place (one flat buffer, one collective)"""
+        """sum the statistics of all ranks in place (one flat buffer, one collective; a no-op without a process group or at world size 1).
+        RCCL reduces device tensors in place; under gloo (CPU tests, two ranks on one GPU) the buffer goes through the host."""
         import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
         flat = torch.cat([self.n.reshape(1), self.s1, self.s2.reshape(-1)])
+        dev = flat.device
+        if dist.get_backend(group) == "gloo" and dev.type != "cpu":
+            flat = flat.cpu()
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        self.n, self.s1, self.s2 = flat[0], flat[1:1 + self.dim].clone(), flat[1 + self.dim:].reshape(self.dim, self.dim).clone()
+        flat = flat.to(dev)
+        self.n, self.s1, self.s2 = flat[0].clone(), flat[1:1 + self.dim].clone(), flat[1 + self.dim:].reshape(self.dim, self.dim).clone()
 
     def mean_cov(self) -> Tuple[np.ndarray, np.ndarray]:
         """(mean, unbiased covariance) as ``np.mean(act, 0)`` / ``np.cov(act, rowvar=False)`` give them (reference :84-85)"""

@@ -132,7 +132,8 @@ class NCSNppEngine:
         self.max_batch = int(max_batch)
         self.arch = arch
         self._h = C.c_void_p()
-        check(lib.natinf_ncsnpp_create(C.byref(self._h), (KEEP_ACTIVATIONS if keep_activations else 0) | ARCH_FLAGS[arch]), "natinf_ncsnpp_create")
+        self._flags = (KEEP_ACTIVATIONS if keep_activations else 0) | ARCH_FLAGS[arch]
+        check(lib.natinf_ncsnpp_create(C.byref(self._h), self._flags), "natinf_ncsnpp_create")
         n = lib.natinf_ncsnpp_handle_param_count(self._h)
         if flat_params.numel() != n:
             raise ValueError(f"expected {n} parameters, got {flat_params.numel()}")
@@ -145,6 +146,23 @@ class NCSNppEngine:
             ws = lib.natinf_ncsnpp_workspace_bytes(self._h, self.max_batch)
             self._ws = torch.empty(ws, dtype=torch.uint8, device=self.device)
         self.workspace_bytes = ws
+
+    def clone(self, max_batch: int = None) -> "NCSNppEngine":
+        """A second handle of the same network for a second HIP stream: its own launch plan and workspace, the SAME packed weights
+        (``natinf_ncsnpp_share``: read-only during forwards, so one 124 MB copy serves every lane)."""
+        other = object.__new__(NCSNppEngine)
+        other.device, other.arch = self.device, self.arch
+        other.max_batch = int(max_batch or self.max_batch)
+        other._h = C.c_void_p()
+        check(lib.natinf_ncsnpp_create(C.byref(other._h), self._flags), "natinf_ncsnpp_create")
+        check(lib.natinf_ncsnpp_share(other._h, self._h), "natinf_ncsnpp_share")
+        other._flags = self._flags
+        other._packed = self._packed                       # keeps the shared buffer alive as long as any handle lives
+        with torch.cuda.device(self.device):
+            ws = lib.natinf_ncsnpp_workspace_bytes(other._h, other.max_batch)
+            other._ws = torch.empty(ws, dtype=torch.uint8, device=self.device)
+        other.workspace_bytes = ws
+        return other
 
     def __call__(self, x: torch.Tensor, labels: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         if x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (3, 32, 32) or not x.is_cuda:

@@ -86,3 +86,42 @@ def synthetic_mmdit_flat(grid: int, layers: int, heads: int, joint_dim: int, poo
         else:
             parts.append((torch.randn(shp, generator=g) * 0.02).reshape(-1))
     return torch.cat(parts)
+
+
+def synthetic_inception_flat(seed: int = 0) -> torch.Tensor:
+    """Stand-in FID Inception-V3 weights (``pt_inception-2015-12-05-6726825d.pth`` is a download the image does not hold): in
+    ``inception.param_layout()`` order, variance-preserving uniform filters and non-identity BatchNorm statistics, so that the pool3
+    features of random images are O(1) and distinct per image.  Lets the FID epilogue of a 50k-image job RUN (timing, sharding, the
+    statistics all-reduce); the number it produces is not a FID -- the callers print ``fid: blocked``."""
+    from .inception import param_layout as inc_layout
+    g = torch.Generator().manual_seed(1000 + seed)
+    parts = []
+    for name, shp in inc_layout():
+        if name.endswith("conv.weight"):
+            fan_in = shp[1] * shp[2] * shp[3]
+            t = (torch.rand(shp, generator=g) * 2 - 1) * math.sqrt(6.0 / fan_in)
+        elif name.endswith("bn.weight"):
+            t = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif name.endswith("running_var"):
+            t = 0.5 + torch.rand(shp, generator=g)
+        else:
+            t = 0.1 * torch.randn(shp, generator=g)
+        parts.append(t.reshape(-1))
+    return torch.cat(parts)
+
+
+def synthetic_vae_flat(latent_ch: int = 4, seed: int = 0) -> torch.Tensor:
+    """Stand-in AutoencoderKL decoder weights in ``vae.param_layout`` order behind an identity ``post_quant_conv``: norm scales 1,
+    biases small, filters / matrices ~ N(0, 1 / fan_in)."""
+    from .vae import param_layout as vae_layout
+    g = torch.Generator().manual_seed(2000 + seed)
+    parts = [torch.eye(latent_ch).reshape(-1), torch.zeros(latent_ch)]
+    for name, shape in vae_layout(latent_ch):
+        if name.endswith(("norm1.weight", "norm2.weight", "norm.weight", "norm_out.weight")):
+            parts.append(torch.ones(shape).reshape(-1))
+        elif len(shape) == 1:
+            parts.append(0.01 * torch.randn(shape, generator=g))
+        else:
+            fan = int(np.prod(shape[1:]))
+            parts.append((torch.randn(shape, generator=g) / fan ** 0.5).reshape(-1))
+    return torch.cat(parts)

@@ -1,9 +1,10 @@
 """GPU parity tests of the NCSN++ HIP engine against the fp32 oracle (itself pinned to the reference's
 nn.Module by tests/test_oracle_ncsnpp.py).  bf16 operands / fp32 accumulate vs an fp32 reference:
 tolerance = 3e-2 of the max magnitude on the network output (SURVEY section 7 proposes <= 3e-2 for bf16
-paths; observed 1.4e-2..1.6e-2) and 4e-2 on every intermediate module output (observed 4e-3 at the stem
-rising to 3.2e-2 in the deepest 4x4 blocks, then falling again); the observed errors are printed and written
-to gpurun_out/ for the record."""
+paths; observed 1.75e-2..1.8e-2) and a PER-LEVEL bound on every intermediate module output (TOL_BY_LEVEL below:
+about 1.2x the largest error observed at that level over the B = 2 and B = 512 plans -- 4e-3 at the stem rising to
+3.5e-2 in the 4x4 blocks, whose outputs are small differences of large sums, then falling again); the observed
+errors are printed and written to gpurun_out/ for the record."""
 import json
 import os
 
@@ -17,7 +18,18 @@ from oracle import ncsnpp_oracle as N
 from oracle import ni_oracle as O
 
 TOL = 3e-2          # final output
-TOL_MODULE = 4e-2   # any intermediate module output (deepest 4x4 blocks reach 3.2e-2)
+# (first module, last module, bound, observed max over rounds 2-3 at B = 2 / B = 512): the module table is ncsnpp.module_table()
+TOL_BY_LEVEL = [(2, 2, 6e-3, "stem 4.3e-3"), (3, 7, 1.2e-2, "down 32x32: 9.4e-3"), (8, 16, 1.8e-2, "down 16x16 + attention: 1.47e-2"),
+                (17, 21, 2.2e-2, "down 8x8: 1.8e-2"), (22, 34, 3.8e-2, "4x4 level, middle and 4x4 up blocks: 3.33e-2 (B = 2, module 27) / 3.48e-2 (B = 512, module 29)"),
+                (35, 40, 2.9e-2, "up 8x8: 2.46e-2"), (41, 47, 2.7e-2, "up 16x16: 2.25e-2"), (48, 52, 1.9e-2, "up 32x32: 1.5e-2")]
+
+
+def tol_module(k: int) -> float:
+    return next(t for a, b, t, _ in TOL_BY_LEVEL if a <= k <= b)
+
+
+def first_module_over_its_bound(report):
+    return next((k for k in range(2, 53) if report[f"tap{k:02d}"] > tol_module(k)), None)
 
 
 @pytest.fixture(scope="module")
@@ -65,8 +77,8 @@ def test_forward_per_module(dev, params, flat, golden_dir, repo_root):
     (repo_root / "gpurun_out" / "ncsnpp_tap_errors.json").write_text(json.dumps(report, indent=1))
     print("per-module max-rel errors:", json.dumps(report))
     assert torch.isfinite(y).all()
-    first_bad = next((k for k in range(2, 53) if report[f"tap{k:02d}"] > TOL_MODULE), None)
-    assert first_bad is None, f"module {first_bad} first exceeds {TOL_MODULE}: {report[f'tap{first_bad:02d}']:.3e}"
+    first_bad = first_module_over_its_bound(report)
+    assert first_bad is None, f"module {first_bad} first exceeds its level's bound {tol_module(first_bad)}: {report[f'tap{first_bad:02d}']:.3e}"
     assert report["y"] <= TOL, report["y"]
 
 
@@ -180,7 +192,7 @@ def test_per_module_taps_at_the_benchmarked_batch(dev, params, flat, golden_dir,
     """Round-2 review, weak #2: the 51 per-module taps at B = 512 -- where k_conv_gn2 launches thousands of blocks and the dispatcher picks
     the LDS-DMA tiles bench.py is timed on -- not only at B = 2.  The two golden samples ride in slots 0-1 and 510-511 of a batch of
     random neighbours on a keep_activations plan (28.7 MB per image: 14.7 GB); every module output of both pairs is held to the same
-    TOL_MODULE as the B = 2 test, and the two pairs are bit-identical to each other at every module."""
+    per-level bound (TOL_BY_LEVEL) as the B = 2 test, and the two pairs are bit-identical to each other at every module."""
     from naturaldiffusion_amd.ncsnpp import NCSNppEngine
     fx = np.load(golden_dir / "ncsnpp_forward.npz")
     gx, gl = torch.from_numpy(fx["x"]), torch.from_numpy(fx["labels"])
@@ -206,8 +218,8 @@ def test_per_module_taps_at_the_benchmarked_batch(dev, params, flat, golden_dir,
     os.makedirs(repo_root / "gpurun_out", exist_ok=True)
     (repo_root / "gpurun_out" / "ncsnpp_tap_errors_b512.json").write_text(json.dumps(report, indent=1))
     print("per-module max-rel errors at B = 512:", json.dumps(report))
-    first_bad = next((k for k in range(2, 53) if report[f"tap{k:02d}"] > TOL_MODULE), None)
-    assert first_bad is None, f"module {first_bad} first exceeds {TOL_MODULE}: {report[f'tap{first_bad:02d}']:.3e}"
+    first_bad = first_module_over_its_bound(report)
+    assert first_bad is None, f"module {first_bad} first exceeds its level's bound {tol_module(first_bad)}: {report[f'tap{first_bad:02d}']:.3e}"
     assert report["y"] <= TOL, report["y"]
 
 
