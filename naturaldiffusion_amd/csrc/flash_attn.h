@@ -215,4 +215,218 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64(const FlashArgs a)
     }
 }
 
+// ---- Round 4: k_flash_attn64_v2 -- fewer vector instructions per score, and no cross-lane chain on the critical path ----------------------
+// Per key tile and wave the kernel above issues 64 MFMAs next to ~215 plain vector instructions and 66 v_exp_f32 (ISA census of the built loop: 64
+// v_fma for scale * s - scale * m, 32 v_max3, 32 v_cvt_pk, ~41 adds for the row sums, 16 v_pk_mul for the O rescale) and, before the first exp2 of a
+// tile can issue, walks max -> ds_bpermute -> max -> ds_bpermute -> max -> exp2: a serial cross-lane chain through the LDS pipe, twice per tile.
+// Here:
+//   * Q is multiplied by scale * log2(e) ONCE when it is loaded (one more bf16 rounding of q), and the score accumulators START at -m_ref (the MFMA's
+//     C operand: a register quadruple per query group that only changes when the reference does) -- S^T leaves the matrix pipe as the exponent
+//     itself: no per-score fma;
+//   * the reference m_ref is the running maximum as of the last RE-REFERENCING, not of every tile: a tile re-references (cross-lane maximum, exp2,
+//     rescale of O and l, subtract from the tile's scores) only when some score of the wave exceeds its reference by more than FA_THR (2^8: P stays
+//     <= 256, far inside bf16 / fp32 range; softmax is invariant to the reference, so this is exact up to rounding) -- a wave-uniform branch taken in
+//     the first tile and then a handful of times per query block on real score distributions; the common path has NO cross-lane operation;
+//   * SUMS = 1: the row sums ride on the matrix pipe -- an all-ones A operand in front of P^T (8 more MFMAs per tile instead of ~41 vector adds;
+//     the sum then uses the bf16-rounded P the numerator uses, and arrives complete in every lane: no final cross-lane reduction).
+// Common path per tile and wave: 64 (+8) MFMAs, 64 v_exp_f32, 32 v_max3, 32 v_cvt_pk, a compare.  tests/test_gpu_mmdit.py forces the branch at a
+// chosen tile (spiked key) and checks both kernels against an fp64 softmax.
+constexpr float FA_THR = 8.0f;
+
+template <int SUMS>
+__global__ __launch_bounds__(256, 2) void k_flash_attn64_v2(const FlashArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nQ = a.Tp / FA_QB, nK = a.Tp / FA_KT;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = tile / nQ, qb = tile - bh * nQ, b = bh / a.H, head = bh - b * a.H;
+    const bf16* qbase = a.q + (int64_t)b * a.qk_bs + head * 64;
+    const bf16* kbase = a.k + (int64_t)b * a.qk_bs + head * 64;
+    const bf16* vbase = a.vT + (int64_t)b * a.vT_bs + (int64_t)head * 64 * a.Tp;
+
+    const int prow = lane >> 3, pch = lane & 7;
+    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+        unsigned char* st = smem + buf * FA_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = wave * 4 + j, row = 8 * p + prow;
+            const int f = ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
+            __builtin_amdgcn_global_load_lds(kbase + (int64_t)(kt * FA_KT + row) * a.ld_qk + ((pch ^ f) << 3), (lds_void*)(st + p * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = wave * 4 + j, sub = p >> 3, d = 8 * (p & 7) + prow;
+            __builtin_amdgcn_global_load_lds(vbase + (int64_t)d * a.Tp + kt * FA_KT + sub * 64 + ((pch ^ ((d >> 1) & 7)) << 3),
+                                             (lds_void*)(st + 16384 + p * 1024), 16, 0, 0);
+        }
+    };
+    issue(0, 0);
+
+    bf16x8 qf[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 raw = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)(qb * FA_QB + wave * 32 + 16 * g + r) * a.ld_qk + 32 * ks + 8 * q);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qf[g][ks][i] = (bf16)((float)raw[i] * a.c1);
+        }
+
+    float mref[2] = {0.f, 0.f}, l[2] = {0.f, 0.f};
+    f32x4 cinit[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // -m_ref: the C operand of every score tile's first MFMA
+    f32x4 lsum[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 oacc[2][4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { oacc[0][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc[1][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
+
+    const int krow = 8 * (r >> 2) + (r & 3), swz = r >> 1;
+    for (int kt = 0; kt < nK; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nK) issue(kt + 1, (kt + 1) & 1);
+        const unsigned char* sK = smem + (kt & 1) * FA_STAGE;
+        const unsigned char* sV = sK + 16384;
+
+        f32x4 acc[2][8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = 32 * (t >> 1) + 4 * (t & 1) + krow;
+            const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(sK + row * 128 + (((0 + q) ^ swz) << 4));
+            const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(sK + row * 128 + (((4 + q) ^ swz) << 4));
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, qf[0][0], cinit[0], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, qf[1][0], cinit[1], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, qf[0][1], acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, qf[1][1], acc[1][t], 0, 0, 0);
+        }
+        if (kt == nK - 1 && a.Ttot < a.Tp) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = kt * FA_KT + 32 * (t >> 1) + 8 * q + 4 * (t & 1) + i < a.Ttot;
+                    acc[0][t][i] = ok ? acc[0][t][i] : -INFINITY;
+                    acc[1][t][i] = ok ? acc[1][t][i] : -INFINITY;
+                }
+        }
+        // the lane's largest exponent of each query group (relative to the group's reference)
+        float lm[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float mx = acc[g][0][0];
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, acc[g][t][i]);
+            lm[g] = mx;
+        }
+        if (kt == 0 || __any(fmaxf(lm[0], lm[1]) > FA_THR)) {
+            // re-reference: the FIRST tile takes the true column maximum (whatever its sign); later tiles only raise the reference
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float mx = lm[g];
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float d = kt == 0 ? mx : fmaxf(mx, 0.f);
+                mref[g] += d;
+                cinit[g] = f32x4{-mref[g], -mref[g], -mref[g], -mref[g]};
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[g][t][i] -= d;
+                if (kt > 0) {                                                  // (first tile: O = l = 0, and exp2(-d) may overflow for a negative maximum)
+                    const float alpha = __builtin_amdgcn_exp2f(-d);
+                    l[g] *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lsum[g][i] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) oacc[g][dt][i] *= alpha;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(acc[g][t][i]);
+                    acc[g][t][i] = p;
+                    if constexpr (!SUMS) s += p;
+                }
+            if constexpr (!SUMS) l[g] += s;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x8 pf[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { pf[g][i] = (bf16)acc[g][2 * c][i]; pf[g][4 + i] = (bf16)acc[g][2 * c + 1][i]; }
+            if constexpr (SUMS) {
+                lsum[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[0], lsum[0], 0, 0, 0);
+                lsum[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[1], lsum[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 fv = *reinterpret_cast<const bf16x8*>(sV + (c >> 1) * 8192 + (16 * dt + r) * 128 + (((4 * (c & 1) + q) ^ swz) << 4));
+                oacc[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pf[0], oacc[0][dt], 0, 0, 0);
+                oacc[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pf[1], oacc[1][dt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float s;
+        if constexpr (SUMS) s = lsum[g][0];                                   // every row of the all-ones product is the complete row sum
+        else {
+            s = l[g];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+        }
+        const float inv = 1.0f / s;
+        const int64_t qrow = (int64_t)b * a.Tp + qb * FA_QB + wave * 32 + 16 * g + r;
+        if (a.o8) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                float amax = 0.f;
+#pragma unroll
+                for (int dt = 2 * blk; dt < 2 * blk + 2; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fabsf(oacc[g][dt][i] * inv));
+                amax = fmaxf(amax, __shfl_xor(amax, 16));
+                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                float qinv;
+                const unsigned e8 = mx_scale_of(amax, qinv);
+                qinv *= inv;
+#pragma unroll
+                for (int dt = 2 * blk; dt < 2 * blk + 2; ++dt)
+                    *reinterpret_cast<unsigned*>(a.o8 + qrow * (a.H * 64) + head * 64 + 16 * dt + 4 * q) =
+                        pack_fp8x4(oacc[g][dt][0] * qinv, oacc[g][dt][1] * qinv, oacc[g][dt][2] * qinv, oacc[g][dt][3] * qinv);
+                if (q == 0)
+                    a.omx[(int64_t)b * a.Tp * (a.H * 2) + ((int64_t)(head >> 1) * a.Tp + (qrow - (int64_t)b * a.Tp)) * 4 + (head & 1) * 2 + blk] = (uint8_t)e8;
+            }
+            continue;
+        }
+        bf16* orow = a.o + (int64_t)b * a.o_bs + (int64_t)(qb * FA_QB + wave * 32 + 16 * g + r) * a.ld_o + head * 64 + 4 * q;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = (bf16)(oacc[g][dt][i] * inv);
+            *reinterpret_cast<bf16x4*>(orow + 16 * dt) = w;
+        }
+    }
+}
+
 }  // namespace ncsn

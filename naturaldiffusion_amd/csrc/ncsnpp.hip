@@ -304,7 +304,9 @@ bool configure_gemm_kernels() {
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
          set_lds<AttnCfg<2, 4>>(&k_attn_fused<2, 4>) && set_lds<AttnCfg<3, 6>>(&k_attn_fused<3, 6>) &&
          set_lds<AttnCfg<3, 5>>(&k_attn_fused<3, 5>) &&
-         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess;
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess &&
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64_v2<0>), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess &&
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64_v2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess;
     if (!ok) (void)hipGetLastError();
     return ok;
 }

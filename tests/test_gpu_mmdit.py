@@ -9,16 +9,52 @@ pytestmark = pytest.mark.gpu
 TOL = 3e-2          # max |engine - oracle| / max |oracle|, bf16 operands vs fp32 oracle
 
 
+@pytest.fixture(params=[0, 1, 2], ids=["online", "deferred", "deferred+mfma_sums"])
+def flash_mode(request):
+    """every head_dim-64 attention kernel of the library (natinf_set_flash_mode): the parity cases run on all of them"""
+    from naturaldiffusion_amd._lib import lib, check
+    check(lib.natinf_set_flash_mode(request.param), "natinf_set_flash_mode")
+    yield request.param
+    check(lib.natinf_set_flash_mode(0), "natinf_set_flash_mode")
+
+
+def _softmax_ref64(q, k, v, B, T, H):
+    hd = lambda t: t.double().reshape(B, T, H, 64).transpose(1, 2)
+    w = torch.softmax(hd(q) @ hd(k).transpose(-2, -1) * 0.125, dim=-1)
+    return (w @ hd(v)).transpose(1, 2).reshape(B, T, H * 64)
+
+
 @pytest.mark.parametrize("B,T,H", [(2, 128, 2), (1, 333, 3), (2, 4429, 2), (1, 77, 1)])
-def test_flash_attention_matches_fp32_softmax(B, T, H):
+def test_flash_attention_matches_fp32_softmax(B, T, H, flash_mode):
     from naturaldiffusion_amd.mmdit import attention_hd64
     g = torch.Generator().manual_seed(T)
     q, k, v = (torch.randn(B, T, H * 64, generator=g).bfloat16() for _ in range(3))
     q = q * 2.0                                                         # sharper softmax: exercises the running-max rescale
-    o = attention_hd64(q.cuda(), k.cuda(), v.cuda()).float().cpu()
-    hd = lambda t: t.float().reshape(B, T, H, 64).transpose(1, 2)
-    w = torch.softmax(hd(q) @ hd(k).transpose(-2, -1) * 0.125, dim=-1)
-    ref = (w @ hd(v)).transpose(1, 2).reshape(B, T, H * 64)
+    o = attention_hd64(q.cuda(), k.cuda(), v.cuda()).double().cpu()
+    ref = _softmax_ref64(q, k, v, B, T, H)
+    assert torch.isfinite(o).all()
+    assert ((o - ref).abs().max() / ref.abs().max()).item() <= 2e-2
+
+
+@pytest.mark.parametrize("spike_tile,spike", [(0, 40.0), (3, 40.0), (7, 200.0), (3, -60.0)])
+def test_flash_attention_rereferencing_branch(spike_tile, spike, flash_mode):
+    """The deferred kernels move their reference only when a score exceeds it by 2^8 -- a rare, data-dependent branch that bounded random data
+    never takes after the first tile.  Force it: one key row (in key tile `spike_tile`) is aligned with every query so that its scores
+    jump ~40 / ~200 exponent units above everything before it (both groups of a wave re-reference at that tile; with 200 the old
+    accumulators are scaled by 2^-200: flushed); a NEGATIVE alignment (scores far below the reference) must NOT trigger anything and must
+    not underflow the rest.  Also: queries whose first tile holds only very negative scores (reference below zero).  fp64 reference."""
+    from naturaldiffusion_amd.mmdit import attention_hd64
+    B, T, H = 1, 1100, 2
+    g = torch.Generator().manual_seed(17 + spike_tile)
+    q, k, v = (torch.randn(B, T, H * 64, generator=g) for _ in range(3))
+    u = torch.randn(64, generator=g); u = u / u.norm()
+    qh = q.view(B, T, H, 64); kh = k.view(B, T, H, 64)
+    qh += 6.0 * u                                                        # every query has a component of ~6 along u ...
+    kh[:, 128 * spike_tile + 37] = (spike * 8.0 / 6.0 / 0.125 / 1.4427 / 8.0) * u      # ... and this key scores ~spike log2-units against it
+    kh[:, :128] = 0.1 * kh[:, :128] - 8.0 * u                            # the whole first key tile scores BELOW zero for every query: the first reference is negative
+    q, k, v = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    o = attention_hd64(q.cuda(), k.cuda(), v.cuda()).double().cpu()
+    ref = _softmax_ref64(q, k, v, B, T, H)
     assert torch.isfinite(o).all()
     assert ((o - ref).abs().max() / ref.abs().max()).item() <= 2e-2
 

@@ -1,4 +1,4 @@
-"""k_flash_attn64 alone at the SD3 shape (8 sequences x 24 heads x 4,429 tokens): time and useful TFLOP/s."""
+"""The head_dim-64 attention kernels alone at the SD3 shape (8 sequences x 24 heads x 4,429 tokens): time and useful TFLOP/s per natinf_set_flash_mode value.  usage: bench_flash.py [modes...]"""
 import sys, time
 from pathlib import Path
 import torch
@@ -13,5 +13,14 @@ vT = torch.randn(B, D, Tp, device="cuda", generator=g).bfloat16(); o = torch.emp
 def run(n):
     for _ in range(n):
         check(lib.natinf_attention_hd64_bf16(ptr(q), ptr(k), D, Tp * D, ptr(vT), ptr(o), D, Tp * D, B, H, Tp, T, 0.125, stream_ptr()), "attn")
-run(2); torch.cuda.synchronize(); t0 = time.perf_counter(); run(10); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-print(f"{dt*1e6:.0f} us  {4.0*T*T*64*H*B/dt/1e12:.0f} TF/s useful")
+modes = [int(v) for v in sys.argv[1:]] or [0, 1, 2]
+ref = None
+for rep in range(3):                                    # interleaved rounds in ONE process (cdna guide rule 24)
+    for m in modes:
+        check(lib.natinf_set_flash_mode(m), "mode")
+        run(2); torch.cuda.synchronize(); t0 = time.perf_counter(); run(10); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+        if rep == 0:
+            cur = o[:, :T].float().clone()
+            if ref is None: ref = cur
+            err = float((cur - ref).abs().max() / ref.abs().max())
+        print(f"mode {m} round {rep}: {dt*1e6:.0f} us  {4.0*T*T*64*H*B/dt/1e12:.0f} TF/s useful" + (f"  max rel diff vs mode {modes[0]}: {err:.2e}" if rep == 0 else ""), flush=True)
