@@ -20,7 +20,7 @@ one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
                     ``natinf_step_f16chain`` launch; a step = one 4-image batch through all 28 steps; SD3-medium-shaped synthetic
                     weights (2.03 B parameters).  fp8 = e4m3 operands (v_mfma_f32_16x16x128_f8f6f4) for the image-stream q|k, v, fc1,
                     fc2 GEMMs, bf16 elsewhere.  Fields: value (images/s), ms_per_step, frac (all 2*MAC flops of the forward / wall time
-                    / 2,500 TFLOP/s), attn {k_flash_attn64 timed IN the engine: HIP events around each launch of one 28-step batch: ms,
+                    / 2,500 TFLOP/s), roofline {k_flash_attn64_v2 timed IN the engine: HIP events around each launch of one 28-step batch: ms,
                     TFLOP/s, frac of the bf16 peak; iso_ms = the same kernel in a back-to-back loop, which this power-capped part clocks
                     lower}, gemm {per image-stream projection shape (M = 32,768): TFLOP/s and frac of ITS operand type's dense peak
                     (bf16 2,500 / fp8 5,000); frac = sum(flops_i / peak_i) / sum(time_i)}, cpu (the MMDiT oracle on one sequence through 2
@@ -237,7 +237,11 @@ def main():
     else:
         line = bench_cifar(args, world, rank, dev)
         tail = {k: line.pop(k) for k in list(line) if k.startswith(("config", "roofline", "cpu_baseline", "accuracy"))}
-        strip = ("metric", "unit", "n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "config", "warmup")
+        strip = ("metric", "unit", "n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "config", "warmup", "steps")
+        drop = ("bound", "peak", "unit", "traffic", "flops_per_launch", "launches", "flop_share", "sample", "kind")       # constants of the sub-objects: in the docstring
+
+        def slim(o):
+            return {k: slim(v) for k, v in o.items() if k not in drop} if isinstance(o, dict) else o
         release()
         if not args.no_sd3 and world == 1:
             # configs 4 / 5 in the same line (one GPU: with N > 1 they are `--workload sd3 [--fp8]` runs -- every rank would repeat them)
@@ -246,16 +250,16 @@ def main():
             flat = synthetic_mmdit_flat(grid=64, seed=0, **SD3_MEDIUM)
             for key, fp8 in (("sd3", False), ("sd3_fp8", True)):
                 sub = bench_sd3(args, world, rank, dev, fp8=fp8, steps=args.sd3_steps, warmup=1, flat=flat)
-                line[key] = {k: v for k, v in sub.items() if k not in strip and k != "dtype"}
+                line[key] = slim({k: v for k, v in sub.items() if k not in strip and k != "dtype"})
                 release()
             del flat
         if not args.no_fid50k:
             sub = bench_fid50k(args, world, rank, dev, steps=1, warmup=0)
-            line["fid50k"] = {k: v for k, v in sub.items() if k not in strip and k not in ("dtype", "cpu_baseline", "roofline")}
+            line["fid50k"] = slim({k: v for k, v in sub.items() if k not in strip and k not in ("dtype", "cpu_baseline", "roofline", "batches", "last_batch")})
             release()
         if not args.no_validate and world == 1:
             sub = bench_validate(args, world, rank, dev, steps=3, warmup=1)
-            line["validate"] = {k: v for k, v in sub.items() if k not in strip and k not in ("dtype", "cpu_baseline", "roofline")}
+            line["validate"] = slim({k: v for k, v in sub.items() if k not in strip and k not in ("dtype", "cpu_baseline", "roofline", "dit_forwards")})
             release()
         line.update(tail)
     if rank == 0:
@@ -586,7 +590,7 @@ def bench_sd3(args, world, rank, dev, fp8=False, steps=2, warmup=1, flat=None):
         check(lib.natinf_attention_profile(0), "attention_profile")
         t_fa = ms_tot.value / max(1, n_l.value) * 1e-3
         fa_flops = 4.0 * T * T * 64 * H * Bs
-        line["roofline"] = {"kernel": "k_flash_attn64", "bound": "mfma", "achieved": r4(fa_flops / t_fa / 1e12), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+        line["roofline"] = {"kernel": "k_flash_attn64_v2", "bound": "mfma", "achieved": r4(fa_flops / t_fa / 1e12), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": r4(fa_flops / t_fa / 1e12 / MFMA_BF16_PEAK_TFLOPS), "traffic": None, "mean_launch_ms": r4(t_fa * 1e3), "launches": int(n_l.value),
                             "flops_per_launch": r4(fa_flops), "iso_ms": r4(t_fa_iso * 1e3), "flop_share": r4(L * fa_flops / (flops_fwd_seq * Bs))}
         M = Bs * tx
@@ -676,7 +680,7 @@ def bench_fid50k(args, world, rank, dev, steps=1, warmup=0):
             torch.cuda.synchronize()
             acc["gen"] += time.perf_counter() - t0
             tm = {}
-            fid = M.calc_fid_sharded(imgs, ref, dev, model=inception, timings=tm)
+            fid = M.calc_fid_sharded(imgs, ref, dev, model=inception, timings=tm, root_only=True)       # (rank 0 holds the job's FID; the others wait in the closing barrier)
             for k in ("inception", "allreduce", "frechet"):
                 acc[k] += tm[k + "_s"]
             res[name] = {"fid": fid, "images_local": int(imgs.shape[0]), "images_all": tm["images_all_ranks"], "imgs": imgs}

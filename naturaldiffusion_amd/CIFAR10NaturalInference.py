@@ -245,11 +245,13 @@ def _ref_statistics(ref):
     return f["mu"], f["sigma"]
 
 
-def calc_fid_sharded(imgs, ref_path, device, group=None, model=None, timings: Optional[dict] = None):
+def calc_fid_sharded(imgs, ref_path, device, group=None, model=None, timings: Optional[dict] = None, root_only: bool = False):
     """``calc_fid`` for a batch-sharded run: every rank scores ITS images (uint8 [n_local, H, W, 3], on the device or the host) in the
     reference's batches of 50, the (count, sum, outer-product sum) statistics are summed over ranks with ONE all-reduce (33.6 MB of fp64,
     fid_stats.ActivationStats) instead of gathering images or activations, and every rank returns the same FID.  ``timings`` (optional
-    dict) receives the wall seconds of the three parts: inception_s, allreduce_s, frechet_s."""
+    dict) receives the wall seconds of the three parts: inception_s, allreduce_s, frechet_s.  ``root_only``: only rank 0 evaluates the
+    Frechet distance (a 2048 x 2048 matrix square root on the host: eight ranks doing it at once fight for the same cores), the others
+    return None."""
     import time
     from .fid_stats import ActivationStats, frechet_distance
     ref_mu, ref_sigma = _ref_statistics(ref_path)
@@ -265,8 +267,12 @@ def calc_fid_sharded(imgs, ref_path, device, group=None, model=None, timings: Op
     st.all_reduce(group)
     sync()
     t2 = time.perf_counter()
-    mu, cov = st.mean_cov()
-    fid = frechet_distance(ref_mu, ref_sigma, mu, cov)
+    import torch.distributed as dist
+    is_root = not (dist.is_available() and dist.is_initialized()) or dist.get_rank(group) == 0
+    fid = None
+    if is_root or not root_only:
+        mu, cov = st.mean_cov()
+        fid = frechet_distance(ref_mu, ref_sigma, mu, cov)
     if timings is not None:
         timings.update(inception_s=t1 - t0, allreduce_s=t2 - t1, frechet_s=time.perf_counter() - t2, images_all_ranks=int(float(st.n)))
     return fid

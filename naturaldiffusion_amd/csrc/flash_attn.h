@@ -248,21 +248,31 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64_v2(const FlashArgs a)
     const bf16* kbase = a.k + (int64_t)b * a.qk_bs + head * 64;
     const bf16* vbase = a.vT + (int64_t)b * a.vT_bs + (int64_t)head * 64 * a.Tp;
 
+    // DMA requests: per wave and stage 4 K pieces + 4 V^T pieces of 1 KiB.  The per-lane part of a source address does not depend on the key tile,
+    // so it is a 32-bit offset computed ONCE (eight registers) next to a scalar base that moves by a constant per tile: the builtin form with a 64-bit
+    // per-lane pointer spent ~30 vector instructions per tile and wave on address arithmetic -- in a loop whose bound is the vector issue port.
     const int prow = lane >> 3, pch = lane & 7;
+    unsigned koff[4], voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = wave * 4 + j, row = 8 * p + prow;
+        const int f = ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
+        koff[j] = (unsigned)(row * a.ld_qk + ((pch ^ f) << 3)) * 2u;
+        const int sub = p >> 3, d = 8 * (p & 7) + prow;
+        voff[j] = (unsigned)(d * a.Tp + sub * 64 + ((pch ^ ((d >> 1) & 7)) << 3)) * 2u;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
+    auto glds = [](unsigned vo, const void* sbase, unsigned dst) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo), "s"(sbase), "s"(dst) : "memory", "m0");
+    };
     auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
-        unsigned char* st = smem + buf * FA_STAGE;
+        const unsigned st = lds0 + buf * FA_STAGE + wave * 4096;
+        const bf16* kb = kbase + (int64_t)kt * FA_KT * a.ld_qk;
+        const bf16* vb = vbase + kt * FA_KT;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = wave * 4 + j, row = 8 * p + prow;
-            const int f = ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
-            __builtin_amdgcn_global_load_lds(kbase + (int64_t)(kt * FA_KT + row) * a.ld_qk + ((pch ^ f) << 3), (lds_void*)(st + p * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j) glds(koff[j], kb, st + j * 1024);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = wave * 4 + j, sub = p >> 3, d = 8 * (p & 7) + prow;
-            __builtin_amdgcn_global_load_lds(vbase + (int64_t)d * a.Tp + kt * FA_KT + sub * 64 + ((pch ^ ((d >> 1) & 7)) << 3),
-                                             (lds_void*)(st + 16384 + p * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j) glds(voff[j], vb, st + 16384 + j * 1024);
     };
     issue(0, 0);
 
@@ -428,5 +438,17 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64_v2(const FlashArgs a)
         }
     }
 }
+
+// Built on top of that and NOT kept (round 4; correct -- it passed every parity case of tests/test_gpu_mmdit.py incl. the forced re-referencing):
+// k_flash_attn64_pp, the two waves of a SIMD in OPPOSITE phases.  The counters of v2 (profiles/r04/flash_pmc_mode2.json) read as if matrix time
+// (1,152 pipe cycles per wave-tile) and vector time (~800) ADD UP on a SIMD (2,160 cycles per wave-tile) instead of overlapping -- the two co-resident
+// waves belong to two blocks that run the same program from the same start.  So: 8-wave blocks of 256 queries, waves w and w + 4 (one SIMD) in two
+// groups one SEGMENT apart -- matrix segment = P(i-1) V(i-1) + S(i), vector segment = softmax(i) + the group's DMA requests for tile i + 2 (K by one
+// group, V^T by the other; rings of three tiles, counted vmcnt(4)), one block-wide s_barrier between segments.  1,007-1,013 us against 966-974 for v2 on
+// the same box (even / odd wave groups instead: 1,134 us, so the w / w + 4 pairing is the right one); SQ_WAIT_ANY 30 % of wave cycles against 18 %, matrix
+// pipe 49 % busy against 53 %.  The reading that fits both: an MFMA occupies the SIMD's vector ISSUE port for 8 of its 16 cycles, so matrix and vector
+// work of two waves do share one resource -- v2's waves already keep that port ~78 % busy (2 x 39 % SQ_ACTIVE_INST_ANY) -- and a barrier per segment
+// only adds the imbalance between the segments.  What is left is fewer issue cycles per score (32x32x16 MFMAs: half the MFMA issue cost, at the lower
+// clock that shape holds on this part), not a different arrangement of the same instructions.
 
 }  // namespace ncsn

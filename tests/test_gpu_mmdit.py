@@ -15,7 +15,7 @@ def flash_mode(request):
     from naturaldiffusion_amd._lib import lib, check
     check(lib.natinf_set_flash_mode(request.param), "natinf_set_flash_mode")
     yield request.param
-    check(lib.natinf_set_flash_mode(0), "natinf_set_flash_mode")
+    check(lib.natinf_set_flash_mode(2), "natinf_set_flash_mode")              # the library's default
 
 
 def _softmax_ref64(q, k, v, B, T, H):
