@@ -316,11 +316,15 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64_v2(const FlashArgs a)
             acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, qf[1][1], acc[1][t], 0, 0, 0);
         }
         if (kt == nK - 1 && a.Ttot < a.Tp) {
+            // (the limit is made opaque HERE: as a loop invariant hipcc evaluates the 32 comparisons in front of the loop and keeps 64 scalar registers of
+            // masks alive across it -- 27 of them spilled into vector-register lanes)
+            int lim = a.Ttot - kt * FA_KT - 8 * q;
+            asm volatile("" : "+v"(lim));
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const bool ok = kt * FA_KT + 32 * (t >> 1) + 8 * q + 4 * (t & 1) + i < a.Ttot;
+                    const bool ok = 32 * (t >> 1) + 4 * (t & 1) + i < lim;
                     acc[0][t][i] = ok ? acc[0][t][i] : -INFINITY;
                     acc[1][t][i] = ok ? acc[1][t][i] : -INFINITY;
                 }
@@ -394,6 +398,23 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64_v2(const FlashArgs a)
             }
         }
     }
+    // the epilogue's arguments are fetched from the kernel-argument segment HERE: kept in scalar registers across the key loop they are what hipcc
+    // spills into vector-register lanes (32 of them, read back with v_readlane inside the loop)
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const unsigned __attribute__((address_space(4))) *kernarg_u32_t;
+    kernarg_u32_t gp = (kernarg_u32_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(gp));
+    FlashArgs e;
+    {
+        unsigned* dw = reinterpret_cast<unsigned*>(&e);
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(FlashArgs) / 4; ++i) dw[i] = gp[i];
+    }
+#else
+    const FlashArgs e = a;
+#endif
+    const int tile_e = xcd_remap(blockIdx.x, gridDim.x), nQ_e = e.Tp / FA_QB;
+    const int bh_e = tile_e / nQ_e, qb_e = tile_e - bh_e * nQ_e, b_e = bh_e / e.H, head_e = bh_e - b_e * e.H;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         float s;
@@ -404,8 +425,8 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64_v2(const FlashArgs a)
             s += __shfl_xor(s, 32);
         }
         const float inv = 1.0f / s;
-        const int64_t qrow = (int64_t)b * a.Tp + qb * FA_QB + wave * 32 + 16 * g + r;
-        if (a.o8) {
+        const int64_t qrow = (int64_t)b_e * e.Tp + qb_e * FA_QB + wave * 32 + 16 * g + r;
+        if (e.o8) {
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
                 float amax = 0.f;
@@ -420,14 +441,14 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64_v2(const FlashArgs a)
                 qinv *= inv;
 #pragma unroll
                 for (int dt = 2 * blk; dt < 2 * blk + 2; ++dt)
-                    *reinterpret_cast<unsigned*>(a.o8 + qrow * (a.H * 64) + head * 64 + 16 * dt + 4 * q) =
+                    *reinterpret_cast<unsigned*>(e.o8 + qrow * (e.H * 64) + head_e * 64 + 16 * dt + 4 * q) =
                         pack_fp8x4(oacc[g][dt][0] * qinv, oacc[g][dt][1] * qinv, oacc[g][dt][2] * qinv, oacc[g][dt][3] * qinv);
                 if (q == 0)
-                    a.omx[(int64_t)b * a.Tp * (a.H * 2) + ((int64_t)(head >> 1) * a.Tp + (qrow - (int64_t)b * a.Tp)) * 4 + (head & 1) * 2 + blk] = (uint8_t)e8;
+                    e.omx[(int64_t)b_e * e.Tp * (e.H * 2) + ((int64_t)(head_e >> 1) * e.Tp + (qrow - (int64_t)b_e * e.Tp)) * 4 + (head_e & 1) * 2 + blk] = (uint8_t)e8;
             }
             continue;
         }
-        bf16* orow = a.o + (int64_t)b * a.o_bs + (int64_t)(qb * FA_QB + wave * 32 + 16 * g + r) * a.ld_o + head * 64 + 4 * q;
+        bf16* orow = e.o + (int64_t)b_e * e.o_bs + (int64_t)(qb_e * FA_QB + wave * 32 + 16 * g + r) * e.ld_o + head_e * 64 + 4 * q;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));

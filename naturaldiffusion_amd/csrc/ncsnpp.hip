@@ -305,7 +305,9 @@ bool configure_gemm_kernels() {
          set_lds<AttnCfg<2, 4>>(&k_attn_fused<2, 4>) && set_lds<AttnCfg<3, 6>>(&k_attn_fused<3, 6>) &&
          set_lds<AttnCfg<3, 5>>(&k_attn_fused<3, 5>) &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess &&
+#ifdef NATINF_DEV
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64_v2<0>), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess &&
+#endif
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64_v2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess;
     if (!ok) (void)hipGetLastError();
     return ok;

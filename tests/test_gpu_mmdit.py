@@ -13,7 +13,10 @@ TOL = 3e-2          # max |engine - oracle| / max |oracle|, bf16 operands vs fp3
 def flash_mode(request):
     """every head_dim-64 attention kernel of the library (natinf_set_flash_mode): the parity cases run on all of them"""
     from naturaldiffusion_amd._lib import lib, check
-    check(lib.natinf_set_flash_mode(request.param), "natinf_set_flash_mode")
+    rc = lib.natinf_set_flash_mode(request.param)
+    if rc == -4 and request.param == 1:                     # NATINF_ESTATE
+        pytest.skip("mode 1 (the intermediate form) exists in -DNATINF_DEV builds only")
+    check(rc, "natinf_set_flash_mode")
     yield request.param
     check(lib.natinf_set_flash_mode(2), "natinf_set_flash_mode")              # the library's default
 
