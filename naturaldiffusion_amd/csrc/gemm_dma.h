@@ -225,8 +225,15 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
         const int sc_ = NCT > 1 ? sm : 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if constexpr (DEQ) v[e] = (acc[i][j][e] * (rsc[i] * dn[j][e]) + ct[sc_][j][e]) + rbm[i];
+            // (DEQ: two vector instructions per element -- (acc * row scale) fma'd with the column scale onto the column terms -- instead of four)
+            if constexpr (DEQ) v[e] = __builtin_fmaf(acc[i][j][e] * rsc[i], dn[j][e], ct[sc_][j][e]);
             else v[e] = acc[i][j][e] + ct[sc_][j][e];
+        }
+        if constexpr (DEQ) {
+            if (g.bias_m) {                                               // (wave-uniform: only the V^T GEMMs carry a row bias)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += rbm[i];
+            }
         }
         if constexpr (LAZY_RV) { v[0] += lrv[j].x; v[1] += lrv[j].y; v[2] += lrv[j].z; v[3] += lrv[j].w; }
         if constexpr (RES) {
@@ -234,8 +241,10 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += (float)x[e];
         }
+        if (scale != 1.0f) {                                              // (wave-uniform; the transformer engines' GEMMs all have scale 1)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= scale;
+            for (int e = 0; e < 4; ++e) v[e] *= scale;
+        }
         if constexpr (ACT != ACT_NONE) apply_act4(v, ACT);
         if constexpr (GN) {
             gs[sm][j] += (v[0] + v[1]) + (v[2] + v[3]);

@@ -119,6 +119,14 @@ __device__ __forceinline__ float gelu_tanh_f(float v) {             // nn.GELU(a
     const float e = __expf(2.0f * u);                               // tanh(u) = 1 - 2/(e^{2u}+1)
     return 0.5f * v * (2.0f - 2.0f / (e + 1.0f));
 }
+// Epilogue form of the same function: 0.5 v (1 + tanh u) = v / (1 + e^(-2u)), u = sqrt(2/pi) (v + 0.044715 v^3), with the constants folded
+// into the exponent's polynomial -- v * rcp(1 + exp2(v * (A + B v^2))), A = -2 sqrt(2/pi) log2(e), B = 0.044715 A: five plain vector instructions
+// and two transcendentals per element (the tanh form above: eight and two).  An fc1 tile's epilogue is 128 elements per lane: its vector work was as
+// long as the K = 1,536 loop it follows.  exp2 -> inf gives rcp -> 0 (v -> -0 for large negative v), exp2 -> 0 gives v: no NaN for finite v.
+__device__ __forceinline__ float gelu_tanh_fast(float v) {
+    const float t = v * __builtin_fmaf(v * v, -0.10294324f, -2.3022082f);
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+}
 __device__ __forceinline__ float apply_act(float v, int act) {
     return act == ACT_SILU ? silu_f(v) : (act == ACT_GELU_TANH ? gelu_tanh_f(v) : (act == ACT_RELU ? fmaxf(v, 0.f) : v));
 }
@@ -133,7 +141,8 @@ __device__ __forceinline__ unsigned mx_scale_of(float amax, float& inv) {
     return (unsigned)(e + 127);
 }
 __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {      // values already scaled; clamp: the cvt does not saturate
-    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f); c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+    a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);      // (one v_med3_f32 per value)
+    c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
     int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
     w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
     return (unsigned)w;
@@ -147,10 +156,7 @@ __device__ __forceinline__ void apply_act8(float (&v)[8], int act) {
         for (int q = 0; q < 8; ++q) v[q] = v[q] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[q]));
     } else if (act == ACT_GELU_TANH) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float u = 0.7978845608028654f * (v[q] + 0.044715f * v[q] * v[q] * v[q]);
-            v[q] = v[q] * (1.0f - __builtin_amdgcn_rcpf(__expf(2.0f * u) + 1.0f));          // 0.5 v (1 + tanh u)
-        }
+        for (int q = 0; q < 8; ++q) v[q] = gelu_tanh_fast(v[q]);
     } else if (act == ACT_RELU) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
@@ -163,10 +169,7 @@ __device__ __forceinline__ void apply_act4(float (&v)[4], int act) {
         for (int q = 0; q < 4; ++q) v[q] = v[q] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[q]));
     } else if (act == ACT_GELU_TANH) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float u = 0.7978845608028654f * (v[q] + 0.044715f * v[q] * v[q] * v[q]);
-            v[q] = v[q] * (1.0f - __builtin_amdgcn_rcpf(__expf(2.0f * u) + 1.0f));
-        }
+        for (int q = 0; q < 4; ++q) v[q] = gelu_tanh_fast(v[q]);
     } else if (act == ACT_RELU) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
