@@ -41,9 +41,9 @@ one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
                     fid = "blocked"; d_matrices = Frechet distance between the two matrices' image statistics (same network, same
                     noise: a sanity figure that needs no asset).
   validate          SURVEY 8f N2 + N4 (``--workload validate`` alone): ``ValidateNaturalInference.natural_inference("ddim", 24)`` --
-                    DiT-XL/2 engine, 8 class-conditional latents, CFG 4 (two forwards per step), 24 steps, one fused
+                    DiT-XL/2 engine, 8 class-conditional latents, CFG 4 (the conditional and unconditional calls of a step as ONE forward of 16), 24 steps, one fused
                     ``natinf_step_f32prod`` launch per step -- then the AutoencoderKL decoder engine (8 x 256x256 images) and the PNG
-                    row.  value = images/s; dit_ms = mean DiT forward (B = 8); vae_ms = decode of the 8 latents; synthetic weights.
+                    row.  value = images/s; dit_ms = mean DiT forward (16 samples); vae_ms = decode of the 8 latents; synthetic weights.
   roofline          the dominant kernel, ``k_conv_gn2`` at 32x32 / 16x16 (3x3 convolution with GroupNorm-apply + SiLU fused into its
                     operand path; MFMA-bound): achieved = algorithmic flops per launch (2*M*N*K of the launches, from the engine's own
                     launch table) / mean launch duration, measured with HIP events on the engine's stream over an instrumented ONE-stream
@@ -747,13 +747,15 @@ def bench_validate(args, world, rank, dev, steps=3, warmup=1):
     _lib.require_gpu()
     n, nstep = 8, 24
     V.device = str(dev)
-    dit = DiTEngine(flatten_state_dict(synthetic_dit_state_dict(XL2["depth"], XL2["hidden"], seed=0), XL2["depth"], XL2["hidden"]), n, device=dev, **XL2)
+    dit = DiTEngine(flatten_state_dict(synthetic_dit_state_dict(XL2["depth"], XL2["hidden"], seed=0), XL2["depth"], XL2["hidden"]), 2 * n, device=dev, **XL2)
     vae = VAEDecoder(synthetic_vae_flat(4), max_batch=n, latent_ch=4, latent_res=32, device=dev)
     outdir = Path(tempfile.mkdtemp(prefix="natinf_validate_"))
     t_acc = {"dit": 0.0, "dit_n": 0, "vae": 0.0, "vae_n": 0}
     ev = lambda: torch.cuda.Event(enable_timing=True)
 
     class TimedDiT:
+        max_batch = 2 * n                                                   # the CFG pair of a step rides in ONE forward of 16 (ValidateNaturalInference._cond_uncond)
+
         def forward(self, z, t, y):
             a, b = ev(), ev()
             a.record(); out = dit(z, t, y); b.record()
@@ -774,14 +776,14 @@ def bench_validate(args, world, rank, dev, steps=3, warmup=1):
     assert torch.isfinite(outs[-1]).all()
     dit_ms = sum(a.elapsed_time(b) for a, b in t_acc["ev"]) / len(t_acc["ev"])
     vae_ms = sum(a.elapsed_time(b) for a, b in t_acc["evv"]) / len(t_acc["evv"])
-    dit_fl = XL2["depth"] * 256 * (24 * XL2["hidden"] ** 2 + 4 * 256 * XL2["hidden"]) * n            # 2*MAC per forward of 8 images (tools/bench_dit.py)
+    dit_fl = XL2["depth"] * 256 * (24 * XL2["hidden"] ** 2 + 4 * 256 * XL2["hidden"]) * 2 * n        # 2*MAC per forward of 16 samples (tools/bench_dit.py)
     line = {"metric": "images/sec at 24-step Natural Inference (DiT-XL/2 256x256, CFG 4, DDIM matrix) incl. VAE decode",
             "value": round(world * n * steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(dt / steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "dit_ms": r4(dit_ms), "dit_forwards": 2 * nstep, "vae_ms": r4(vae_ms),
-            "config": {"workload": "ValidateNaturalInference.natural_inference('ddim', 24): DiT-XL/2 engine B=8, CFG 4 (2 forwards / step), natinf_step_f32prod, "
+            "dit_ms": r4(dit_ms), "dit_forwards": len(t_acc["ev"]) // (steps + warmup), "vae_ms": r4(vae_ms),
+            "config": {"workload": "ValidateNaturalInference.natural_inference('ddim', 24): DiT-XL/2 engine, CFG 4 (cond + uncond as one forward of 16), natinf_step_f32prod, "
                                    "AutoencoderKL decoder engine 8 x 256x256 + PNG row", "nfe": 2 * nstep, "images_per_gpu": n},
-            "roofline": {"kernel": "DiT-XL/2 forward B=8 (k_gemm_* + k_attn_fused)", "bound": "mfma", "achieved": r4(dit_fl / (dit_ms * 1e-3) / 1e12),
+            "roofline": {"kernel": "DiT-XL/2 forward B=16 (k_gemm_* + k_attn_fused)", "bound": "mfma", "achieved": r4(dit_fl / (dit_ms * 1e-3) / 1e12),
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": r4(dit_fl / (dit_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS), "traffic": None}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "validate":
         from oracle import dit_oracle as DO

@@ -123,11 +123,23 @@ def calc_x0_mean_z(input_z, eps, coeff, ii):
 
 
 @torch.no_grad()
+def _cond_uncond(model, zt, timesteps, classlabels, classnulls):
+    """The two denoiser calls of a CFG step (reference :190-191).  A denoiser that takes 2n samples (the gfx950 DiT engine: ``max_batch``) gets them
+    as ONE forward of [z; z] with [labels; nulls] -- at n = 8 a DiT-XL/2 forward is ~300 dependent launches of 10-30 us each, so two forwards
+    of 8 cost almost twice one of 16; samples are independent inside the engine, so the halves are what the two calls return."""
+    n = len(zt)
+    if getattr(model, "max_batch", 0) >= 2 * n:
+        both = model.forward(torch.cat([zt, zt]), torch.cat([timesteps, timesteps]), torch.cat([classlabels.to(classnulls.dtype), classnulls]))
+        return both[:n], both[n:]
+    return model.forward(zt, timesteps, classlabels), model.forward(zt, timesteps, classnulls)
+
+
+@torch.no_grad()
 def forward_cfg(model, zt, timesteps, classlabels, cfg_scale, cls):
-    """Reference :185-195: two denoiser calls, first 4 of 8 channels, CFG fuse."""
+    """Reference :185-195: two denoiser calls (batched into one where the denoiser allows), first 4 of 8 channels, CFG fuse."""
     classnulls = torch.tensor([cls] * len(zt), device=zt.device)
-    cond_eps = model.forward(zt, timesteps, classlabels)[:, :4, :, :]
-    uncond_eps = model.forward(zt, timesteps, classnulls)[:, :4, :, :]
+    cond, uncond = _cond_uncond(model, zt, timesteps, classlabels, classnulls)
+    cond_eps, uncond_eps = cond[:, :4, :, :], uncond[:, :4, :, :]
     return cond_eps, uncond_eps, uncond_eps + cfg_scale * (cond_eps - uncond_eps)
 
 
@@ -147,7 +159,7 @@ def weighted_sum(weights, seq_elem):
 _engine_cache = {}
 
 
-def load_dit_engine(path, max_batch=8):
+def load_dit_engine(path, max_batch=16):
     """Reference :150-154 (``DiT_models['DiT-XL/2'](input_size=32, num_classes=1000)`` + ``load_state_dict``) on the
     gfx950 engine: the checkpoint's tensors go straight into ``natinf_dit_load``; one engine per checkpoint path."""
     from .dit import DiTEngine, flatten_state_dict, XL2
@@ -267,8 +279,7 @@ def natural_inference(alg_name="ddpm", num_step=24):
     for kk in range(num_step):
         timesteps = torch.ones(n, dtype=torch.int32, device=device) * int(node[kk, 0])
         classnulls = torch.tensor([1000] * n, device=device)
-        cond = model.forward(input_z, timesteps, labels)          # [n, 8, 32, 32]; first 4 channels used
-        uncond = model.forward(input_z, timesteps, classnulls)
+        cond, uncond = _cond_uncond(model, input_z, timesteps, labels, classnulls)      # [n, 8, 32, 32] each; first 4 channels used
         ni.hist_eps[kk + 1].copy_(torch.randn_like(input_z, dtype=torch.float32, device=device).reshape(-1))
         per, stride = 4 * 32 * 32, cond.shape[1] * 32 * 32
         z = ni.step(kk, input_z.reshape(-1), cond.contiguous(), uncond.contiguous(), 4.0, per, stride)

@@ -88,16 +88,18 @@ def test_argument_errors():
         DiTEngine(_flat(P, 1, 128), max_batch=2, depth=1, hidden=100, heads=2)
 
 
-def test_validate_natural_inference_end_to_end(monkeypatch):
-    """src/ValidateNaturalInference.py:311-372 with the HIP DiT engine as the denoiser (two CFG forwards per step, one
-    fused natinf_step_f32prod launch per step) against the oracle's restatement driven by the DiT oracle."""
+@pytest.mark.parametrize("max_batch", [8, 16], ids=["two_forwards_of_8", "one_forward_of_16"])
+def test_validate_natural_inference_end_to_end(monkeypatch, max_batch):
+    """src/ValidateNaturalInference.py:311-372 with the HIP DiT engine as the denoiser (the CFG pair of a step as two forwards of 8 or -- when the
+    engine takes 16 samples -- as one forward of [z; z], one fused natinf_step_f32prod launch per step) against the oracle's restatement driven
+    by the DiT oracle."""
     from oracle import dit_oracle as D, ni_oracle as O
     from naturaldiffusion_amd import ValidateNaturalInference as V
     from naturaldiffusion_amd.dit import DiTEngine
     from naturaldiffusion_amd.coeff import load_coeff_npz
     depth, hid, heads = 2, 128, 2
     P = D.make_params(depth, hid, seed=11)
-    eng = DiTEngine(_flat(P, depth, hid), max_batch=8, depth=depth, hidden=hid, heads=heads)
+    eng = DiTEngine(_flat(P, depth, hid), max_batch=max_batch, depth=depth, hidden=hid, heads=heads)
     g = torch.Generator().manual_seed(0)
     draws = [torch.randn(8, 4, 32, 32, generator=g) for _ in range(25)]
     it = iter(draws)
