@@ -313,6 +313,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
     u32x4 nv = {0u, 0u, 0u, 0u}, ns0 = nv, ns1 = nv, nh0 = nv, nh1 = nv;
     unsigned npk[4] = {0u, 0u, 0u, 0u};
     float nf_even = 0.f;
+    float nst[3] = {0.f, 0.f, 0.f}, nse[3] = {0.f, 0.f, 0.f};                // the three elements in flight of the staged normalisation (t, then exp2(t), then 1 / (1 + exp2(t)))
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto norm_load = [&](auto j_tag, auto buf_tag) __attribute__((always_inline)) {
         constexpr int J = decltype(j_tag)::value, BUF = decltype(buf_tag)::value;
@@ -329,30 +330,46 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
         ns0 = lds_read16<BUF * Cfg::TAB_BYTES>(tbase); ns1 = lds_read16<BUF * Cfg::TAB_BYTES + 16>(tbase);
         nh0 = lds_read16<BUF * Cfg::TAB_BYTES + 128>(tbase); nh1 = lds_read16<BUF * Cfg::TAB_BYTES + 144>(tbase);
     };
-#define NATINF_CG_NORM_PRE(I) asm volatile("" : "+v"(nv), "+v"(ns0), "+v"(ns1), "+v"(nh0), "+v"(nh1));
+#define NATINF_CG_NORM_PRE(I) asm volatile("" : "+v"(nv), "+v"(ns0), "+v"(ns1), "+v"(nh0), "+v"(nh1)); if constexpr ((I) == 0) NATINF_CG_NORM_A(0)
     // (Round 3: the in-loop elements in packed-fp32 form -- channel pairs, v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32, ten vector instructions
     // per pair instead of thirteen -- were built and measured: +-0 on every shape.  hipcc's SIPreEmitPeephole splits packed-fp32 instructions
     // that sit in the shadow of an MFMA back into scalar ones (packed fp32 cannot be co-issued behind an MFMA on gfx950, the scalar forms can),
     // and the two extra registers a pair holds across a step tipped the EPI 1 instantiation into scratch reloads inside the loop.  The packed
     // form stays where no MFMA is in flight: the prologue's norm_round below, NATINF_CG_PK.)
-#define NATINF_CG_NORM_EL(I)                                                                                                \
+    // Round 4: the element's chain unpack -> fma -> exp2 | add -> rcp | mul (-> pack) is cut into three stages that run ONE MFMA GROUP APART: behind
+    // group I the wave issues stage A of element I + 1, stage B of element I and stage C of element I - 1 -- nothing it issues there depends on a result
+    // produced behind the same group.  (In the single-stage form every instruction of the chain waited for the transcendental in front of it, with only
+    // one or two MFMAs in between: an in-order wave then holds back its own next MFMAs.)  A (0) runs in front of group 0 (NORM_PRE), C (7) behind group 7
+    // (NORM_POST); TM = 4: the round spans two taps and the stages carry over (the variables live at kernel scope).  Four more live registers.
+#define NATINF_CG_NORM_A(I)                                                                                                 \
         {                                                                                                                    \
             const unsigned w_ = nv[(I) >> 1];                                                                                \
             const float x_ = __uint_as_float(((I) & 1) ? (w_ & 0xffff0000u) : (w_ << 16));                                   \
-            const float t_ = x_ * __uint_as_float((I) < 4 ? ns0[(I) & 3] : ns1[(I) & 3]) + __uint_as_float((I) < 4 ? nh0[(I) & 3] : nh1[(I) & 3]); \
-            const float y_ = t_ * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t_));                                  \
+            nst[(I) % 3] = x_ * __uint_as_float((I) < 4 ? ns0[(I) & 3] : ns1[(I) & 3]) + __uint_as_float((I) < 4 ? nh0[(I) & 3] : nh1[(I) & 3]); \
+            nse[(I) % 3] = __builtin_amdgcn_exp2f(nst[(I) % 3]);                                                             \
+            asm volatile("" : "+v"(nst[(I) % 3]), "+v"(nse[(I) % 3]));        /* (pinned: or hipcc sinks the stages back together) */ \
+        }
+#define NATINF_CG_NORM_B(I) { nse[(I) % 3] = __builtin_amdgcn_rcpf(1.0f + nse[(I) % 3]); asm volatile("" : "+v"(nse[(I) % 3])); }
+#define NATINF_CG_NORM_C(I)                                                                                                 \
+        {                                                                                                                    \
+            const float y_ = nst[(I) % 3] * nse[(I) % 3];                                                                    \
             if constexpr (((I) & 1) == 0) nf_even = y_;                                                                      \
             else {                                                                                                           \
                 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));                                                 \
                 const bf16x2_t pr_ = {(bf16)nf_even, (bf16)y_};                                                              \
                 npk[(I) >> 1] = __builtin_bit_cast(unsigned, pr_);                                                           \
             }                                                                                                                \
-        }                                                                                                                    \
+            if constexpr (((I) & 1) == 0) asm volatile("" : "+v"(nf_even)); else asm volatile("" : "+v"(npk[(I) >> 1]));       \
+        }
+#define NATINF_CG_NORM_EL(I)                                                                                                \
+        if constexpr ((I) >= 1) NATINF_CG_NORM_C((I) - 1)                                                                    \
+        NATINF_CG_NORM_B(I)                                                                                                  \
+        if constexpr ((I) + 1 < 8) NATINF_CG_NORM_A((I) + 1)                                                                 \
         _Pragma("unroll") for (int g_ = 0; g_ < TN; ++g_) {                                                                  \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       /* one MFMA */                                           \
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);       /* two vector instructions */                            \
         }
-#define NATINF_CG_NORM_POST(I) if constexpr (((I) & 1) == 0) asm volatile("" : "+v"(nf_even)); else asm volatile("" : "+v"(npk[(I) >> 1]));
+#define NATINF_CG_NORM_POST(I) if constexpr ((I) == 7) NATINF_CG_NORM_C(7)
     auto norm_store = [&](auto j_tag, auto buf_tag) __attribute__((always_inline)) {
         constexpr int J = decltype(j_tag)::value, BUF = decltype(buf_tag)::value;
         u32x4 ou = {npk[0], npk[1], npk[2], npk[3]};
@@ -560,6 +577,9 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
 #undef NATINF_CG_NO_POST
 #undef NATINF_CG_NORM_PRE
 #undef NATINF_CG_NORM_EL
+#undef NATINF_CG_NORM_A
+#undef NATINF_CG_NORM_B
+#undef NATINF_CG_NORM_C
 #undef NATINF_CG_NORM_POST
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done with the tiles before the epilogue reuses them
     if constexpr (NG > 1) {
