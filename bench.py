@@ -15,6 +15,9 @@ alternate between two HIP streams (two engine handles sharing one copy of the pa
 one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
   single_stream     {value, ms_per_step}: the same K steps one batch after the other on ONE stream (the reference's order; the
                     like-for-like number for rounds 1-2, whose headline was this).  ``--streams 1`` makes it the headline.
+  pipeline          {value}: images/s of the same K batches through the production pipeline (``generate_sharded`` on the same two lanes): Philox noise by
+                    global index drawn inside the timed span, the 15 steps, ``to_pixel``, and the ONE copy of the uint8 images to the host -- everything the
+                    reference's per-batch loop contains (:290, :308-309) that the contract's "inputs resident in HBM" region leaves out.
   sd3, sd3_fp8      BASELINE configs 4 / 5 (``--workload sd3 [--fp8]`` alone): 28-step SD3-form NI at 1024x1024, 4 images x CFG per
                     GPU = ONE batched MMDiT forward of 8 sequences (4,096 image + 333 text tokens) per step + one fused
                     ``natinf_step_f16chain`` launch; a step = one 4-image batch through all 28 steps; SD3-medium-shaped synthetic
@@ -353,6 +356,15 @@ def bench_cifar(args, world, rank, dev):
     }
     if n_str > 1 and dt1 is not None:
         line["single_stream"] = {"value": round(imgs / dt1, 2), "ms_per_step": round(dt1 / args.steps * 1e3, 3)}
+    if rank == 0 and n_str > 1:
+        # the same K batches through the PRODUCTION pipeline (generate_sharded: Philox noise by global index drawn on the lane's stream, 15 steps, to_pixel, uint8
+        # images to the host once at the end) -- what the reference's per-batch loop contains beyond the timed region above (:290 noise, :308-309 to_pixel + copy)
+        from naturaldiffusion_amd.CIFAR10NaturalInference import generate_sharded
+        pl = [e_ for e_, _, _ in lanes]
+        generate_sharded(pl, None, 2 * Bz, Bz, device=dev, coeff=(C, Bm, node))                   # slabs of the lanes' first use
+        torch.cuda.synchronize(); tp = time.perf_counter()
+        im, _ = generate_sharded(pl, None, args.steps * Bz, Bz, device=dev, coeff=(C, Bm, node), to_cpu=True)
+        line["pipeline"] = {"value": round(args.steps * Bz / (time.perf_counter() - tp), 2), "images": int(im.shape[0])}
     line["config"] = {"workload": f"CIFAR10 NI 15-step {os.path.basename(args.weights)} B={Bz}/GPU NCSN++ 61.8M bf16 MFMA, ni_step fp64 history",
                       "nfe": n_step, "batch_per_gpu": Bz, "streams": n_str, "sharding": f"batch x{world}, no collective"}
 

@@ -90,7 +90,10 @@ __device__ __forceinline__ float dpp_row_sum(float v) {
     // ANOTHER kernel shared the SIMD (two engines on two HIP streams), lanes 48-63 of the DPP source were still the old value -- one partial sum of
     // one tile off by 10-50 %, a whole image's GroupNorm statistics slightly off, run-to-run.  Alone on its SIMD the kernel never showed it.
     // (tools/debug_det5.py reproduces it on a single launch; tools/scan_pk_hazard.py looks for the shape in the assembly)
-    asm volatile("" : "+v"(v));
+    // Round 4: the FIRST stage's input is whatever the caller computed last -- possibly a packed result (the gs / gq accumulation) -- so that statement
+    // carries five wait states of its own: the hazard cannot occur here whatever the vectoriser does in front of the call (the scanner, run by the
+    // Makefile on every build, stays as the check for the rest of the library).
+    asm volatile("s_nop 4" : "+v"(v));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
     asm volatile("" : "+v"(v));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));

@@ -7,7 +7,7 @@ result -- the shape hipcc gave the GroupNorm partial sums once the SLP vectorise
 in lanes 48-63 whenever a wave of another kernel shared the SIMD (two engines on two streams); alone on its SIMD it never did.
 hipcc keeps two wait states between a VALU write and a DPP read, whatever the writer is.
 
-usage: scan_pk_hazard.py file.s [max distance, default 6]   (tests/test_build_isa.py imports scan())"""
+usage: scan_pk_hazard.py [--fail] file.s [max distance, default 6]   (tests/test_build_isa.py imports scan(); the Makefile runs it with --fail on every build)"""
 import re, sys
 
 
@@ -51,7 +51,9 @@ def scan(path, maxd=6):
 
 
 if __name__ == "__main__":
-    hits = scan(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 6)
+    fail = "--fail" in sys.argv                                   # the Makefile's form: exit 1 when a DPP / lane-read source follows a multi-pass producer
+    argv = [a for a in sys.argv[1:] if a != "--fail"]
+    hits = scan(argv[0], int(argv[1]) if len(argv) > 1 else 6)
     tot = {}
     for (fn, kind), hs in sorted(hits.items()):
         tot[kind] = tot.get(kind, 0) + len(hs)
@@ -59,3 +61,5 @@ if __name__ == "__main__":
         if kind in ('dpp', 'lane'):
             for h in hs[:2]: print(f"        {h[1]}  ->  {h[2]}   ({h[0]} between)")
     print("totals:", tot)
+    if fail and (tot.get("dpp", 0) or tot.get("lane", 0)):
+        sys.exit(1)
