@@ -66,8 +66,11 @@ struct ConvGnCfg {
 #ifndef NATINF_CG_ABL
 #define NATINF_CG_ABL 0            // development: 1 = no normalisation inside the K loop (timing ablation, wrong results)
 #endif
-#ifdef NATINF_DEV
-// development builds: shader-clock stamps at the section boundaries of a K-tile (block 0 / wave 0), summed over the tile's K loop
+// The tile-timeline stamps of k_conv_gn2 (tools/conv_gn_timeline.py) have their own switch since round 4: `make EXTRA="-DNATINF_DEV -DNATINF_CG_TIMELINE"`.
+// With them in every -DNATINF_DEV build the 256-register instantiations spilled 2-4 vector registers (130 scalar spills parked in vector lanes on top of the
+// round-3 kernel) -- among them destinations of asm loads in flight: the development library faulted in its first fused convolution.
+#if defined(NATINF_DEV) && defined(NATINF_CG_TIMELINE)
+// timeline builds: shader-clock stamps at the section boundaries of a K-tile (block 0 / wave 0), summed over the tile's K loop
 __device__ __forceinline__ unsigned long long cg_stamp() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
         else { if (next_b) wait_vm_lgkm_barrier<PSW + PB>(); else wait_vm_lgkm_barrier<PSW>(); }
     };
 
-#ifdef NATINF_DEV
+#ifdef NATINF_CG_TIMELINE
     unsigned long long dbg_wait = 0, dbg_norm = 0, dbg_mfma = 0;
     const unsigned long long dbg_t0 = cg_stamp();
 #endif
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
         tap(buf_tag, integral_constant<int, 6>{}, hc, next_half, aux0); tap(buf_tag, integral_constant<int, 7>{}, hc, next_half, aux0);
         tap(buf_tag, integral_constant<int, 8>{}, hc, next_half, aux0);
     };
-#ifdef NATINF_DEV
+#ifdef NATINF_CG_TIMELINE
     const unsigned long long dbg_t1 = cg_stamp();
 #endif
     for (int hc = 0; hc < n_half; hc += 2) {                              // a0_C is a multiple of 64: half-chunks come in pairs
@@ -431,11 +434,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
 #else
     const GemmArgs ge = g;
 #endif
-#ifdef NATINF_DEV
+#ifdef NATINF_CG_TIMELINE
     const unsigned long long dbg_t2 = cg_stamp();
 #endif
     tile_epilogue<Cfg::WM, Cfg::WN, TM, TN, typename Cfg::Epi, EPI>(ge, smem, acc, m0, n0, 0, tid, lane, wm, wn);
-#ifdef NATINF_DEV
+#ifdef NATINF_CG_TIMELINE
     if (ge.dbg_ts && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 777)) {
         unsigned long long* o = ge.dbg_ts + (blockIdx.x ? 8 : 0);
         o[0] = dbg_t1 - dbg_t0; o[1] = dbg_wait; o[2] = dbg_norm; o[3] = dbg_mfma; o[4] = dbg_t2 - dbg_t1; o[5] = cg_stamp() - dbg_t2; o[6] = (unsigned long long)nk;

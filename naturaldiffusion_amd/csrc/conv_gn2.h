@@ -27,6 +27,11 @@
 //     residual fetch hits L2: +-0 (the +20-30 us of a residual launch are its 134 MB of extra HBM traffic, not latency);
 //   * v_mfma_f32_32x32x16_bf16 (half the MFMA instructions, 1.5x the vector-issue room per matrix-pipe cycle -- tools/probes/
 //     mfma_issue_probe.hip --, swizzle by patch column, 32x32 packed epilogue): 5 % fewer shader cycles (PMC), equal wall time.
+//   * (round 4) the element's chain cut into three stages ONE MFMA GROUP APART (group I issues unpack-fma-exp2 of element I + 1, add-rcp of element I, mul-pack
+//     of element I - 1: nothing issued behind a group depends on a result produced behind the same group; each stage pinned with an opaque asm, or hipcc
+//     sinks them back together and spills 60-200 registers; 0 spills at 255-256 registers with the pins): 32x32 K = 3,456 +2-5 %, 16x16 K = 4,608 +1.5 %,
+//     everything else +-1 % -- the in-order wave's dependency chain is not what holds the loop back -- and the four extra live registers tip the
+//     -DNATINF_DEV build (130 scalar spills in vector lanes) into spilling the destination of an asm load in flight: a fault.  Not kept.
 // PMC picture of the 256x128 tile (tools/pmc_conv_gn.sh): matrix pipe 48-55 % busy, LDS 25 %, L1/TA ~45 %, waves 24 % in s_waitcnt and
 // 38 % ready-but-not-issued: no unit is saturated; two waves per SIMD do not cover each other's dependency stalls.
 #pragma once
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
         }
     };
 
-#ifdef NATINF_DEV
+#ifdef NATINF_CG_TIMELINE
     const unsigned long long dbg_t0 = cg_stamp();
 #endif
     // Weight warm-up (GemmArgs::w_warm).  Inside a forward pass the weights of a layer are cold: every block streams the same matrix one tap
@@ -313,7 +318,6 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
     u32x4 nv = {0u, 0u, 0u, 0u}, ns0 = nv, ns1 = nv, nh0 = nv, nh1 = nv;
     unsigned npk[4] = {0u, 0u, 0u, 0u};
     float nf_even = 0.f;
-    float nst[3] = {0.f, 0.f, 0.f}, nse[3] = {0.f, 0.f, 0.f};                // the three elements in flight of the staged normalisation (t, then exp2(t), then 1 / (1 + exp2(t)))
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto norm_load = [&](auto j_tag, auto buf_tag) __attribute__((always_inline)) {
         constexpr int J = decltype(j_tag)::value, BUF = decltype(buf_tag)::value;
@@ -330,46 +334,30 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
         ns0 = lds_read16<BUF * Cfg::TAB_BYTES>(tbase); ns1 = lds_read16<BUF * Cfg::TAB_BYTES + 16>(tbase);
         nh0 = lds_read16<BUF * Cfg::TAB_BYTES + 128>(tbase); nh1 = lds_read16<BUF * Cfg::TAB_BYTES + 144>(tbase);
     };
-#define NATINF_CG_NORM_PRE(I) asm volatile("" : "+v"(nv), "+v"(ns0), "+v"(ns1), "+v"(nh0), "+v"(nh1)); if constexpr ((I) == 0) NATINF_CG_NORM_A(0)
+#define NATINF_CG_NORM_PRE(I) asm volatile("" : "+v"(nv), "+v"(ns0), "+v"(ns1), "+v"(nh0), "+v"(nh1));
     // (Round 3: the in-loop elements in packed-fp32 form -- channel pairs, v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32, ten vector instructions
     // per pair instead of thirteen -- were built and measured: +-0 on every shape.  hipcc's SIPreEmitPeephole splits packed-fp32 instructions
     // that sit in the shadow of an MFMA back into scalar ones (packed fp32 cannot be co-issued behind an MFMA on gfx950, the scalar forms can),
     // and the two extra registers a pair holds across a step tipped the EPI 1 instantiation into scratch reloads inside the loop.  The packed
     // form stays where no MFMA is in flight: the prologue's norm_round below, NATINF_CG_PK.)
-    // Round 4: the element's chain unpack -> fma -> exp2 | add -> rcp | mul (-> pack) is cut into three stages that run ONE MFMA GROUP APART: behind
-    // group I the wave issues stage A of element I + 1, stage B of element I and stage C of element I - 1 -- nothing it issues there depends on a result
-    // produced behind the same group.  (In the single-stage form every instruction of the chain waited for the transcendental in front of it, with only
-    // one or two MFMAs in between: an in-order wave then holds back its own next MFMAs.)  A (0) runs in front of group 0 (NORM_PRE), C (7) behind group 7
-    // (NORM_POST); TM = 4: the round spans two taps and the stages carry over (the variables live at kernel scope).  Four more live registers.
-#define NATINF_CG_NORM_A(I)                                                                                                 \
+#define NATINF_CG_NORM_EL(I)                                                                                                \
         {                                                                                                                    \
             const unsigned w_ = nv[(I) >> 1];                                                                                \
             const float x_ = __uint_as_float(((I) & 1) ? (w_ & 0xffff0000u) : (w_ << 16));                                   \
-            nst[(I) % 3] = x_ * __uint_as_float((I) < 4 ? ns0[(I) & 3] : ns1[(I) & 3]) + __uint_as_float((I) < 4 ? nh0[(I) & 3] : nh1[(I) & 3]); \
-            nse[(I) % 3] = __builtin_amdgcn_exp2f(nst[(I) % 3]);                                                             \
-            asm volatile("" : "+v"(nst[(I) % 3]), "+v"(nse[(I) % 3]));        /* (pinned: or hipcc sinks the stages back together) */ \
-        }
-#define NATINF_CG_NORM_B(I) { nse[(I) % 3] = __builtin_amdgcn_rcpf(1.0f + nse[(I) % 3]); asm volatile("" : "+v"(nse[(I) % 3])); }
-#define NATINF_CG_NORM_C(I)                                                                                                 \
-        {                                                                                                                    \
-            const float y_ = nst[(I) % 3] * nse[(I) % 3];                                                                    \
+            const float t_ = x_ * __uint_as_float((I) < 4 ? ns0[(I) & 3] : ns1[(I) & 3]) + __uint_as_float((I) < 4 ? nh0[(I) & 3] : nh1[(I) & 3]); \
+            const float y_ = t_ * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t_));                                  \
             if constexpr (((I) & 1) == 0) nf_even = y_;                                                                      \
             else {                                                                                                           \
                 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));                                                 \
                 const bf16x2_t pr_ = {(bf16)nf_even, (bf16)y_};                                                              \
                 npk[(I) >> 1] = __builtin_bit_cast(unsigned, pr_);                                                           \
             }                                                                                                                \
-            if constexpr (((I) & 1) == 0) asm volatile("" : "+v"(nf_even)); else asm volatile("" : "+v"(npk[(I) >> 1]));       \
-        }
-#define NATINF_CG_NORM_EL(I)                                                                                                \
-        if constexpr ((I) >= 1) NATINF_CG_NORM_C((I) - 1)                                                                    \
-        NATINF_CG_NORM_B(I)                                                                                                  \
-        if constexpr ((I) + 1 < 8) NATINF_CG_NORM_A((I) + 1)                                                                 \
+        }                                                                                                                    \
         _Pragma("unroll") for (int g_ = 0; g_ < TN; ++g_) {                                                                  \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       /* one MFMA */                                           \
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);       /* two vector instructions */                            \
         }
-#define NATINF_CG_NORM_POST(I) if constexpr ((I) == 7) NATINF_CG_NORM_C(7)
+#define NATINF_CG_NORM_POST(I) if constexpr (((I) & 1) == 0) asm volatile("" : "+v"(nf_even)); else asm volatile("" : "+v"(npk[(I) >> 1]));
     auto norm_store = [&](auto j_tag, auto buf_tag) __attribute__((always_inline)) {
         constexpr int J = decltype(j_tag)::value, BUF = decltype(buf_tag)::value;
         u32x4 ou = {npk[0], npk[1], npk[2], npk[3]};
@@ -464,7 +452,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
 
     // ---- prologue: this wave's table + patch pieces of half-chunk 0 and weight step 0; its pieces are normalised before the loop ----
     using std::integral_constant;
-#ifdef NATINF_DEV
+#ifdef NATINF_CG_TIMELINE
     unsigned long long dbg_wait = 0, dbg_head = 0, dbg_mfma = 0;
 #endif
     NATINF_CG_STAMP(dbg_p0)
@@ -537,7 +525,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
         tap(buf_tag, integral_constant<int, 6>{}, hc, next_half); tap(buf_tag, integral_constant<int, 7>{}, hc, next_half);
         tap(buf_tag, integral_constant<int, 8>{}, hc, next_half);
     };
-#ifdef NATINF_DEV
+#ifdef NATINF_CG_TIMELINE
     const unsigned long long dbg_t1 = cg_stamp();
 #endif
     for (int hc = 0; hc < nh_g; hc += 2) {                                // a0_C is a multiple of 64 (128 with two K groups): a group's half-chunks come in pairs
@@ -577,9 +565,6 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
 #undef NATINF_CG_NO_POST
 #undef NATINF_CG_NORM_PRE
 #undef NATINF_CG_NORM_EL
-#undef NATINF_CG_NORM_A
-#undef NATINF_CG_NORM_B
-#undef NATINF_CG_NORM_C
 #undef NATINF_CG_NORM_POST
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done with the tiles before the epilogue reuses them
     if constexpr (NG > 1) {
@@ -617,7 +602,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
 #else
     const GemmArgs ge = g;
 #endif
-#ifdef NATINF_DEV
+#ifdef NATINF_CG_TIMELINE
     const unsigned long long dbg_t2 = cg_stamp();
 #endif
     // (thread / lane id recomputed: the prologue's copies, kept alive across the K loops for the epilogue alone, are among the values hipcc spills in the
@@ -626,7 +611,7 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
     const int tid_e = wave_all * 64 + lane_e;
     tile_epilogue<Cfg::WM, Cfg::WN, TM, TN, typename Cfg::Epi, EPI, NIMG, (RES <= 8), true>(ge, smem, acc, m0, n0, 0, tid_e, lane_e, wm, wn);      // (two K groups: tid < 256 here)
-#ifdef NATINF_DEV
+#ifdef NATINF_CG_TIMELINE
     if (ge.dbg_ts && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 777)) {          // development builds: tools/conv_gn_timeline.py
         // block 0: [2..4] are the epilogue's own stamps (NATINF_TS: start, slab written, copied out), [7] = the stamp in front of it
         unsigned long long* o = ge.dbg_ts + (blockIdx.x ? 16 : 8);

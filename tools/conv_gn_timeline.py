@@ -1,4 +1,4 @@
-"""Where a k_conv_gn tile spends its shader clocks (needs a -DNATINF_DEV build: NATINF_LIB=gpurun_in/libnatinf_dev.so).
+"""Where a k_conv_gn tile spends its shader clocks (needs a build with EXTRA="-DNATINF_DEV -DNATINF_CG_TIMELINE": NATINF_LIB=...; that build spills 2-4 vector registers in the 256-register instantiations of k_conv_gn2 and can fault -- see csrc/conv_gn.h).
 usage: conv_gn_timeline.py res B cin N c1"""
 import sys
 from pathlib import Path
