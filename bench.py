@@ -602,7 +602,7 @@ def bench_sd3(args, world, rank, dev, fp8=False, steps=2, warmup=1, flat=None):
         check(lib.natinf_attention_profile(0), "attention_profile")
         t_fa = ms_tot.value / max(1, n_l.value) * 1e-3
         fa_flops = 4.0 * T * T * 64 * H * Bs
-        line["roofline"] = {"kernel": "k_flash_attn64_v2", "bound": "mfma", "achieved": r4(fa_flops / t_fa / 1e12), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+        line["roofline"] = {"kernel": "k_flash_attn64_v2<1,64>", "bound": "mfma", "achieved": r4(fa_flops / t_fa / 1e12), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": r4(fa_flops / t_fa / 1e12 / MFMA_BF16_PEAK_TFLOPS), "traffic": None, "mean_launch_ms": r4(t_fa * 1e3), "launches": int(n_l.value),
                             "flops_per_launch": r4(fa_flops), "iso_ms": r4(t_fa_iso * 1e3), "flop_share": r4(L * fa_flops / (flops_fwd_seq * Bs))}
         M = Bs * tx

@@ -71,10 +71,10 @@ int natinf_attention_hd64_bf16(const void* q, const void* k, int ld_qk, int64_t 
  * summed duration (ms) and the launch count since the last read.  Not thread-safe; for bench.py / tools. */
 int natinf_attention_profile(int enable);
 /* Which head_dim-64 attention kernel subsequent launches use (engine forwards and natinf_attention_hd64_bf16 alike): 0 = k_flash_attn64 (online
- * softmax, the running maximum updated every key tile; rounds 1-3), 1 = k_flash_attn64_v2 (q pre-multiplied by scale * log2 e, scores leave the matrix
- * pipe as exponents relative to a reference that is only moved when a score exceeds it by more than 2^8: no per-score fma, no cross-lane step on the
- * common path; -DNATINF_DEV builds only: NATINF_ESTATE elsewhere), 2 (default) = the same with the row sums on the matrix pipe.  Same function up
- * to rounding; NATINF_EINVAL outside 0..2. */
+ * softmax, the running maximum updated every key tile; rounds 1-3), 3 (default) = k_flash_attn64_v2<1, 64>: q pre-multiplied by scale * log2 e,
+ * scores leave the matrix pipe as exponents relative to a reference that is only moved when a score exceeds it by more than 2^8 (no per-score fma, no
+ * cross-lane step on the common path), row sums on the matrix pipe, 64-key tiles (three to four waves per SIMD).  1 / 2 = intermediate forms of it
+ * (vector-pipe row sums / 128-key tiles): -DNATINF_DEV builds only, NATINF_ESTATE elsewhere.  Same function up to rounding; NATINF_EINVAL outside 0..3. */
 int natinf_set_flash_mode(int mode);
 int natinf_attention_profile_read(double* ms_total, int64_t* launches);
 

@@ -233,15 +233,16 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64(const FlashArgs a)
 // chosen tile (spiked key) and checks both kernels against an fp64 softmax.
 constexpr float FA_THR = 8.0f;
 
-template <int SUMS>
-__global__ __launch_bounds__(256, 2) void k_flash_attn64_v2(const FlashArgs a)
+template <int SUMS, int KT = FA_KT>      // KT = 64: 16-KiB stages, 136 registers -- three blocks per CU (three waves per SIMD) instead of two
+__global__ __launch_bounds__(256, KT == 64 ? 3 : 2) void k_flash_attn64_v2(const FlashArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     lds_poison();
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nQ = a.Tp / FA_QB, nK = a.Tp / FA_KT;
+    constexpr int NT = KT / 16, NC = KT / 32, NPW = KT / 32, STAGE = 256 * KT;      // score tiles, PV steps, DMA pieces per wave and operand, bytes per stage
+    const int nQ = a.Tp / FA_QB, nK = a.Tp / KT;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = tile / nQ, qb = tile - bh * nQ, b = bh / a.H, head = bh - b * a.H;
     const bf16* qbase = a.q + (int64_t)b * a.qk_bs + head * 64;
@@ -252,10 +253,10 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64_v2(const FlashArgs a)
     // so it is a 32-bit offset computed ONCE (eight registers) next to a scalar base that moves by a constant per tile: the builtin form with a 64-bit
     // per-lane pointer spent ~30 vector instructions per tile and wave on address arithmetic -- in a loop whose bound is the vector issue port.
     const int prow = lane >> 3, pch = lane & 7;
-    unsigned koff[4], voff[4];
+    unsigned koff[NPW], voff[NPW];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = wave * 4 + j, row = 8 * p + prow;
+    for (int j = 0; j < NPW; ++j) {
+        const int p = wave * NPW + j, row = 8 * p + prow;
         const int f = ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
         koff[j] = (unsigned)(row * a.ld_qk + ((pch ^ f) << 3)) * 2u;
         const int sub = p >> 3, d = 8 * (p & 7) + prow;
@@ -266,13 +267,13 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64_v2(const FlashArgs a)
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo), "s"(sbase), "s"(dst) : "memory", "m0");
     };
     auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
-        const unsigned st = lds0 + buf * FA_STAGE + wave * 4096;
-        const bf16* kb = kbase + (int64_t)kt * FA_KT * a.ld_qk;
-        const bf16* vb = vbase + kt * FA_KT;
+        const unsigned st = lds0 + buf * STAGE + wave * (NPW * 1024);
+        const bf16* kb = kbase + (int64_t)kt * KT * a.ld_qk;
+        const bf16* vb = vbase + kt * KT;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds(koff[j], kb, st + j * 1024);
+        for (int j = 0; j < NPW; ++j) glds(koff[j], kb, st + j * 1024);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds(voff[j], vb, st + 16384 + j * 1024);
+        for (int j = 0; j < NPW; ++j) glds(voff[j], vb, st + KT * 128 + j * 1024);
     };
     issue(0, 0);
 
@@ -301,12 +302,12 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64_v2(const FlashArgs a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < nK) issue(kt + 1, (kt + 1) & 1);
-        const unsigned char* sK = smem + (kt & 1) * FA_STAGE;
-        const unsigned char* sV = sK + 16384;
+        const unsigned char* sK = smem + (kt & 1) * STAGE;
+        const unsigned char* sV = sK + KT * 128;
 
-        f32x4 acc[2][8];
+        f32x4 acc[2][NT];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
+        for (int t = 0; t < NT; ++t) {
             const int row = 32 * (t >> 1) + 4 * (t & 1) + krow;
             const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(sK + row * 128 + (((0 + q) ^ swz) << 4));
             const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(sK + row * 128 + (((4 + q) ^ swz) << 4));
@@ -315,13 +316,13 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64_v2(const FlashArgs a)
             acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, qf[0][1], acc[0][t], 0, 0, 0);
             acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, qf[1][1], acc[1][t], 0, 0, 0);
         }
-        if (kt == nK - 1 && a.Ttot < a.Tp) {
+        if ((kt + 1) * KT > a.Ttot) {                                          // (the padding -- up to 127 keys -- can reach into the last TWO 64-key tiles)
             // (the limit is made opaque HERE: as a loop invariant hipcc evaluates the 32 comparisons in front of the loop and keeps 64 scalar registers of
             // masks alive across it -- 27 of them spilled into vector-register lanes)
-            int lim = a.Ttot - kt * FA_KT - 8 * q;
+            int lim = a.Ttot - kt * KT - 8 * q;
             asm volatile("" : "+v"(lim));
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const bool ok = 32 * (t >> 1) + 4 * (t & 1) + i < lim;
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64_v2(const FlashArgs a)
         for (int g = 0; g < 2; ++g) {
             float mx = acc[g][0][0];
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) mx = fmaxf(mx, acc[g][t][i]);
             lm[g] = mx;
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64_v2(const FlashArgs a)
                 mref[g] += d;
                 cinit[g] = f32x4{-mref[g], -mref[g], -mref[g], -mref[g]};
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[g][t][i] -= d;
                 if (kt > 0) {                                                  // (first tile: O = l = 0, and exp2(-d) may overflow for a negative maximum)
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64_v2(const FlashArgs a)
         for (int g = 0; g < 2; ++g) {
             float s = 0.f;
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float p = __builtin_amdgcn_exp2f(acc[g][t][i]);
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64_v2(const FlashArgs a)
             if constexpr (!SUMS) l[g] += s;
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NC; ++c) {
             bf16x8 pf[2];
 #pragma unroll
             for (int g = 0; g < 2; ++g)

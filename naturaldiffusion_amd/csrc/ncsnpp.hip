@@ -307,8 +307,9 @@ bool configure_gemm_kernels() {
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess &&
 #ifdef NATINF_DEV
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64_v2<0>), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess &&
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64_v2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess &&
 #endif
-         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64_v2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess;
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64_v2<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES / 2) == hipSuccess;
     if (!ok) (void)hipGetLastError();
     return ok;
 }

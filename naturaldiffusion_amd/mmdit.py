@@ -125,8 +125,8 @@ def attention_hd64(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.T
     B, T, D = q.shape
     H = D // 64
     Tp = (T + 127) // 128 * 128
-    pad = lambda t: torch.nn.functional.pad(t.to(torch.bfloat16), (0, 0, 0, Tp - T)).contiguous()
-    qp, kp = pad(q), pad(k)
+    pad = lambda t, value=0.0: torch.nn.functional.pad(t.to(torch.bfloat16), (0, 0, 0, Tp - T), value=value).contiguous()
+    qp, kp = pad(q), pad(k, 25.0)       # (the padded KEY rows hold a large value on purpose: the kernel must mask them, whatever they contain; V^T padding must be finite)
     vT = pad(v).transpose(1, 2).contiguous()
     o = torch.empty_like(qp)
     check(lib.natinf_attention_hd64_bf16(ptr(qp), ptr(kp), D, Tp * D, ptr(vT), ptr(o), D, Tp * D, B, H, Tp, T, 0.125, stream_ptr()),

@@ -9,16 +9,16 @@ pytestmark = pytest.mark.gpu
 TOL = 3e-2          # max |engine - oracle| / max |oracle|, bf16 operands vs fp32 oracle
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["online", "deferred", "deferred+mfma_sums"])
+@pytest.fixture(params=[0, 1, 2, 3], ids=["online", "deferred", "deferred+mfma_sums", "deferred+mfma_sums_64key"])
 def flash_mode(request):
     """every head_dim-64 attention kernel of the library (natinf_set_flash_mode): the parity cases run on all of them"""
     from naturaldiffusion_amd._lib import lib, check
     rc = lib.natinf_set_flash_mode(request.param)
-    if rc == -4 and request.param == 1:                     # NATINF_ESTATE
-        pytest.skip("mode 1 (the intermediate form) exists in -DNATINF_DEV builds only")
+    if rc == -4 and request.param in (1, 2):                # NATINF_ESTATE
+        pytest.skip("modes 1 / 2 (intermediate forms) exist in -DNATINF_DEV builds only")
     check(rc, "natinf_set_flash_mode")
     yield request.param
-    check(lib.natinf_set_flash_mode(2), "natinf_set_flash_mode")              # the library's default
+    check(lib.natinf_set_flash_mode(3), "natinf_set_flash_mode")              # the library's default
 
 
 def _softmax_ref64(q, k, v, B, T, H):
@@ -27,7 +27,8 @@ def _softmax_ref64(q, k, v, B, T, H):
     return (w @ hd(v)).transpose(1, 2).reshape(B, T, H * 64)
 
 
-@pytest.mark.parametrize("B,T,H", [(2, 128, 2), (1, 333, 3), (2, 4429, 2), (1, 77, 1)])
+# (285 = 256 + 29 tokens: 99 padded keys -- more than one 64-key tile: the padding reaches into the last TWO tiles of the 64-key kernel; 129: 127 padded keys)
+@pytest.mark.parametrize("B,T,H", [(2, 128, 2), (1, 333, 3), (2, 4429, 2), (1, 77, 1), (2, 285, 4), (1, 129, 1), (1, 65, 2), (1, 64, 1)])
 def test_flash_attention_matches_fp32_softmax(B, T, H, flash_mode):
     from naturaldiffusion_amd.mmdit import attention_hd64
     g = torch.Generator().manual_seed(T)

@@ -13,7 +13,7 @@ vT = torch.randn(B, D, Tp, device="cuda", generator=g).bfloat16(); o = torch.emp
 def run(n):
     for _ in range(n):
         check(lib.natinf_attention_hd64_bf16(ptr(q), ptr(k), D, Tp * D, ptr(vT), ptr(o), D, Tp * D, B, H, Tp, T, 0.125, stream_ptr()), "attn")
-modes = [int(v) for v in sys.argv[1:]] or [0, 2]        # (mode 1: -DNATINF_DEV builds)
+modes = [int(v) for v in sys.argv[1:]] or [0, 3]        # (modes 1, 2: -DNATINF_DEV builds)
 ref = None
 for rep in range(3):                                    # interleaved rounds in ONE process (cdna guide rule 24)
     for m in modes:
