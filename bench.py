@@ -36,7 +36,7 @@ one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
                     512 + one ragged batch) with ``generate_sharded`` (two lanes, Philox noise by global index, uint8 images kept on
                     the device), scores it with the Inception-V3 pool3 engine in the reference's batches of 50, and
                     ``calc_fid_sharded`` sums (n, sum, outer-product sum) over ranks with ONE all-reduce and evaluates the Frechet
-                    distance (scipy sqrtm on the host, as pytorch_fid does).  With ONE GPU the default share is rank 0 of 8
+                    distance on the host (the trace term through two symmetric eigen-decompositions: fid_stats.frechet_distance; pytorch_fid's scipy sqrtm form gives the same number 2-5x slower).  With ONE GPU the default share is rank 0 of 8
                     (``share_of``: 6,250 images; ``--fid-share-of 1`` runs all 50,000).  value = images generated AND scored per second
                     over all ranks, both matrices; s = wall seconds {gen, inception, allreduce, frechet} summed over the two matrices;
                     gen_rate = images/s of generation alone; inc_rate = Inception images/s.  The checkpoint, the Inception weights and

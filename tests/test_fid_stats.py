@@ -37,6 +37,20 @@ def test_frechet_distance_closed_forms():
     assert abs(frechet_distance(mu[:1].repeat(6), A, mu[:1].repeat(6), B) - frechet_distance(mu[:1].repeat(6), B, mu[:1].repeat(6), A)) < 1e-8
 
 
+def test_eigh_form_equals_the_sqrtm_form():
+    """the default (symmetric eigen-decompositions) against the pytorch_fid form (scipy sqrtm of the product), full-rank and rank-deficient statistics"""
+    r = np.random.RandomState(3)
+    for n, dim in ((400, 96), (60, 96), (3000, 256)):                     # 60 samples in 96 dimensions: singular covariances
+        a = r.randn(n, dim) @ r.randn(dim, dim) * 0.2
+        b = r.randn(n, dim) @ r.randn(dim, dim) * 0.2 + 0.3
+        s1, s2, m1, m2 = np.cov(a, rowvar=False), np.cov(b, rowvar=False), a.mean(0), b.mean(0)
+        e, q = frechet_distance(m1, s1, m2, s2), frechet_distance(m1, s1, m2, s2, method="sqrtm")
+        assert abs(e - q) <= 1e-6 * abs(q), (n, dim, e, q)
+        assert abs(frechet_distance(m1, s1, m1, s1)) <= 1e-6 * np.trace(s1)      # (square roots of eigenvalues near zero: sqrt(eps) of the trace at best)
+    with pytest.raises(ValueError):
+        frechet_distance(m1, s1, m2, s2, method="cholesky")
+
+
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -7,7 +7,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from naturaldiffusion_amd._lib import lib, check, stream_ptr
 
-NAMES = {1: "generic128", 2: "dma256x256", 3: "dma256x128", 4: "dma128x128", 5: "ring256x256", 6: "ring256x128", 7: "ring128x128", 8: "ring64x128", 9: "ring256x128w4", 10: "dma256x128w4", 11: "dma256x256s", 12: "dma128x128s", 13: "dma512x128", 14: "patch256x256", 15: "patch256x128", 16: "dma256x256p", 17: "dma128x128p", 18: "dma256x128w4p", 19: "gemm8ph", 20: "gemm8ph_np", 21: "gemm8ph_rf", 22: "gemm8ph_nprf", 23: "fp8", 24: "abl_nodma", 25: "abl_nomfma", 26: "dma256x256h", 27: "dma512x128h"}
+NAMES = {0: "auto", 1: "generic128", 2: "dma256x256", 3: "dma256x128", 4: "dma128x128", 5: "ring256x256", 6: "ring256x128", 7: "ring128x128", 8: "ring64x128", 9: "ring256x128w4", 10: "dma256x128w4", 11: "dma256x256s", 12: "dma128x128s", 13: "dma512x128", 14: "patch256x256", 15: "patch256x128", 16: "dma256x256p", 17: "dma128x128p", 18: "dma256x128w4p", 19: "gemm8ph", 20: "gemm8ph_np", 21: "gemm8ph_rf", 22: "gemm8ph_nprf", 23: "fp8", 24: "abl_nodma", 25: "abl_nomfma", 26: "dma256x256h", 27: "dma512x128h"}
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 
@@ -107,7 +107,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
     ms, tf, _ = run(v, M, N, K0, K1, taps, res, iters=it)
     print(f"{NAMES[v]} {(M, N, K0 + K1, taps)}: {ms*1e3:.1f} us  {tf:.0f} TF/s")
     sys.exit(0)
-variants = [int(v) for v in sys.argv[1:]] or [2, 3, 4, 5, 6, 7, 8]
+variants = ([int(v) for v in sys.argv[1:]] or [26, 27, 4, 6, 8]) if __name__ == "__main__" else []      # (imported by bench_blaslt.py: nothing runs; the defaults are shipped variants)
 # correctness (plain GEMM with both K segments) for every variant first
 for v in variants:
     ms, tf, err = run(v, 1000, 384, 256, 128, 1, 0, iters=2, check_ref=True)
@@ -119,7 +119,7 @@ for v in variants:
             continue
         errs.append(check_conv(v, Bn, res, Cin, N, K1))
     print(f"conv check {NAMES[v]:>12}: " + " ".join(f"{e:.2e}" for e in errs))
-print(f"{'shape':>34} " + " ".join(f"{NAMES[v]:>12}" for v in variants))
+if variants: print(f"{'shape':>34} " + " ".join(f"{NAMES[v]:>12}" for v in variants))
 for (M, N, K0, K1, taps, res) in SHAPES:
     cells = []
     for v in variants:
