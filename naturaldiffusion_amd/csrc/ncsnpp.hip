@@ -187,6 +187,7 @@ inline bool variant_shipped(int v) {
 unsigned long long* g_dbg_ts = nullptr;
 int g_force_variant = V_AUTO;
 int g_half_issue = 1;              // natinf_set_gemm_half_issue(0): every wave issues its own LDS-DMA pieces (A/B runs)
+int g_round_model = 1;             // natinf_set_gemm_round_model(0): small-M plain GEMMs by the pre-round-4 rules (A/B runs)
 int g_pref_512 = 1;                // N <= 128 layers with >= 2 tiles per CU: the 512x128 hand-pipelined tile (natinf_set_gemm_pref512: A/B runs)      // tuning / tests: force one variant for every DMA-eligible launch
 std::string* g_record = nullptr;   // when set, launch_gemm describes the launch instead of issuing it
 
@@ -387,6 +388,14 @@ int choose_variant(const GemmArgs& g) {
 #else
     constexpr bool half = true;
 #endif
+    // Round 4: small-M plain GEMMs (the text stream of the MMDiT: M = 8 x 333 rows) by ROUNDS of blocks, not by "enough tiles for every CU": at
+    // (2664, 6144, 1536) the rule below took 256 x 256 tiles -- 264 of them: a second round for eight tiles, 77 us -- where 1,008 tiles of 128 x 128 run as two rounds of
+    // two blocks per CU in 55 us; at (2664, 4608, 1536) it took 128 x 128 (756 tiles, two rounds, 52 us) where 198 tiles of 256 x 256 are ONE round (43 us).  Measured
+    // cost of a round at K = 1,536: 25-28 us (128 x 128, two blocks per CU) against 37-43 us (256 x 256): ratio 1.5 (gpurun_in/scan_text.py).
+    if (g_round_model && g.taps == 1 && !g.gn_part && g.batch == 1 && g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) < 2 * NUM_CU) {
+        const int64_t r256 = (mt256 * (g.N / 256) + NUM_CU - 1) / NUM_CU, r128 = (mt128 * nt128 + 2 * NUM_CU - 1) / (2 * NUM_CU);
+        if (mt128 * nt128 >= NUM_CU / 2) return 3 * r256 < 2 * r128 ? (half ? V_DMA_256x256_H : V_DMA_256x256_P) : V_DMA_128x128_P;
+    }
     if (g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) * g.batch >= NUM_CU) return half ? V_DMA_256x256_H : V_DMA_256x256_P;
     if (g_pref_512 && g.N <= 128 && K0 + K1 >= 1024 && ((g.M + 511) / 512) * g.batch >= 2 * NUM_CU &&
         (!g.gn_part || (g.taps == 9 && (1 << g.logHW) % 512 == 0)))           // GroupNorm partials: a tile inside one sample
@@ -1611,6 +1620,7 @@ int natinf_set_attn_qkv(int on) { g_attn_qkv = on != 0; return NATINF_OK; }
 int natinf_set_attn_waves8(int on) { g_attn_w8 = on != 0; return NATINF_OK; }
 int natinf_set_attn_proj(int on) { g_attn_proj = on != 0; return NATINF_OK; }
 int natinf_set_fuse_fin(int on) { g_fuse_fin = on != 0; return NATINF_OK; }
+int natinf_set_gemm_round_model(int on) { g_round_model = on != 0; return NATINF_OK; }
 int natinf_set_fuse_gn4(int on) { g_fuse_gn4 = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn8_tile(int one_image) {
 #ifndef NATINF_DEV
