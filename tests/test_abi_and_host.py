@@ -206,3 +206,48 @@ def test_validation_grid_is_one_row_of_eight(tmp_path):
     from naturaldiffusion_amd.ValidateNaturalInference import save_image_grid
     save_image_grid(torch.zeros(8, 3, 16, 16), tmp_path / "g.png")
     assert Image.open(tmp_path / "g.png").size == (8 * 18 + 2, 18 + 2)
+
+
+def test_generation_pipeline_host_logic(tmp_path):
+    """Round 4 host pieces that need no GPU: how `generate_sharded` / `natural_inference_tx` pick their lanes, the reference-statistics argument of the FID
+    functions, the FidBlocked result, the handle-sharing ABI's argument checks, the per-workload defaults of bench.py."""
+    import ctypes as C
+    from naturaldiffusion_amd import CIFAR10NaturalInference as M
+    from naturaldiffusion_amd._lib import lib
+    f, g = (lambda x, t: x), (lambda x, t: -x)
+    assert M._lane_models([f, g], 2, 10) == [f, g]                         # a sequence: one lane each, as given
+    assert M._lane_models(f, 2, 10) == [f]                                  # an opaque callable owns state we cannot duplicate: one lane
+    mu, sg = np.zeros(4), np.eye(4)
+    a, b = M._ref_statistics((mu, sg))
+    assert a is not None and np.array_equal(b, sg)
+    np.savez(tmp_path / "ref.npz", mu=mu + 1, sigma=2 * sg)
+    a, b = M._ref_statistics(tmp_path / "ref.npz")
+    assert np.array_equal(a, mu + 1) and np.array_equal(b, 2 * sg)
+    with pytest.raises(FileNotFoundError, match="fid: blocked"):
+        M._ref_statistics(tmp_path / "absent.npz")
+    fb = M.FidBlocked(torch.zeros(3, 32, 32, 3, dtype=torch.uint8), "fid: blocked -- test")
+    assert tuple(fb.images.shape) == (3, 32, 32, 3) and "blocked" in fb.reason and "FidBlocked" in repr(fb)
+    # natinf_ncsnpp_share: host-side argument / state checks (no GPU involved)
+    h1, h2, h3 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert lib.natinf_ncsnpp_create(C.byref(h1), 0) == 0 and lib.natinf_ncsnpp_create(C.byref(h2), 0) == 0 and lib.natinf_ncsnpp_create(C.byref(h3), 2) == 0
+    assert lib.natinf_ncsnpp_share(h2, h1) == -4                            # NATINF_ESTATE: nothing loaded into h1
+    assert lib.natinf_ncsnpp_share(h1, h1) == -1 and lib.natinf_ncsnpp_share(None, h1) == -1      # NATINF_EINVAL
+    for h in (h1, h2, h3):
+        lib.natinf_ncsnpp_destroy(h)
+    assert lib.natinf_set_flash_mode(7) == -1 and lib.natinf_set_flash_mode(3) == 0 and lib.natinf_set_flash_mode(0) == 0 and lib.natinf_set_flash_mode(3) == 0
+    assert lib.natinf_set_flash_mode(1) in (0, -4) and lib.natinf_set_flash_mode(3) == 0           # intermediate forms: -DNATINF_DEV builds only
+
+
+def test_bench_line_stays_small(repo_root):
+    """the default line must survive a 3 KB log tail: the committed line of the round's final run is the check (bench.py moved every explanation to its docstring)"""
+    import json
+    f = repo_root / "profiles" / "r04" / "final_bench.json"
+    line = f.read_text().strip()
+    assert len(line) <= 3072, len(line)
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
+    assert list(d)[:14][-2:] == ["single_stream", "pipeline"] or "single_stream" in list(d)[:16]       # the like-for-like figure sits with the headline, in front of the sub-objects
+    for k in ("sd3", "sd3_fp8", "fid50k", "validate"):
+        assert "value" in d[k], k
