@@ -189,8 +189,7 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn64(const FlashArgs a)
                 for (int dt = 2 * blk; dt < 2 * blk + 2; ++dt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fabsf(oacc[g][dt][i] * inv));
-                amax = fmaxf(amax, __shfl_xor(amax, 16));
-                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                amax = group4_max_nonneg(amax);
                 float qinv;
                 const unsigned e8 = mx_scale_of(amax, qinv);
                 qinv *= inv;
@@ -435,8 +434,7 @@ __global__ __launch_bounds__(256, KT == 64 ? 3 : 2) void k_flash_attn64_v2(const
                 for (int dt = 2 * blk; dt < 2 * blk + 2; ++dt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fabsf(oacc[g][dt][i] * inv));
-                amax = fmaxf(amax, __shfl_xor(amax, 16));
-                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                amax = group4_max_nonneg(amax);
                 float qinv;
                 const unsigned e8 = mx_scale_of(amax, qinv);
                 qinv *= inv;

@@ -234,6 +234,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
         }
         if constexpr (DEQ) {
             if (g.bias_m) {                                               // (wave-uniform: only the V^T GEMMs carry a row bias)
+                asm volatile("");                                         // (a real branch: without it hipcc if-converts this into an add + four selects per value on EVERY launch)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += rbm[i];
             }
@@ -245,6 +246,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
             for (int e = 0; e < 4; ++e) v[e] += (float)x[e];
         }
         if (scale != 1.0f) {                                              // (wave-uniform; the transformer engines' GEMMs all have scale 1)
+            asm volatile("");                                             // (a real branch, as above)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= scale;
         }
@@ -299,8 +301,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
                 value(i, 2 * b + 1, v1);
                 float amax = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
                                    fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
-                amax = fmaxf(amax, __shfl_xor(amax, 16));
-                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                amax = group4_max_nonneg(amax);
                 float inv;
                 const unsigned e8 = mx_scale_of(amax, inv);
                 *reinterpret_cast<unsigned*>(wbase + i * 16 * PROW + (2 * b) * 16) = pack_fp8x4(v0[0] * inv, v0[1] * inv, v0[2] * inv, v0[3] * inv);

@@ -140,6 +140,18 @@ __device__ __forceinline__ unsigned mx_scale_of(float amax, float& inv) {
     inv = __uint_as_float((unsigned)(127 - e) << 23);
     return (unsigned)(e + 127);
 }
+// max over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (the four lane groups that hold one accumulator row) of a NON-NEGATIVE value, on the vector pipe:
+// v_permlane16_swap (odd rows of one copy <-> even rows of the other) and v_permlane32_swap (the wave's halves), unsigned integer maxima (the bit pattern of a
+// non-negative float orders like the float: no canonicalising v_max in front).  The ds_bpermute form of __shfl_xor costs an LDS round trip per stage behind an
+// s_waitcnt lgkmcnt(0) that also waits for every LDS store in flight -- in an epilogue that is writing its slab.
+__device__ __forceinline__ float group4_max_nonneg(float a) {
+    unsigned u = __float_as_uint(a);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    u = r[0] > r[1] ? r[0] : r[1];
+    const auto t = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    u = t[0] > t[1] ? t[0] : t[1];
+    return __uint_as_float(u);
+}
 __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {      // values already scaled; clamp: the cvt does not saturate
     a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);      // (one v_med3_f32 per value)
     c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
