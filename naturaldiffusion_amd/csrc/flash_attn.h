@@ -459,6 +459,8 @@ __global__ __launch_bounds__(256, KT == 64 ? 3 : 2) void k_flash_attn64_v2(const
     }
 }
 
+// Also measured on the 64-key form and not kept (one process, three interleaved rounds, 885-891 us every one of them): `s_setprio 1` around the two MFMA clusters;
+// each PV step's 32 exponentials pinned in front of its own MFMAs instead of all 64 ahead of the first step; both together.
 // Built on top of that and NOT kept (round 4; correct -- it passed every parity case of tests/test_gpu_mmdit.py incl. the forced re-referencing):
 // k_flash_attn64_pp, the two waves of a SIMD in OPPOSITE phases.  The counters of v2 (profiles/r04/flash_pmc_mode2.json) read as if matrix time
 // (1,152 pipe cycles per wave-tile) and vector time (~800) ADD UP on a SIMD (2,160 cycles per wave-tile) instead of overlapping -- the two co-resident
