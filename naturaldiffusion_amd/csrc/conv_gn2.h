@@ -32,6 +32,9 @@
 //     sinks them back together and spills 60-200 registers; 0 spills at 255-256 registers with the pins): 32x32 K = 3,456 +2-5 %, 16x16 K = 4,608 +1.5 %,
 //     everything else +-1 % -- the in-order wave's dependency chain is not what holds the loop back -- and the four extra live registers tip the
 //     -DNATINF_DEV build (130 scalar spills in vector lanes) into spilling the destination of an asm load in flight: a fault.  Not kept.
+//   * (round 4) THREE weight register sets for the TM = 4 instantiations (8x8 / 4x4: tap t + 2 requested while tap t is multiplied, set t % 3, counted vmcnt(TN) from
+//     tap 2 on; 204 / 114 registers, 0 spills, parity green): +-1 % on every 8x8 / 4x4 shape of tools/bench_conv_gn.py -- the one-tap-ahead weight request is not what
+//     a 4x4 tap's ~1,100 clocks (for 128 clocks of MFMAs) are made of.  Not kept.
 // PMC picture of the 256x128 tile (tools/pmc_conv_gn.sh): matrix pipe 48-55 % busy, LDS 25 %, L1/TA ~45 %, waves 24 % in s_waitcnt and
 // 38 % ready-but-not-issued: no unit is saturated; two waves per SIMD do not cover each other's dependency stalls.
 #pragma once
