@@ -391,7 +391,7 @@ int choose_variant(const GemmArgs& g) {
     // Round 4: small-M plain GEMMs (the text stream of the MMDiT: M = 8 x 333 rows) by ROUNDS of blocks, not by "enough tiles for every CU": at
     // (2664, 6144, 1536) the rule below took 256 x 256 tiles -- 264 of them: a second round for eight tiles, 77 us -- where 1,008 tiles of 128 x 128 run as two rounds of
     // two blocks per CU in 55 us; at (2664, 4608, 1536) it took 128 x 128 (756 tiles, two rounds, 52 us) where 198 tiles of 256 x 256 are ONE round (43 us).  Measured
-    // cost of a round at K = 1,536: 25-28 us (128 x 128, two blocks per CU) against 37-43 us (256 x 256): ratio 1.5 (gpurun_in/scan_text.py).
+    // cost of a round at K = 1,536: 25-28 us (128 x 128, two blocks per CU) against 37-43 us (256 x 256): ratio 1.5 (tools/scan_small_m_gemm.py).
     if (g_round_model && g.taps == 1 && !g.gn_part && g.batch == 1 && g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) < 2 * NUM_CU) {
         const int64_t r256 = (mt256 * (g.N / 256) + NUM_CU - 1) / NUM_CU, r128 = (mt128 * nt128 + 2 * NUM_CU - 1) / (2 * NUM_CU);
         if (mt128 * nt128 >= NUM_CU / 2) return 3 * r256 < 2 * r128 ? (half ? V_DMA_256x256_H : V_DMA_256x256_P) : V_DMA_128x128_P;

@@ -6,7 +6,6 @@
 # gpurun_out/pmc/<tag>/summary.json; copy it to profiles/rNN/.
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; K=$1; TAG=$2; shift 2
 O=$R/gpurun_out/pmc/$TAG; rm -rf $O; mkdir -p $O
-for i in 0 1 2 3; do [ -f "$R/$3" ] && break; done
 ARGS=(); for a in "$@"; do if [ -f "$R/$a" ]; then ARGS+=("$R/$a"); else ARGS+=("$a"); fi; done
 cd /tmp
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/sq1 -- "${ARGS[@]}" > $O/sq1.log 2>&1
