@@ -72,6 +72,22 @@ def test_generate_sharded_lanes_and_calc_fid_sharded_world1(dev):
     assert tm["images_all_ranks"] == N_TOTAL and tm["allreduce_s"] < 0.5 and tm["inception_s"] > 0
 
 
+def test_sharding_invariance_with_the_real_engine(dev):
+    """An image depends on (seed, its GLOBAL index) only -- also through the bf16 engine, as long as the batches have one size (the launch plan's tile choices
+    depend on the batch size, a sample's arithmetic does not depend on its neighbours: GroupNorm is per sample): 128 images as one rank's 4 batches of 32 and as
+    four ranks' single batches of 32 give the same bytes per global index."""
+    from naturaldiffusion_amd import CIFAR10NaturalInference as M
+    eng, _ = _engines(dev)
+    co = _coeff()
+    one, i1 = M.generate_sharded(eng, None, 128, 32, device=dev, coeff=co)
+    full = torch.empty_like(one)
+    for r in range(4):
+        im, ix = M.generate_sharded(eng, None, 128, 32, rank=r, world=4, device=dev, coeff=co)
+        assert torch.equal(ix, torch.arange(r, 128, 4)) and im.shape[0] == 32
+        full[ix] = im
+    assert torch.equal(i1, torch.arange(128)) and torch.equal(full, one)
+
+
 _RANK_SCRIPT = r"""
 import os, sys, json
 import numpy as np, torch, torch.distributed as dist
