@@ -135,6 +135,9 @@ int natinf_set_gemm_half_issue(int on);
 /* A/B switch for tuning: 1 (default) = small-M plain GEMMs (fewer than two rounds of 256 x 256 tiles) choose between 256 x 256 and 128 x 128 tiles by the number of
  * ROUNDS of blocks each needs (128 x 128: two blocks per CU; a 256 x 256 round costs 1.5 of a 128 x 128 one), 0 = by the pre-round-4 rules. */
 int natinf_set_gemm_round_model(int on);
+/* A/B switch for tuning: 1 (default) = plain GEMMs that took the 256 x 256 tile of eight waves (two per SIMD, 128 x 64 wave tiles) take the 256 x 256 x 64 tile of FOUR
+ * waves (one per SIMD, 128 x 128 wave tiles, accumulators in AGPRs: csrc/gemm_w128.h), 0 = the eight-wave tile as before round 4. */
+int natinf_set_gemm_w128(int on);
 /* Tuning: row-tiles per raster group of launches with >= 8 column tiles (default 8; 0 = plain row-major tile order). */
 int natinf_set_gemm_raster(int rows);
 /* 1 (default): plans built from now on run GroupNorm-apply + SiLU inside the consuming 3x3 convolution where a fused kernel

@@ -61,6 +61,7 @@ SIGNATURES = {
     "natinf_set_gemm_half_issue": (C.c_int, [_i32]),
     "natinf_set_gemm_raster": (C.c_int, [_i32]),
     "natinf_set_gemm_round_model": (C.c_int, [_i32]),
+    "natinf_set_gemm_w128": (C.c_int, [_i32]),
     "natinf_set_fuse_gn": (C.c_int, [_i32]),
     "natinf_set_conv_gn_wide": (C.c_int, [_i32]),
     "natinf_set_conv_gn_regw": (C.c_int, [_i32]),

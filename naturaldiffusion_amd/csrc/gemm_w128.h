@@ -1,0 +1,226 @@
+// gemm_w128.h -- k_gemm_w128: the plain bf16 GEMM (taps = 1, one K segment) on 256 x 256 x 64 block tiles worked by FOUR waves -- ONE WAVE PER SIMD, wave tile
+// 128 x 128, its 256 fp32 accumulators in AGPRs -- with both LDS stages (2 x 64 KB) filled by LDS-DMA TWO K-tiles ahead.
+//
+// Why (round 4, calibration against the vendor library on the transformer engines' shapes: 1,336-1,495 TFLOP/s against 1,026-1,259 for k_gemm_dma<2,4,8,4,6> on the same
+// box): k_gemm_dma / k_gemm_ring run two waves per SIMD with 128 x 64 wave tiles -- 12 fragment reads per 32 MFMAs, twice the waves issuing LDS-DMA, barriers and
+// waits through the one vector-issue port a SIMD has, and a 256-register budget that leaves no room for a second fragment set.  Here
+//   * a 128 x 128 wave tile needs 16 fragment reads per 64 MFMAs (0.25 per MFMA instead of 0.375) and the block 16 DMA pieces per wave and 128 MFMAs;
+//   * the accumulators live in a[0:255] (inline-asm "+a" operands), which leaves the 256 VGPRs for TWO complete fragment sets (8 A + 8 B fragments per 32-wide
+//     K step): the reads of K step s + 1 are issued while step s multiplies, so an MFMA never waits for an LDS read issued just before it;
+//   * with a single wave per SIMD nothing else competes for the issue port: the loop is ONE instruction stream, written out slot by slot (W128Step below: every
+//     instruction of the K loop is a volatile asm statement, so hipcc keeps the order; it only allocates the registers);
+//   * LDS-DMA two tiles ahead into a two-stage ring: the A half of stage `cur` is released as soon as every wave holds its K-step-1 A fragments (barrier 1), the B half
+//     after the B fragments (barrier 2); tile kt + 2 is then requested into the half just released, and tile kt + 1 -- requested a whole iteration earlier -- is
+//     awaited with a COUNTED vmcnt at two thirds of the iteration (barrier 3).  A request has ~1.3 iterations (~2,700 clocks) to land.
+// The tile is multiplied as two 256 x 128 halves (wave column wn owns columns wn * 64 .. + 63 of EACH half), so the epilogue is tile_epilogue<2, 2, 8, 4> of
+// gemm_dma.h called once per half: every fused epilogue of the 4-wave 256 x 128 tile works unchanged.
+// Limits (launch_gemm checks): taps == 1, no second K segment, K % 64 == 0, K >= 128, N % 8 == 0, operand matrices < 4 GiB (32-bit lane offsets).
+#pragma once
+#include "gemm_dma.h"
+
+namespace ncsn {
+
+struct W128Cfg {
+    static constexpr int WM = 2, WN = 2, TM = 8, TN = 8, NW = 4, THREADS = 256, BM_ = 256, BN_ = 256;
+    static constexpr int HALF_BYTES = 256 * BK * 2, STAGE_BYTES = 2 * HALF_BYTES;      // A half, B half of a stage: 32 KB each
+    using Epi = EpiCfg<2, 2, 8, 4, 2 * STAGE_BYTES + 8192>;                            // the 256 x 128 half tile
+    static constexpr int LDS_BYTES = Epi::NEED > 2 * STAGE_BYTES ? Epi::NEED : 2 * STAGE_BYTES;
+    static_assert(BK == 64 && LDS_BYTES <= 163840, "two 64-KB stages");
+};
+
+struct W128Addr {
+    unsigned a_cur, b_cur, a_nxt, b_nxt;      // per-lane LDS byte address of fragment 0, K step 0 (K step 1: ^ 64), in stage cur / cur ^ 1
+    unsigned da, db;                          // LDS-DMA destinations of this wave's piece 0 in stage cur (wave-uniform)
+    const bf16* pa; const bf16* pb;           // operand bases advanced to tile kt + 2 (wave-uniform)
+};
+
+__device__ __forceinline__ void w128_mfma(f32x4& acc, const u32x4& b, const u32x4& a) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(b), "v"(a));
+}
+__device__ __forceinline__ void w128_glds(unsigned vo, const void* sbase, unsigned dst) {       // prologue form: destination set right in front
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo), "s"(sbase), "s"(dst) : "memory", "m0");
+}
+// K-loop form: M0 is set ONE MFMA EARLIER (w128_m0_set / w128_m0_next: the MFMA in between is the wait state the hardware asks for between a write of M0 and an
+// LDS-DMA instruction), so that a request costs its gap one instruction, not four.  Nothing else in the loop touches M0 (the loop holds no compiler-generated code).
+__device__ __forceinline__ void w128_m0_set(unsigned dst) { asm volatile("s_mov_b32 m0, %0" :: "s"(dst) : "memory", "m0"); }
+__device__ __forceinline__ void w128_m0_next() { asm volatile("s_add_u32 m0, m0, 0x1000" ::: "memory", "m0", "scc"); }
+__device__ __forceinline__ void w128_glds_m0(unsigned vo, const void* sbase) {
+    asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(vo), "s"(sbase) : "memory");
+}
+
+// The slot table of one iteration (slot S = the instructions issued in front of MFMA S; MFMA S = K step S / 64, A fragment (S / 8) % 8, B fragment S % 8).
+// MODE 0: steady state; 1: second-to-last tile (nothing left to request; the last tile is awaited with vmcnt(0)); 2: last tile (K step 1's reads only).
+// A schedule SCH names the slots: K step 1's fragment reads (rd1: 0..7 = A, 8..15 = B), the two "half is free" barriers, the sixteen requests (piece p: 0..7 = A,
+// 8..15 = B; destinations 4 KB apart in that order; wave WV of the block may have its own slots), the counted wait for tile kt + 1, K step 0's reads of tile kt + 1.
+struct W128SchB {          // shipped: both halves released by ONE barrier behind the sixteen reads of K step 1 (all in the first seventeen slots); the requests four
+    static constexpr bool PER_WAVE = false, NO_DMA = false;      // MFMAs apart in gaps that carry no fragment read; tile kt + 1 awaited at slot 60
+    static constexpr int WAIT1 = 24, WAIT2 = 24, WAIT3 = 60;
+    static constexpr int rd1(int n) { return n < 8 ? 1 + 2 * n : 2 + 2 * (n - 8); }
+    static constexpr int dma(int p, int) { return 27 + 4 * p; }
+    static constexpr int rd0(int n) { return 90 + 2 * n; }                                      // 0..7 = B, 8..15 = A
+};
+#ifdef NATINF_DEV
+// Measured beside it (tools/ab_w128_sched.py, one box, TFLOP/s at 8192^3 / (32768, 6144, 1536) / (32768, 1536, 1536) / (32768, 1536, 6144); SchB: 1,526-1,620 / 1,325-1,342 /
+// 1,331-1,338 / 1,332-1,381; the two-waves-per-SIMD 256 x 256 tile: 1,243-1,396 / 1,084-1,225 / 1,254-1,262 / 1,109-1,228):
+struct W128SchA {          // the first form: A half and B half released by two barriers, requests two MFMAs apart between the B fragment reads: 1,366-1,581 / 1,272-1,301 / 1,281-1,298 / 1,312-1,358
+    static constexpr bool PER_WAVE = false, NO_DMA = false;
+    static constexpr int WAIT1 = 21, WAIT2 = 50, WAIT3 = 88;
+    static constexpr int rd1(int n) { return n < 8 ? 1 + 2 * n : 24 + 2 * (n - 8); }
+    static constexpr int dma(int p, int) { return p < 8 ? 23 + 2 * p : (p < 13 ? 52 + 2 * (p - 8) : 91 + 4 * (p - 13)); }
+    static constexpr int rd0(int n) { return n < 8 ? 90 + 2 * n : 106 + 2 * (n - 8); }
+};
+struct W128SchD : W128SchB {   // the reads of tile kt + 1 spread over the second half of the iteration, between the requests: 1,511-1,540 / 1,237 / 1,280-1,290 / 1,308-1,327
+    static constexpr int rd0(int n) { return 65 + 4 * n - (n == 15 ? 1 : 0); }
+};
+struct W128SchX : W128SchB { static constexpr bool NO_DMA = true; };      // ablation: nothing requested after the prologue (wrong results): 1,806-1,842 / 1,467-1,483 / 1,308-1,408 /
+                                                                           // 1,765-1,784 -- what the sixteen requests of an iteration cost (~19 clocks of matrix pipe each)
+// (the four waves' requests one MFMA apart from each other -- four copies of the loop behind a branch on the wave index -- made hipcc spill: 1,630 scratch
+// accesses, fragment registers spilled with their loads in flight: wrong results at 85 TFLOP/s.  Not kept.)
+#endif
+template <class SCH, int WV> constexpr int w128_early() { int c = 0; for (int p = 0; p < 16; ++p) c += SCH::dma(p, WV) < SCH::WAIT3; return c; }
+
+template <class SCH, int MODE, int S, int WV>
+struct W128Step {
+    template <int P>
+    static __device__ __forceinline__ void dma(const W128Addr& ad, const unsigned (&voa)[8], const unsigned (&vob)[8]) {
+        if constexpr (P < 16) {
+            constexpr int at = SCH::dma(P, WV);
+            static_assert(P == 0 || SCH::dma(P - 1, WV) < at, "requests in piece order, at most one per slot");
+            static_assert(at > (P < 8 ? SCH::WAIT1 + 1 : SCH::WAIT2 + 1) && at >= 2 && at < 128, "behind the barrier that frees its half");
+            if constexpr (S == at - 1) { if constexpr (P == 0) w128_m0_set(ad.da); else w128_m0_next(); }
+            if constexpr (S == at) w128_glds_m0(P < 8 ? voa[P] : vob[P - 8], P < 8 ? (const void*)ad.pa : (const void*)ad.pb);
+            dma<P + 1>(ad, voa, vob);
+        }
+    }
+    template <int N>
+    static __device__ __forceinline__ void reads(u32x4 (&fa)[2][8], u32x4 (&fb)[2][8], const W128Addr& ad) {
+        if constexpr (N < 16) {
+            if constexpr (S == SCH::rd1(N)) {
+                if constexpr (N < 8) fa[1][N] = lds_read16<N * 2048>(ad.a_cur ^ 64u);
+                else fb[1][N - 8] = lds_read16<((N - 8) >> 2) * 16384 + ((N - 8) & 3) * 2048>(ad.b_cur ^ 64u);
+            }
+            if constexpr (MODE < 2 && S == SCH::rd0(N)) {
+                if constexpr (N < 8) fb[0][N] = lds_read16<(N >> 2) * 16384 + (N & 3) * 2048>(ad.b_nxt);
+                else fa[0][N - 8] = lds_read16<(N - 8) * 2048>(ad.a_nxt);
+            }
+            reads<N + 1>(fa, fb, ad);
+        }
+    }
+    static __device__ __forceinline__ void run(f32x4 (&accL)[8][4], f32x4 (&accH)[8][4], u32x4 (&fa)[2][8], u32x4 (&fb)[2][8], const W128Addr& ad,
+                                               const unsigned (&voa)[8], const unsigned (&vob)[8])
+    {
+        static_assert(SCH::rd1(7) < SCH::WAIT1 && SCH::rd1(15) < SCH::WAIT2 && SCH::rd0(0) > SCH::WAIT3 + 1 && SCH::rd0(15) < 127, "reads in front of their waits");
+        if constexpr (S == SCH::WAIT1 || S == SCH::WAIT2 || (S == 127 && MODE < 2)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr ((S == SCH::WAIT1 + 1 || S == SCH::WAIT2 + 1) && MODE == 0) asm volatile("s_barrier" ::: "memory");          // the A / B half of stage cur is free
+        if constexpr (MODE < 2) {
+            if constexpr (S == SCH::WAIT3 && !(SCH::NO_DMA && MODE == 0)) {          // tile kt + 1 has landed: MODE 0 retires exactly the previous iteration's sixteen requests
+                if constexpr (MODE == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(w128_early<SCH, WV>()) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if constexpr (S == SCH::WAIT3 + 1) asm volatile("s_barrier" ::: "memory");
+        }
+        reads<0>(fa, fb, ad);
+        if constexpr (MODE == 0 && !SCH::NO_DMA) dma<0>(ad, voa, vob);
+        constexpr int ks = S >> 6, i = (S >> 3) & 7, j = S & 7;
+        if constexpr (j < 4) w128_mfma(accL[i][j], fb[ks][j], fa[ks][i]);
+        else w128_mfma(accH[i][j - 4], fb[ks][j], fa[ks][i]);
+        if constexpr (S + 1 < 128) W128Step<SCH, MODE, S + 1, WV>::run(accL, accH, fa, fb, ad, voa, vob);
+    }
+};
+
+template <int EPI, class SCH = W128SchB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_gemm_w128(const GemmArgs g)
+{
+    using Cfg = W128Cfg;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nN = (g.N + 255) / 256, nM = (g.M + 255) / 256;
+    const int tile = xcd_remap(blockIdx.x, nM * nN);
+    int mt_, nt_;
+    tile_coords(tile, nM, nN, g.raster_g, mt_, nt_);
+    const int m0 = mt_ * 256, n0 = nt_ * 256;
+    const int z = blockIdx.z;
+    const bf16* abase = g.a0 + (int64_t)z * g.a_bs;
+    const bf16* bbase = g.b + (int64_t)z * g.b_bs;
+    const int nk = g.a0_C / BK;                                       // >= 2
+
+    // LDS-DMA: piece n of this wave = rows n * 32 + wave * 8 .. + 7 of the A (B) half, one 128-byte row per eight lanes, the row's 16-byte chunks stored at
+    // chunk ^ ((row >> 1) & 7) (the image k_gemm_dma's fragment reads are conflict-free on)
+    unsigned voa[8], vob[8];
+    {
+        const int chunk = (lane & 7) ^ ((wave & 1) * 4 + (lane >> 4));
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int r = n * 32 + wave * 8 + (lane >> 3);
+            voa[n] = (unsigned)(((int64_t)min(m0 + r, g.M - 1) * g.a0_ld + chunk * 8) * 2);
+            vob[n] = (unsigned)(((int64_t)min(n0 + r, g.N - 1) * g.b_ld + chunk * 8) * 2);
+        }
+    }
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    const unsigned lds0 = (unsigned)(uintptr_t)((lds_u8*)smem);
+    const unsigned dw = lds0 + wave * 1024;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {                                     // tiles 0 and 1 -> stages 0 and 1
+#pragma unroll
+        for (int n = 0; n < 8; ++n) w128_glds(voa[n], abase + t * BK, dw + t * Cfg::STAGE_BYTES + n * 4096);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) w128_glds(vob[n], bbase + t * BK, dw + t * Cfg::STAGE_BYTES + Cfg::HALF_BYTES + n * 4096);
+    }
+
+    f32x4 accL[8][4], accH[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { accL[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; accH[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int frow = lane & 15, fq = lane >> 4, fswz = (frow >> 1) & 7;
+    const unsigned a_off = lds0 + (wm * 128 + frow) * 128 + ((fq ^ fswz) << 4);
+    const unsigned b_off = lds0 + Cfg::HALF_BYTES + (wn * 64 + frow) * 128 + ((fq ^ fswz) << 4);
+    u32x4 fa[2][8], fb[2][8];
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");    // tile 0 is in stage 0
+#pragma unroll
+    for (int n = 0; n < 8; ++n) fb[0][n] = lds_read16<0>(b_off + (n >> 2) * 16384 + (n & 3) * 2048);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) fa[0][n] = lds_read16<0>(a_off + n * 2048);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    W128Addr ad;
+    auto iter = [&](auto mode) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode)::value;
+        if constexpr (SCH::PER_WAVE) {
+            if (wave == 0) W128Step<SCH, MODE, 0, 0>::run(accL, accH, fa, fb, ad, voa, vob);
+            else if (wave == 1) W128Step<SCH, MODE, 0, 1>::run(accL, accH, fa, fb, ad, voa, vob);
+            else if (wave == 2) W128Step<SCH, MODE, 0, 2>::run(accL, accH, fa, fb, ad, voa, vob);
+            else W128Step<SCH, MODE, 0, 3>::run(accL, accH, fa, fb, ad, voa, vob);
+        } else W128Step<SCH, MODE, 0, 0>::run(accL, accH, fa, fb, ad, voa, vob);
+    };
+    for (int kt = 0; kt < nk - 2; ++kt) {
+        const unsigned cur = (kt & 1) * Cfg::STAGE_BYTES, nxt = cur ^ Cfg::STAGE_BYTES;
+        ad.a_cur = a_off + cur; ad.b_cur = b_off + cur; ad.a_nxt = a_off + nxt; ad.b_nxt = b_off + nxt;
+        ad.da = dw + cur; ad.db = dw + cur + Cfg::HALF_BYTES;
+        ad.pa = abase + (int64_t)(kt + 2) * BK; ad.pb = bbase + (int64_t)(kt + 2) * BK;
+        iter(std::integral_constant<int, 0>{});
+    }
+    {
+        const unsigned cur = ((nk - 2) & 1) * Cfg::STAGE_BYTES, nxt = cur ^ Cfg::STAGE_BYTES;
+        ad.a_cur = a_off + cur; ad.b_cur = b_off + cur; ad.a_nxt = a_off + nxt; ad.b_nxt = b_off + nxt;
+        ad.da = 0; ad.db = 0; ad.pa = abase; ad.pb = bbase;
+        iter(std::integral_constant<int, 1>{});
+        ad.a_cur = a_off + nxt; ad.b_cur = b_off + nxt;
+        iter(std::integral_constant<int, 2>{});
+    }
+    // the last MFMAs' results (inline asm: hipcc does not see the writes it would pad for) before anything reads an accumulator
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    tile_epilogue<2, 2, 8, 4, typename Cfg::Epi, EPI>(g, smem, accL, m0, n0, z, tid, lane, wm, wn);
+    if (n0 + 128 < g.N) {
+        __syncthreads();
+        tile_epilogue<2, 2, 8, 4, typename Cfg::Epi, EPI>(g, smem, accH, m0, n0 + 128, z, tid, lane, wm, wn);
+    }
+}
+
+}  // namespace ncsn

@@ -29,6 +29,7 @@
 #include "natinf_ncsnpp.h"
 #include "ncsnpp_kernels.h"
 #include "gemm_dma.h"
+#include "gemm_w128.h"
 #include "conv_gn.h"
 #include "conv_gn2.h"
 #include "head_conv.h"
@@ -163,11 +164,13 @@ enum GemmVariant {
     V_ABL_NODMA = 24, V_ABL_NOMFMA = 25,
     V_DMA_256x256_H = 26, V_DMA_512x128_H = 27,                         // hand pipeline, DMA issued by one wave per SIMD only
     V_CONV_GN = 28,                                                     // 3x3 conv with fused GroupNorm-apply + SiLU of its input (conv_gn.h); GemmArgs::gn_scale callers only
+    V_W128 = 29,                                                        // 256x256x64, four waves with 128x128 wave tiles (one per SIMD, AGPR accumulators; gemm_w128.h)
+    V_W128_A = 30, V_W128_D = 31, V_W128_X = 32,                               // -DNATINF_DEV: other K-loop schedules of k_gemm_w128 (EPI 1 launches only)
     V_COUNT
 };
 const char* variant_name(int v) {
     static const char* n[] = {"auto", "generic128", "dma256x256", "dma256x128", "dma128x128", "ring256x256", "ring256x128",
-                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s", "dma512x128", "patch256x256", "patch256x128", "dma256x256p", "dma128x128p", "dma256x128w4p", "gemm8ph", "gemm8ph_np", "gemm8ph_rf", "gemm8ph_nprf", "fp8_256x256", "abl_nodma", "abl_nomfma", "dma256x256h", "dma512x128h", "conv_gn"};
+                              "ring128x128", "ring64x128", "ring256x128w4", "dma256x128w4", "dma256x256s", "dma128x128s", "dma512x128", "patch256x256", "patch256x128", "dma256x256p", "dma128x128p", "dma256x128w4p", "gemm8ph", "gemm8ph_np", "gemm8ph_rf", "gemm8ph_nprf", "fp8_256x256", "abl_nodma", "abl_nomfma", "dma256x256h", "dma512x128h", "conv_gn", "w128_256x256", "w128_a", "w128_d", "w128_x"};
     return v >= 0 && v < V_COUNT ? n[v] : "?";
 }
 // The shipped library instantiates only the tile variants the dispatcher selects (choose_variant, splitk) plus the generic kernel; every other
@@ -179,7 +182,7 @@ inline bool variant_shipped(int v) {
 #else
     switch (v) {
         case V_AUTO: case V_GENERIC: case V_RING_64x128: case V_RING_256x128_W4: case V_DMA_128x128_P: case V_FP8_256x256:
-        case V_DMA_256x256_H: case V_DMA_512x128_H: case V_CONV_GN: return true;
+        case V_DMA_256x256_H: case V_DMA_512x128_H: case V_CONV_GN: case V_W128: return true;
         default: return false;
     }
 #endif
@@ -242,7 +245,8 @@ int g_fuse_gn = 1;                 // natinf_set_fuse_gn (read when a plan is BU
 // of which ever reaches the N <= 128 tile.
 constexpr unsigned EPI_ALL = 0x1FF;
 constexpr unsigned EPI_R64 = EPI_ALL, EPI_D128 = EPI_ALL, EPI_RW4 = EPI_ALL & ~(1u << 3), EPI_D256H = EPI_ALL & ~(1u << 3),
-                   EPI_D512H = EPI_ALL & ~((1u << 3) | (1u << 4) | (1u << 7) | (1u << 8));
+                   EPI_D512H = EPI_ALL & ~((1u << 3) | (1u << 4) | (1u << 7) | (1u << 8)),
+                   EPI_W128 = EPI_ALL & ~((1u << 2) | (1u << 3) | (1u << 6));          // plain long-K GEMMs: the transformer engines (GroupNorm partials take the general epilogue there)
 template <unsigned MASK, int E, class F> inline void epi_case(F&& f) { if constexpr ((MASK >> E) & 1u) f(std::integral_constant<int, E>{}); }
 template <unsigned MASK, class F> inline bool for_each_epi(F&& f) {             // f(integral_constant<int, E>) -> bool, over the instantiated ones
     bool ok = true;
@@ -257,8 +261,10 @@ bool set_lds_epi_all() {
            for_each_epi<EPI_RW4>([](auto t) { return set_lds<CfgR256x128W4>(&k_gemm_ring<2, 2, 8, 4, 3, NATINF_EPI_OF(t)>); }) &&
            for_each_epi<EPI_R64>([](auto t) { return set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4, NATINF_EPI_OF(t)>); }) &&
            for_each_epi<EPI_D256H>([](auto t) { return set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 6, NATINF_EPI_OF(t)>); }) &&
-           for_each_epi<EPI_D512H>([](auto t) { return set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4, 6, NATINF_EPI_OF(t)>); })
+           for_each_epi<EPI_D512H>([](auto t) { return set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4, 6, NATINF_EPI_OF(t)>); }) &&
+           for_each_epi<EPI_W128>([](auto t) { return set_lds<W128Cfg>(&k_gemm_w128<NATINF_EPI_OF(t)>); })
 #ifdef NATINF_DEV
+           && set_lds<W128Cfg>(&k_gemm_w128<1, W128SchA>) && set_lds<W128Cfg>(&k_gemm_w128<1, W128SchD>) && set_lds<W128Cfg>(&k_gemm_w128<1, W128SchX>)
            && for_each_epi<EPI_ALL>([](auto t) { return set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2, NATINF_EPI_OF(t)>); })
            && for_each_epi<EPI_ALL>([](auto t) { return set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4, 2, NATINF_EPI_OF(t)>); })
 #endif
@@ -360,6 +366,13 @@ inline bool conv_gn_ok(const GemmArgs& g) {
     const int e = conv_gn_epi(g);
     return e == 1 || e == 2 || e == 5 || e == 6;
 }
+int g_w128 = 1;                    // natinf_set_gemm_w128(0): plain GEMMs on the two-waves-per-SIMD 256x256 tile as before round 4 (A/B runs)
+// k_gemm_w128 (gemm_w128.h): plain GEMMs only, 32-bit lane offsets into the operands
+bool w128_ok(const GemmArgs& g) {
+    if (g.taps != 1 || g.a1 || g.gn_scale || g.deq_m || g.deq_n || g.splitk > 1) return false;
+    if (g.a0_C % BK || g.a0_C < 2 * BK || g.N % 8) return false;
+    return (int64_t)g.M * g.a0_ld * 2 < (int64_t)1 << 32 && (int64_t)g.N * g.b_ld * 2 < (int64_t)1 << 32;
+}
 int choose_variant(const GemmArgs& g) {
     if (g.gn_scale) return V_CONV_GN;               // the operand is raw: no other kernel can read it (launch_gemm checks conv_gn_ok)
     const int K0 = g.taps * g.a0_C, K1 = g.a1 ? g.a1_C : 0;
@@ -372,6 +385,14 @@ int choose_variant(const GemmArgs& g) {
         if (patch_ok && (g_force_variant == V_PATCH_256x128 || g.logW >= 4)) return g_force_variant;
     } else if (g_force_variant >= V_8PH_256x256 && g_force_variant <= V_8PH_BOTH) {
         if (eligible_8ph(g)) return g_force_variant;
+    }
+#endif
+    else if (g_force_variant == V_W128) {
+        if (w128_ok(g) && (!g.gn_part || (1 << g.logHW) % 256 == 0)) return V_W128;
+    }
+#ifdef NATINF_DEV
+    else if (g_force_variant >= V_W128_A && g_force_variant <= V_W128_X) {
+        if (w128_ok(g) && packed_epi(g, 256) == 1) return g_force_variant;
     }
 #endif
     else if (g_force_variant > V_GENERIC && g_force_variant != V_CONV_GN && g_force_variant != V_FP8_256x256) {
@@ -388,15 +409,16 @@ int choose_variant(const GemmArgs& g) {
 #else
     constexpr bool half = true;
 #endif
+    const bool w128 = g_w128 && w128_ok(g) && (!g.gn_part || (1 << g.logHW) % 256 == 0);       // round 4: plain GEMMs on the one-wave-per-SIMD tile (gemm_w128.h)
     // Round 4: small-M plain GEMMs (the text stream of the MMDiT: M = 8 x 333 rows) by ROUNDS of blocks, not by "enough tiles for every CU": at
     // (2664, 6144, 1536) the rule below took 256 x 256 tiles -- 264 of them: a second round for eight tiles, 77 us -- where 1,008 tiles of 128 x 128 run as two rounds of
     // two blocks per CU in 55 us; at (2664, 4608, 1536) it took 128 x 128 (756 tiles, two rounds, 52 us) where 198 tiles of 256 x 256 are ONE round (43 us).  Measured
     // cost of a round at K = 1,536: 25-28 us (128 x 128, two blocks per CU) against 37-43 us (256 x 256): ratio 1.5 (tools/scan_small_m_gemm.py).
     if (g_round_model && g.taps == 1 && !g.gn_part && g.batch == 1 && g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) < 2 * NUM_CU) {
         const int64_t r256 = (mt256 * (g.N / 256) + NUM_CU - 1) / NUM_CU, r128 = (mt128 * nt128 + 2 * NUM_CU - 1) / (2 * NUM_CU);
-        if (mt128 * nt128 >= NUM_CU / 2) return 3 * r256 < 2 * r128 ? (half ? V_DMA_256x256_H : V_DMA_256x256_P) : V_DMA_128x128_P;
+        if (mt128 * nt128 >= NUM_CU / 2) return 3 * r256 < 2 * r128 ? (w128 ? V_W128 : half ? V_DMA_256x256_H : V_DMA_256x256_P) : V_DMA_128x128_P;
     }
-    if (g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) * g.batch >= NUM_CU) return half ? V_DMA_256x256_H : V_DMA_256x256_P;
+    if (g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) * g.batch >= NUM_CU) return w128 ? V_W128 : half ? V_DMA_256x256_H : V_DMA_256x256_P;
     if (g_pref_512 && g.N <= 128 && K0 + K1 >= 1024 && ((g.M + 511) / 512) * g.batch >= 2 * NUM_CU &&
         (!g.gn_part || (g.taps == 9 && (1 << g.logHW) % 512 == 0)))           // GroupNorm partials: a tile inside one sample
         return half ? V_DMA_512x128_H : V_DMA_512x128;
@@ -408,7 +430,7 @@ int choose_variant(const GemmArgs& g) {
 int variant_bm(int v) {
     switch (v) {
         case V_CONV_GN: case V_DMA_256x256: case V_DMA_256x128: case V_RING_256x256: case V_RING_256x128: case V_RING_256x128_W4: case V_DMA_256x128_W4:
-        case V_ABL_NODMA: case V_ABL_NOMFMA: case V_DMA_256x256_H: case V_DMA_256x256_S: case V_PATCH_256x256: case V_PATCH_256x128: case V_DMA_256x256_P: case V_DMA_256x128W4_P: case V_8PH_256x256: case V_8PH_NOPRIO: case V_8PH_READFIRST: case V_8PH_BOTH: case V_FP8_256x256: return 256;
+        case V_ABL_NODMA: case V_ABL_NOMFMA: case V_DMA_256x256_H: case V_DMA_256x256_S: case V_PATCH_256x256: case V_PATCH_256x128: case V_DMA_256x256_P: case V_DMA_256x128W4_P: case V_8PH_256x256: case V_8PH_NOPRIO: case V_8PH_READFIRST: case V_8PH_BOTH: case V_FP8_256x256: case V_W128: case V_W128_A: case V_W128_D: case V_W128_X: return 256;
         case V_DMA_512x128: case V_DMA_512x128_H: return 512;
         case V_RING_64x128: return 64;
         default: return 128;
@@ -457,6 +479,7 @@ inline unsigned epi_mask(int v) {
         case V_RING_64x128: return EPI_R64;  case V_DMA_128x128_P: return EPI_D128;  case V_RING_256x128_W4: return EPI_RW4;
         case V_DMA_256x256_H: return EPI_D256H;  case V_DMA_512x128_H: return EPI_D512H;
         case V_DMA_256x256_P: case V_DMA_512x128: return EPI_ALL;
+        case V_W128: return EPI_W128;
         default: return 1u;
     }
 }
@@ -544,6 +567,21 @@ int launch_gemm(const GemmArgs& g0, hipStream_t s) {
         case V_FP8_256x256: launch_tiles<CfgD256x256>(&k_gemm_fp8<false, 0>, g, s); break;
         case V_DMA_256x256_H: NATINF_LAUNCH_EPI(EPI_D256H, CfgD256x256, k_gemm_dma, 2, 4, 8, 4, 6) break;
         case V_DMA_512x128_H: NATINF_LAUNCH_EPI(EPI_D512H, CfgD512x128, k_gemm_dma, 4, 2, 8, 4, 6) break;
+#ifdef NATINF_DEV
+        case V_W128_A: launch_tiles<W128Cfg>(&k_gemm_w128<1, W128SchA>, g, s); break;
+        case V_W128_D: launch_tiles<W128Cfg>(&k_gemm_w128<1, W128SchD>, g, s); break;
+        case V_W128_X: launch_tiles<W128Cfg>(&k_gemm_w128<1, W128SchX>, g, s); break;
+#endif
+        case V_W128: {
+            auto run_ = [&](auto t_) { launch_tiles<W128Cfg>(&k_gemm_w128<NATINF_EPI_OF(t_)>, g, s); };
+            switch (effective_epi(v, g)) {
+                case 1: epi_case<EPI_W128, 1>(run_); break;  case 4: epi_case<EPI_W128, 4>(run_); break;
+                case 5: epi_case<EPI_W128, 5>(run_); break;  case 7: epi_case<EPI_W128, 7>(run_); break;
+                case 8: epi_case<EPI_W128, 8>(run_); break;
+                default: run_(std::integral_constant<int, 0>{}); break;
+            }
+            break;
+        }
 #ifdef NATINF_DEV
         case V_DMA_256x256: launch_tiles<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4>, g, s); break;
         case V_DMA_256x128: launch_tiles<CfgD256x128>(&k_gemm_dma<4, 2, 4, 4>, g, s); break;
@@ -1621,6 +1659,7 @@ int natinf_set_attn_waves8(int on) { g_attn_w8 = on != 0; return NATINF_OK; }
 int natinf_set_attn_proj(int on) { g_attn_proj = on != 0; return NATINF_OK; }
 int natinf_set_fuse_fin(int on) { g_fuse_fin = on != 0; return NATINF_OK; }
 int natinf_set_gemm_round_model(int on) { g_round_model = on != 0; return NATINF_OK; }
+int natinf_set_gemm_w128(int on) { g_w128 = on != 0; return NATINF_OK; }
 int natinf_set_fuse_gn4(int on) { g_fuse_gn4 = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn8_tile(int one_image) {
 #ifndef NATINF_DEV

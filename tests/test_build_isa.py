@@ -168,8 +168,8 @@ def test_no_development_kernels_in_the_shipped_library(listings):
                                        r"k_gemm_ring<2, 2, 4, 4, 4, 0>", n)]
     assert not dead, dead
     tiles = [n for n in ks if re.search(r"k_gemm_|k_conv_gn|k_conv_patch", n)]
-    assert len(tiles) <= 76, len(tiles)                                        # the matmul tile families: 117 instantiations in round 2
-    assert len(ks) < 122, len(ks)                                              # all kernels (146 in round 2; round 3 added the Inception, head and vectorised LayerNorm kernels)
+    assert len(tiles) <= 82, len(tiles)                                        # the matmul tile families: 117 instantiations in round 2; round 4 added k_gemm_w128 (six epilogues)
+    assert len(ks) < 128, len(ks)                                              # all kernels (146 in round 2; round 3 added the Inception, head and vectorised LayerNorm kernels)
     code = listings["ncsnpp"]
     assert "s_memtime" not in code[:code.index("amdhsa.kernels:")]           # tile-timeline stamps: -DNATINF_DEV builds only
 

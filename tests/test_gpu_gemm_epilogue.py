@@ -8,6 +8,7 @@ pytestmark = pytest.mark.gpu
 
 # the shipped tile variants (ncsnpp.hip variant_shipped): 256x256 / 512x128 with one issuing wave per SIMD, 128x128, the two rings
 V_DMA256P, V_DMA128P, V_RING256W4, V_RING64, V_DMA512 = 26, 17, 9, 8, 27
+V_W128 = 29        # 256x256x64, one wave per SIMD with a 128x128 wave tile (gemm_w128.h): two 256x128 half-tile epilogues
 
 
 def _run(variant, M, N, K, lrs, terms, act=0, c_f32=False, fp32_slab=False, scale=1.0, seed=0, splitk=0):
@@ -58,6 +59,15 @@ CASES = [   # (variant, M, N, K, log2 rows per sample, fused terms, activation, 
     (V_DMA128P, 512, 256, 128, 6, ("bias_n", "rowvec"), 0, False),               # two samples per tile -> general epilogue
     (V_DMA256P, 2200, 2568, 128, 30, ("bias_n",), 0, False),                     # 9 x 11 tiles: grouped rasterisation, partial last group
     (V_DMA128P, 2100, 1160, 64, 30, ("bias_n", "gate", "resid_f32"), 0, True),   # 17 x 10 tiles of 128: grouped rasterisation
+    (V_W128, 1000, 392, 192, 8, ("bias_n",), 0, False),                          # EPI 1, ragged M and N, three K-tiles (one steady-state iteration)
+    (V_W128, 1024, 512, 128, 8, ("bias_n", "rowvec", "gn"), 0, False),           # GroupNorm partials (general epilogue on this tile), two K-tiles (no steady-state iteration)
+    (V_W128, 777, 1160, 256, 8, ("bias_n",), 2, False),                          # EPI 4, second half tile ragged
+    (V_W128, 1000, 136, 1536, 8, ("bias_n", "resid"), 0, False),                 # EPI 5, 24 K-tiles, second half tile of eight columns
+    (V_W128, 2048, 128, 1152, 9, ("bias_n", "rowvec", "resid", "gn"), 0, False), # residual + partials (general epilogue), no second half tile
+    (V_W128, 1000, 392, 192, 30, ("bias_n", "gate", "resid_f32"), 0, True),      # EPI 7
+    (V_W128, 520, 328, 128, 8, ("bias_m",), 0, False),                           # EPI 8
+    (V_W128, 2200, 2568, 320, 30, ("bias_n",), 0, False),                        # 9 x 11 tiles, five K-tiles
+    (V_W128, 4096, 1536, 6144, 30, ("bias_n",), 0, False),                       # 96 K-tiles, 96 tiles
 ]
 
 
