@@ -136,7 +136,8 @@ int natinf_set_gemm_half_issue(int on);
  * ROUNDS of blocks each needs (128 x 128: two blocks per CU; a 256 x 256 round costs 1.5 of a 128 x 128 one), 0 = by the pre-round-4 rules. */
 int natinf_set_gemm_round_model(int on);
 /* A/B switch for tuning: 1 (default) = plain GEMMs that took the 256 x 256 tile of eight waves (two per SIMD, 128 x 64 wave tiles) take the 256 x 256 x 64 tile of FOUR
- * waves (one per SIMD, 128 x 128 wave tiles, accumulators in AGPRs: csrc/gemm_w128.h), 0 = the eight-wave tile as before round 4. */
+ * waves (one per SIMD, 128 x 128 wave tiles, accumulators in AGPRs: csrc/gemm_w128.h) -- bf16 and e4m3 operands alike, except the e4m3 GEMMs that write e4m3 + E8M0 behind a
+ * tanh-GELU --; 2 = those too; 0 = the eight-wave tiles as before round 4. */
 int natinf_set_gemm_w128(int on);
 /* Tuning: row-tiles per raster group of launches with >= 8 column tiles (default 8; 0 = plain row-major tile order). */
 int natinf_set_gemm_raster(int rows);

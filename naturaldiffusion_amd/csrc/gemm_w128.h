@@ -14,7 +14,7 @@
 //     awaited with a COUNTED vmcnt at two thirds of the iteration (barrier 3).  A request has ~1.3 iterations (~2,700 clocks) to land.
 // The tile is multiplied as two 256 x 128 halves (wave column wn owns columns wn * 64 .. + 63 of EACH half), so the epilogue is tile_epilogue<2, 2, 8, 4> of
 // gemm_dma.h called once per half: every fused epilogue of the 4-wave 256 x 128 tile works unchanged.
-// Limits (launch_gemm checks): taps == 1, no second K segment, K % 64 == 0, K >= 128, N % 8 == 0, operand matrices < 4 GiB (32-bit lane offsets).
+// Limits (launch_gemm checks): taps == 1, no second K segment, K % 64 == 0, K >= 128, M % 8 == 0, N % 8 == 0, operand matrices < 4 GiB (32-bit offsets).
 #pragma once
 #include "gemm_dma.h"
 
@@ -28,10 +28,15 @@ struct W128Cfg {
     static_assert(BK == 64 && LDS_BYTES <= 163840, "two 64-KB stages");
 };
 
+typedef int w128_rsrc __attribute__((ext_vector_type(4)));
+struct W128Dma {
+    unsigned voa, vob;                        // the lane's byte offset inside an 8-row piece of A / B (row lane >> 3, its swizzled 16-byte chunk)
+    unsigned soa[8], sob[8];                  // byte offset of this wave's piece n from the operand's base (wave-uniform)
+    w128_rsrc ra, rb;                         // buffer descriptors at the operand bases advanced to the K-tile being requested
+};
 struct W128Addr {
     unsigned a_cur, b_cur, a_nxt, b_nxt;      // per-lane LDS byte address of fragment 0, K step 0 (K step 1: ^ 64), in stage cur / cur ^ 1
     unsigned da, db;                          // LDS-DMA destinations of this wave's piece 0 in stage cur (wave-uniform)
-    const bf16* pa; const bf16* pb;           // operand bases advanced to tile kt + 2 (wave-uniform)
 };
 
 __device__ __forceinline__ void w128_mfma(f32x4& acc, const u32x4& b, const u32x4& a) {
@@ -44,8 +49,18 @@ __device__ __forceinline__ void w128_glds(unsigned vo, const void* sbase, unsign
 // LDS-DMA instruction), so that a request costs its gap one instruction, not four.  Nothing else in the loop touches M0 (the loop holds no compiler-generated code).
 __device__ __forceinline__ void w128_m0_set(unsigned dst) { asm volatile("s_mov_b32 m0, %0" :: "s"(dst) : "memory", "m0"); }
 __device__ __forceinline__ void w128_m0_next() { asm volatile("s_add_u32 m0, m0, 0x1000" ::: "memory", "m0", "scc"); }
-__device__ __forceinline__ void w128_glds_m0(unsigned vo, const void* sbase) {
-    asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(vo), "s"(sbase) : "memory");
+// The requests are BUFFER loads: address = descriptor base + the lane's offset inside an 8-row piece (ONE register per operand) + the piece's scalar offset -- fourteen
+// lane registers fewer than global_load_lds with an offset per piece (the fp8 kernel spilled them, and hipcc put a vmcnt(0) behind every reload).  A piece whose rows
+// lie beyond the matrix is pointed at the last valid 8-row group (M % 8 == 0, N % 8 == 0): every address is in bounds, the epilogue masks the rows.
+__device__ __forceinline__ w128_rsrc w128_make_rsrc(const void* base) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    return w128_rsrc{(int)__builtin_amdgcn_readfirstlane((unsigned)a), (int)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu), -1, 0x00020000};
+}
+__device__ __forceinline__ void w128_bufdma(unsigned vo, const w128_rsrc& rs, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(vo), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void w128_bufdma_at(unsigned vo, const w128_rsrc& rs, unsigned soff, unsigned dst) {       // prologue form: destination set right in front
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(vo), "s"(rs), "s"(soff), "s"(dst) : "memory", "m0");
 }
 
 // The slot table of one iteration (slot S = the instructions issued in front of MFMA S; MFMA S = K step S / 64, A fragment (S / 8) % 8, B fragment S % 8).
@@ -82,14 +97,14 @@ template <class SCH, int WV> constexpr int w128_early() { int c = 0; for (int p 
 template <class SCH, int MODE, int S, int WV>
 struct W128Step {
     template <int P>
-    static __device__ __forceinline__ void dma(const W128Addr& ad, const unsigned (&voa)[8], const unsigned (&vob)[8]) {
+    static __device__ __forceinline__ void dma(const W128Addr& ad, const W128Dma& dm) {
         if constexpr (P < 16) {
             constexpr int at = SCH::dma(P, WV);
             static_assert(P == 0 || SCH::dma(P - 1, WV) < at, "requests in piece order, at most one per slot");
             static_assert(at > (P < 8 ? SCH::WAIT1 + 1 : SCH::WAIT2 + 1) && at >= 2 && at < 128, "behind the barrier that frees its half");
             if constexpr (S == at - 1) { if constexpr (P == 0) w128_m0_set(ad.da); else w128_m0_next(); }
-            if constexpr (S == at) w128_glds_m0(P < 8 ? voa[P] : vob[P - 8], P < 8 ? (const void*)ad.pa : (const void*)ad.pb);
-            dma<P + 1>(ad, voa, vob);
+            if constexpr (S == at) w128_bufdma(P < 8 ? dm.voa : dm.vob, P < 8 ? dm.ra : dm.rb, P < 8 ? dm.soa[P] : dm.sob[P - 8]);
+            dma<P + 1>(ad, dm);
         }
     }
     template <int N>
@@ -107,7 +122,7 @@ struct W128Step {
         }
     }
     static __device__ __forceinline__ void run(f32x4 (&accL)[8][4], f32x4 (&accH)[8][4], u32x4 (&fa)[2][8], u32x4 (&fb)[2][8], const W128Addr& ad,
-                                               const unsigned (&voa)[8], const unsigned (&vob)[8])
+                                               const W128Dma& dm)
     {
         static_assert(SCH::rd1(7) < SCH::WAIT1 && SCH::rd1(15) < SCH::WAIT2 && SCH::rd0(0) > SCH::WAIT3 + 1 && SCH::rd0(15) < 127, "reads in front of their waits");
         if constexpr (S == SCH::WAIT1 || S == SCH::WAIT2 || (S == 127 && MODE < 2)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -120,11 +135,11 @@ struct W128Step {
             if constexpr (S == SCH::WAIT3 + 1) asm volatile("s_barrier" ::: "memory");
         }
         reads<0>(fa, fb, ad);
-        if constexpr (MODE == 0 && !SCH::NO_DMA) dma<0>(ad, voa, vob);
+        if constexpr (MODE == 0 && !SCH::NO_DMA) dma<0>(ad, dm);
         constexpr int ks = S >> 6, i = (S >> 3) & 7, j = S & 7;
         if constexpr (j < 4) w128_mfma(accL[i][j], fb[ks][j], fa[ks][i]);
         else w128_mfma(accH[i][j - 4], fb[ks][j], fa[ks][i]);
-        if constexpr (S + 1 < 128) W128Step<SCH, MODE, S + 1, WV>::run(accL, accH, fa, fb, ad, voa, vob);
+        if constexpr (S + 1 < 128) W128Step<SCH, MODE, S + 1, WV>::run(accL, accH, fa, fb, ad, dm);
     }
 };
 
@@ -149,14 +164,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // LDS-DMA: piece n of this wave = rows n * 32 + wave * 8 .. + 7 of the A (B) half, one 128-byte row per eight lanes, the row's 16-byte chunks stored at
     // chunk ^ ((row >> 1) & 7) (the image k_gemm_dma's fragment reads are conflict-free on)
-    unsigned voa[8], vob[8];
+    W128Dma dm;
     {
         const int chunk = (lane & 7) ^ ((wave & 1) * 4 + (lane >> 4));
+        dm.voa = (unsigned)(((lane >> 3) * g.a0_ld + chunk * 8) * 2);
+        dm.vob = (unsigned)(((lane >> 3) * g.b_ld + chunk * 8) * 2);
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
-            const int r = n * 32 + wave * 8 + (lane >> 3);
-            voa[n] = (unsigned)(((int64_t)min(m0 + r, g.M - 1) * g.a0_ld + chunk * 8) * 2);
-            vob[n] = (unsigned)(((int64_t)min(n0 + r, g.N - 1) * g.b_ld + chunk * 8) * 2);
+            const int r = n * 32 + wave * 8;
+            dm.soa[n] = (unsigned)((int64_t)min(m0 + r, g.M - 8) * g.a0_ld * 2);
+            dm.sob[n] = (unsigned)((int64_t)min(n0 + r, g.N - 8) * g.b_ld * 2);
         }
     }
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
@@ -165,9 +182,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int t = 0; t < 2; ++t) {                                     // tiles 0 and 1 -> stages 0 and 1
 #pragma unroll
-        for (int n = 0; n < 8; ++n) w128_glds(voa[n], abase + t * BK, dw + t * Cfg::STAGE_BYTES + n * 4096);
+        for (int n = 0; n < 8; ++n) w128_bufdma_at(dm.voa, w128_make_rsrc(abase + t * BK), dm.soa[n], dw + t * Cfg::STAGE_BYTES + n * 4096);
 #pragma unroll
-        for (int n = 0; n < 8; ++n) w128_glds(vob[n], bbase + t * BK, dw + t * Cfg::STAGE_BYTES + Cfg::HALF_BYTES + n * 4096);
+        for (int n = 0; n < 8; ++n) w128_bufdma_at(dm.vob, w128_make_rsrc(bbase + t * BK), dm.sob[n], dw + t * Cfg::STAGE_BYTES + Cfg::HALF_BYTES + n * 4096);
     }
 
     f32x4 accL[8][4], accH[8][4];
@@ -191,23 +208,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto iter = [&](auto mode) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mode)::value;
         if constexpr (SCH::PER_WAVE) {
-            if (wave == 0) W128Step<SCH, MODE, 0, 0>::run(accL, accH, fa, fb, ad, voa, vob);
-            else if (wave == 1) W128Step<SCH, MODE, 0, 1>::run(accL, accH, fa, fb, ad, voa, vob);
-            else if (wave == 2) W128Step<SCH, MODE, 0, 2>::run(accL, accH, fa, fb, ad, voa, vob);
-            else W128Step<SCH, MODE, 0, 3>::run(accL, accH, fa, fb, ad, voa, vob);
-        } else W128Step<SCH, MODE, 0, 0>::run(accL, accH, fa, fb, ad, voa, vob);
+            if (wave == 0) W128Step<SCH, MODE, 0, 0>::run(accL, accH, fa, fb, ad, dm);
+            else if (wave == 1) W128Step<SCH, MODE, 0, 1>::run(accL, accH, fa, fb, ad, dm);
+            else if (wave == 2) W128Step<SCH, MODE, 0, 2>::run(accL, accH, fa, fb, ad, dm);
+            else W128Step<SCH, MODE, 0, 3>::run(accL, accH, fa, fb, ad, dm);
+        } else W128Step<SCH, MODE, 0, 0>::run(accL, accH, fa, fb, ad, dm);
     };
     for (int kt = 0; kt < nk - 2; ++kt) {
         const unsigned cur = (kt & 1) * Cfg::STAGE_BYTES, nxt = cur ^ Cfg::STAGE_BYTES;
         ad.a_cur = a_off + cur; ad.b_cur = b_off + cur; ad.a_nxt = a_off + nxt; ad.b_nxt = b_off + nxt;
         ad.da = dw + cur; ad.db = dw + cur + Cfg::HALF_BYTES;
-        ad.pa = abase + (int64_t)(kt + 2) * BK; ad.pb = bbase + (int64_t)(kt + 2) * BK;
+        dm.ra = w128_make_rsrc(abase + (int64_t)(kt + 2) * BK); dm.rb = w128_make_rsrc(bbase + (int64_t)(kt + 2) * BK);
         iter(std::integral_constant<int, 0>{});
     }
     {
         const unsigned cur = ((nk - 2) & 1) * Cfg::STAGE_BYTES, nxt = cur ^ Cfg::STAGE_BYTES;
         ad.a_cur = a_off + cur; ad.b_cur = b_off + cur; ad.a_nxt = a_off + nxt; ad.b_nxt = b_off + nxt;
-        ad.da = 0; ad.db = 0; ad.pa = abase; ad.pb = bbase;
+        ad.da = 0; ad.db = 0; dm.ra = w128_make_rsrc(abase); dm.rb = dm.ra;
         iter(std::integral_constant<int, 1>{});
         ad.a_cur = a_off + nxt; ad.b_cur = b_off + nxt;
         iter(std::integral_constant<int, 2>{});
@@ -220,6 +237,209 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (n0 + 128 < g.N) {
         __syncthreads();
         tile_epilogue<2, 2, 8, 4, typename Cfg::Epi, EPI>(g, smem, accH, m0, n0 + 128, z, tid, lane, wm, wn);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------
+// k_gemm_w128_fp8: the same tile for e4m3 operands (gemm_fp8.h's contract: one fp32 scale per row / column applied in the epilogue, optionally E8M0 block scales on
+// the A operand).  A K-tile is 128 BYTES per row -- the LDS image, pieces and swizzle of the bf16 kernel -- and ONE K step of v_mfma_(scale_)f32_16x16x128_f8f6f4:
+// 64 MFMAs of 32 clocks per wave and tile.  A fragment is eight registers (two 16-byte reads: chunks q and 4 + q of the row), so two complete fragment sets do not
+// fit beside nothing; instead the B fragments are double-buffered as a set (2 x 64 registers) and the A fragments roll: A fragment i of tile kt + 1 is read as soon as
+// row i of tile kt has been multiplied (A fragment 7 at the top of the next iteration).  Every read of stage `cur` is therefore complete a few slots into iteration
+// kt + 1 -- where ONE barrier both releases the stage to the requests for tile kt + 2 and publishes tile kt + 1 (awaited with vmcnt(0): its sixteen requests were
+// this wave's last).  One barrier and two waits per 64 MFMAs.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+struct W128F8Cfg {
+    static constexpr int THREADS = 256, BM_ = 256, BN_ = 256, HALF_BYTES = 32768, STAGE_BYTES = 65536, MX_BASE = 2 * STAGE_BYTES;     // + 2 x 1 KB of E8M0 scales
+    using Epi = EpiCfg<2, 2, 8, 4, 2 * STAGE_BYTES + 8192>;
+    static constexpr int LDS_BYTES = Epi::NEED > MX_BASE + 2048 ? Epi::NEED : MX_BASE + 2048;
+    static_assert(LDS_BYTES <= 163840, "two 64-KB stages");
+};
+template <bool MXA>
+__device__ __forceinline__ void w128_mfma8(f32x4& acc, const u32x4& bl, const u32x4& bh, const u32x4& al, const u32x4& ah, unsigned unit, unsigned sc) {
+    const i32x8 b = i32x8{(int)bl[0], (int)bl[1], (int)bl[2], (int)bl[3], (int)bh[0], (int)bh[1], (int)bh[2], (int)bh[3]};
+    const i32x8 a = i32x8{(int)al[0], (int)al[1], (int)al[2], (int)al[3], (int)ah[0], (int)ah[1], (int)ah[2], (int)ah[3]};
+    if constexpr (MXA) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+a"(acc) : "v"(b), "v"(a), "v"(unit), "v"(sc));
+    else asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(acc) : "v"(b), "v"(a));
+}
+template <int OFF> __device__ __forceinline__ unsigned lds_read_u8(unsigned addr) {
+    unsigned v;
+    asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+struct W128F8Addr {
+    unsigned a_rd[2], b_rd[2], mx_rd;         // per-lane LDS byte addresses (chunk q; chunk 4 + q: ^ 64) of fragment 0 in stage 0 / 1; of the lane's first scale byte
+    unsigned d[2], mxd[2], mx_vo;             // LDS-DMA destination of this wave's piece 0 in stage 0 / 1; of the scale piece; the lane's offset into the scale piece
+    const uint8_t* pmx;                       // scale bytes of tile kt + 2
+    int wave;
+};
+// slots of an iteration (in front of MFMA S = A fragment S / 8, B fragment S % 8).  PAR = kt & 1 = the stage of tile kt = the B fragment set it multiplies.
+namespace w128f8 {
+constexpr int WAIT = 5, BAR = 6, MXDMA = 7;
+constexpr int dma(int p) { return 8 + 3 * p; }
+constexpr int rd_b(int j) { return 9 + 3 * j; }                                   // low half; the high half one slot later
+constexpr int rd_a(int i) { return i < 6 ? 33 + 3 * i : 57; }                    // A fragment i of tile kt + 1 (i <= 6): behind row i of tile kt (slot 8 i + 7)
+}
+template <bool MXA, int MODE, int PAR, int S>
+struct W128F8Step {
+    template <int P>
+    static __device__ __forceinline__ void dma(const W128F8Addr& ad, const W128Dma& dm) {
+        if constexpr (P < 16) {
+            constexpr int at = w128f8::dma(P);
+            if constexpr (S == at - 1) { if constexpr (P == 0) w128_m0_set(ad.d[PAR]); else w128_m0_next(); }
+            if constexpr (S == at) w128_bufdma(P < 8 ? dm.voa : dm.vob, P < 8 ? dm.ra : dm.rb, P < 8 ? dm.soa[P] : dm.sob[P - 8]);
+            dma<P + 1>(ad, dm);
+        }
+    }
+    template <int N>
+    static __device__ __forceinline__ void reads(u32x4 (&fal)[8], u32x4 (&fah)[8], u32x4 (&fbl)[2][8], u32x4 (&fbh)[2][8], unsigned (&sc)[8], const W128F8Addr& ad) {
+        using namespace w128f8;
+        if constexpr (N < 8) {
+            constexpr int NX = PAR ^ 1;
+            if constexpr (S == rd_b(N)) fbl[NX][N] = lds_read16<(N >> 2) * 16384 + (N & 3) * 2048>(ad.b_rd[NX]);
+            if constexpr (S == rd_b(N) + 1) fbh[NX][N] = lds_read16<(N >> 2) * 16384 + (N & 3) * 2048>(ad.b_rd[NX] ^ 64u);
+            if constexpr (N < 7) {
+                static_assert(rd_a(N) > 8 * N + 7 && rd_a(N) + 1 < 63 && rd_a(N) < 8 * N + 64, "behind the last use of the register, ahead of the next");
+                if constexpr (S == rd_a(N)) {
+                    fal[N] = lds_read16<N * 2048>(ad.a_rd[NX]);
+                    if constexpr (MXA) sc[N] = lds_read_u8<NX * 1024 + N * 64>(ad.mx_rd);
+                }
+                if constexpr (S == rd_a(N) + 1) fah[N] = lds_read16<N * 2048>(ad.a_rd[NX] ^ 64u);
+            }
+            reads<N + 1>(fal, fah, fbl, fbh, sc, ad);
+        }
+    }
+    static __device__ __forceinline__ void run(f32x4 (&accL)[8][4], f32x4 (&accH)[8][4], u32x4 (&fal)[8], u32x4 (&fah)[8], u32x4 (&fbl)[2][8], u32x4 (&fbh)[2][8],
+                                               unsigned (&sc)[8], unsigned unit, const W128F8Addr& ad, const W128Dma& dm)
+    {
+        using namespace w128f8;
+        // A fragment 7 of THIS tile: the last read of stage PAR
+        if constexpr (S == 0) { fal[7] = lds_read16<7 * 2048>(ad.a_rd[PAR]); if constexpr (MXA) sc[7] = lds_read_u8<PAR * 1024 + 7 * 64>(ad.mx_rd); }
+        if constexpr (S == 1) fah[7] = lds_read16<7 * 2048>(ad.a_rd[PAR] ^ 64u);
+        if constexpr (S == WAIT) {
+            if constexpr (MODE < 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // tile kt + 1 is in LDS (this wave's pieces); my reads of stage PAR are done
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if constexpr (S == BAR && MODE < 2) asm volatile("s_barrier" ::: "memory");
+        if constexpr (MODE == 0) {
+            if constexpr (MXA && S == MXDMA) { if (ad.wave == 0) w128_glds(ad.mx_vo, ad.pmx, ad.mxd[PAR]); }      // the 256 rows x 4 scale bytes of tile kt + 2: 1 KB
+            dma<0>(ad, dm);
+        }
+        if constexpr (MODE < 2) {
+            reads<0>(fal, fah, fbl, fbh, sc, ad);
+            if constexpr (S == 63) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        constexpr int i = S >> 3, j = S & 7;
+        if constexpr (j < 4) w128_mfma8<MXA>(accL[i][j], fbl[PAR][j], fbh[PAR][j], fal[i], fah[i], unit, sc[i]);
+        else w128_mfma8<MXA>(accH[i][j - 4], fbl[PAR][j], fbh[PAR][j], fal[i], fah[i], unit, sc[i]);
+        if constexpr (S + 1 < 64) W128F8Step<MXA, MODE, PAR, S + 1>::run(accL, accH, fal, fah, fbl, fbh, sc, unit, ad, dm);
+    }
+};
+
+// prologue: tile 0's B fragments and A fragments 0..6 from stage T
+template <bool MXA, int T>
+__device__ __forceinline__ void w128f8_first(u32x4 (&fal)[8], u32x4 (&fah)[8], u32x4 (&fbl)[2][8], u32x4 (&fbh)[2][8], unsigned (&sc)[8], const W128F8Addr& ad) {
+#define NATINF_W128F8_B(N) fbl[T][N] = lds_read16<((N) >> 2) * 16384 + ((N) & 3) * 2048>(ad.b_rd[T]); fbh[T][N] = lds_read16<((N) >> 2) * 16384 + ((N) & 3) * 2048>(ad.b_rd[T] ^ 64u);
+#define NATINF_W128F8_A(N) fal[N] = lds_read16<(N) * 2048>(ad.a_rd[T]); fah[N] = lds_read16<(N) * 2048>(ad.a_rd[T] ^ 64u); if constexpr (MXA) sc[N] = lds_read_u8<T * 1024 + (N) * 64>(ad.mx_rd);
+    NATINF_W128F8_B(0) NATINF_W128F8_B(1) NATINF_W128F8_B(2) NATINF_W128F8_B(3) NATINF_W128F8_B(4) NATINF_W128F8_B(5) NATINF_W128F8_B(6) NATINF_W128F8_B(7)
+    NATINF_W128F8_A(0) NATINF_W128F8_A(1) NATINF_W128F8_A(2) NATINF_W128F8_A(3) NATINF_W128F8_A(4) NATINF_W128F8_A(5) NATINF_W128F8_A(6)
+#undef NATINF_W128F8_A
+#undef NATINF_W128F8_B
+}
+
+// EPI as k_gemm_fp8: 0 = general fp32-slab epilogue, 1 = packed bf16, 2 = packed e4m3 + E8M0 with tanh-GELU, 3 = direct fp32 residual stream.
+template <bool MXA, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_gemm_w128_fp8(const GemmArgs g)
+{
+    using Cfg = W128F8Cfg;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nN = (g.N + 255) / 256, nM = (g.M + 255) / 256;
+    const int tile = xcd_remap(blockIdx.x, nM * nN);
+    int mt_, nt_;
+    tile_coords(tile, nM, nN, g.raster_g, mt_, nt_);
+    const int m0 = mt_ * 256, n0 = nt_ * 256;
+    const int z = blockIdx.z;
+    const uint8_t* abase = reinterpret_cast<const uint8_t*>(g.a0) + (int64_t)z * g.a_bs;         // strides in bytes = elements
+    const uint8_t* bbase = reinterpret_cast<const uint8_t*>(g.b) + (int64_t)z * g.b_bs;
+    const uint8_t* mxbase = MXA ? g.a_mx + (int64_t)z * g.a_mx_bs + (int64_t)m0 * 4 : nullptr;  // K-tile major: the tile's 256 rows x 4 blocks are 1 KB of consecutive bytes
+    const int64_t mx_step = MXA ? (int64_t)g.a_mx_ld * 4 : 0;
+    const int nk = g.a0_C / 128;                                      // >= 2, even
+
+    W128Dma dm;
+    {
+        const int chunk = (lane & 7) ^ ((wave & 1) * 4 + (lane >> 4));
+        dm.voa = (unsigned)((lane >> 3) * g.a0_ld + chunk * 16);
+        dm.vob = (unsigned)((lane >> 3) * g.b_ld + chunk * 16);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int r = n * 32 + wave * 8;
+            dm.soa[n] = (unsigned)((int64_t)min(m0 + r, g.M - 8) * g.a0_ld);
+            dm.sob[n] = (unsigned)((int64_t)min(n0 + r, g.N - 8) * g.b_ld);
+        }
+    }
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    const unsigned lds0 = (unsigned)(uintptr_t)((lds_u8*)smem);
+    const int frow = lane & 15, fq = lane >> 4, fswz = (frow >> 1) & 7;
+    W128F8Addr ad;
+    ad.wave = wave; ad.mx_vo = lane * 16;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        ad.d[t] = lds0 + t * Cfg::STAGE_BYTES + wave * 1024; ad.mxd[t] = lds0 + Cfg::MX_BASE + t * 1024;
+        ad.a_rd[t] = lds0 + t * Cfg::STAGE_BYTES + (wm * 128 + frow) * 128 + ((fq ^ fswz) << 4);
+        ad.b_rd[t] = lds0 + t * Cfg::STAGE_BYTES + Cfg::HALF_BYTES + (wn * 64 + frow) * 128 + ((fq ^ fswz) << 4);
+    }
+    ad.mx_rd = lds0 + Cfg::MX_BASE + (wm * 128 + frow) * 4 + fq;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {                                     // tiles 0 and 1 -> stages 0 and 1
+#pragma unroll
+        for (int n = 0; n < 8; ++n) w128_bufdma_at(dm.voa, w128_make_rsrc(abase + t * 128), dm.soa[n], ad.d[t] + n * 4096);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) w128_bufdma_at(dm.vob, w128_make_rsrc(bbase + t * 128), dm.sob[n], ad.d[t] + Cfg::HALF_BYTES + n * 4096);
+        if constexpr (MXA) { if (wave == 0) w128_glds(ad.mx_vo, mxbase + t * mx_step, ad.mxd[t]); }
+    }
+
+    f32x4 accL[8][4], accH[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { accL[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; accH[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    u32x4 fal[8], fah[8], fbl[2][8], fbh[2][8];
+    unsigned sc[8] = {127u, 127u, 127u, 127u, 127u, 127u, 127u, 127u};
+    const unsigned unit = 127u;                                       // E8M0 2^0
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    w128f8_first<MXA, 0>(fal, fah, fbl, fbh, sc, ad);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    auto ptrs = [&](int kt) __attribute__((always_inline)) {
+        dm.ra = w128_make_rsrc(abase + (int64_t)(kt + 2) * 128); dm.rb = w128_make_rsrc(bbase + (int64_t)(kt + 2) * 128); ad.pmx = mxbase + (int64_t)(kt + 2) * mx_step;
+    };
+    // nk is EVEN (launch_gemm_fp8 checks K % 256 == 0): the stage / B-set parity of an iteration is a template parameter, and a tail that chose between two
+    // parities at run time made hipcc spill ~100 accumulator tiles where the branches join
+    for (int kt = 0; kt < nk - 2; kt += 2) {
+        ptrs(kt); W128F8Step<MXA, 0, 0, 0>::run(accL, accH, fal, fah, fbl, fbh, sc, unit, ad, dm);
+        ptrs(kt + 1); W128F8Step<MXA, 0, 1, 0>::run(accL, accH, fal, fah, fbl, fbh, sc, unit, ad, dm);
+    }
+    dm.ra = w128_make_rsrc(abase); dm.rb = dm.ra; ad.pmx = mxbase;
+    W128F8Step<MXA, 1, 0, 0>::run(accL, accH, fal, fah, fbl, fbh, sc, unit, ad, dm);
+    W128F8Step<MXA, 2, 1, 0>::run(accL, accH, fal, fah, fbl, fbh, sc, unit, ad, dm);
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    auto epi = [&](f32x4 (&acc)[8][4], int nb) __attribute__((always_inline)) {
+        if constexpr (EPI == 1) packed_tile_epilogue<2, 2, 8, 4, typename Cfg::Epi, ACT_NONE, false, false, true, false>(g, smem, acc, m0, nb, z, tid, lane, wm, wn);
+        else if constexpr (EPI == 2) packed_tile_epilogue<2, 2, 8, 4, typename Cfg::Epi, ACT_GELU_TANH, false, false, true, true>(g, smem, acc, m0, nb, z, tid, lane, wm, wn);
+        else if constexpr (EPI == 3) direct_f32_epilogue<2, 2, 8, 4, true>(g, acc, m0, nb, z, lane, wm, wn);
+        else dma_tile_epilogue<2, 2, 8, 4, typename Cfg::Epi>(g, smem, acc, m0, nb, z, tid, lane, wm, wn);
+    };
+    epi(accL, n0);
+    if (n0 + 128 < g.N) {
+        __syncthreads();
+        epi(accH, n0 + 128);
     }
 }
 

@@ -302,6 +302,8 @@ bool configure_gemm_kernels() {
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 1>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 1>) &&
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 2>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 2>) &&
          set_lds<CfgD256x256>(&k_gemm_fp8<false, 3>) && set_lds<CfgD256x256>(&k_gemm_fp8<true, 3>) &&
+         set_lds<W128F8Cfg>(&k_gemm_w128_fp8<false, 0>) && set_lds<W128F8Cfg>(&k_gemm_w128_fp8<true, 0>) && set_lds<W128F8Cfg>(&k_gemm_w128_fp8<false, 1>) && set_lds<W128F8Cfg>(&k_gemm_w128_fp8<true, 1>) &&
+         set_lds<W128F8Cfg>(&k_gemm_w128_fp8<false, 2>) && set_lds<W128F8Cfg>(&k_gemm_w128_fp8<true, 2>) && set_lds<W128F8Cfg>(&k_gemm_w128_fp8<false, 3>) && set_lds<W128F8Cfg>(&k_gemm_w128_fp8<true, 3>) &&
 #ifdef NATINF_DEV
          set_lds<AttnCfg<8, 16, true>>(&k_attn_fused<8, 16, true>) &&      // the LDS-resident K / V^T form of the 16x16 attention: superseded by k_attn256
 #endif
@@ -366,11 +368,11 @@ inline bool conv_gn_ok(const GemmArgs& g) {
     const int e = conv_gn_epi(g);
     return e == 1 || e == 2 || e == 5 || e == 6;
 }
-int g_w128 = 1;                    // natinf_set_gemm_w128(0): plain GEMMs on the two-waves-per-SIMD 256x256 tile as before round 4 (A/B runs)
+int g_w128 = 1;                     // natinf_set_gemm_w128(0): plain GEMMs on the two-waves-per-SIMD 256x256 tile as before round 4 (A/B runs)
 // k_gemm_w128 (gemm_w128.h): plain GEMMs only, 32-bit lane offsets into the operands
 bool w128_ok(const GemmArgs& g) {
     if (g.taps != 1 || g.a1 || g.gn_scale || g.deq_m || g.deq_n || g.splitk > 1) return false;
-    if (g.a0_C % BK || g.a0_C < 2 * BK || g.N % 8) return false;
+    if (g.a0_C % BK || g.a0_C < 2 * BK || g.N % 8 || g.M % 8) return false;
     return (int64_t)g.M * g.a0_ld * 2 < (int64_t)1 << 32 && (int64_t)g.N * g.b_ld * 2 < (int64_t)1 << 32;
 }
 int choose_variant(const GemmArgs& g) {
@@ -447,8 +449,25 @@ int fp8_epi(const GemmArgs& g) {
     if (g.c_mode == OUT_FP8_MX && g.act == ACT_GELU_TANH && g.c_mx && g.N % 32 == 0) return 2;
     return 0;
 }
+extern int g_w128;
+// k_gemm_w128_fp8 (gemm_w128.h): an even number of 128-byte K-tiles, 32-bit offsets into the operands
+bool w128_fp8_ok(const GemmArgs& g) {
+    return g.taps == 1 && !g.a1 && g.a0_C % 256 == 0 && g.N % 8 == 0 && g.M % 8 == 0 &&
+           (int64_t)g.M * g.a0_ld < (int64_t)1 << 32 && (int64_t)g.N * g.b_ld < (int64_t)1 << 32;
+}
 template <bool MXA>
 void launch_gemm_fp8_t(const GemmArgs& g, hipStream_t s) {
+    // (the e4m3 + E8M0 epilogue with its tanh-GELU -- fc1 -- stays on the eight-wave tile unless natinf_set_gemm_w128(2): with ONE block per CU nothing multiplies while
+    // a block runs that epilogue; same-process A/B at K = 1,536: 1,100-1,130 TFLOP/s against 1,300-1,520, where the bf16 / fp32 epilogues gain 6-38 %)
+    if (g_w128 && w128_fp8_ok(g) && (fp8_epi(g) != 2 || g_w128 == 2)) {
+        switch (fp8_epi(g)) {
+            case 1: launch_tiles<W128F8Cfg>(&k_gemm_w128_fp8<MXA, 1>, g, s); break;
+            case 2: launch_tiles<W128F8Cfg>(&k_gemm_w128_fp8<MXA, 2>, g, s); break;
+            case 3: launch_tiles<W128F8Cfg>(&k_gemm_w128_fp8<MXA, 3>, g, s); break;
+            default: launch_tiles<W128F8Cfg>(&k_gemm_w128_fp8<MXA, 0>, g, s); break;
+        }
+        return;
+    }
     switch (fp8_epi(g)) {
         case 1: launch_tiles<CfgD256x256>(&k_gemm_fp8<MXA, 1>, g, s); break;
         case 2: launch_tiles<CfgD256x256>(&k_gemm_fp8<MXA, 2>, g, s); break;
@@ -1659,7 +1678,7 @@ int natinf_set_attn_waves8(int on) { g_attn_w8 = on != 0; return NATINF_OK; }
 int natinf_set_attn_proj(int on) { g_attn_proj = on != 0; return NATINF_OK; }
 int natinf_set_fuse_fin(int on) { g_fuse_fin = on != 0; return NATINF_OK; }
 int natinf_set_gemm_round_model(int on) { g_round_model = on != 0; return NATINF_OK; }
-int natinf_set_gemm_w128(int on) { g_w128 = on != 0; return NATINF_OK; }
+int natinf_set_gemm_w128(int on) { g_w128 = on < 0 ? 0 : (on > 2 ? 2 : on); return NATINF_OK; }
 int natinf_set_fuse_gn4(int on) { g_fuse_gn4 = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn8_tile(int one_image) {
 #ifndef NATINF_DEV

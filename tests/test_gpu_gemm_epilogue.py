@@ -61,7 +61,7 @@ CASES = [   # (variant, M, N, K, log2 rows per sample, fused terms, activation, 
     (V_DMA128P, 2100, 1160, 64, 30, ("bias_n", "gate", "resid_f32"), 0, True),   # 17 x 10 tiles of 128: grouped rasterisation
     (V_W128, 1000, 392, 192, 8, ("bias_n",), 0, False),                          # EPI 1, ragged M and N, three K-tiles (one steady-state iteration)
     (V_W128, 1024, 512, 128, 8, ("bias_n", "rowvec", "gn"), 0, False),           # GroupNorm partials (general epilogue on this tile), two K-tiles (no steady-state iteration)
-    (V_W128, 777, 1160, 256, 8, ("bias_n",), 2, False),                          # EPI 4, second half tile ragged
+    (V_W128, 776, 1160, 256, 8, ("bias_n",), 2, False),                          # EPI 4, second half tile ragged
     (V_W128, 1000, 136, 1536, 8, ("bias_n", "resid"), 0, False),                 # EPI 5, 24 K-tiles, second half tile of eight columns
     (V_W128, 2048, 128, 1152, 9, ("bias_n", "rowvec", "resid", "gn"), 0, False), # residual + partials (general epilogue), no second half tile
     (V_W128, 1000, 392, 192, 30, ("bias_n", "gate", "resid_f32"), 0, True),      # EPI 7

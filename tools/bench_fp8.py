@@ -51,5 +51,7 @@ def run_mx(M, N, K, iters=10):
         ms = e0.elapsed_time(e1) / iters
         res[name] = round(2.0 * M * N * K / ms / 1e9)
     return res
-for shp in ((32768, 1536, 1536), (32768, 1536, 6144), (32768, 6144, 1536)):
-    print("mx", shp, run_mx(*shp))
+for w in (0, 1, 0, 1):          # the eight-wave 256x256 tile (k_gemm_fp8) against the four-wave one (k_gemm_w128_fp8), same process
+    check(lib.natinf_set_gemm_w128(w), "set")
+    for shp in ((32768, 1536, 1536), (32768, 1536, 6144), (32768, 6144, 1536), (32768, 4608, 1536)):
+        print(f"w128={w} mx", shp, run_mx(*shp), flush=True)
