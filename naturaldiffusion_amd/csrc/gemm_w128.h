@@ -24,8 +24,9 @@ struct W128Cfg {
     static constexpr int WM = 2, WN = 2, TM = 8, TN = 8, NW = 4, THREADS = 256, BM_ = 256, BN_ = 256;
     static constexpr int HALF_BYTES = 256 * BK * 2, STAGE_BYTES = 2 * HALF_BYTES;      // A half, B half of a stage: 32 KB each
     using Epi = EpiCfg<2, 2, 8, 4, 2 * STAGE_BYTES + 8192>;                            // the 256 x 128 half tile
-    static constexpr int LDS_BYTES = Epi::NEED > 2 * STAGE_BYTES ? Epi::NEED : 2 * STAGE_BYTES;
-    static_assert(BK == 64 && LDS_BYTES <= 163840, "two 64-KB stages");
+    static constexpr int SLAB2_OFF = (Epi::PACK_BYTES + 1023) / 1024 * 1024;           // the second half tile's packed slab: its own LDS, so no barrier between the halves
+    static constexpr int LDS_BYTES = Epi::NEED > SLAB2_OFF + Epi::PACK_BYTES ? Epi::NEED : SLAB2_OFF + Epi::PACK_BYTES;
+    static_assert(BK == 64 && LDS_BYTES <= 163840 && LDS_BYTES >= 2 * STAGE_BYTES, "two 64-KB stages");
 };
 
 typedef int w128_rsrc __attribute__((ext_vector_type(4)));
@@ -33,6 +34,7 @@ struct W128Dma {
     unsigned voa, vob;                        // the lane's byte offset inside an 8-row piece of A / B (row lane >> 3, its swizzled 16-byte chunk)
     unsigned soa[8], sob[8];                  // byte offset of this wave's piece n from the operand's base (wave-uniform)
     w128_rsrc ra, rb;                         // buffer descriptors at the operand bases advanced to the K-tile being requested
+    unsigned pfa, pfb, junk;                  // L2 prefetch: the lane's row of A / B (one 128-byte line per lane and K-tile); the loads' common destination
 };
 struct W128Addr {
     unsigned a_cur, b_cur, a_nxt, b_nxt;      // per-lane LDS byte address of fragment 0, K step 0 (K step 1: ^ 64), in stage cur / cur ^ 1
@@ -52,9 +54,16 @@ __device__ __forceinline__ void w128_m0_next() { asm volatile("s_add_u32 m0, m0,
 // The requests are BUFFER loads: address = descriptor base + the lane's offset inside an 8-row piece (ONE register per operand) + the piece's scalar offset -- fourteen
 // lane registers fewer than global_load_lds with an offset per piece (the fp8 kernel spilled them, and hipcc put a vmcnt(0) behind every reload).  A piece whose rows
 // lie beyond the matrix is pointed at the last valid 8-row group (M % 8 == 0, N % 8 == 0): every address is in bounds, the epilogue masks the rows.
-__device__ __forceinline__ w128_rsrc w128_make_rsrc(const void* base) {
+__device__ __forceinline__ w128_rsrc w128_make_rsrc(const void* base, unsigned bytes = 0xffffffffu) {
     const uint64_t a = reinterpret_cast<uint64_t>(base);
-    return w128_rsrc{(int)__builtin_amdgcn_readfirstlane((unsigned)a), (int)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu), -1, 0x00020000};
+    return w128_rsrc{(int)__builtin_amdgcn_readfirstlane((unsigned)a), (int)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu),
+                     (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000};
+}
+// L2 prefetch (W128SchP, development builds; measured slower): one dword per 128-byte line of K-tile kt + 2 + PF, ahead of the LDS-DMA requests -- an HBM round trip
+// under load is longer than the ~1.3 iterations a request has (tile timeline, tools/w128_timeline.py, at (32768, 1536, 6144), where a row panel of A is read by six
+// tiles only: 3,282 clocks per K-tile against 2,222 at 8192^3).  The descriptor's num_records is the operand's real extent: a lane past the last row or K-tile reads nothing.
+template <int OFF> __device__ __forceinline__ void w128_prefetch(unsigned& junk, unsigned vo, const w128_rsrc& rs) {
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:%3" : "+v"(junk) : "v"(vo), "s"(rs), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void w128_bufdma(unsigned vo, const w128_rsrc& rs, unsigned soff) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(vo), "s"(rs), "s"(soff) : "memory");
@@ -73,6 +82,7 @@ struct W128SchB {          // shipped: both halves released by ONE barrier behin
     static constexpr int rd1(int n) { return n < 8 ? 1 + 2 * n : 2 + 2 * (n - 8); }
     static constexpr int dma(int p, int) { return 27 + 4 * p; }
     static constexpr int rd0(int n) { return 90 + 2 * n; }                                      // 0..7 = B, 8..15 = A
+    static constexpr int PF = 0, PF_A = 89, PF_B = 123;                                         // L2 prefetch of K-tile kt + 2 + PF (0 = none; W128SchP): behind the last request / read
 };
 #ifdef NATINF_DEV
 // Measured beside it (tools/ab_w128_sched.py, one box, TFLOP/s at 8192^3 / (32768, 6144, 1536) / (32768, 1536, 1536) / (32768, 1536, 6144); SchB: 1,526-1,620 / 1,325-1,342 /
@@ -83,16 +93,19 @@ struct W128SchA {          // the first form: A half and B half released by two 
     static constexpr int rd1(int n) { return n < 8 ? 1 + 2 * n : 24 + 2 * (n - 8); }
     static constexpr int dma(int p, int) { return p < 8 ? 23 + 2 * p : (p < 13 ? 52 + 2 * (p - 8) : 91 + 4 * (p - 13)); }
     static constexpr int rd0(int n) { return n < 8 ? 90 + 2 * n : 106 + 2 * (n - 8); }
+    static constexpr int PF = 0, PF_A = 0, PF_B = 0;
 };
 struct W128SchD : W128SchB {   // the reads of tile kt + 1 spread over the second half of the iteration, between the requests: 1,511-1,540 / 1,237 / 1,280-1,290 / 1,308-1,327
     static constexpr int rd0(int n) { return 65 + 4 * n - (n == 15 ? 1 : 0); }
 };
+struct W128SchP : W128SchB { static constexpr int PF = 3; };              // + L2 prefetch three K-tiles ahead of the requests (w128_prefetch): 8192^3 1,354 against 1,570, (32768, 6144, 1536) 1,125 against
+                                                                           // 1,260 -- a dword load of 64 different lines costs the L1 path eight requests' worth.  Not kept.
 struct W128SchX : W128SchB { static constexpr bool NO_DMA = true; };      // ablation: nothing requested after the prologue (wrong results): 1,806-1,842 / 1,467-1,483 / 1,308-1,408 /
                                                                            // 1,765-1,784 -- what the sixteen requests of an iteration cost (~19 clocks of matrix pipe each)
 // (the four waves' requests one MFMA apart from each other -- four copies of the loop behind a branch on the wave index -- made hipcc spill: 1,630 scratch
 // accesses, fragment registers spilled with their loads in flight: wrong results at 85 TFLOP/s.  Not kept.)
 #endif
-template <class SCH, int WV> constexpr int w128_early() { int c = 0; for (int p = 0; p < 16; ++p) c += SCH::dma(p, WV) < SCH::WAIT3; return c; }
+template <class SCH, int WV> constexpr int w128_early() { int c = SCH::PF ? 2 : 0; for (int p = 0; p < 16; ++p) c += SCH::dma(p, WV) < SCH::WAIT3; return c; }      // + the two prefetch loads of the iteration before
 
 template <class SCH, int MODE, int S, int WV>
 struct W128Step {
@@ -122,7 +135,7 @@ struct W128Step {
         }
     }
     static __device__ __forceinline__ void run(f32x4 (&accL)[8][4], f32x4 (&accH)[8][4], u32x4 (&fa)[2][8], u32x4 (&fb)[2][8], const W128Addr& ad,
-                                               const W128Dma& dm)
+                                               W128Dma& dm)
     {
         static_assert(SCH::rd1(7) < SCH::WAIT1 && SCH::rd1(15) < SCH::WAIT2 && SCH::rd0(0) > SCH::WAIT3 + 1 && SCH::rd0(15) < 127, "reads in front of their waits");
         if constexpr (S == SCH::WAIT1 || S == SCH::WAIT2 || (S == 127 && MODE < 2)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -136,6 +149,11 @@ struct W128Step {
         }
         reads<0>(fa, fb, ad);
         if constexpr (MODE == 0 && !SCH::NO_DMA) dma<0>(ad, dm);
+        if constexpr (MODE == 0 && SCH::PF > 0) {
+            static_assert(SCH::PF == 0 || (SCH::PF_A > SCH::dma(15, WV) && SCH::PF_B > SCH::PF_A && SCH::PF_A > SCH::WAIT3), "behind this iteration's requests: the next counted wait leaves them in flight");
+            if constexpr (S == SCH::PF_A) w128_prefetch<SCH::PF * 128>(dm.junk, dm.pfa, dm.ra);
+            if constexpr (S == SCH::PF_B) w128_prefetch<SCH::PF * 128>(dm.junk, dm.pfb, dm.rb);
+        }
         constexpr int ks = S >> 6, i = (S >> 3) & 7, j = S & 7;
         if constexpr (j < 4) w128_mfma(accL[i][j], fb[ks][j], fa[ks][i]);
         else w128_mfma(accH[i][j - 4], fb[ks][j], fa[ks][i]);
@@ -161,6 +179,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bf16* abase = g.a0 + (int64_t)z * g.a_bs;
     const bf16* bbase = g.b + (int64_t)z * g.b_bs;
     const int nk = g.a0_C / BK;                                       // >= 2
+    NATINF_TS(0);
 
     // LDS-DMA: piece n of this wave = rows n * 32 + wave * 8 .. + 7 of the A (B) half, one 128-byte row per eight lanes, the row's 16-byte chunks stored at
     // chunk ^ ((row >> 1) & 7) (the image k_gemm_dma's fragment reads are conflict-free on)
@@ -175,16 +194,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             dm.soa[n] = (unsigned)((int64_t)min(m0 + r, g.M - 8) * g.a0_ld * 2);
             dm.sob[n] = (unsigned)((int64_t)min(n0 + r, g.N - 8) * g.b_ld * 2);
         }
+        dm.pfa = (unsigned)((int64_t)min(m0 + wave * 64 + lane, g.M - 1) * g.a0_ld * 2);
+        dm.pfb = (unsigned)((int64_t)min(n0 + wave * 64 + lane, g.N - 1) * g.b_ld * 2);
+        dm.junk = 0;
     }
+    // the operands' extents behind their bases (the descriptors' num_records: what keeps a prefetch past the last K-tile from touching memory)
+    const unsigned a_bytes = (unsigned)((((int64_t)g.M - 1) * g.a0_ld + g.a0_C) * 2), b_bytes = (unsigned)((((int64_t)g.N - 1) * g.b_ld + g.a0_C) * 2);
+    auto rsrc_at = [&](int kt) __attribute__((always_inline)) {
+        dm.ra = w128_make_rsrc(abase + (int64_t)kt * BK, a_bytes - (unsigned)kt * (BK * 2)); dm.rb = w128_make_rsrc(bbase + (int64_t)kt * BK, b_bytes - (unsigned)kt * (BK * 2));
+    };
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     const unsigned lds0 = (unsigned)(uintptr_t)((lds_u8*)smem);
     const unsigned dw = lds0 + wave * 1024;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {                                     // tiles 0 and 1 -> stages 0 and 1
+        rsrc_at(t);
 #pragma unroll
-        for (int n = 0; n < 8; ++n) w128_bufdma_at(dm.voa, w128_make_rsrc(abase + t * BK), dm.soa[n], dw + t * Cfg::STAGE_BYTES + n * 4096);
+        for (int n = 0; n < 8; ++n) w128_bufdma_at(dm.voa, dm.ra, dm.soa[n], dw + t * Cfg::STAGE_BYTES + n * 4096);
 #pragma unroll
-        for (int n = 0; n < 8; ++n) w128_bufdma_at(dm.vob, w128_make_rsrc(bbase + t * BK), dm.sob[n], dw + t * Cfg::STAGE_BYTES + Cfg::HALF_BYTES + n * 4096);
+        for (int n = 0; n < 8; ++n) w128_bufdma_at(dm.vob, dm.rb, dm.sob[n], dw + t * Cfg::STAGE_BYTES + Cfg::HALF_BYTES + n * 4096);
+    }
+    if constexpr (SCH::PF > 0) {                                      // (every iteration's counted wait assumes two prefetch loads behind the previous iteration's requests)
+        w128_prefetch<SCH::PF * 128>(dm.junk, dm.pfa, dm.ra);
+        w128_prefetch<SCH::PF * 128>(dm.junk, dm.pfb, dm.rb);
     }
 
     f32x4 accL[8][4], accH[8][4];
@@ -197,7 +229,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned a_off = lds0 + (wm * 128 + frow) * 128 + ((fq ^ fswz) << 4);
     const unsigned b_off = lds0 + Cfg::HALF_BYTES + (wn * 64 + frow) * 128 + ((fq ^ fswz) << 4);
     u32x4 fa[2][8], fb[2][8];
-    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");    // tile 0 is in stage 0
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(SCH::PF > 0 ? 18 : 16) : "memory");    // tile 0 is in stage 0
+    NATINF_TS(1);
 #pragma unroll
     for (int n = 0; n < 8; ++n) fb[0][n] = lds_read16<0>(b_off + (n >> 2) * 16384 + (n & 3) * 2048);
 #pragma unroll
@@ -218,13 +251,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned cur = (kt & 1) * Cfg::STAGE_BYTES, nxt = cur ^ Cfg::STAGE_BYTES;
         ad.a_cur = a_off + cur; ad.b_cur = b_off + cur; ad.a_nxt = a_off + nxt; ad.b_nxt = b_off + nxt;
         ad.da = dw + cur; ad.db = dw + cur + Cfg::HALF_BYTES;
-        dm.ra = w128_make_rsrc(abase + (int64_t)(kt + 2) * BK); dm.rb = w128_make_rsrc(bbase + (int64_t)(kt + 2) * BK);
+        rsrc_at(kt + 2);
         iter(std::integral_constant<int, 0>{});
     }
     {
         const unsigned cur = ((nk - 2) & 1) * Cfg::STAGE_BYTES, nxt = cur ^ Cfg::STAGE_BYTES;
         ad.a_cur = a_off + cur; ad.b_cur = b_off + cur; ad.a_nxt = a_off + nxt; ad.b_nxt = b_off + nxt;
-        ad.da = 0; ad.db = 0; dm.ra = w128_make_rsrc(abase); dm.rb = dm.ra;
+        ad.da = 0; ad.db = 0;
         iter(std::integral_constant<int, 1>{});
         ad.a_cur = a_off + nxt; ad.b_cur = b_off + nxt;
         iter(std::integral_constant<int, 2>{});
@@ -232,13 +265,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // the last MFMAs' results (inline asm: hipcc does not see the writes it would pad for) before anything reads an accumulator
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    NATINF_TS(5);
+    asm volatile("" :: "v"(dm.junk));
     __syncthreads();
     tile_epilogue<2, 2, 8, 4, typename Cfg::Epi, EPI>(g, smem, accL, m0, n0, z, tid, lane, wm, wn);
+    NATINF_TS(6);
     if (n0 + 128 < g.N) {
-        __syncthreads();
-        tile_epilogue<2, 2, 8, 4, typename Cfg::Epi, EPI>(g, smem, accH, m0, n0 + 128, z, tid, lane, wm, wn);
+        // packed epilogues: the second half has a slab of its own (a wave goes from the first half's copy-out straight to the second half's register phase);
+        // the fp32-slab epilogue reuses the one slab behind a barrier; the direct epilogue (7) has none
+        if constexpr (EPI == 0) __syncthreads();
+        tile_epilogue<2, 2, 8, 4, typename Cfg::Epi, EPI>(g, smem + (EPI == 0 || EPI == 7 ? 0 : Cfg::SLAB2_OFF), accH, m0, n0 + 128, z, tid, lane, wm, wn);
     }
+    NATINF_TS(7);
 }
+
+// Built, measured and not kept (round 4): the PERSISTENT form -- one block per CU walking output tiles, the sixteen requests for the next tile's first K-tile issued
+// inside the last iteration of the current one (stage 0 is free by then when the K-tile count is even), the epilogue slab behind stage 0, the accumulators zeroed while
+// the requests land.  Parity green; (32768, 1536, 1536) +8 %, every other shape of tools/bench_w128.py +-1 % (the epilogue's stores sit in front of the next tile's
+// requests in vmcnt order, and what a block-per-tile launch loses between tiles is ~3-6k clocks of a 70-330k-clock tile).
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------------------
 // k_gemm_w128_fp8: the same tile for e4m3 operands (gemm_fp8.h's contract: one fp32 scale per row / column applied in the epilogue, optionally E8M0 block scales on
@@ -252,7 +296,9 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 struct W128F8Cfg {
     static constexpr int THREADS = 256, BM_ = 256, BN_ = 256, HALF_BYTES = 32768, STAGE_BYTES = 65536, MX_BASE = 2 * STAGE_BYTES;     // + 2 x 1 KB of E8M0 scales
     using Epi = EpiCfg<2, 2, 8, 4, 2 * STAGE_BYTES + 8192>;
-    static constexpr int LDS_BYTES = Epi::NEED > MX_BASE + 2048 ? Epi::NEED : MX_BASE + 2048;
+    static constexpr int SLAB2_OFF = (Epi::PACK_BYTES + 1023) / 1024 * 1024;
+    static constexpr int LDS_A = Epi::NEED > MX_BASE + 2048 ? Epi::NEED : MX_BASE + 2048;
+    static constexpr int LDS_BYTES = LDS_A > SLAB2_OFF + Epi::PACK_BYTES ? LDS_A : SLAB2_OFF + Epi::PACK_BYTES;
     static_assert(LDS_BYTES <= 163840, "two 64-KB stages");
 };
 template <bool MXA>
@@ -430,16 +476,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    auto epi = [&](f32x4 (&acc)[8][4], int nb) __attribute__((always_inline)) {
-        if constexpr (EPI == 1) packed_tile_epilogue<2, 2, 8, 4, typename Cfg::Epi, ACT_NONE, false, false, true, false>(g, smem, acc, m0, nb, z, tid, lane, wm, wn);
-        else if constexpr (EPI == 2) packed_tile_epilogue<2, 2, 8, 4, typename Cfg::Epi, ACT_GELU_TANH, false, false, true, true>(g, smem, acc, m0, nb, z, tid, lane, wm, wn);
+    auto epi = [&](f32x4 (&acc)[8][4], int nb, unsigned char* slab) __attribute__((always_inline)) {
+        if constexpr (EPI == 1) packed_tile_epilogue<2, 2, 8, 4, typename Cfg::Epi, ACT_NONE, false, false, true, false>(g, slab, acc, m0, nb, z, tid, lane, wm, wn);
+        else if constexpr (EPI == 2) packed_tile_epilogue<2, 2, 8, 4, typename Cfg::Epi, ACT_GELU_TANH, false, false, true, true>(g, slab, acc, m0, nb, z, tid, lane, wm, wn);
         else if constexpr (EPI == 3) direct_f32_epilogue<2, 2, 8, 4, true>(g, acc, m0, nb, z, lane, wm, wn);
-        else dma_tile_epilogue<2, 2, 8, 4, typename Cfg::Epi>(g, smem, acc, m0, nb, z, tid, lane, wm, wn);
+        else dma_tile_epilogue<2, 2, 8, 4, typename Cfg::Epi>(g, slab, acc, m0, nb, z, tid, lane, wm, wn);
     };
-    epi(accL, n0);
+    epi(accL, n0, smem);
     if (n0 + 128 < g.N) {
-        __syncthreads();
-        epi(accH, n0 + 128);
+        if constexpr (EPI == 0) __syncthreads();
+        epi(accH, n0 + 128, smem + (EPI == 0 || EPI == 3 ? 0 : Cfg::SLAB2_OFF));      // packed epilogues: a slab of its own, no barrier between the halves
     }
 }
 

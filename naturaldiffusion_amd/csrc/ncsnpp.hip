@@ -264,7 +264,7 @@ bool set_lds_epi_all() {
            for_each_epi<EPI_D512H>([](auto t) { return set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4, 6, NATINF_EPI_OF(t)>); }) &&
            for_each_epi<EPI_W128>([](auto t) { return set_lds<W128Cfg>(&k_gemm_w128<NATINF_EPI_OF(t)>); })
 #ifdef NATINF_DEV
-           && set_lds<W128Cfg>(&k_gemm_w128<1, W128SchA>) && set_lds<W128Cfg>(&k_gemm_w128<1, W128SchD>) && set_lds<W128Cfg>(&k_gemm_w128<1, W128SchX>)
+           && set_lds<W128Cfg>(&k_gemm_w128<1, W128SchA>) && set_lds<W128Cfg>(&k_gemm_w128<1, W128SchP>) && set_lds<W128Cfg>(&k_gemm_w128<1, W128SchX>)
            && for_each_epi<EPI_ALL>([](auto t) { return set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2, NATINF_EPI_OF(t)>); })
            && for_each_epi<EPI_ALL>([](auto t) { return set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4, 2, NATINF_EPI_OF(t)>); })
 #endif
@@ -588,7 +588,7 @@ int launch_gemm(const GemmArgs& g0, hipStream_t s) {
         case V_DMA_512x128_H: NATINF_LAUNCH_EPI(EPI_D512H, CfgD512x128, k_gemm_dma, 4, 2, 8, 4, 6) break;
 #ifdef NATINF_DEV
         case V_W128_A: launch_tiles<W128Cfg>(&k_gemm_w128<1, W128SchA>, g, s); break;
-        case V_W128_D: launch_tiles<W128Cfg>(&k_gemm_w128<1, W128SchD>, g, s); break;
+        case V_W128_D: launch_tiles<W128Cfg>(&k_gemm_w128<1, W128SchP>, g, s); break;        // (variant 31: the shipped schedule + the L2 prefetch)
         case V_W128_X: launch_tiles<W128Cfg>(&k_gemm_w128<1, W128SchX>, g, s); break;
 #endif
         case V_W128: {

@@ -23,9 +23,9 @@ def lib_rate(M, N, K):
 
 shapes = [(32768, 1536, 1536), (32768, 6144, 1536), (32768, 1536, 6144), (32768, 4608, 1536), (65536, 1152, 1152), (65536, 4608, 1152), (65536, 1152, 4608),
           (8192, 8192, 8192), (4096, 4096, 4096), (131072, 512, 256), (131072, 256, 256)]
-print(f"{'M,N,K':>24} {'vendor':>8} {'v26':>8} {'v29':>8} {'auto':>8}   (TFLOP/s)   err29")
+print(f"{'M,N,K':>24} {'vendor':>8} {'v26':>8} {'v29':>8} {'v29/vendor':>10}   (TFLOP/s)   err")
 for (M, N, K) in shapes:
     r26 = BG.run(26, M, N, K, 0, 1, 0, iters=iters)[1]
     ms, r29, err = BG.run(29, M, N, K, 0, 1, 0, iters=iters, check_ref=(M * N <= 1 << 28))
-    r0 = BG.run(0, M, N, K, 0, 1, 0, iters=iters)[1]
-    print(f"{str((M, N, K)):>24} {lib_rate(M, N, K):8.0f} {r26:8.0f} {r29:8.0f} {r0:8.0f}   {ms * 1e3:7.1f} us   {err}", flush=True)
+    rv = lib_rate(M, N, K)
+    print(f"{str((M, N, K)):>24} {rv:8.0f} {r26:8.0f} {r29:8.0f} {r29 / rv:10.3f}   {ms * 1e3:7.1f} us   {err}", flush=True)
