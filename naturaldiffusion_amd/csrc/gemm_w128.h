@@ -283,6 +283,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // inside the last iteration of the current one (stage 0 is free by then when the K-tile count is even), the epilogue slab behind stage 0, the accumulators zeroed while
 // the requests land.  Parity green; (32768, 1536, 1536) +8 %, every other shape of tools/bench_w128.py +-1 % (the epilogue's stores sit in front of the next tile's
 // requests in vmcnt order, and what a block-per-tile launch loses between tiles is ~3-6k clocks of a 70-330k-clock tile).
+// Also not kept: bf16 outputs straight from the accumulator registers (8-byte stores, no slab, no barrier -- the slab round trip is ~6.6k clocks per half tile,
+// tools/w128_timeline.py): 4-8 % SLOWER per GEMM at K <= 1,536 (bf16 and fp8 operands alike), SD3 forward +0.5 / +0.7 ms -- a store instruction that covers sixteen
+// 32-byte pieces costs the store path what one covering eight full lines does.
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------------------
 // k_gemm_w128_fp8: the same tile for e4m3 operands (gemm_fp8.h's contract: one fp32 scale per row / column applied in the epilogue, optionally E8M0 block scales on
