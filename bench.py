@@ -624,7 +624,7 @@ def bench_sd3(args, world, rank, dev, fp8=False, steps=2, warmup=1, flat=None):
             f_ = 2.0 * M * N_ * K_
             per[name] = [r4(f_ / t_ / 1e12), r4(f_ / t_ / 1e12 / pk_)]             # [TFLOP/s, fraction of the operand type's dense peak]
             tot_t += t_; tot_f += f_; tot_ideal += f_ / (pk_ * 1e12)
-        line["roofline_gemm"] = {"kernel": "k_gemm_fp8+k_gemm_dma" if fp8 else "k_gemm_dma", "achieved": r4(tot_f / tot_t / 1e12), "peak": r4(tot_f / tot_ideal / 1e12),
+        line["roofline_gemm"] = {"kernel": "k_gemm_w128_fp8+k_gemm_w128" if fp8 else "k_gemm_w128", "achieved": r4(tot_f / tot_t / 1e12), "peak": r4(tot_f / tot_ideal / 1e12),
                                  "frac": r4(tot_ideal / tot_t), "shapes": per}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the MMDiT oracle (fp32, eager PyTorch) on ONE sequence through TWO blocks at full width, extrapolated to the

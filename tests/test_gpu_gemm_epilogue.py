@@ -91,6 +91,23 @@ def test_epilogue_matches_fp32_reference(variant, M, N, K, lrs, terms, act, c_f3
             assert (g_[..., 1] - q).abs().max().item() <= 2e-3 * q.max().item()
 
 
+def test_w128_tile_equals_the_eight_wave_tile():
+    """k_gemm_w128 (one wave per SIMD, 128 x 128 wave tiles, AGPR accumulators) adds the same K steps in the same order as k_gemm_dma<2, 4, 8, 4, 6>: the two
+    tiles' bf16 outputs are the same bytes, fused terms included; and the dispatcher takes it for a plain long-K GEMM unless natinf_set_gemm_w128(0)"""
+    from naturaldiffusion_amd._lib import lib, check
+    for terms, act, c_f32 in ((("bias_n",), 0, False), (("bias_n",), 2, False), (("bias_n", "gate", "resid_f32"), 0, True)):
+        a = _run(V_W128, 2048, 1536, 1536, 30, terms, act, c_f32)
+        b = _run(V_DMA256P, 2048, 1536, 1536, 30, terms, act, c_f32)
+        assert torch.equal(a[0], b[0])
+        auto = _run(0, 65536, 1536, 1536, 30, terms, act, c_f32, seed=1)            # 1,536 tiles: the automatic choice ...
+        check(lib.natinf_set_gemm_w128(0), "set")
+        try:
+            old = _run(0, 65536, 1536, 1536, 30, terms, act, c_f32, seed=1)         # ... and the pre-round-4 one
+        finally:
+            check(lib.natinf_set_gemm_w128(1), "set")
+        assert torch.equal(auto[0], old[0])
+
+
 def test_packed_epilogue_is_deterministic():
     a = _run(V_DMA256P, 1024, 512, 128, 8, ("bias_n", "rowvec", "gn"))
     b = _run(V_DMA256P, 1024, 512, 128, 8, ("bias_n", "rowvec", "gn"))

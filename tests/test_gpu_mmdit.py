@@ -200,12 +200,22 @@ def test_forward_is_deterministic_and_ignores_workspace_contents(fp8):
     assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
-def test_fp8_gemm_matches_the_dequantised_product():
-    """k_gemm_fp8 on its own: same quantised operands, fp32 reference -> only the bf16 output rounding remains."""
+@pytest.fixture(params=[0, 1, 2], ids=["eight_wave_tile", "w128", "w128_incl_fc1"])
+def fp8_tile(request):
+    """natinf_set_gemm_w128: 0 = k_gemm_fp8 (eight waves, two per SIMD) for every launch, 1 (the default) = k_gemm_w128_fp8 (four waves, 128 x 128 wave tiles) where the
+    K-tile count is even, except the e4m3 + E8M0 output epilogue; 2 = that one too"""
+    from naturaldiffusion_amd._lib import lib, check
+    check(lib.natinf_set_gemm_w128(request.param), "set")
+    yield request.param
+    check(lib.natinf_set_gemm_w128(1), "set")
+
+
+def test_fp8_gemm_matches_the_dequantised_product(fp8_tile):
+    """k_gemm_fp8 / k_gemm_w128_fp8 on their own: same quantised operands, fp32 reference -> only the bf16 output rounding remains."""
     from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
     g = torch.Generator().manual_seed(3)
     # K = 1536 / 6144: the SD3-medium projections (q|k|v, fc1 / fc2): 12 and 48 K-tiles through the two-stage DMA pipeline
-    for (M, N, K) in ((512, 256, 256), (1000, 520, 384), (300, 264, 128), (768, 1536, 1536), (520, 1536, 6144)):
+    for (M, N, K) in ((512, 256, 256), (1000, 520, 384), (300, 264, 128), (768, 1536, 1536), (520, 1536, 6144), (1000, 392, 512), (264, 1288, 768)):      # (the last two: ragged tiles on the w128 kernel)
         a = (torch.randn(M, K, generator=g) * (torch.rand(M, 1, generator=g) * 3 + 0.1)).cuda()
         b = (torch.randn(N, K, generator=g) * 0.05).cuda()
         bias = torch.randn(N, generator=g).cuda()
@@ -247,7 +257,7 @@ def _ktile_major(sc):
     return torch.cat([t, torch.full((1024,), 127, dtype=torch.uint8, device=sc.device)])
 
 
-def test_fp8_gemm_with_mx_block_scales_in_and_out():
+def test_fp8_gemm_with_mx_block_scales_in_and_out(fp8_tile):
     """A operand with E8M0 block scales per 32 K-elements (fed to the MFMA lane by lane), and the fp8 + block-scale OUTPUT
     mode of the epilogue (what fc1 hands to fc2 in the fp8 engine)."""
     from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
