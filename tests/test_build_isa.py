@@ -168,8 +168,8 @@ def test_no_development_kernels_in_the_shipped_library(listings):
                                        r"k_gemm_ring<2, 2, 4, 4, 4, 0>", n)]
     assert not dead, dead
     tiles = [n for n in ks if re.search(r"k_gemm_|k_conv_gn|k_conv_patch", n)]
-    assert len(tiles) <= 82, len(tiles)                                        # the matmul tile families: 117 instantiations in round 2; round 4 added k_gemm_w128 (six epilogues)
-    assert len(ks) < 128, len(ks)                                              # all kernels (146 in round 2; round 3 added the Inception, head and vectorised LayerNorm kernels)
+    assert len(tiles) <= 88, len(tiles)                                        # the matmul tile families: 117 instantiations in round 2; round 4 added k_gemm_w128 (six epilogues) and k_gemm_w128_fp8 (2 x 4)
+    assert len(ks) < 136, len(ks)                                              # all kernels (146 in round 2; round 3 added the Inception, head and vectorised LayerNorm kernels)
     code = listings["ncsnpp"]
     assert "s_memtime" not in code[:code.index("amdhsa.kernels:")]           # tile-timeline stamps: -DNATINF_DEV builds only
 
@@ -235,3 +235,35 @@ def test_packed_fp32_scanner_recognises_the_shape(tmp_path):
     good.write_text("_Zgood:\n\tv_add_f32_e32 v2, v2, v3\n\tv_add_f32_dpp v0, v36, v36 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
                     "\tv_pk_mul_f32 v[6:7], v[6:7], v[8:9]\n\tv_mov_b32_e32 v6, v1\n\tv_add_f32_dpp v1, v6, v6 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_endpgm\n")
     assert not {k: v for k, v in mod.scan(str(good), 8).items() if k[1] in ("dpp", "lane")}      # (v6 was overwritten by a plain move in between)
+
+
+def test_w128_gemm_loops_are_the_written_instruction_stream(listings):
+    """k_gemm_w128 / k_gemm_w128_fp8 (gemm_w128.h): every instruction of the K loop is a volatile asm statement of a slot table; hipcc only allocates registers.  The built
+    steady-state loop must hold exactly what the table lists -- bf16: 128 MFMAs, 32 fragment reads, 16 LDS-DMA requests, 2 barriers per K-tile; fp8: two K-tiles per trip,
+    each 64 scaled / unscaled MFMAs, 32 fragment reads, 16 requests, 1 barrier -- no register copy, no scratch access and no full vmcnt drain (the fp8 loop waits vmcnt(0) by
+    design: its requests are the wave's last); the accumulators live in all 256 AGPRs."""
+    code = listings["ncsnpp"]
+    ks = _kernels(code)
+    code = code[:code.index("amdhsa.kernels:")]
+    w = {n: v for n, v in ks.items() if "k_gemm_w128" in n}
+    # (outside the loop: the general epilogue, EPI 0, parks scalars in vector lanes; the tanh-GELU one keeps one lane constant in scratch from the prologue to the epilogue)
+    assert len(w) == 6 + 8 and all(v["scratch"] <= 8 and v["spill"] <= 1 for v in w.values()), w
+    seen = 0
+    for m in re.finditer(r"^(_ZN4ncsn(?:11k_gemm_w128|15k_gemm_w128_fp8)\w+):\s*; @", code, flags=re.M):
+        end = re.compile(r"^\.Lfunc_end\d+:", flags=re.M).search(code, m.end()).start()
+        body = code[m.end():end]
+        assert re.search(r"; NumAgprs: 256", code[end:end + 3000])
+        seen += 1
+        if "fp8ILb1" in m.group(1):
+            continue                                   # (E8M0 scales on the A operand: wave 0 requests one more piece per K-tile behind a branch, which splits the loop into blocks)
+        a = body.index("Inner Loop Header")
+        loop = body[a:body.index("s_cbranch_scc", a)]
+        ins = [ln.strip().split()[0] for ln in loop.split("\n") if ln.strip() and not ln.strip().startswith((";", "."))]
+        fp8 = "fp8" in m.group(1)
+        n_mfma = sum(i.startswith("v_mfma") for i in ins)
+        assert n_mfma == 128 and ins.count("ds_read_b128") == (64 if fp8 else 32) and ins.count("buffer_load_dwordx4") == (32 if fp8 else 16), (m.group(1), n_mfma)
+        assert ins.count("s_barrier") == 2
+        assert not [i for i in ins if i.startswith(("v_mov", "v_accvgpr", "scratch_", "v_readlane", "v_writelane"))], m.group(1)
+        waits = [ln.strip() for ln in loop.split("\n") if "s_waitcnt" in ln and "vmcnt" in ln]
+        assert waits and (fp8 or all("vmcnt(0)" not in wt for wt in waits)), waits
+    assert seen == 14

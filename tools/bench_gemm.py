@@ -7,7 +7,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from naturaldiffusion_amd._lib import lib, check, stream_ptr
 
-NAMES = {0: "auto", 1: "generic128", 2: "dma256x256", 3: "dma256x128", 4: "dma128x128", 5: "ring256x256", 6: "ring256x128", 7: "ring128x128", 8: "ring64x128", 9: "ring256x128w4", 10: "dma256x128w4", 11: "dma256x256s", 12: "dma128x128s", 13: "dma512x128", 14: "patch256x256", 15: "patch256x128", 16: "dma256x256p", 17: "dma128x128p", 18: "dma256x128w4p", 19: "gemm8ph", 20: "gemm8ph_np", 21: "gemm8ph_rf", 22: "gemm8ph_nprf", 23: "fp8", 24: "abl_nodma", 25: "abl_nomfma", 26: "dma256x256h", 27: "dma512x128h", 28: "conv_gn", 29: "w128_256x256"}
+NAMES = {0: "auto", 1: "generic128", 2: "dma256x256", 3: "dma256x128", 4: "dma128x128", 5: "ring256x256", 6: "ring256x128", 7: "ring128x128", 8: "ring64x128", 9: "ring256x128w4", 10: "dma256x128w4", 11: "dma256x256s", 12: "dma128x128s", 13: "dma512x128", 14: "patch256x256", 15: "patch256x128", 16: "dma256x256p", 17: "dma128x128p", 18: "dma256x128w4p", 19: "gemm8ph", 20: "gemm8ph_np", 21: "gemm8ph_rf", 22: "gemm8ph_nprf", 23: "fp8", 24: "abl_nodma", 25: "abl_nomfma", 26: "dma256x256h", 27: "dma512x128h", 28: "conv_gn", 29: "w128_256x256", 30: "w128_schA", 31: "w128_prefetch", 32: "w128_no_dma"}
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 
