@@ -36,9 +36,11 @@ one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
                     512 + one ragged batch) with ``generate_sharded`` (two lanes, Philox noise by global index, uint8 images kept on
                     the device), scores it with the Inception-V3 pool3 engine in the reference's batches of 50, and
                     ``calc_fid_sharded`` sums (n, sum, outer-product sum) over ranks with ONE all-reduce and evaluates the Frechet
-                    distance on the host (the trace term through two symmetric eigen-decompositions: fid_stats.frechet_distance; pytorch_fid's scipy sqrtm form gives the same number 2-5x slower).  With ONE GPU the default share is rank 0 of 8
+                    distance on the host (the trace term through two symmetric eigen-decompositions: fid_stats.frechet_distance; pytorch_fid's scipy sqrtm form gives the same number 2-5x slower;
+                    the reference statistics' side of it is taken once per job, and rank 0 evaluates each distance on a host thread while the next matrix's images are generated).  With ONE GPU the default share is rank 0 of 8
                     (``share_of``: 6,250 images; ``--fid-share-of 1`` runs all 50,000).  value = images generated AND scored per second
-                    over all ranks, both matrices; s = wall seconds {gen, inception, allreduce, frechet} summed over the two matrices;
+                    over all ranks, both matrices; s = wall seconds {gen, inception, allreduce, frechet = the host threads' own time, frechet_wait = what of it the step
+                    still waits for at its end} summed over the two matrices;
                     gen_rate = images/s of generation alone; inc_rate = Inception images/s.  The checkpoint, the Inception weights and
                     cifar10_mu_sigma.npz are downloads: without them synthetic weights / (0, I) reference statistics stand in and
                     fid = "blocked"; d_matrices = Frechet distance between the two matrices' image statistics (same network, same
@@ -675,7 +677,8 @@ def bench_fid50k(args, world, rank, dev, steps=1, warmup=0):
     engine = NCSNppEngine(flat, max_batch=args.batch, device=dev)
     lanes = [engine] + [engine.clone() for _ in range(max(1, args.streams) - 1)]
     inception = InceptionEngine(load_fid_inception_weights(inc_path) if Path(inc_path).exists() else synthetic_inception_flat(0), max_batch=50, device=dev)
-    ref = (str(ref_path) if ref_path.exists() else (np.zeros(2048), np.eye(2048)))
+    from naturaldiffusion_amd.fid_stats import FrechetReference
+    ref = (str(ref_path) if ref_path.exists() else FrechetReference(np.zeros(2048), np.eye(2048)))       # (one object for the whole job: the reference covariance's square root is taken once)
     mats = [("dpmsolverpp2s_018", load_coeff_npz(ROOT / "results/dpmsolverpp/dpmsolverpp2s_018.npz")),
             ("ddim_vp_018", coeffgen.ddim_vp_continuous(np.linspace(1.0, 1e-3, 19)))]
     for e_ in lanes:                                                       # set-up, not a step: code objects load, workspaces are touched
@@ -686,16 +689,24 @@ def bench_fid50k(args, world, rank, dev, steps=1, warmup=0):
     res = {}
 
     def one_step(i):
+        pend = []
         for name, coeff in mats:
             t0 = time.perf_counter()
             imgs, idx = M.generate_sharded(lanes, None, total, args.batch, rank=vrank, world=share_of, seed=888, device=dev, to_cpu=False, coeff=coeff)
             torch.cuda.synchronize()
             acc["gen"] += time.perf_counter() - t0
             tm = {}
-            fid = M.calc_fid_sharded(imgs, ref, dev, model=inception, timings=tm, root_only=True)       # (rank 0 holds the job's FID; the others wait in the closing barrier)
-            for k in ("inception", "allreduce", "frechet"):
+            # rank 0 holds the job's FID (the others wait in the closing barrier); its host part runs on a thread while the next matrix's images are generated
+            fid = M.calc_fid_sharded(imgs, ref, dev, model=inception, timings=tm, root_only=True, defer=True)
+            for k in ("inception", "allreduce"):
                 acc[k] += tm[k + "_s"]
-            res[name] = {"fid": fid, "images_local": int(imgs.shape[0]), "images_all": tm["images_all_ranks"], "imgs": imgs}
+            pend.append((name, fid))
+            res[name] = {"fid": None, "images_local": int(imgs.shape[0]), "images_all": tm["images_all_ranks"], "imgs": imgs}
+        t0 = time.perf_counter()
+        for name, fid in pend:
+            res[name]["fid"] = fid.result()
+            acc["frechet"] += fid.seconds                                   # the threads' own time ...
+        acc["frechet_wait"] = acc.get("frechet_wait", 0.0) + time.perf_counter() - t0      # ... and what of it the step still waits for
         return res
 
     dt, _ = timed_region(one_step, steps, warmup, world, torch.cuda.synchronize, dist, dev)

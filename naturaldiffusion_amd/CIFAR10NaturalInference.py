@@ -228,51 +228,102 @@ def calc_fid(imgs, ref_path, device, model=None):
     """Reference :73-86 (InceptionV3 pool3 + Frechet distance).  Needs the Inception weights and the ``cifar10_mu_sigma.npz``
     statistics, neither of which ships with the reference."""
     from .fid_stats import frechet_distance
-    ref_mu, ref_sigma = _ref_statistics(ref_path)
+    ref = _ref_statistics(ref_path).prefetch()                           # (the reference covariance's square root is taken while the images go through Inception)
     model = model or fid_inception(device, tuple(imgs.shape[1:3]))
     act = get_activation(imgs, model, 2048, device)
     mu, sigma = np.mean(act, axis=0), np.cov(act, rowvar=False)
-    return frechet_distance(ref_mu, ref_sigma, mu, sigma)
+    return frechet_distance(ref, None, mu, sigma)
+
+
+_REF_CACHE = {}
 
 
 def _ref_statistics(ref):
-    """``ref``: path of a ``cifar10_mu_sigma.npz``-style file (keys mu, sigma) or a (mu, sigma) pair."""
+    """``ref``: path of a ``cifar10_mu_sigma.npz``-style file (keys mu, sigma), a (mu, sigma) pair, or a ``fid_stats.FrechetReference`` -> a FrechetReference
+    (unpacks as (mu, sigma); a file's object is kept per path and modification time, so every FID of a job shares the square root of the reference covariance)."""
+    from .fid_stats import FrechetReference
+    if isinstance(ref, FrechetReference):
+        return ref
     if isinstance(ref, (tuple, list)):
-        return np.asarray(ref[0]), np.asarray(ref[1])
+        return FrechetReference(ref[0], ref[1])
     if not os.path.exists(ref):
         raise FileNotFoundError(f"fid: blocked -- {ref} (CIFAR10 Inception statistics) is missing")
-    f = np.load(ref)
-    return f["mu"], f["sigma"]
+    key = (os.path.abspath(str(ref)), os.path.getmtime(ref))
+    if key not in _REF_CACHE:
+        f = np.load(ref)
+        _REF_CACHE.clear()
+        _REF_CACHE[key] = FrechetReference(f["mu"], f["sigma"])
+    return _REF_CACHE[key]
 
 
-def calc_fid_sharded(imgs, ref_path, device, group=None, model=None, timings: Optional[dict] = None, root_only: bool = False):
+class PendingFid:
+    """A Frechet distance being evaluated on a host thread (``calc_fid_sharded(..., defer=True)``): ``result()`` waits for it and returns the FID
+    (None on the ranks that do not evaluate it); ``seconds`` is the thread's own wall time once it is done."""
+
+    def __init__(self, fn):
+        import threading
+        self._value, self._error, self.seconds = None, None, 0.0
+
+        def run():
+            import time
+            t0 = time.perf_counter()
+            try:
+                self._value = fn()
+            except BaseException as e:                                   # surfaced by result()
+                self._error = e
+            self.seconds = time.perf_counter() - t0
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def result(self):
+        self._thread.join()
+        if self._error is not None:
+            raise self._error
+        return self._value
+
+
+def calc_fid_sharded(imgs, ref_path, device, group=None, model=None, timings: Optional[dict] = None, root_only: bool = False, defer: bool = False):
     """``calc_fid`` for a batch-sharded run: every rank scores ITS images (uint8 [n_local, H, W, 3], on the device or the host) in the
     reference's batches of 50, the (count, sum, outer-product sum) statistics are summed over ranks with ONE all-reduce (33.6 MB of fp64,
     fid_stats.ActivationStats) instead of gathering images or activations, and every rank returns the same FID.  ``timings`` (optional
     dict) receives the wall seconds of the three parts: inception_s, allreduce_s, frechet_s.  ``root_only``: only rank 0 evaluates the
     Frechet distance (a 2048 x 2048 matrix square root on the host: eight ranks doing it at once fight for the same cores), the others
-    return None."""
+    return None.  ``defer``: the host part (two symmetric eigen-decompositions, ~1.7 s on 8 cores; the reference side's is shared by every FID against the
+    same statistics and starts when this function is entered) runs on a thread and a ``PendingFid`` is returned -- a job that scores several image sets
+    (config 3 scores two coefficient matrices) generates the next set on the GPU meanwhile."""
     import time
     from .fid_stats import ActivationStats, frechet_distance
-    ref_mu, ref_sigma = _ref_statistics(ref_path)
+    import torch.distributed as dist
+    is_root = not (dist.is_available() and dist.is_initialized()) or dist.get_rank(group) == 0
+    ref = _ref_statistics(ref_path)
+    if is_root or not root_only:
+        ref.prefetch()
     model = model or fid_inception(device, tuple(imgs.shape[1:3]))
     dev = torch.device(device)
     sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)
     t0 = time.perf_counter()
-    st = ActivationStats(2048, device=device)
+    st = None
     for i in range(0, len(imgs), 50):
-        st.update(model(imgs[i:i + 50]))
+        a = model(imgs[i:i + 50])
+        if st is None:
+            st = ActivationStats(a.shape[-1], device=device)             # (pool3: 2048)
+        st.update(a)
+    if st is None:                                                       # a rank without images still takes part in the all-reduce
+        st = ActivationStats(2048, device=device)
     sync()
     t1 = time.perf_counter()
     st.all_reduce(group)
     sync()
     t2 = time.perf_counter()
-    import torch.distributed as dist
-    is_root = not (dist.is_available() and dist.is_initialized()) or dist.get_rank(group) == 0
     fid = None
     if is_root or not root_only:
         mu, cov = st.mean_cov()
-        fid = frechet_distance(ref_mu, ref_sigma, mu, cov)
+        if defer:
+            fid = PendingFid(lambda: frechet_distance(ref, None, mu, cov))
+        else:
+            fid = frechet_distance(ref, None, mu, cov)
+    elif defer:
+        fid = PendingFid(lambda: None)
     if timings is not None:
         timings.update(inception_s=t1 - t0, allreduce_s=t2 - t1, frechet_s=time.perf_counter() - t2, images_all_ranks=int(float(st.n)))
     return fid

@@ -51,6 +51,35 @@ def test_eigh_form_equals_the_sqrtm_form():
         frechet_distance(m1, s1, m2, s2, method="cholesky")
 
 
+def test_reference_object_shares_its_root_and_deferred_evaluation_gives_the_same_number(tmp_path):
+    """FrechetReference: the reference side's square root is taken once (also from a background thread) and frechet_distance(ref, None, ...) equals the plain call;
+    calc_fid_sharded(defer=True) hands back a PendingFid whose result() is the undeferred FID; a file's reference object is shared between calls."""
+    from naturaldiffusion_amd.fid_stats import FrechetReference
+    from naturaldiffusion_amd import CIFAR10NaturalInference as M
+    r = np.random.RandomState(7)
+    a, b = r.randn(500, 64) @ r.randn(64, 64) * 0.3, r.randn(700, 64) @ r.randn(64, 64) * 0.3 + 0.1
+    m1, s1, m2, s2 = a.mean(0), np.cov(a, rowvar=False), b.mean(0), np.cov(b, rowvar=False)
+    ref = FrechetReference(m1, s1).prefetch()
+    mu_, sg_ = ref
+    assert mu_ is ref.mu and sg_ is ref.sigma
+    want = frechet_distance(m1, s1, m2, s2)
+    assert abs(frechet_distance(ref, None, m2, s2) - want) <= 1e-12 * abs(want) and ref.root() is ref.root()
+    assert abs(frechet_distance(ref, None, m2, s2, method="sqrtm") - want) <= 1e-6 * abs(want)          # (the sqrtm form ignores the cached root)
+    # through calc_fid_sharded on the host, a stand-in for the Inception engine (features = a fixed projection of the pixels)
+    np.savez(tmp_path / "ref.npz", mu=m1, sigma=s1)
+    proj = torch.from_numpy(r.randn(32 * 32 * 3, 64) * 0.01)
+    model = lambda im: im.reshape(im.shape[0], -1).double() @ proj
+    imgs = torch.from_numpy(r.randint(0, 256, (230, 32, 32, 3)).astype(np.uint8))
+    tm = {}
+    now = M.calc_fid_sharded(imgs, tmp_path / "ref.npz", "cpu", model=model, timings=tm)
+    later = M.calc_fid_sharded(imgs, tmp_path / "ref.npz", "cpu", model=model, defer=True)
+    assert isinstance(later, M.PendingFid) and later.result() == now and later.seconds > 0 and tm["images_all_ranks"] == 230
+    assert M._ref_statistics(tmp_path / "ref.npz") is M._ref_statistics(tmp_path / "ref.npz")
+    bad = M.PendingFid(lambda: 1 / 0)
+    with pytest.raises(ZeroDivisionError):
+        bad.result()
+
+
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
