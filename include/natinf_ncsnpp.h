@@ -133,7 +133,8 @@ int natinf_set_gemm_pref512(int on);
 /* A/B switch for tuning: 1 (default) = in the 256x256 / 512x128 kernels one wave per SIMD issues all LDS-DMA pieces, 0 = every wave its own. */
 int natinf_set_gemm_half_issue(int on);
 /* A/B switch for tuning: 1 (default) = small-M plain GEMMs (fewer than two rounds of 256 x 256 tiles) choose between 256 x 256 and 128 x 128 tiles by the number of
- * ROUNDS of blocks each needs (128 x 128: two blocks per CU; a 256 x 256 round costs 1.5 of a 128 x 128 one), 0 = by the pre-round-4 rules. */
+ * ROUNDS of blocks each needs (128 x 128: two blocks per CU; a 256 x 256 round costs 1.5 of a 128 x 128 one, 1.3 on the four-wave tile of csrc/gemm_w128.h),
+ * 0 = by the pre-round-4 rules; a value >= 10 sets the four-wave tile's ratio to value / 10 (tuning runs). */
 int natinf_set_gemm_round_model(int on);
 /* A/B switch for tuning: 1 (default) = plain GEMMs that took the 256 x 256 tile of eight waves (two per SIMD, 128 x 64 wave tiles) take the 256 x 256 x 64 tile of FOUR
  * waves (one per SIMD, 128 x 128 wave tiles, accumulators in AGPRs: csrc/gemm_w128.h) -- bf16 and e4m3 operands alike, except the e4m3 GEMMs that write e4m3 + E8M0 behind a

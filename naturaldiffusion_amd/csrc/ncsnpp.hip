@@ -191,6 +191,7 @@ unsigned long long* g_dbg_ts = nullptr;
 int g_force_variant = V_AUTO;
 int g_half_issue = 1;              // natinf_set_gemm_half_issue(0): every wave issues its own LDS-DMA pieces (A/B runs)
 int g_round_model = 1;             // natinf_set_gemm_round_model(0): small-M plain GEMMs by the pre-round-4 rules (A/B runs)
+int g_round_model_w128 = 13;       // cost of a round of k_gemm_w128 tiles in tenths of a round of 128 x 128 tiles (two blocks per CU)
 int g_pref_512 = 1;                // N <= 128 layers with >= 2 tiles per CU: the 512x128 hand-pipelined tile (natinf_set_gemm_pref512: A/B runs)      // tuning / tests: force one variant for every DMA-eligible launch
 std::string* g_record = nullptr;   // when set, launch_gemm describes the launch instead of issuing it
 
@@ -418,7 +419,10 @@ int choose_variant(const GemmArgs& g) {
     // cost of a round at K = 1,536: 25-28 us (128 x 128, two blocks per CU) against 37-43 us (256 x 256): ratio 1.5 (tools/scan_small_m_gemm.py).
     if (g_round_model && g.taps == 1 && !g.gn_part && g.batch == 1 && g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) < 2 * NUM_CU) {
         const int64_t r256 = (mt256 * (g.N / 256) + NUM_CU - 1) / NUM_CU, r128 = (mt128 * nt128 + 2 * NUM_CU - 1) / (2 * NUM_CU);
-        if (mt128 * nt128 >= NUM_CU / 2) return 3 * r256 < 2 * r128 ? (w128 ? V_W128 : half ? V_DMA_256x256_H : V_DMA_256x256_P) : V_DMA_128x128_P;
+        // (a round of the four-wave 256 x 256 tile costs ~1.3 rounds of 128 x 128 tiles, not 1.5: DiT-XL/2's fc1 at B = 16, (4096, 4608, 1152), is 288 tiles = two rounds of
+        // ~28 us against three rounds of two 128 x 128 blocks per CU in 74.6 us; natinf_set_gemm_round_model(v >= 10) sets the ratio to v / 10 for A/B runs)
+        const int64_t c256 = w128 ? g_round_model_w128 : 15;
+        if (mt128 * nt128 >= NUM_CU / 2) return c256 * r256 < 10 * r128 ? (w128 ? V_W128 : half ? V_DMA_256x256_H : V_DMA_256x256_P) : V_DMA_128x128_P;
     }
     if (g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) * g.batch >= NUM_CU) return w128 ? V_W128 : half ? V_DMA_256x256_H : V_DMA_256x256_P;
     if (g_pref_512 && g.N <= 128 && K0 + K1 >= 1024 && ((g.M + 511) / 512) * g.batch >= 2 * NUM_CU &&
@@ -1677,7 +1681,7 @@ int natinf_set_attn_qkv(int on) { g_attn_qkv = on != 0; return NATINF_OK; }
 int natinf_set_attn_waves8(int on) { g_attn_w8 = on != 0; return NATINF_OK; }
 int natinf_set_attn_proj(int on) { g_attn_proj = on != 0; return NATINF_OK; }
 int natinf_set_fuse_fin(int on) { g_fuse_fin = on != 0; return NATINF_OK; }
-int natinf_set_gemm_round_model(int on) { g_round_model = on != 0; return NATINF_OK; }
+int natinf_set_gemm_round_model(int on) { g_round_model = on != 0; g_round_model_w128 = on >= 10 ? on : 13; return NATINF_OK; }
 int natinf_set_gemm_w128(int on) { g_w128 = on < 0 ? 0 : (on > 2 ? 2 : on); return NATINF_OK; }
 int natinf_set_fuse_gn4(int on) { g_fuse_gn4 = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn8_tile(int one_image) {
