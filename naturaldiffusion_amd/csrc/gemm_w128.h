@@ -75,9 +75,9 @@ __device__ __forceinline__ void w128_bufdma_at(unsigned vo, const w128_rsrc& rs,
 // The slot table of one iteration (slot S = the instructions issued in front of MFMA S; MFMA S = K step S / 64, A fragment (S / 8) % 8, B fragment S % 8).
 // MODE 0: steady state; 1: second-to-last tile (nothing left to request; the last tile is awaited with vmcnt(0)); 2: last tile (K step 1's reads only).
 // A schedule SCH names the slots: K step 1's fragment reads (rd1: 0..7 = A, 8..15 = B), the two "half is free" barriers, the sixteen requests (piece p: 0..7 = A,
-// 8..15 = B; destinations 4 KB apart in that order; wave WV of the block may have its own slots), the counted wait for tile kt + 1, K step 0's reads of tile kt + 1.
+// 8..15 = B; destinations 4 KB apart in that order; a schedule may give wave WV of the block its own slots -- unused: see below), the counted wait for tile kt + 1, K step 0's reads of tile kt + 1.
 struct W128SchB {          // shipped: both halves released by ONE barrier behind the sixteen reads of K step 1 (all in the first seventeen slots); the requests four
-    static constexpr bool PER_WAVE = false, NO_DMA = false;      // MFMAs apart in gaps that carry no fragment read; tile kt + 1 awaited at slot 60
+    static constexpr bool NO_DMA = false;                        // MFMAs apart in gaps that carry no fragment read; tile kt + 1 awaited at slot 60
     static constexpr int WAIT1 = 24, WAIT2 = 24, WAIT3 = 60;
     static constexpr int rd1(int n) { return n < 8 ? 1 + 2 * n : 2 + 2 * (n - 8); }
     static constexpr int dma(int p, int) { return 27 + 4 * p; }
@@ -88,16 +88,14 @@ struct W128SchB {          // shipped: both halves released by ONE barrier behin
 // Measured beside it (tools/ab_w128_sched.py, one box, TFLOP/s at 8192^3 / (32768, 6144, 1536) / (32768, 1536, 1536) / (32768, 1536, 6144); SchB: 1,526-1,620 / 1,325-1,342 /
 // 1,331-1,338 / 1,332-1,381; the two-waves-per-SIMD 256 x 256 tile: 1,243-1,396 / 1,084-1,225 / 1,254-1,262 / 1,109-1,228):
 struct W128SchA {          // the first form: A half and B half released by two barriers, requests two MFMAs apart between the B fragment reads: 1,366-1,581 / 1,272-1,301 / 1,281-1,298 / 1,312-1,358
-    static constexpr bool PER_WAVE = false, NO_DMA = false;
+    static constexpr bool NO_DMA = false;
     static constexpr int WAIT1 = 21, WAIT2 = 50, WAIT3 = 88;
     static constexpr int rd1(int n) { return n < 8 ? 1 + 2 * n : 24 + 2 * (n - 8); }
     static constexpr int dma(int p, int) { return p < 8 ? 23 + 2 * p : (p < 13 ? 52 + 2 * (p - 8) : 91 + 4 * (p - 13)); }
     static constexpr int rd0(int n) { return n < 8 ? 90 + 2 * n : 106 + 2 * (n - 8); }
     static constexpr int PF = 0, PF_A = 0, PF_B = 0;
 };
-struct W128SchD : W128SchB {   // the reads of tile kt + 1 spread over the second half of the iteration, between the requests: 1,511-1,540 / 1,237 / 1,280-1,290 / 1,308-1,327
-    static constexpr int rd0(int n) { return 65 + 4 * n - (n == 15 ? 1 : 0); }
-};
+// (the reads of tile kt + 1 spread over the second half of the iteration, between the requests -- rd0(n) = 65 + 4 n --: 1,511-1,540 / 1,237 / 1,280-1,290 / 1,308-1,327.  Not kept.)
 struct W128SchP : W128SchB { static constexpr int PF = 3; };              // + L2 prefetch three K-tiles ahead of the requests (w128_prefetch): 8192^3 1,354 against 1,570, (32768, 6144, 1536) 1,125 against
                                                                            // 1,260 -- a dword load of 64 different lines costs the L1 path eight requests' worth.  Not kept.
 struct W128SchX : W128SchB { static constexpr bool NO_DMA = true; };      // ablation: nothing requested after the prologue (wrong results): 1,806-1,842 / 1,467-1,483 / 1,308-1,408 /
@@ -238,15 +236,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     W128Addr ad;
-    auto iter = [&](auto mode) __attribute__((always_inline)) {
-        constexpr int MODE = decltype(mode)::value;
-        if constexpr (SCH::PER_WAVE) {
-            if (wave == 0) W128Step<SCH, MODE, 0, 0>::run(accL, accH, fa, fb, ad, dm);
-            else if (wave == 1) W128Step<SCH, MODE, 0, 1>::run(accL, accH, fa, fb, ad, dm);
-            else if (wave == 2) W128Step<SCH, MODE, 0, 2>::run(accL, accH, fa, fb, ad, dm);
-            else W128Step<SCH, MODE, 0, 3>::run(accL, accH, fa, fb, ad, dm);
-        } else W128Step<SCH, MODE, 0, 0>::run(accL, accH, fa, fb, ad, dm);
-    };
+    auto iter = [&](auto mode) __attribute__((always_inline)) { W128Step<SCH, decltype(mode)::value, 0, 0>::run(accL, accH, fa, fb, ad, dm); };
     for (int kt = 0; kt < nk - 2; ++kt) {
         const unsigned cur = (kt & 1) * Cfg::STAGE_BYTES, nxt = cur ^ Cfg::STAGE_BYTES;
         ad.a_cur = a_off + cur; ad.b_cur = b_off + cur; ad.a_nxt = a_off + nxt; ad.b_nxt = b_off + nxt;
