@@ -76,6 +76,11 @@ int natinf_attention_profile(int enable);
  * cross-lane step on the common path), row sums on the matrix pipe, 64-key tiles (three to four waves per SIMD).  1 / 2 = intermediate forms of it
  * (vector-pipe row sums / 128-key tiles): -DNATINF_DEV builds only, NATINF_ESTATE elsewhere.  Same function up to rounding; NATINF_EINVAL outside 0..3. */
 int natinf_set_flash_mode(int mode);
+/* 1 (default): a forward puts the text stream's launches (M = ctx_tokens rows per sequence: small GEMMs that fill a fraction of the chip) on a HIP stream of the
+ * engine's own, forked from and joined to the caller's stream by events -- in front of the joint attention of every block and behind it, and at both ends of the
+ * forward, so that on return everything the forward enqueued is ordered on the caller's stream as before.  0: every launch on the caller's stream, one after the
+ * other.  Same launches, same arguments: the outputs are the same bytes. */
+int natinf_set_mmdit_text_stream(int on);
 int natinf_attention_profile_read(double* ms_total, int64_t* launches);
 
 #ifdef __cplusplus

@@ -68,6 +68,7 @@ struct Ctx {                     // per-forward launch context
     int B; unsigned char* ws; const unsigned char* wp; hipStream_t stream;
     const float* x; const float* labels; float* out;
     int* part_bm;                // [n_parts] block-tile rows (BM) of the GEMM variant that wrote each partial table
+    hipStream_t stream2 = nullptr; hipEvent_t* ev = nullptr;      // MMDiT engine: the text stream's own HIP stream and the fork / join events (null: everything on `stream`)
     bf16* act(const TRef& t) const { return reinterpret_cast<bf16*>(ws + t.off * B) + t.coff; }
     template <class T> T* at(int64_t off) const { return reinterpret_cast<T*>(ws + off * B); }
     template <class T> const T* w(int64_t off) const { return reinterpret_cast<const T*>(wp + off); }

@@ -210,6 +210,36 @@ def fp8_tile(request):
     check(lib.natinf_set_gemm_w128(1), "set")
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+def test_text_stream_on_its_own_hip_stream_gives_the_same_bytes(fp8):
+    """natinf_set_mmdit_text_stream: the text stream's launches on the engine's second HIP stream (fork / join events around every joint attention) against
+    everything on the caller's stream -- same launches, same arguments, so the same bytes; repeated forwards (the events are re-recorded) and a forward on a
+    non-default caller stream included."""
+    from naturaldiffusion_amd._lib import lib, check
+    from naturaldiffusion_amd.mmdit import MMDiTEngine
+    from naturaldiffusion_amd.synth import synthetic_mmdit_flat
+    cfg = dict(layers=3, heads=4, joint_dim=64, pooled_dim=32, in_ch=16)
+    eng = MMDiTEngine(synthetic_mmdit_flat(8, seed=3, **cfg), max_batch=3, grid=8, ctx_tokens=37, fp8=fp8, **cfg)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(3, 16, 16, 16, device="cuda", generator=g); t = torch.rand(3, device="cuda", generator=g) * 1000
+    e = torch.randn(3, 37, 64, device="cuda", generator=g); p = torch.randn(3, 32, device="cuda", generator=g)
+    try:
+        check(lib.natinf_set_mmdit_text_stream(0), "set")
+        ref = eng.forward(x, t, e, p)
+        check(lib.natinf_set_mmdit_text_stream(1), "set")
+        for _ in range(3):
+            assert torch.equal(eng.forward(x, t, e, p), ref)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                out = eng.forward(x, t, e, p)
+        side.synchronize()
+        assert torch.equal(out, ref) and torch.isfinite(ref).all()
+    finally:
+        check(lib.natinf_set_mmdit_text_stream(1), "set")
+
+
 def test_fp8_gemm_matches_the_dequantised_product(fp8_tile):
     """k_gemm_fp8 / k_gemm_w128_fp8 on their own: same quantised operands, fp32 reference -> only the bf16 output rounding remains."""
     from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
