@@ -19,7 +19,8 @@ one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
                     global index drawn inside the timed span, the 15 steps, ``to_pixel``, and the ONE copy of the uint8 images to the host -- everything the
                     reference's per-batch loop contains (:290, :308-309) that the contract's "inputs resident in HBM" region leaves out.
   sd3, sd3_fp8      BASELINE configs 4 / 5 (``--workload sd3 [--fp8]`` alone): 28-step SD3-form NI at 1024x1024, 4 images x CFG per
-                    GPU = ONE batched MMDiT forward of 8 sequences (4,096 image + 333 text tokens) per step + one fused
+                    GPU = ONE batched MMDiT forward of 8 sequences (4,096 image + 333 text tokens; inside it the text stream's launches run on a HIP
+                    stream of the engine's own, joined with the image stream at every joint attention: same bytes) per step + one fused
                     ``natinf_step_f16chain`` launch; a step = one 4-image batch through all 28 steps; SD3-medium-shaped synthetic
                     weights (2.03 B parameters).  fp8 = e4m3 operands (v_mfma_f32_16x16x128_f8f6f4) for the image-stream q|k, v, fc1,
                     fc2 GEMMs, bf16 elsewhere.  Fields: value (images/s), ms_per_step, frac (all 2*MAC flops of the forward / wall time
@@ -573,7 +574,7 @@ def bench_sd3(args, world, rank, dev, fp8=False, steps=2, warmup=1, flat=None):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8+bf16" if fp8 else "bf16", "data": "synthetic",
             "frac": r4(tf / MFMA_BF16_PEAK_TFLOPS),
             "config": {"workload": f"SD3 NI 28-step {wname} 1024x1024, 4 img x CFG/GPU = 8 seq x (4096+333) tokens, MMDiT 2.03B " + ("fp8 e4m3 + bf16" if fp8 else "bf16"),
-                       "nfe": 2 * nstep, "images_per_gpu": n, "sharding": f"batch x{world}, no collective"},
+                       "nfe": 2 * nstep, "images_per_gpu": n, "sharding": f"batch x{world}, no collective", "streams": "image + text stream of one forward on two HIP streams"},
             "roofline": {"kernel": "whole forward", "bound": "mfma", "achieved": r4(tf), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": r4(tf / MFMA_BF16_PEAK_TFLOPS), "traffic": None}}
     if rank == 0 and not args.no_roofline:
