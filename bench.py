@@ -79,6 +79,8 @@ import sys
 import time
 from pathlib import Path
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the first HIP call (naturaldiffusion_amd/_lib.py says why): streams that share a hardware queue do not overlap
+
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 

@@ -9,6 +9,11 @@ import ctypes as C
 import os
 from pathlib import Path
 
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); two streams that share a queue run one after the other.
+# The engines count on concurrency between a few streams (the two lanes of the CIFAR10 pipeline, the MMDiT's text stream beside its image stream) next to whatever
+# streams the host framework made: ask for eight unless the user chose.  It only takes effect when set before the process's first HIP call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("NATINF_LIB", _HERE / "libnatinf.so"))
 
