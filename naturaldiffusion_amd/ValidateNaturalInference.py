@@ -276,9 +276,9 @@ def natural_inference(alg_name="ddpm", num_step=24):
     noise = torch.randn(n, 4, 32, 32, device=device)
     ni.hist_eps[0].copy_(noise.reshape(-1))
     input_z = noise.clone()
+    classnulls = torch.full((n,), 1000, dtype=labels.dtype, device=device)             # (reference :352 builds it per step from a host list: a blocking copy each time)
     for kk in range(num_step):
-        timesteps = torch.ones(n, dtype=torch.int32, device=device) * int(node[kk, 0])
-        classnulls = torch.tensor([1000] * n, device=device)
+        timesteps = torch.full((n,), int(node[kk, 0]), dtype=torch.int32, device=device)
         cond, uncond = _cond_uncond(model, input_z, timesteps, labels, classnulls)      # [n, 8, 32, 32] each; first 4 channels used
         ni.hist_eps[kk + 1].copy_(torch.randn_like(input_z, dtype=torch.float32, device=device).reshape(-1))
         per, stride = 4 * 32 * 32, cond.shape[1] * 32 * 32
