@@ -575,7 +575,9 @@ __device__ __forceinline__ void dma_tile_epilogue(const GemmArgs& g, unsigned ch
 // gate / row vector constant over the block tile (one sample per tile), straight from the accumulator registers -- a lane holds
 // four consecutive columns of a row, so the fp32 residual is read and the result written as 16-byte accesses (64 B per row and
 // instruction), no LDS, no barrier.  The residual rows are fetched half a tile at a time (64 VGPRs in flight).
-template <int WM, int WN, int TM, int TN, bool DEQ = false>
+// HI_ (0 = by the register budget of a 256-register kernel): residual row-tiles fetched per round trip.  The w128 kernels (accumulators in AGPRs, the fragment
+// registers dead by the epilogue) fetch all eight at once: one memory round trip per half tile instead of four -- with one block per CU nothing hides them.
+template <int WM, int WN, int TM, int TN, bool DEQ = false, int HI_ = 0>
 __device__ __forceinline__ void direct_f32_epilogue(const GemmArgs& g, f32x4 (&acc)[TM][TN], int m0, int n0, int z, int lane, int wm, int wn)
 {
     const int r = lane & 15, q = lane >> 4;
@@ -611,7 +613,7 @@ __device__ __forceinline__ void direct_f32_epilogue(const GemmArgs& g, f32x4 (&a
     const float scale = g.scale;
     const float* rb = g.resid_f32 + (int64_t)z * g.c_bs + n0 + wn * TN * 16 + q * 4;
     float* cb = reinterpret_cast<float*>(g.c) + (int64_t)z * g.c_bs + n0 + wn * TN * 16 + q * 4;
-    constexpr int HI = DEQ ? (TM > 2 ? 2 : TM) : (TM > 4 ? TM / 2 : TM);      // residual row-tiles in flight (register budget)
+    constexpr int HI = HI_ > 0 ? HI_ : (DEQ ? (TM > 2 ? 2 : TM) : (TM > 4 ? TM / 2 : TM));      // residual row-tiles in flight (register budget)
 #pragma unroll
     for (int h = 0; h < TM / HI; ++h) {
         f32x4 rs[HI][TN];

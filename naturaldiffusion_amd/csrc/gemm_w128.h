@@ -257,6 +257,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __builtin_amdgcn_sched_barrier(0);
     NATINF_TS(5);
     asm volatile("" :: "v"(dm.junk));
+    if constexpr (EPI == 7) {                                            // direct fp32 residual stream: no LDS, the whole half tile's residual in one round trip
+        direct_f32_epilogue<2, 2, 8, 4, false, 8>(g, accL, m0, n0, z, lane, wm, wn);
+        if (n0 + 128 < g.N) direct_f32_epilogue<2, 2, 8, 4, false, 8>(g, accH, m0, n0 + 128, z, lane, wm, wn);
+        return;
+    }
     __syncthreads();
     tile_epilogue<2, 2, 8, 4, typename Cfg::Epi, EPI>(g, smem, accL, m0, n0, z, tid, lane, wm, wn);
     NATINF_TS(6);
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto epi = [&](f32x4 (&acc)[8][4], int nb, unsigned char* slab) __attribute__((always_inline)) {
         if constexpr (EPI == 1) packed_tile_epilogue<2, 2, 8, 4, typename Cfg::Epi, ACT_NONE, false, false, true, false>(g, slab, acc, m0, nb, z, tid, lane, wm, wn);
         else if constexpr (EPI == 2) packed_tile_epilogue<2, 2, 8, 4, typename Cfg::Epi, ACT_GELU_TANH, false, false, true, true>(g, slab, acc, m0, nb, z, tid, lane, wm, wn);
-        else if constexpr (EPI == 3) direct_f32_epilogue<2, 2, 8, 4, true>(g, acc, m0, nb, z, lane, wm, wn);
+        else if constexpr (EPI == 3) direct_f32_epilogue<2, 2, 8, 4, true, 8>(g, acc, m0, nb, z, lane, wm, wn);      // (the whole half tile's residual in one round trip)
         else dma_tile_epilogue<2, 2, 8, 4, typename Cfg::Epi>(g, slab, acc, m0, nb, z, tid, lane, wm, wn);
     };
     epi(accL, n0, smem);

@@ -1,0 +1,20 @@
+"""Wall time of the SD3-size MMDiT forward (8 sequences) with the library NATINF_LIB points at: for same-box A/Bs of two builds.  usage: time_sd3_forward.py [fp8] (GPU box)"""
+import sys, time
+from pathlib import Path
+import torch
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from naturaldiffusion_amd.mmdit import MMDiTEngine, SD3_MEDIUM
+from naturaldiffusion_amd.synth import synthetic_mmdit_flat
+fp8 = "fp8" in sys.argv
+cfg = dict(SD3_MEDIUM)
+eng = MMDiTEngine(synthetic_mmdit_flat(64, seed=0, **cfg), max_batch=8, grid=64, ctx_tokens=333, fp8=fp8, **cfg)
+g = torch.Generator(device="cuda").manual_seed(0)
+x = torch.randn(8, 16, 128, 128, device="cuda", generator=g); t = torch.rand(8, device="cuda", generator=g) * 1000
+e = torch.randn(8, 333, cfg["joint_dim"], device="cuda", generator=g); p = torch.randn(8, cfg["pooled_dim"], device="cuda", generator=g)
+for rep in range(3):
+    for _ in range(2): out = eng.forward(x, t, e, p)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): out = eng.forward(x, t, e, p)
+    torch.cuda.synchronize()
+    print(f"{'fp8' if fp8 else 'bf16'}: {(time.perf_counter() - t0) * 200:.2f} ms per forward of 8 sequences, checksum {out.double().abs().sum().item():.6e}", flush=True)
