@@ -206,7 +206,8 @@ def load_vae_decoder(path, max_batch=8):
 def save_image_grid(images: torch.Tensor, path, nrow: int = 8) -> None:
     """``torchvision.utils.save_image(samples, path, nrow=8, normalize=True, value_range=(-1, 1))`` (reference :236; the 8
     validation images come out as one row of 8) without
-    torchvision: clamp to [-1, 1], map to [0, 255], tile with 2-pixel padding, write with PIL."""
+    torchvision: clamp to [-1, 1], map to [0, 255], tile with 2-pixel padding, write with PIL -- the same pixels; the file is deflated at PIL's
+    level 1 instead of torchvision's default 6 (lossless either way: 60 -> ~15 ms for the 2066 x 260 row, a quarter of a 24-step run of 8 images on this engine)."""
     from PIL import Image
     x = ((images.detach().float().cpu().clamp(-1, 1) + 1) * 0.5)
     n, c, h, w = x.shape
@@ -216,7 +217,7 @@ def save_image_grid(images: torch.Tensor, path, nrow: int = 8) -> None:
         r0, c0 = (i // ncol) * (h + 2) + 2, (i % ncol) * (w + 2) + 2
         grid[:, r0:r0 + h, c0:c0 + w] = x[i]
     arr = (grid * 255 + 0.5).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).numpy()
-    Image.fromarray(arr).save(str(path))
+    Image.fromarray(arr).save(str(path), compress_level=1)
 
 
 def _finish(input_z, name):
