@@ -290,7 +290,9 @@ def calc_fid_sharded(imgs, ref_path, device, group=None, model=None, timings: Op
     Frechet distance (a 2048 x 2048 matrix square root on the host: eight ranks doing it at once fight for the same cores), the others
     return None.  ``defer``: the host part (two symmetric eigen-decompositions, ~1.7 s on 8 cores; the reference side's is shared by every FID against the
     same statistics and starts when this function is entered) runs on a thread and a ``PendingFid`` is returned -- a job that scores several image sets
-    (config 3 scores two coefficient matrices) generates the next set on the GPU meanwhile."""
+    (config 3 scores two coefficient matrices) generates the next set on the GPU meanwhile.  (The Inception PASS beside the next generation too -- the whole scoring
+    on a thread and a HIP stream of its own -- was built and measured: both are bound by the same compute units; generation 4.67 -> 5.27 s, the job's 7.05-7.17 s
+    unchanged.  Not kept.)"""
     import time
     from .fid_stats import ActivationStats, frechet_distance
     import torch.distributed as dist
@@ -300,7 +302,7 @@ def calc_fid_sharded(imgs, ref_path, device, group=None, model=None, timings: Op
         ref.prefetch()
     model = model or fid_inception(device, tuple(imgs.shape[1:3]))
     dev = torch.device(device)
-    sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)
+    sync = (lambda: torch.cuda.current_stream(dev).synchronize()) if dev.type == "cuda" else (lambda: None)      # (this call's stream, not the device)
     t0 = time.perf_counter()
     st = None
     for i in range(0, len(imgs), 50):
