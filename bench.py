@@ -35,7 +35,7 @@ one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
                     (results/dpmsolverpp/dpmsolverpp2s_018.npz) and DDIM on the continuous VP grid (coeffgen.ddim_vp_continuous over
                     linspace(1, 1e-3, 19)), 18 NFE each.  This rank generates ITS share (global indices rank, rank + W, ...; batches of
                     512 + one ragged batch) with ``generate_sharded`` (two lanes, Philox noise by global index, uint8 images kept on
-                    the device), scores it with the Inception-V3 pool3 engine in the reference's batches of 50, and
+                    the device), scores it with the Inception-V3 pool3 engine (500 images per call: the reference's 50 give the same features, a quarter slower), and
                     ``calc_fid_sharded`` sums (n, sum, outer-product sum) over ranks with ONE all-reduce and evaluates the Frechet
                     distance on the host (the trace term through two symmetric eigen-decompositions: fid_stats.frechet_distance; pytorch_fid's scipy sqrtm form gives the same number 2-5x slower;
                     the reference statistics' side of it is taken once per job, and rank 0 evaluates each distance on a host thread while the next matrix's images are generated).  With ONE GPU the default share is rank 0 of 8
@@ -679,7 +679,7 @@ def bench_fid50k(args, world, rank, dev, steps=1, warmup=0):
     flat = load_score_sde_checkpoint(str(ckpt)) if ckpt.exists() else synthetic_flat_params(0)
     engine = NCSNppEngine(flat, max_batch=args.batch, device=dev)
     lanes = [engine] + [engine.clone() for _ in range(max(1, args.streams) - 1)]
-    inception = InceptionEngine(load_fid_inception_weights(inc_path) if Path(inc_path).exists() else synthetic_inception_flat(0), max_batch=50, device=dev)
+    inception = InceptionEngine(load_fid_inception_weights(inc_path) if Path(inc_path).exists() else synthetic_inception_flat(0), max_batch=M.FID_BATCH, device=dev)
     from naturaldiffusion_amd.fid_stats import FrechetReference
     ref = (str(ref_path) if ref_path.exists() else FrechetReference(np.zeros(2048), np.eye(2048)))       # (one object for the whole job: the reference covariance's square root is taken once)
     mats = [("dpmsolverpp2s_018", load_coeff_npz(ROOT / "results/dpmsolverpp/dpmsolverpp2s_018.npz")),
@@ -725,7 +725,7 @@ def bench_fid50k(args, world, rank, dev, steps=1, warmup=0):
             "s": {k: r4(v) for k, v in per.items()}, "gen_rate": r4(len(mats) * n_local / per["gen"]), "inc_rate": r4(len(mats) * n_local / per["inception"]),
             "fid": ("blocked" if blocked else {k: r4(v["fid"]) for k, v in res.items()}),
             "config": {"workload": f"CIFAR10 FID job {total} images / {share_of} shares, dpmsolverpp2s_018.npz + coeffgen.ddim_vp_continuous(19 nodes), B={args.batch}, "
-                                   "Inception pool3 engine in 50s, one statistics all-reduce", "nfe": 18, "streams": len(lanes), "sharding": f"batch x{share_of}"}}
+                                   "Inception pool3 engine in 500s, one statistics all-reduce", "nfe": 18, "streams": len(lanes), "sharding": f"batch x{share_of}"}}
     if blocked:
         line["frechet_vs_synthetic_ref"] = {k: r4(v["fid"]) for k, v in res.items()}
     # untimed sanity figure that needs no asset: the two matrices integrate the same ODE from the same noise with the same network, so their image

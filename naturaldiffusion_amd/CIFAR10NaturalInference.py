@@ -203,7 +203,15 @@ def inception_weights_path() -> Path:
     return root_path / "weights" / INCEPTION_WEIGHTS
 
 
-def fid_inception(device, image_hw=(32, 32), max_batch: int = 50):
+FID_BATCH = 500      # images per Inception call.  The reference feeds 50 (:47); an image's features do not depend on its batch (the same bytes at 50 and 500,
+                     # tests/test_gpu_inception.py) and the engine runs 8,500 images/s in 50s, 11,400 in 500s
+
+
+def _fid_batch(model) -> int:
+    return max(1, min(FID_BATCH, int(getattr(model, "max_batch", 50))))
+
+
+def fid_inception(device, image_hw=(32, 32), max_batch: int = FID_BATCH):
     """The pool3 network of ``calc_fid`` on the HIP library (include/natinf_inception.h) -- the reference builds
     ``InceptionV3([BLOCK_INDEX_BY_DIM[2048]])`` here (:75-77).  The weights are a download the image does not hold: without the file
     this raises (``fid: blocked``); there is no torch-module fallback."""
@@ -215,12 +223,14 @@ def fid_inception(device, image_hw=(32, 32), max_batch: int = 50):
 
 
 def get_activation(imgs, model, dims: int = 2048, device=None) -> np.ndarray:
-    """Reference :44-70: uint8 [n, H, W, 3] images -> pool3 activations [n, dims] in batches of 50 (the /255, the NCHW permutation, the
-    299 x 299 resize and the 2x - 1 scaling happen inside the engine's stem kernel)."""
+    """Reference :44-70: uint8 [n, H, W, 3] images -> pool3 activations [n, dims], ``FID_BATCH`` (or the engine's ``max_batch``) images per call
+    -- the reference's 50 give the same features -- (the /255, the NCHW permutation, the 299 x 299 resize and the 2x - 1 scaling happen inside the
+    engine's stem kernel)."""
     assert dims == 2048, "the HIP engine implements the pool3 (2048-dimensional) output"
     pred = np.empty((len(imgs), dims))
-    for ii in range(0, len(imgs), 50):
-        pred[ii:ii + 50] = model(imgs[ii:ii + 50]).cpu().numpy()
+    bs = _fid_batch(model)
+    for ii in range(0, len(imgs), bs):
+        pred[ii:ii + bs] = model(imgs[ii:ii + bs]).cpu().numpy()
     return pred
 
 
@@ -283,8 +293,8 @@ class PendingFid:
 
 
 def calc_fid_sharded(imgs, ref_path, device, group=None, model=None, timings: Optional[dict] = None, root_only: bool = False, defer: bool = False):
-    """``calc_fid`` for a batch-sharded run: every rank scores ITS images (uint8 [n_local, H, W, 3], on the device or the host) in the
-    reference's batches of 50, the (count, sum, outer-product sum) statistics are summed over ranks with ONE all-reduce (33.6 MB of fp64,
+    """``calc_fid`` for a batch-sharded run: every rank scores ITS images (uint8 [n_local, H, W, 3], on the device or the host; ``FID_BATCH`` or the
+    engine's ``max_batch`` per Inception call -- the reference's 50 give the same features), the (count, sum, outer-product sum) statistics are summed over ranks with ONE all-reduce (33.6 MB of fp64,
     fid_stats.ActivationStats) instead of gathering images or activations, and every rank returns the same FID.  ``timings`` (optional
     dict) receives the wall seconds of the three parts: inception_s, allreduce_s, frechet_s.  ``root_only``: only rank 0 evaluates the
     Frechet distance (a 2048 x 2048 matrix square root on the host: eight ranks doing it at once fight for the same cores), the others
@@ -305,8 +315,9 @@ def calc_fid_sharded(imgs, ref_path, device, group=None, model=None, timings: Op
     sync = (lambda: torch.cuda.current_stream(dev).synchronize()) if dev.type == "cuda" else (lambda: None)      # (this call's stream, not the device)
     t0 = time.perf_counter()
     st = None
-    for i in range(0, len(imgs), 50):
-        a = model(imgs[i:i + 50])
+    bs = _fid_batch(model)
+    for i in range(0, len(imgs), bs):
+        a = model(imgs[i:i + bs])
         if st is None:
             st = ActivationStats(a.shape[-1], device=device)             # (pool3: 2048)
         st.update(a)

@@ -66,6 +66,21 @@ def test_other_input_sizes(dev, params):
         eng(torch.rand(2, 3, 32, 32))
 
 
+def test_features_do_not_depend_on_the_batch(params, dev):
+    """calc_fid scores FID_BATCH (500) images per engine call where the reference feeds 50: an image's pool3 features are the same bytes either way (also for a
+    ragged last batch), so the statistics -- and the FID -- are those of the reference's batching"""
+    from naturaldiffusion_amd.inception import InceptionEngine, flatten_state_dict
+    from naturaldiffusion_amd import CIFAR10NaturalInference as M
+    flat = flatten_state_dict(params)
+    g = torch.Generator().manual_seed(9)
+    imgs = torch.randint(0, 256, (620, 32, 32, 3), dtype=torch.uint8, generator=g).to(dev)
+    small, big = InceptionEngine(flat, max_batch=50, in_hw=(32, 32), device=dev), InceptionEngine(flat, max_batch=M.FID_BATCH, in_hw=(32, 32), device=dev)
+    a = torch.cat([small(imgs[i:i + 50]) for i in range(0, 620, 50)])
+    b = torch.cat([big(imgs[i:i + M.FID_BATCH]) for i in range(0, 620, M.FID_BATCH)])
+    assert torch.equal(a, b) and M._fid_batch(small) == 50 and M._fid_batch(big) == M.FID_BATCH == 500
+    assert np.array_equal(M.get_activation(imgs, small, 2048, dev), M.get_activation(imgs, big, 2048, dev))
+
+
 def test_frechet_distance_between_hip_and_oracle_statistics(engine, params, repo_root):
     """2,000 synthetic images (smooth random fields + noise, uint8): (mu, Sigma) of the engine's features vs (mu, Sigma) of the fp32
     oracle's, through the product's own statistics / Frechet code (fid_stats.py).  This is the FID a perfect sampler would be charged
