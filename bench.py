@@ -37,7 +37,7 @@ one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
                     512 + one ragged batch) with ``generate_sharded`` (two lanes, Philox noise by global index, uint8 images kept on
                     the device), scores it with the Inception-V3 pool3 engine (500 images per call: the reference's 50 give the same features, a quarter slower), and
                     ``calc_fid_sharded`` sums (n, sum, outer-product sum) over ranks with ONE all-reduce and evaluates the Frechet
-                    distance on the host (the trace term through two symmetric eigen-decompositions: fid_stats.frechet_distance; pytorch_fid's scipy sqrtm form gives the same number 2-5x slower;
+                    distance (the trace term through two symmetric eigen-decompositions, in float64 on the GPU: fid_stats.frechet_distance; pytorch_fid's scipy sqrtm form on the host gives the same number in 5-14 s;
                     the reference statistics' side of it is taken once per job, and rank 0 evaluates each distance on a host thread while the next matrix's images are generated).  With ONE GPU the default share is rank 0 of 8
                     (``share_of``: 6,250 images; ``--fid-share-of 1`` runs all 50,000).  value = images generated AND scored per second
                     over all ranks, both matrices; s = wall seconds {gen, inception, allreduce, frechet = the host threads' own time, frechet_wait = what of it the step

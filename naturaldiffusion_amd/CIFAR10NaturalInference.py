@@ -238,11 +238,14 @@ def calc_fid(imgs, ref_path, device, model=None):
     """Reference :73-86 (InceptionV3 pool3 + Frechet distance).  Needs the Inception weights and the ``cifar10_mu_sigma.npz``
     statistics, neither of which ships with the reference."""
     from .fid_stats import frechet_distance
-    ref = _ref_statistics(ref_path).prefetch()                           # (the reference covariance's square root is taken while the images go through Inception)
+    ref = _ref_statistics(ref_path)
+    on_gpu = torch.device(device).type == "cuda"
+    if not on_gpu:
+        ref.prefetch()                                                  # (host path: the reference covariance's square root is taken while the images go through Inception)
     model = model or fid_inception(device, tuple(imgs.shape[1:3]))
     act = get_activation(imgs, model, 2048, device)
     mu, sigma = np.mean(act, axis=0), np.cov(act, rowvar=False)
-    return frechet_distance(ref, None, mu, sigma)
+    return frechet_distance(ref, None, mu, sigma, device=device if on_gpu else None)
 
 
 _REF_CACHE = {}
@@ -308,7 +311,8 @@ def calc_fid_sharded(imgs, ref_path, device, group=None, model=None, timings: Op
     import torch.distributed as dist
     is_root = not (dist.is_available() and dist.is_initialized()) or dist.get_rank(group) == 0
     ref = _ref_statistics(ref_path)
-    if is_root or not root_only:
+    fdev = device if torch.device(device).type == "cuda" else None       # the Frechet distance's eigen-decompositions on the GPU (0.1 s) or, on a CPU device, on the host (1.4-2 s)
+    if (is_root or not root_only) and fdev is None:
         ref.prefetch()
     model = model or fid_inception(device, tuple(imgs.shape[1:3]))
     dev = torch.device(device)
@@ -332,9 +336,9 @@ def calc_fid_sharded(imgs, ref_path, device, group=None, model=None, timings: Op
     if is_root or not root_only:
         mu, cov = st.mean_cov()
         if defer:
-            fid = PendingFid(lambda: frechet_distance(ref, None, mu, cov))
+            fid = PendingFid(lambda: frechet_distance(ref, None, mu, cov, device=fdev))
         else:
-            fid = frechet_distance(ref, None, mu, cov)
+            fid = frechet_distance(ref, None, mu, cov, device=fdev)
     elif defer:
         fid = PendingFid(lambda: None)
     if timings is not None:

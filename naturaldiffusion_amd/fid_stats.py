@@ -73,6 +73,17 @@ class FrechetReference:
                 self._root = (v * np.sqrt(np.clip(w, 0.0, None))) @ v.T
             return self._root
 
+    def root_on(self, device) -> torch.Tensor:
+        """the same square root as a float64 tensor on ``device``, taken there (``torch.linalg.eigh``: 0.05 s for 2048 x 2048 on an MI355X against 1.7 s on its host)"""
+        key = str(torch.device(device))
+        with self._lock:
+            cache = self.__dict__.setdefault("_root_dev", {})
+            if key not in cache:
+                s1 = torch.as_tensor(self.sigma, dtype=torch.float64, device=device)
+                w, v = torch.linalg.eigh((s1 + s1.T) * 0.5)
+                cache[key] = (v * w.clamp_min(0.0).sqrt()) @ v.T
+            return cache[key]
+
     def prefetch(self) -> "FrechetReference":
         import threading
         if self._root is None and self._thread is None:
@@ -81,7 +92,7 @@ class FrechetReference:
         return self
 
 
-def frechet_distance(mu1, sigma1, mu2: np.ndarray, sigma2: np.ndarray, eps: float = 1e-6, method: str = "eigh") -> float:
+def frechet_distance(mu1, sigma1, mu2: np.ndarray, sigma2: np.ndarray, eps: float = 1e-6, method: str = "eigh", device=None) -> float:
     """|mu1 - mu2|^2 + Tr(S1 + S2 - 2 (S1 S2)^(1/2))  (Dowson & Landau 1982).
 
     ``method="sqrtm"`` is the form ``pytorch_fid.calculate_frechet_distance`` evaluates (reference src/CIFAR10NaturalInference.py:86 via
@@ -91,13 +102,26 @@ def frechet_distance(mu1, sigma1, mu2: np.ndarray, sigma2: np.ndarray, eps: floa
     Tr (S1 S2)^(1/2) = sum sqrt(eigvalsh(S1^(1/2) S2 S1^(1/2))) with S1^(1/2) from ``eigh(S1)`` -- two symmetric eigen-decompositions instead of
     a Schur-based matrix square root: 2-5x faster at 2048 x 2048 (2.0 s against 4.7-9.6 s on 8 cores), real by construction, and agrees with
     the sqrtm form to 1e-13 relative on full-rank statistics (7e-8 on rank-deficient ones, where the sqrtm form itself returns a complex root);
-    tests/test_fid_stats.py compares the two.  ``mu1`` may be a ``FrechetReference`` (``sigma1`` is then ignored): the eigh form takes its cached root."""
+    tests/test_fid_stats.py compares the two.  ``mu1`` may be a ``FrechetReference`` (``sigma1`` is then ignored): the eigh form takes its cached root.
+    ``device`` (a CUDA device; eigh form only): the two eigen-decompositions and the products run there in float64 through ``torch.linalg`` -- the eigenvalues agree
+    with LAPACK's to 1e-14 relative, and a distance takes ~0.1 s instead of 1.4-2 s of host time."""
     ref = mu1 if isinstance(mu1, FrechetReference) else None
     if ref is not None:
         mu1, sigma1 = ref.mu, ref.sigma
     mu1, mu2 = np.atleast_1d(mu1), np.atleast_1d(mu2)
     sigma1, sigma2 = np.atleast_2d(sigma1), np.atleast_2d(sigma2)
     diff = mu1 - mu2
+    if method == "eigh" and device is not None and torch.device(device).type == "cuda":
+        s2 = torch.as_tensor(np.ascontiguousarray(sigma2), dtype=torch.float64, device=device)
+        if ref is not None:
+            root1 = ref.root_on(device)
+        else:
+            s1 = torch.as_tensor(np.ascontiguousarray(sigma1), dtype=torch.float64, device=device)
+            w, v = torch.linalg.eigh((s1 + s1.T) * 0.5)
+            root1 = (v * w.clamp_min(0.0).sqrt()) @ v.T
+        m = root1 @ s2 @ root1
+        tr_covmean = float(torch.linalg.eigvalsh((m + m.T) * 0.5).clamp_min(0.0).sqrt().sum())
+        return float(diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2.0 * tr_covmean)
     if method == "eigh":
         if ref is not None:
             root1 = ref.root()

@@ -81,6 +81,23 @@ def test_features_do_not_depend_on_the_batch(params, dev):
     assert np.array_equal(M.get_activation(imgs, small, 2048, dev), M.get_activation(imgs, big, 2048, dev))
 
 
+def test_frechet_distance_on_the_gpu_equals_the_host_forms(dev):
+    """frechet_distance(..., device=cuda): torch.linalg.eigh / eigvalsh in float64 on the device against the LAPACK eigh form and the scipy sqrtm form on the host,
+    full-rank and rank-deficient statistics, with and without a FrechetReference (whose device-side root is cached)"""
+    from naturaldiffusion_amd.fid_stats import FrechetReference, frechet_distance
+    r = np.random.RandomState(11)
+    for n, dim in ((900, 256), (100, 256), (3000, 512)):
+        a = r.randn(n, dim) @ r.randn(dim, dim) * 0.1
+        b = r.randn(n, dim) @ r.randn(dim, dim) * 0.1 + 0.2
+        m1, s1, m2, s2 = a.mean(0), np.cov(a, rowvar=False), b.mean(0), np.cov(b, rowvar=False)
+        host, gpu = frechet_distance(m1, s1, m2, s2), frechet_distance(m1, s1, m2, s2, device=dev)
+        ref = FrechetReference(m1, s1)
+        via_ref = frechet_distance(ref, None, m2, s2, device=dev)
+        assert abs(gpu - host) <= 1e-9 * abs(host) + 1e-9 * np.trace(s1) and abs(via_ref - gpu) <= 1e-12 * abs(gpu) + 1e-12 * np.trace(s1), (n, dim, host, gpu, via_ref)
+        assert ref.root_on(dev) is ref.root_on(dev)
+        assert abs(gpu - frechet_distance(m1, s1, m2, s2, method="sqrtm")) <= 1e-6 * abs(host)
+
+
 def test_frechet_distance_between_hip_and_oracle_statistics(engine, params, repo_root):
     """2,000 synthetic images (smooth random fields + noise, uint8): (mu, Sigma) of the engine's features vs (mu, Sigma) of the fp32
     oracle's, through the product's own statistics / Frechet code (fid_stats.py).  This is the FID a perfect sampler would be charged
