@@ -174,9 +174,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     tile_coords(tile, nM, nN, g.raster_g, mt_, nt_);
     const int m0 = mt_ * 256, n0 = nt_ * 256;
     const int z = blockIdx.z;
-    const bf16* abase = g.a0 + (int64_t)z * g.a_bs;
-    const bf16* bbase = g.b + (int64_t)z * g.b_bs;
-    const int nk = g.a0_C / BK;                                       // >= 2
+    // EPI 9 (split-K, launch_gemm): blockIdx.y = K slice; the tile's fp32 partial sums go to g.c [slice][batch][M][N], k_splitk_reduce_f32 sums the slices in order
+    const int nk_all = g.a0_C / BK;
+    const int kt_lo = EPI == 9 ? (int)((int64_t)nk_all * blockIdx.y / g.splitk) : 0;
+    const int nk = EPI == 9 ? (int)((int64_t)nk_all * (blockIdx.y + 1) / g.splitk) - kt_lo : nk_all;      // >= 2
+    const bf16* abase = g.a0 + (int64_t)z * g.a_bs + (int64_t)kt_lo * BK;
+    const bf16* bbase = g.b + (int64_t)z * g.b_bs + (int64_t)kt_lo * BK;
     NATINF_TS(0);
 
     // LDS-DMA: piece n of this wave = rows n * 32 + wave * 8 .. + 7 of the A (B) half, one 128-byte row per eight lanes, the row's 16-byte chunks stored at
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         dm.junk = 0;
     }
     // the operands' extents behind their bases (the descriptors' num_records: what keeps a prefetch past the last K-tile from touching memory)
-    const unsigned a_bytes = (unsigned)((((int64_t)g.M - 1) * g.a0_ld + g.a0_C) * 2), b_bytes = (unsigned)((((int64_t)g.N - 1) * g.b_ld + g.a0_C) * 2);
+    const unsigned a_bytes = (unsigned)((((int64_t)g.M - 1) * g.a0_ld + g.a0_C - (int64_t)kt_lo * BK) * 2), b_bytes = (unsigned)((((int64_t)g.N - 1) * g.b_ld + g.a0_C - (int64_t)kt_lo * BK) * 2);
     auto rsrc_at = [&](int kt) __attribute__((always_inline)) {
         dm.ra = w128_make_rsrc(abase + (int64_t)kt * BK, a_bytes - (unsigned)kt * (BK * 2)); dm.rb = w128_make_rsrc(bbase + (int64_t)kt * BK, b_bytes - (unsigned)kt * (BK * 2));
     };
@@ -257,6 +260,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __builtin_amdgcn_sched_barrier(0);
     NATINF_TS(5);
     asm volatile("" :: "v"(dm.junk));
+    if constexpr (EPI == 9) {                                            // split-K partial sums, straight from the registers (16-byte stores)
+        float* out = reinterpret_cast<float*>(g.c) + ((int64_t)blockIdx.y * g.batch + z) * g.M * g.N;
+        const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            if (n0 + hh * 128 >= g.N) break;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + wm * 128 + i * 16 + r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + hh * 128 + wn * 64 + j * 16 + q * 4;
+                    if (m < g.M && n < g.N) *reinterpret_cast<f32x4*>(out + (int64_t)m * g.N + n) = hh ? accH[i][j] : accL[i][j];
+                }
+            }
+        }
+        return;
+    }
     if constexpr (EPI == 7) {                                            // direct fp32 residual stream: no LDS, the whole half tile's residual in one round trip
         direct_f32_epilogue<2, 2, 8, 4, false, 8>(g, accL, m0, n0, z, lane, wm, wn);
         if (n0 + 128 < g.N) direct_f32_epilogue<2, 2, 8, 4, false, 8>(g, accH, m0, n0 + 128, z, lane, wm, wn);
@@ -281,6 +302,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // Also not kept: bf16 outputs straight from the accumulator registers (8-byte stores, no slab, no barrier -- the slab round trip is ~6.6k clocks per half tile,
 // tools/w128_timeline.py): 4-8 % SLOWER per GEMM at K <= 1,536 (bf16 and fp8 operands alike), SD3 forward +0.5 / +0.7 ms -- a store instruction that covers sixteen
 // 32-byte pieces costs the store path what one covering eight full lines does.
+
+// Split-K of an under-filled long-K GEMM whose epilogue is the gated fp32 residual stream (DiT-XL/2's fc2 at Validate's size: (4096, 1152, 4608) is 80 tiles of
+// 256 x 256 -- or 288 of 128 x 128 on 512 slots -- for 72 K-tiles each): S slices of K as S x 80 blocks of k_gemm_w128<9>, then this pass sums the slices IN ORDER
+// (deterministic) and applies out = (resid + gate[sample] * (sum + bias)) * scale, four columns per thread.  resid may be out (same element, same thread).
+__global__ __launch_bounds__(256) void k_splitk_reduce_f32(const float* __restrict__ part, int S, int64_t slice_stride, int M, int N, const float* __restrict__ bias_n,
+                                                            const float* __restrict__ gate, int gate_ld, int log_rows_per_sample, int z_samples,
+                                                            const float* resid, int resid_ld, int64_t c_bs, float scale, float* c, int c_ld)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, per = (int64_t)M * (N >> 2);
+    const int z = blockIdx.y;
+    if (idx >= per) return;
+    const int m = (int)(idx / (N >> 2)), n = (int)(idx - (int64_t)m * (N >> 2)) * 4;
+    const float* p = part + ((int64_t)z * M + m) * N + n;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    for (int sl = 1; sl < S; ++sl) { const f32x4 u = *reinterpret_cast<const f32x4*>(p + sl * slice_stride); v += u; }
+    if (bias_n) { const f32x4 b = *reinterpret_cast<const f32x4*>(bias_n + n); v += b; }
+    if (gate) { const f32x4 gt = *reinterpret_cast<const f32x4*>(gate + (int64_t)((m >> log_rows_per_sample) + z * z_samples) * gate_ld + n); v *= gt; }
+    if (resid) { const f32x4 rs = *reinterpret_cast<const f32x4*>(resid + (int64_t)z * c_bs + (int64_t)m * resid_ld + n); v += rs; }
+    v *= scale;
+    *reinterpret_cast<f32x4*>(c + (int64_t)z * c_bs + (int64_t)m * c_ld + n) = v;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------------------
 // k_gemm_w128_fp8: the same tile for e4m3 operands (gemm_fp8.h's contract: one fp32 scale per row / column applied in the epilogue, optionally E8M0 block scales on

@@ -264,7 +264,7 @@ bool set_lds_epi_all() {
            for_each_epi<EPI_R64>([](auto t) { return set_lds<CfgR64x128>(&k_gemm_ring<2, 2, 2, 4, 4, NATINF_EPI_OF(t)>); }) &&
            for_each_epi<EPI_D256H>([](auto t) { return set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 6, NATINF_EPI_OF(t)>); }) &&
            for_each_epi<EPI_D512H>([](auto t) { return set_lds<CfgD512x128>(&k_gemm_dma<4, 2, 8, 4, 6, NATINF_EPI_OF(t)>); }) &&
-           for_each_epi<EPI_W128>([](auto t) { return set_lds<W128Cfg>(&k_gemm_w128<NATINF_EPI_OF(t)>); })
+           for_each_epi<EPI_W128>([](auto t) { return set_lds<W128Cfg>(&k_gemm_w128<NATINF_EPI_OF(t)>); }) && set_lds<W128Cfg>(&k_gemm_w128<9>)
 #ifdef NATINF_DEV
            && set_lds<W128Cfg>(&k_gemm_w128<1, W128SchA>) && set_lds<W128Cfg>(&k_gemm_w128<1, W128SchP>) && set_lds<W128Cfg>(&k_gemm_w128<1, W128SchX>)
            && for_each_epi<EPI_ALL>([](auto t) { return set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4, 2, NATINF_EPI_OF(t)>); })
@@ -543,8 +543,41 @@ int splitk_slices(const GemmArgs& g) {
     while (S > 1 && (K0 + K1) / 32 / S < 16) --S;                       // at least 16 K-tiles per slice
     return S;
 }
+// Split-K on the four-wave tile for under-filled long-K GEMMs with the gated fp32 residual epilogue (gemm_w128.h: k_gemm_w128<9> + k_splitk_reduce_f32).  Returns the
+// slice count (1 = do not split): the tiles of 256 x 256 fill less than half the chip, every slice keeps >= 16 K-tiles.
+int w128_splitk_slices(const GemmArgs& g) {
+    if (!g_splitk || !g_w128 || !g.splitk_ws || g.splitk_max < 2 || !w128_ok(g) || g.a0_C < 3072) return 1;
+    if (g.c_mode != OUT_F32 || !g.resid_f32 || g.resid || g.rowvec || g.bias_m || g.gn_part || g.act != ACT_NONE || g.epi_fp32_slab || g.N % 4 || g.c_ld % 4 || g.resid_f32_ld % 4) return 1;
+    const int64_t tiles = (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.batch;
+    if (tiles * 2 > NUM_CU) return 1;
+    int S = (int)(NUM_CU / tiles);
+    if (S > g.splitk_max) S = g.splitk_max;
+    while (S > 1 && g.a0_C / BK / S < 16) --S;
+    return S;
+}
 // returns the block-tile row count of the variant used
 int launch_gemm(const GemmArgs& g0, hipStream_t s) {
+    if (g_force_variant == V_AUTO) {
+        const int S8 = w128_splitk_slices(g0);
+        if (S8 > 1) {
+            if (g_record) {
+                char line[160];
+                snprintf(line, sizeof(line), "%d %d %d %d %d %d splitk%d_w128_256x256/e7\n", g0.M, g0.N, g0.taps * g0.a0_C, 0, g0.taps, g0.batch, S8);
+                *g_record += line;
+                return 256;
+            }
+            GemmArgs p = g0;
+            p.splitk = S8; p.c = g0.splitk_ws; p.c_mode = OUT_F32;
+            const int nM = (p.M + 255) / 256, nN = (p.N + 255) / 256;
+            p.raster_g = 0;
+            hipLaunchKernelGGL((k_gemm_w128<9>), dim3(nM * nN, S8, p.batch), dim3(256), W128Cfg::LDS_BYTES, s, p);
+            const int64_t per = (int64_t)g0.M * (g0.N / 4);
+            hipLaunchKernelGGL(k_splitk_reduce_f32, dim3((unsigned)((per + 255) / 256), (unsigned)g0.batch), dim3(256), 0, s, g0.splitk_ws, S8, (int64_t)g0.batch * g0.M * g0.N, g0.M, g0.N,
+                               g0.bias_n, g0.gate, g0.gate_ld, g0.log_rows_per_sample, g0.z_samples, g0.resid_f32, g0.resid_f32_ld, g0.c_bs, g0.scale,
+                               reinterpret_cast<float*>(g0.c), g0.c_ld);
+            return 256;
+        }
+    }
     const int S = g_force_variant == V_AUTO ? splitk_slices(g0) : 1;
     if (S > 1) {
         if (g_record) {

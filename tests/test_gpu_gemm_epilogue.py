@@ -108,6 +108,20 @@ def test_w128_tile_equals_the_eight_wave_tile():
         assert torch.equal(auto[0], old[0])
 
 
+def test_w128_splitk_with_the_gated_fp32_residual_epilogue():
+    """an under-filled long-K GEMM with the transformer engines' residual epilogue (DiT-XL/2's fc2 at 16 samples: 80 tiles of 256 x 256, 72 K-tiles): K slices on
+    k_gemm_w128<9> + k_splitk_reduce_f32 against the fp32 reference and against the unsplit launch; deterministic; the in-place form (residual == output) is what the
+    engines run"""
+    for (M, N, K, lrs) in ((4096, 1152, 4608, 8), (1000, 392, 3072, 30), (2048, 1152, 4608, 8)):
+        terms = ("bias_n", "gate", "resid_f32")
+        out, ref, _, bm = _run(0, M, N, K, lrs, terms, 0, True, splitk=4)
+        out2, _, _, _ = _run(0, M, N, K, lrs, terms, 0, True, splitk=4)
+        out1, _, _, _ = _run(0, M, N, K, lrs, terms, 0, True)
+        tol = 2e-6 * ref.abs().max().item() + 1e-5
+        assert bm == 256 and torch.isfinite(out).all() and torch.equal(out, out2)
+        assert (out - ref).abs().max().item() <= tol and (out1 - ref).abs().max().item() <= tol
+
+
 def test_packed_epilogue_is_deterministic():
     a = _run(V_DMA256P, 1024, 512, 128, 8, ("bias_n", "rowvec", "gn"))
     b = _run(V_DMA256P, 1024, 512, 128, 8, ("bias_n", "rowvec", "gn"))
