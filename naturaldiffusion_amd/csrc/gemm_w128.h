@@ -195,9 +195,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             dm.soa[n] = (unsigned)((int64_t)min(m0 + r, g.M - 8) * g.a0_ld * 2);
             dm.sob[n] = (unsigned)((int64_t)min(n0 + r, g.N - 8) * g.b_ld * 2);
         }
-        dm.pfa = (unsigned)((int64_t)min(m0 + wave * 64 + lane, g.M - 1) * g.a0_ld * 2);
-        dm.pfb = (unsigned)((int64_t)min(n0 + wave * 64 + lane, g.N - 1) * g.b_ld * 2);
-        dm.junk = 0;
+        dm.pfa = dm.pfb = dm.junk = 0;
+        if constexpr (SCH::PF > 0) {                                  // (development schedules only)
+            dm.pfa = (unsigned)((int64_t)min(m0 + wave * 64 + lane, g.M - 1) * g.a0_ld * 2);
+            dm.pfb = (unsigned)((int64_t)min(n0 + wave * 64 + lane, g.N - 1) * g.b_ld * 2);
+        }
     }
     // the operands' extents behind their bases (the descriptors' num_records: what keeps a prefetch past the last K-tile from touching memory)
     const unsigned a_bytes = (unsigned)((((int64_t)g.M - 1) * g.a0_ld + g.a0_C - (int64_t)kt_lo * BK) * 2), b_bytes = (unsigned)((((int64_t)g.N - 1) * g.b_ld + g.a0_C - (int64_t)kt_lo * BK) * 2);
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     NATINF_TS(5);
-    asm volatile("" :: "v"(dm.junk));
+    if constexpr (SCH::PF > 0) asm volatile("" :: "v"(dm.junk));
     if constexpr (EPI == 9) {                                            // split-K partial sums, straight from the registers (16-byte stores)
         float* out = reinterpret_cast<float*>(g.c) + ((int64_t)blockIdx.y * g.batch + z) * g.M * g.N;
         const int r = lane & 15, q = lane >> 4;
