@@ -366,6 +366,14 @@ def test_sd3_medium_width_joint_block_matches_oracle(fp8):
     err = ((out - ref).abs().max() / ref.abs().max()).item()
     print(f"SD3-medium-width block, fp8={fp8}: max rel err {err:.3e}")
     assert err <= (8e-2 if fp8 else TOL), err
+    # the benchmarked batch: the same sequence eight times (every GEMM of the forward batched over eight sequences, the image stream's on the four-wave tiles)
+    # must give the one-sequence result eight times
+    eng8 = MMDiTEngine(flatten_state_dict(P, 64, **cfg), max_batch=8, grid=64, ctx_tokens=333, fp8=fp8, **cfg)
+    rep = lambda v: v.cuda().repeat(8, *([1] * (v.dim() - 1)))
+    out8 = eng8.forward(rep(x), rep(t), rep(e), rep(p)).cpu()
+    diff = [((out8[i] - out[0]).abs().max() / ref.abs().max()).item() for i in range(8)]
+    print("eight sequences vs one:", ["%.2e" % d for d in diff])
+    assert max(diff) <= 2e-3, diff
 
 
 @pytest.mark.parametrize("csv", ["sd3_step_28_weight.csv", "sd3_step_28_weight_sharp.csv"])
