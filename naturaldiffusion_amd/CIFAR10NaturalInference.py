@@ -112,6 +112,7 @@ class BatchLanes:
         self.depth = int(depth)
         self.count = 0
         self.out = []
+        self.joined = [False] * len(self.models)                       # lane k has been ordered behind the caller's stream
 
     def _sampler(self, k: int, n: int) -> CifarNI:
         if n not in self.samplers[k]:
@@ -127,8 +128,13 @@ class BatchLanes:
         if len(self.pending[k]) >= self.depth:                          # bound the host's run-ahead (and the noise tensors in flight)
             self.pending[k].pop(0).synchronize()
         with torch.cuda.device(self.device):
-            if st is not None and noise is not None:
+            # A lane's first launch is ordered behind everything the caller's stream has queued: the engine's workspace and packed weights (and
+            # the blocks clone() got from the caching allocator, which may be recycled ones with work pending) were allocated THERE, and a
+            # still-queued forward of lane 0's engine on the caller's stream would otherwise race with the lane's.  With `noise` every submit waits.
+            if st is not None and (noise is not None or not self.joined[k]):
                 st.wait_stream(torch.cuda.current_stream())
+                self.joined[k] = True
+            if st is not None and noise is not None:
                 noise.record_stream(st)
             with torch.cuda.stream(st):
                 ni = self._sampler(k, n)                                # (first use allocates on the lane's stream)
@@ -147,7 +153,11 @@ class BatchLanes:
             for st in self.streams:
                 if st is not None:
                     main.wait_stream(st)
+            if any(st is not None for st in self.streams):
+                for pix in self.out:                                     # allocated on a lane's stream, consumed (and freed) on the caller's: the allocator must
+                    pix.record_stream(main)                              # not hand the block back to the lane while the caller's torch.cat is still queued
         self.pending = [[] for _ in self.models]
+        self.joined = [False] * len(self.models)
         out, self.out = self.out, []
         return out
 

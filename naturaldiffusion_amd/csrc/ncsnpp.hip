@@ -128,6 +128,7 @@ struct natinf_ncsnpp {
     std::vector<hipEvent_t> pool;
     std::map<int, TRef> taps;            // module idx -> output tensor
     int64_t ws_per_image = 0, packed_bytes = 0;
+    uint64_t plan_sig = 0;               // the natinf_set_* switches a plan reads when it is BUILT (they decide the pack offsets): natinf_ncsnpp_share compares them
     const unsigned char* packed = nullptr;
     bool attr_set = false;
     int last_B = 0; unsigned char* last_ws = nullptr;
@@ -457,7 +458,8 @@ int fp8_epi(const GemmArgs& g) {
 extern int g_w128;
 // k_gemm_w128_fp8 (gemm_w128.h): an even number of 128-byte K-tiles, 32-bit offsets into the operands
 bool w128_fp8_ok(const GemmArgs& g) {
-    return g.taps == 1 && !g.a1 && g.a0_C % 256 == 0 && g.N % 8 == 0 && g.M % 8 == 0 &&
+    // (E8M0 block scales of A arrive by DMA as whole 256-row groups per K-tile: the plane must hold them -- whole row tiles only)
+    return g.taps == 1 && !g.a1 && g.a0_C % 256 == 0 && g.N % 8 == 0 && g.M % 8 == 0 && (!g.a_mx || g.M % 256 == 0) &&
            (int64_t)g.M * g.a0_ld < (int64_t)1 << 32 && (int64_t)g.N * g.b_ld < (int64_t)1 << 32;
 }
 template <bool MXA>
@@ -546,7 +548,8 @@ int splitk_slices(const GemmArgs& g) {
 // Split-K on the four-wave tile for under-filled long-K GEMMs with the gated fp32 residual epilogue (gemm_w128.h: k_gemm_w128<9> + k_splitk_reduce_f32).  Returns the
 // slice count (1 = do not split): the tiles of 256 x 256 fill less than half the chip, every slice keeps >= 16 K-tiles.
 int w128_splitk_slices(const GemmArgs& g) {
-    if (!g_splitk || !g_w128 || !g.splitk_ws || g.splitk_max < 2 || !w128_ok(g) || g.a0_C < 3072) return 1;
+    // (batch 1 only: the workspace contract is splitk_max * M * N floats; a batched launch would need batch times that)
+    if (!g_splitk || !g_w128 || !g.splitk_ws || g.splitk_max < 2 || g.batch != 1 || !w128_ok(g) || g.a0_C < 3072) return 1;
     if (g.c_mode != OUT_F32 || !g.resid_f32 || g.resid || g.rowvec || g.bias_m || g.gn_part || g.act != ACT_NONE || g.epi_fp32_slab || g.N % 4 || g.c_ld % 4 || g.resid_f32_ld % 4) return 1;
     const int64_t tiles = (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.batch;
     if (tiles * 2 > NUM_CU) return 1;
@@ -1490,10 +1493,19 @@ int64_t natinf_ncsnpp_workspace_bytes(natinf_ncsnpp_t h, int max_batch) {
     return h->ws_per_image * (int64_t)max_batch;
 }
 
+// every switch a plan builder reads (layout of the packed weights included), one byte each
+static uint64_t plan_signature() {
+    const int k[] = {g_fuse_head, g_cg8_tm4, g_attn_qkv, g_attn_w8, g_attn_proj, g_attn256, g_fuse_gn8, g_fuse_fin, g_fuse_gn4, g_fuse_gn, g_cg_wide, g_fuse_up, g_cg_regw};
+    uint64_t h = 1469598103934665603ull;
+    for (int v : k) h = (h ^ (uint64_t)(v & 0xff)) * 1099511628211ull;
+    return h;
+}
+
 int natinf_ncsnpp_create(natinf_ncsnpp_t* out, int flags) {
     if (!out || (flags & ~(NATINF_NCSNPP_KEEP_ACTIVATIONS | NATINF_NCSNPP_DDPM))) return NATINF_EINVAL;
     natinf_ncsnpp* e = make_engine(flags);
     if (!e) return NATINF_ESTATE;
+    e->plan_sig = plan_signature();
     *out = e;
     return NATINF_OK;
 }
@@ -1534,7 +1546,7 @@ int natinf_ncsnpp_share(natinf_ncsnpp_t h, natinf_ncsnpp_t loaded) {
     if (!loaded->packed) return NATINF_ESTATE;
     // same network, same plan-build-time switches: the two plans address the packed buffer identically
     if ((h->flags & NATINF_NCSNPP_DDPM) != (loaded->flags & NATINF_NCSNPP_DDPM) || h->n_params != loaded->n_params || h->packed_bytes != loaded->packed_bytes ||
-        h->packs.size() != loaded->packs.size())
+        h->packs.size() != loaded->packs.size() || h->plan_sig != loaded->plan_sig)
         return NATINF_EINVAL;
     h->packed = loaded->packed;
     return NATINF_OK;

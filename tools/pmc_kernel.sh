@@ -4,14 +4,18 @@
 # Three separate --pmc passes (counter slots) + one --stats pass, kernel trace only (gpurun refuses --pmc with the runtime traces; the program itself
 # follows `--`, no shell in between).  Writes the per-counter means over the kernel's launches and the derived fractions to
 # gpurun_out/pmc/<tag>/summary.json; copy it to profiles/rNN/.
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; K=$1; TAG=$2; shift 2
-O=$R/gpurun_out/pmc/$TAG; rm -rf $O; mkdir -p $O
+set -eu
+if [ "$#" -lt 3 ] || [ -z "${GRAFT_REPO_ROOT:-}" ] || [ -z "$2" ]; then echo "usage (GPU box, GRAFT_REPO_ROOT set): $0 <kernel substring> <tag> <program> [args...]" >&2; exit 2; fi
+case "$2" in */*|.*) echo "tag must be a plain name" >&2; exit 2;; esac
+export TMPDIR=/tmp; R="$GRAFT_REPO_ROOT"; K="$1"; TAG="$2"; shift 2
+O="$R/gpurun_out/pmc/$TAG"; rm -rf -- "$O"; mkdir -p "$O"
+set +e
 ARGS=(); for a in "$@"; do if [ -f "$R/$a" ]; then ARGS+=("$R/$a"); else ARGS+=("$a"); fi; done
 cd /tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/sq1 -- "${ARGS[@]}" > $O/sq1.log 2>&1
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM --output-format csv -d $O/sq2 -- "${ARGS[@]}" > $O/sq2.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAVES SQ_INST_LEVEL_LDS --output-format csv -d $O/sq3 -- "${ARGS[@]}" > $O/sq3.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- "${ARGS[@]}" > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$O/sq1" -- "${ARGS[@]}" > "$O/sq1.log" 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM --output-format csv -d "$O/sq2" -- "${ARGS[@]}" > "$O/sq2.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAVES SQ_INST_LEVEL_LDS --output-format csv -d "$O/sq3" -- "${ARGS[@]}" > "$O/sq3.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- "${ARGS[@]}" > "$O/stats.log" 2>&1
 python3 - <<PY
 import csv, glob, json
 from collections import defaultdict
