@@ -263,11 +263,11 @@ def main():
             del flat
         if not args.no_fid50k:
             sub = bench_fid50k(args, world, rank, dev, steps=1, warmup=0)
-            line["fid50k"] = slim({k: v for k, v in sub.items() if k not in strip and k not in ("dtype", "cpu_baseline", "roofline", "batches", "last_batch", "frechet_vs_synthetic_ref")})
+            line["fid50k"] = slim({k: v for k, v in sub.items() if k not in strip and k not in ("dtype", "cpu_baseline", "batches", "last_batch", "frechet_vs_synthetic_ref")})
             release()
         if not args.no_validate and world == 1:
             sub = bench_validate(args, world, rank, dev, steps=3, warmup=1)
-            line["validate"] = slim({k: v for k, v in sub.items() if k not in strip and k not in ("dtype", "cpu_baseline", "roofline", "dit_forwards")})
+            line["validate"] = slim({k: v for k, v in sub.items() if k not in strip and k not in ("dtype", "cpu_baseline", "dit_forwards")})
             release()
         line.update(tail)
     if rank == 0:
@@ -551,7 +551,10 @@ def bench_sd3(args, world, rank, dev, fp8=False, steps=2, warmup=1, flat=None):
         flat = synthetic_mmdit_flat(grid=64, seed=0, **SD3_MEDIUM)
     eng = MMDiTEngine(flat, max_batch=2 * n, grid=64, ctx_tokens=tc, device=dev, fp8=fp8, **SD3_MEDIUM)
     g = torch.Generator(device=dev).manual_seed(10 + rank)
-    noises = torch.randn(n, 16, 128, 128, device=dev, dtype=torch.float16, generator=g)
+    # this rank's images of a world * n image job sharded by global index (SD3NaturalInference.sd_generate_sharded's rule): Philox noise keyed by the index
+    from naturaldiffusion_amd.SD3NaturalInference import philox_noise_f16
+    from naturaldiffusion_amd.shard import rank_indices
+    noises = philox_noise_f16(rank_indices(world * n, rank, world), (16, 128, 128), 10, dev)
     text = torch.randn(2 * n, tc, 4096, device=dev, generator=g)
     pooled = torch.randn(2 * n, 2048, device=dev, generator=g)
     ni = SD3NI(W, sigmas, noises.numel(), device=dev, cfg=7.0)

@@ -110,6 +110,14 @@ def _load_pipe(pipe, device, dtype, n=4):
     return use_native_vae(use_native_transformer(pipe, n, device=device), n, device=device)
 
 
+def philox_noise_f16(indices, shape_per_image=(16, 128, 128), seed: int = 10, device="cuda:0") -> torch.Tensor:
+    """fp16 N(0,1) latents, image i keyed by its GLOBAL index (include/natinf.h natinf_randn_philox_f32, rounded to fp16 once): the
+    same image for any GPU count / batch split -- the sharded counterpart of the reference's one ``torch.randn(n, 16, 128, 128)`` (:184-186),
+    as ``CIFAR10NaturalInference.philox_noise`` is for config 3."""
+    from .CIFAR10NaturalInference import philox_noise
+    return philox_noise(indices, shape_per_image, seed, device).to(torch.float16)
+
+
 def _prepare(pipe, device, dtype, n, seed, num_step, noises):
     prompts = [PROMPT] * n
     if noises is None:
@@ -153,13 +161,61 @@ def _velocities(pipe, x, ts, emb):
 
 
 @torch.no_grad()
+def sd_generate_sharded(pipe, sample_count: int, n: int = 4, rank: int = 0, world: int = 1, seed: int = 10, num_step: int = 28,
+                        weight_name: str = "sd3_step_28_weight.csv", device="cuda:0", latent_shape=(16, 128, 128)):
+    """Batch-sharded SD3 generation (BASELINE configs 4 / 5): this rank runs the reference's loop (:198-223) for the images
+    whose GLOBAL index is rank, rank + world, ... in batches of ``n`` -- no collective on the data path, Philox noise keyed by the global index
+    (``philox_noise_f16``), so image i is the same bytes whatever the GPU count or batch split.  ``pipe`` as in ``sd_natural_inference_tx``
+    (``encode_prompt`` is asked for ``n`` prompts once; a ragged last batch uses the first rows).
+    Returns (final latents [n_local, *latent_shape] fp16 on the device, their global indices [n_local] int64 on the CPU)."""
+    from .shard import rank_batches
+    _lib.require_gpu()
+    dev = torch.device(device)
+    batches = list(rank_batches(sample_count, n, rank, world))
+    if not batches:
+        return torch.empty((0,) + tuple(latent_shape), dtype=torch.float16, device=dev), torch.empty(0, dtype=torch.int64)
+    emb = pipe.encode_prompt(prompt=[PROMPT] * n, prompt_2=None, prompt_3=None, negative_prompt="")
+    pipe.scheduler.set_timesteps(num_step, device=dev)
+    timesteps, sigmas = pipe.scheduler.timesteps.to(dev), pipe.scheduler.sigmas.to(dev)
+    weights = load_sd3_csv(os.path.join(root_path / "weights", weight_name))
+    samplers, outs = {}, []
+    for batch in batches:
+        nb = len(batch)
+        noises = philox_noise_f16(batch, latent_shape, seed, dev)
+        if nb not in samplers:                                          # (a ragged last batch gets its own history slabs)
+            samplers[nb] = SD3NI(weights, sigmas, noises.numel(), device=dev, cfg=7.0)
+        ni, e = samplers[nb], tuple(t[:nb] for t in emb)
+        flat_noise = noises.reshape(-1)
+        x = ni.first_input(flat_noise)
+        for kk in range(num_step):
+            vt, vn = _velocities(pipe, x.view(noises.shape), timesteps[kk].expand(nb), e)
+            mean, x = ni.step(kk, x, vt.reshape(-1), vn.reshape(-1), flat_noise, want_next=kk + 1 < num_step)
+        outs.append(mean.view(noises.shape).clone())
+    return torch.cat(outs), torch.cat([torch.tensor(b, dtype=torch.int64) for b in batches])
+
+
+@torch.no_grad()
 def sd_natural_inference_tx(pipe=None, device="cuda", noises: Optional[torch.Tensor] = None, n: int = 4, seed: int = 10,
                             num_step: int = 28, weight_names=("sd3_step_28_weight.csv", "sd3_step_28_weight_sharp.csv"),
-                            decode: bool = True) -> List[torch.Tensor]:
+                            decode: bool = True, rank: int = 0, world: int = 1, sample_count: Optional[int] = None):
     """Reference :172-245.  Returns the final latents per weight file (and writes ``results/sd3/sgl_*.png``
-    when ``decode``)."""
+    when ``decode``).  With ``sample_count`` (not in the reference: its job is one batch of four) the job is ``sample_count`` images sharded by
+    global index over ``world`` ranks (``sd_generate_sharded``): returns [(latents of this rank, global indices)] per weight file and, when
+    ``decode``, writes this rank's images to ``results/sd3/sgl_<weights>_<index>.png``."""
     dtype = torch.float16
     pipe = _load_pipe(pipe, device, dtype, n)
+    if sample_count is not None:
+        finals = []
+        for weight_name in weight_names:
+            lat, idx = sd_generate_sharded(pipe, sample_count, n, rank, world, seed, num_step, weight_name, device if str(device) != "cuda" else "cuda:0")
+            finals.append((lat, idx))
+            if decode:
+                for s0 in range(0, lat.shape[0], n):
+                    for im, gi in zip(_decode(pipe, lat[s0:s0 + n]), idx[s0:s0 + n].tolist()):
+                        _write_row(results_path / ("results/sd3/sgl_%s_%06d.png" % (weight_name[:-4], gi)), [im])
+        return finals
+    if world != 1 or rank != 0:
+        raise ValueError("rank / world need sample_count (the reference's job is one batch: nothing to shard)")
     noises, emb, timesteps, sigmas = _prepare(pipe, device, dtype, n, seed, num_step, noises)
     shape, finals = noises.shape, []
     for weight_name in weight_names:

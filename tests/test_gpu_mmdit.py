@@ -198,6 +198,13 @@ def test_forward_is_deterministic_and_ignores_workspace_contents(fp8):
     eng._ws.zero_()
     b = eng.forward(x, t, e, p)
     assert torch.isfinite(a).all() and torch.equal(a, b)
+    # FINITE garbage (what an allocator block of an earlier engine holds): NaN cannot stand in for it -- a NaN compares false, so a padded query row of NaNs never
+    # tripped the attention kernel's wave-wide re-referencing test, while finite left-overs did and moved the real rows' last bits (round 4's red test: the padded
+    # q | k rows of the joint buffer were never written; tools/diag_fp8_ws.py bisected the workspace to them)
+    junk = torch.randint(0, 0x60, (eng._ws.numel(),), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    eng._ws.copy_(junk)
+    c = eng.forward(x, t, e, p)
+    assert torch.equal(c, b)
 
 
 @pytest.fixture(params=[0, 1, 2], ids=["eight_wave_tile", "w128", "w128_incl_fc1"])
@@ -370,10 +377,22 @@ def test_sd3_medium_width_joint_block_matches_oracle(fp8):
     # must give the one-sequence result eight times
     eng8 = MMDiTEngine(flatten_state_dict(P, 64, **cfg), max_batch=8, grid=64, ctx_tokens=333, fp8=fp8, **cfg)
     rep = lambda v: v.cuda().repeat(8, *([1] * (v.dim() - 1)))
+    # (over a workspace of finite left-overs: what this engine gets from the allocator in the middle of a test session)
+    eng8._ws.copy_(torch.randint(0, 0x60, (eng8._ws.numel(),), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2)))
     out8 = eng8.forward(rep(x), rep(t), rep(e), rep(p)).cpu()
+    # the benchmarked plan against the oracle DIRECTLY, at the same bound as the one-sequence plan
+    err8 = ((out8 - ref).abs().amax(dim=(1, 2, 3)) / ref.abs().max()).tolist()
+    print("eight sequences vs the oracle:", ["%.3e" % d for d in err8])
+    assert max(err8) <= (8e-2 if fp8 else TOL), err8
+    # the eight sequences are the same sequence: the same bytes eight times (one launch, one plan, one arithmetic per row)
+    assert all(torch.equal(out8[i], out8[0]) for i in range(1, 8))
+    # eight against one: the two batches may take different plans (one sequence under-fills the chip: split-K on the long-K GEMMs, the round model's tile choice), i.e.
+    # a different order of the fp32 sums over K; measured on this case: identical bytes under every plan knob (tools/diag_fp8_batch.py, profiles/r05/diag_fp8_batch.json).
+    # Round 4's 3.6e-3 here was not the plan: the padded query rows of the joint buffer were never written, and finite garbage in them re-referenced the attention
+    # kernel's waves that also hold real rows (mmdit_engine.inc: the rows are zeroed per forward now).  Bound: a tenth of the fp8 (bf16) error against the oracle.
     diff = [((out8[i] - out[0]).abs().max() / ref.abs().max()).item() for i in range(8)]
     print("eight sequences vs one:", ["%.2e" % d for d in diff])
-    assert max(diff) <= 2e-3, diff
+    assert max(diff) <= (2e-3 if fp8 else 5e-4), diff
 
 
 @pytest.mark.parametrize("csv", ["sd3_step_28_weight.csv", "sd3_step_28_weight_sharp.csv"])
