@@ -197,17 +197,22 @@ def sd_generate_sharded(pipe, sample_count: int, n: int = 4, rank: int = 0, worl
 @torch.no_grad()
 def sd_natural_inference_tx(pipe=None, device="cuda", noises: Optional[torch.Tensor] = None, n: int = 4, seed: int = 10,
                             num_step: int = 28, weight_names=("sd3_step_28_weight.csv", "sd3_step_28_weight_sharp.csv"),
-                            decode: bool = True, rank: int = 0, world: int = 1, sample_count: Optional[int] = None):
+                            decode: bool = True, rank: int = 0, world: int = 1, sample_count: Optional[int] = None, latent_shape=None):
     """Reference :172-245.  Returns the final latents per weight file (and writes ``results/sd3/sgl_*.png``
     when ``decode``).  With ``sample_count`` (not in the reference: its job is one batch of four) the job is ``sample_count`` images sharded by
     global index over ``world`` ranks (``sd_generate_sharded``): returns [(latents of this rank, global indices)] per weight file and, when
-    ``decode``, writes this rank's images to ``results/sd3/sgl_<weights>_<index>.png``."""
+    ``decode``, writes this rank's images to ``results/sd3/sgl_<weights>_<index>.png``.  ``latent_shape`` of the sharded job: the native
+    transformer's own (in_ch, 2 grid, 2 grid) when ``pipe.transformer`` is the HIP engine, the reference's (16, 128, 128) otherwise."""
     dtype = torch.float16
     pipe = _load_pipe(pipe, device, dtype, n)
     if sample_count is not None:
+        if latent_shape is None:
+            tr = getattr(pipe, "transformer", None)
+            latent_shape = (tr.in_ch, 2 * tr.grid, 2 * tr.grid) if hasattr(tr, "in_ch") and hasattr(tr, "grid") else (16, 128, 128)
         finals = []
         for weight_name in weight_names:
-            lat, idx = sd_generate_sharded(pipe, sample_count, n, rank, world, seed, num_step, weight_name, device if str(device) != "cuda" else "cuda:0")
+            lat, idx = sd_generate_sharded(pipe, sample_count, n, rank, world, seed, num_step, weight_name, device if str(device) != "cuda" else "cuda:0",
+                                           latent_shape=tuple(latent_shape))
             finals.append((lat, idx))
             if decode:
                 for s0 in range(0, lat.shape[0], n):
