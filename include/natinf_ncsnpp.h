@@ -148,6 +148,11 @@ int natinf_set_fuse_gn(int on);
 /* Bit mask (default 3; NATINF_EINVAL outside 0..3): fused-convolution launches with N % 256 == 0 use the 128-pixel x 256-channel tile (the patch is
  * normalised once for all 256 output channels) on 16x16 images (bit 0) and on 32x32 images (bit 1: the 16 -> 32 up-sampling block); 0: 256 x 128 tiles. */
 int natinf_set_conv_gn_wide(int mask);
+/* Bit mask (NATINF_EINVAL outside 0..7): fused-convolution launches on k_conv_gn3 (csrc/conv_gn3.h: four waves per block, one per SIMD, 128-pixel x
+ * 128-channel wave tiles, AGPR accumulators, a K loop written slot by slot) -- bit 0: 32x32 images, N % 256 != 0, 512-pixel x 128-channel tiles; bit 1:
+ * 32x32 images, N % 256 == 0, 256 x 256 tiles; bit 2: 16x16 images, N % 256 == 0, 256 x 256 tiles (one image per tile).  The convolution sums are the
+ * bytes k_conv_gn2 gives (same K order, same normalisation arithmetic); GroupNorm partial rows then cover 512 / 256 pixels (natinf_debug_conv_gn: rows). */
+int natinf_set_conv_gn_w128(int mask);
 int natinf_set_conv_gn_regw(int on);
 /* 1 (default; read when a plan is built): the up-sampling blocks at 16x16 / 32x32 read their half-resolution input inside the fused
  * convolution (nearest up-sampling in the patch fetch and in the residual fetch); 0: through the separate GroupNorm-apply + up-sample pass. */

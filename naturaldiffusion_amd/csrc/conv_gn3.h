@@ -58,8 +58,6 @@ struct ConvGn3Cfg {
     static_assert(gp(NROUND - 1) + 38 < G_END, "the rounds end in front of the barrier of tap 8");
 };
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
 // ---- instruction wrappers (volatile: the order of the K loop is the order written) ----
 __device__ __forceinline__ void cg3_mfma(f32x4& acc, const u32x4& b, const u32x4& a) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(b), "v"(a));
@@ -77,7 +75,8 @@ __device__ __forceinline__ void cg3_gtab(unsigned toff, const float* sc, const f
     unsigned long long save;
     asm volatile("s_mov_b32 m0, %4\n\t"
                  "s_mov_b64 %0, exec\n\t"
-                 "s_mov_b64 exec, 0xffffffff\n\t"
+                 "s_mov_b32 exec_lo, -1\n\t"
+                 "s_mov_b32 exec_hi, 0\n\t"
                  "global_load_lds_dword %1, %2\n\t"
                  "s_not_b64 exec, exec\n\t"
                  "global_load_lds_dword %1, %3\n\t"
@@ -104,11 +103,12 @@ struct CG3Ctx {
     unsigned a_dx[3];                         // A fragment bases (dx = -1, 0, +1 at dy = -1) in patch buffer 0
     unsigned a_sc;                            // A fragment base in shortcut buffer 0
     unsigned n_addr[2];                       // the lane's 16 bytes of its piece of round 0 in patch buffer 0 / 1
-    unsigned n_tab;                           // the lane's row (channel chunk lane & 3) of table 0
-    unsigned nmask;                           // bit r: the pixel of round r lies inside the image; bit 16 + r: bit 2 of its patch column (the swizzle key)
+    unsigned ntb[Cfg::NROUND];                // the lane's row of table 0 in round r: channel chunk (lane & 3) ^ 2 * (bit 2 of its patch column: the swizzle key)
+    unsigned tvo;                             // table request: (lane & 31) * 4
+    unsigned nmask;                           // bit r: the pixel of round r lies inside the image
     // normalisation rounds
     u32x4 nv, ns0, ns1, nh0, nh1, npk;
-    unsigned ntb, nin[2], u0, u1, t0, t1;
+    unsigned nin[2], nx[8], ne[8];
     // wave-uniform
     const unsigned char* wnext;               // weight fragments of the NEXT K step
     const bf16* pnext;                        // raw patch source of the next half-chunk
@@ -117,35 +117,37 @@ struct CG3Ctx {
     unsigned lds_patch, lds_tab, lds_sc, wave;
 };
 
-// ---- one channel pair of a normalisation round, gap g (0..8) ----
-template <int P, int G, class Cfg>
-__device__ __forceinline__ void cg3_pair_gap(CG3Ctx<Cfg>& c, int rpar) {
-    // scale / shift of channels 2 P, 2 P + 1 of the lane's chunk
-    if constexpr (G == 0) {
-        asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(c.u0) : "v"(c.nv[P]));
-        asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(c.u1) : "v"(c.nv[P]));
-    } else if constexpr (G == 1) {
+// ---- the normalisation of one round (eight elements per lane = four channel pairs), STAGE BY STAGE over 36 MFMA gaps: unpack x 8 (gaps 0-3), fma x 8
+// ---- (4-7), exp2 x 8 (8-15), + 1 x 8 (16-19), rcp x 8 (20-27), mul x 8 (28-31), pack + mask x 4 (32-35): two plain vector instructions or one
+// ---- transcendental per gap (8 issue cycles beside the MFMA's 8).  Stage by stage, not element by element, because hipcc's hazard recogniser assumes
+// ---- a forwarding hazard between ANY inline-asm definition of a vector register and its first reader and does not count inline-asm statements as
+// ---- wait states: it puts an `s_nop 0` in front of the first statement that reads a register another statement wrote (unless a nop or a real
+// ---- instruction lies between them).  A dependent chain per element costs one nop per link (26 per round); eight elements a stage cost one per stage (7).
+template <int GG, int RPAR, class Cfg>
+__device__ __forceinline__ void cg3_norm_gap(CG3Ctx<Cfg>& c) {
+    if constexpr (GG < 4) {                                     // unpack pair GG: x[2 GG] = low half << 16, x[2 GG + 1] = high half
+        asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(c.nx[2 * GG]) : "v"(c.nv[GG]));
+        asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(c.nx[2 * GG + 1]) : "v"(c.nv[GG]));
+    } else if constexpr (GG < 8) {                              // t = x * scale + shift (scale / shift carry -log2 e: gn_folded)
+        constexpr int P = GG - 4;
         if constexpr (P < 2) {
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(c.t0) : "v"(c.u0), "v"(c.ns0[2 * P]), "v"(c.nh0[2 * P]));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(c.t1) : "v"(c.u1), "v"(c.ns0[2 * P + 1]), "v"(c.nh0[2 * P + 1]));
+            asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(c.nx[2 * P]) : "v"(c.ns0[2 * P]), "v"(c.nh0[2 * P]));
+            asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(c.nx[2 * P + 1]) : "v"(c.ns0[2 * P + 1]), "v"(c.nh0[2 * P + 1]));
         } else {
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(c.t0) : "v"(c.u0), "v"(c.ns1[2 * P - 4]), "v"(c.nh1[2 * P - 4]));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(c.t1) : "v"(c.u1), "v"(c.ns1[2 * P - 3]), "v"(c.nh1[2 * P - 3]));
+            asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(c.nx[2 * P]) : "v"(c.ns1[2 * P - 4]), "v"(c.nh1[2 * P - 4]));
+            asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(c.nx[2 * P + 1]) : "v"(c.ns1[2 * P - 3]), "v"(c.nh1[2 * P - 3]));
         }
-    } else if constexpr (G == 2) asm volatile("v_exp_f32 %0, %1" : "=v"(c.u0) : "v"(c.t0));
-    else if constexpr (G == 3) asm volatile("v_exp_f32 %0, %1" : "=v"(c.u1) : "v"(c.t1));
-    else if constexpr (G == 4) {
-        asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(c.u0));
-        asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(c.u1));
-    } else if constexpr (G == 5) asm volatile("v_rcp_f32 %0, %0" : "+v"(c.u0));
-    else if constexpr (G == 6) asm volatile("v_rcp_f32 %0, %0" : "+v"(c.u1));
-    else if constexpr (G == 7) {
-        asm volatile("v_mul_f32 %0, %0, %1" : "+v"(c.t0) : "v"(c.u0));
-        asm volatile("v_mul_f32 %0, %0, %1" : "+v"(c.t1) : "v"(c.u1));
-    } else {
-        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(c.npk[P]) : "v"(c.t0), "v"(c.t1));
-        if (rpar) asm volatile("v_and_b32 %0, %0, %1" : "+v"(c.npk[P]) : "v"(c.nin[1]));
-        else asm volatile("v_and_b32 %0, %0, %1" : "+v"(c.npk[P]) : "v"(c.nin[0]));
+    } else if constexpr (GG < 16) asm volatile("v_exp_f32 %0, %1" : "=v"(c.ne[GG - 8]) : "v"(c.nx[GG - 8]));
+    else if constexpr (GG < 20) {
+        asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(c.ne[2 * (GG - 16)]));
+        asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(c.ne[2 * (GG - 16) + 1]));
+    } else if constexpr (GG < 28) asm volatile("v_rcp_f32 %0, %0" : "+v"(c.ne[GG - 20]));
+    else if constexpr (GG < 32) {                               // t / (1 + 2^t) = -log2 e * silu(v)
+        asm volatile("v_mul_f32 %0, %0, %1" : "+v"(c.nx[2 * (GG - 28)]) : "v"(c.ne[2 * (GG - 28)]));
+        asm volatile("v_mul_f32 %0, %0, %1" : "+v"(c.nx[2 * (GG - 28) + 1]) : "v"(c.ne[2 * (GG - 28) + 1]));
+    } else {                                                    // round to bf16 (RNE), pixels outside the image -> 0; ONE statement: no nop between the two
+        constexpr int P = GG - 32;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_and_b32 %0, %0, %3" : "=&v"(c.npk[P]) : "v"(c.nx[2 * P]), "v"(c.nx[2 * P + 1]), "v"(c.nin[RPAR]));
     }
 }
 
@@ -154,28 +156,22 @@ template <class Cfg, int NB, int G, int R = 0>
 __device__ __forceinline__ void cg3_norm_slot(CG3Ctx<Cfg>& c) {
     if constexpr (R < Cfg::NROUND) {
         constexpr int GP = Cfg::gp(R);
-        // the loads of round R: round 0 at G = 1..4, round R > 0 inside the tail of round R - 1 (its last pair's unpack / fma are at GP' + 27 / + 28)
-        constexpr int GL = R == 0 ? 1 : Cfg::gp(R - 1) + 29;
+        // the loads of round R: round 0 at G = 1..3; round R > 0 inside round R - 1: its patch bytes behind that round's unpack stage (gaps 0-3), its table
+        // rows behind the fma stage (gaps 4-7)
+        constexpr int GL = R == 0 ? 1 : Cfg::gp(R - 1) + 5;
         if constexpr (G == GL) c.nv = lds_read16<R * Cfg::NW * 1024>(c.n_addr[NB]);
-        if constexpr (G == GL + 1) {
-            asm volatile("v_bfe_u32 %0, %1, %2, 1" : "=v"(c.ntb) : "v"(c.nmask), "n"(16 + R));
-            asm volatile("v_lshlrev_b32 %0, 6, %0" : "+v"(c.ntb));
-        }
-        if constexpr (G == GL + 2) {
-            asm volatile("v_xor_b32 %0, %0, %1" : "+v"(c.ntb) : "v"(c.n_tab));
+        if constexpr (G == GL + 4) {
+            // the inside mask of the round as a full word (v_bfe_i32 sign-extends the bit) and the lane's table row (chunk (lane & 3) ^ 2 * key)
             asm volatile("v_bfe_i32 %0, %1, %2, 1" : "=v"(c.nin[R & 1]) : "v"(c.nmask), "n"(R));
-            c.ns0 = lds_read16<NB * Cfg::TAB_BYTES>(c.ntb);
-            c.ns1 = lds_read16<NB * Cfg::TAB_BYTES + 16>(c.ntb);
+            c.ns0 = lds_read16<NB * Cfg::TAB_BYTES>(c.ntb[R]);
+            c.ns1 = lds_read16<NB * Cfg::TAB_BYTES + 16>(c.ntb[R]);
         }
-        if constexpr (G == GL + 3) {
-            c.nh0 = lds_read16<NB * Cfg::TAB_BYTES + 128>(c.ntb);
-            c.nh1 = lds_read16<NB * Cfg::TAB_BYTES + 144>(c.ntb);
+        if constexpr (G == GL + 5) {
+            c.nh0 = lds_read16<NB * Cfg::TAB_BYTES + 128>(c.ntb[R]);
+            c.nh1 = lds_read16<NB * Cfg::TAB_BYTES + 144>(c.ntb[R]);
         }
         if constexpr (G == GP) cg3_wait_lgkm0();
-        if constexpr (G >= GP && G < GP + 36) {
-            constexpr int P = (G - GP) / 9, GG = (G - GP) % 9;
-            cg3_pair_gap<P, GG>(c, R & 1);
-        }
+        if constexpr (G >= GP && G < GP + 36) cg3_norm_gap<G - GP, (R & 1)>(c);
         if constexpr (G == GP + 36) cg3_lds_write16<R * Cfg::NW * 1024>(c.n_addr[NB], c.npk);
         cg3_norm_slot<Cfg, NB, G, R + 1>(c);
     }
@@ -216,7 +212,7 @@ struct CG3Tap {
         if constexpr (S >= 1 && S <= 8) c.fb[P ^ 1][S - 1] = cg3_gload16(c.boff[S - 1], c.wnext);
         reads<0>(c);
         if constexpr (T == 0 && NEXT) {
-            if constexpr (S == Cfg::DMA_TAB) cg3_gtab((c.wave * 0u) + 0u + c.vo[0] * 0u + c.scv[0] * 0u + c.nin[0] * 0u + c.a_sc * 0u + c.n_tab * 0u + c.nmask * 0u + c.boff[0] * 0u + c.n_addr[0] * 0u + c.tabvo(), c.tsc, c.tsh, c.lds_tab + (HP ^ 1) * Cfg::TAB_BYTES);
+            if constexpr (S == Cfg::DMA_TAB) cg3_gtab(c.tvo, c.tsc, c.tsh, c.lds_tab + (HP ^ 1) * Cfg::TAB_BYTES);
             requests<0>(c);
         }
         if constexpr (T >= 2 && NEXT) cg3_norm_slot<Cfg, HP ^ 1, (T - 2) * 64 + S>(c);
@@ -229,3 +225,189 @@ struct CG3Tap {
         if constexpr (S + 1 < 64) CG3Tap<Cfg, T, HP, NEXT, S + 1>::run(acc, c);
     }
 };
+
+// ---- one step of the 1x1 shortcut segment: tile s (register set P = s & 1) is multiplied; behind the barrier tile s + 2 is requested into the
+// ---- buffer tile s was read from, and the A fragments of tile s + 1 are read from the other one
+template <class Cfg, int P, int S>
+struct CG3Sc {
+    static __device__ __forceinline__ void run(f32x4 (&acc)[8][8], CG3Ctx<Cfg>& c) {
+        if constexpr (S == 0) cg3_wait<0, 0>();                                     // this wave's pieces of tile s + 1 and the weights of step s have landed
+        if constexpr (S >= 1 && S <= 8) c.fb[P ^ 1][S - 1] = cg3_gload16(c.boff[S - 1], c.wnext);
+        if constexpr (S == Cfg::BAR) cg3_barrier();                                  // every wave's pieces of tile s + 1 are in LDS; nobody reads tile s any more
+        if constexpr (S > Cfg::BAR && (S - Cfg::BAR - 1) % 2 == 0 && (S - Cfg::BAR - 1) / 2 < Cfg::PSW) {
+            constexpr int n = (S - Cfg::BAR - 1) / 2;
+            cg3_glds16(c.scv[n], c.scnext, c.lds_sc + P * Cfg::SC_BYTES + n * 1024 + c.wave * (Cfg::PSW * 1024));
+        }
+        if constexpr (S > Cfg::BAR + 1 && (S - Cfg::BAR - 2) % 2 == 0 && (S - Cfg::BAR - 2) / 2 < 8) {
+            constexpr int i = (S - Cfg::BAR - 2) / 2;
+            c.fa[P ^ 1][i] = lds_read16<(P ^ 1) * Cfg::SC_BYTES + i * 1024>(c.a_sc);
+        }
+        constexpr int i = S >> 3, j = S & 7;
+        cg3_mfma(acc[i][j], c.fb[P][j], c.fa[P][i]);
+        if constexpr (S + 1 < 64) CG3Sc<Cfg, P, S + 1>::run(acc, c);
+    }
+};
+
+// EPI: the packed epilogues of gemm_dma.h (1 plain, 2 + GroupNorm partials, 5 + bf16 residual, 6 both).  g.b_frag = k_pack_frag's output (conv_gn2.h).
+template <int RES, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_conv_gn3(const GemmArgs g)
+{
+    using Cfg = ConvGn3Cfg<RES, WM, WN>;
+    constexpr int W = Cfg::W, WS = Cfg::WS, HW = Cfg::HW, BM_ = Cfg::BM_, BN_ = Cfg::BN_, NROUND = Cfg::NROUND, PSW = Cfg::PSW, KT = Cfg::KT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nN = g.N / BN_, nM = g.M / BM_;
+    const int tile = xcd_remap(blockIdx.x, nM * nN);
+    const int mt = tile / nN, nt = tile - mt * nN;
+    const int m0 = mt * BM_, n0 = nt * BN_;
+    const int b = m0 / HW, y0 = (m0 % HW) / W;                            // image and first image row of this tile
+    const int ush = g.a0_up;                                              // 1: the source image has half the resolution (nearest up-sampling in the fetch)
+    const bf16* const img = g.a0 + (int64_t)b * (HW >> (2 * ush)) * g.a0_ld;
+    const float* const gsc = g.gn_scale + (int64_t)b * g.gn_ld;
+    const float* const gsh = g.gn_shift + (int64_t)b * g.gn_ld;
+    const int n_half = g.a0_C / KT, n_sc = g.a1 ? g.a1_C / KT : 0;       // both even (a0_C, a1_C multiples of 64)
+    const int nk = 9 * n_half, NT = nk + n_sc;
+    const unsigned char* const wfrag = reinterpret_cast<const unsigned char*>(g.b_frag);
+    const int sup = g.a1_up;
+    const bf16* const a1base = g.a1 ? g.a1 + (int64_t)(sup ? b * (HW >> 2) : m0) * g.a1_ld : nullptr;
+
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    CG3Ctx<Cfg> c;
+    c.wave = (unsigned)wave;
+    c.lds_patch = (unsigned)(uintptr_t)((lds_u8*)smem);
+    c.lds_tab = c.lds_patch + Cfg::OFF_TAB;
+    c.lds_sc = c.lds_patch + Cfg::OFF_SC;
+    const int prow = lane >> 2, pslot = lane & 3;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c.boff[j] = (unsigned)(((n0 >> 4) + wn * 8 + j) * NT) * 1024u + (unsigned)lane * 16u;
+    // patch requests: piece r * 4 + wave, patch row pp = piece * 16 + (lane >> 2) = pixel (y0 - 1 + yy, xx - 1), clamped (halo / pad rows: any readable pixel)
+    c.nmask = 0;
+#pragma unroll
+    for (int r = 0; r < NROUND; ++r) {
+        const int pp = (r * 4 + wave) * 16 + prow;
+        const int yy = pp / WS, xx = pp - yy * WS;
+        const int y = min(max(y0 - 1 + yy, 0), RES - 1), x = min(max(xx - 1, 0), RES - 1);
+        c.vo[r] = (unsigned)(((y >> ush) * (W >> ush) + (x >> ush)) * g.a0_ld + ((pslot ^ Cfg::swz_key(xx)) << 3)) * 2u;
+        if ((unsigned)(y0 - 1 + yy) < (unsigned)RES && (unsigned)(xx - 1) < (unsigned)RES) c.nmask |= 1u << r;
+        c.ntb[r] = c.lds_tab + ((unsigned)((lane & 3) ^ Cfg::swz_key(xx)) << 5);
+    }
+#pragma unroll
+    for (int n = 0; n < PSW; ++n) {
+        const int pp = (wave * PSW + n) * 16 + prow;
+        const int src = sup ? ((y0 + pp / W) >> 1) * (W >> 1) + ((pp % W) >> 1) : pp;
+        c.scv[n] = (unsigned)(src * g.a1_ld + ((pslot ^ ((pp >> 1) & 2)) << 3)) * 2u;
+    }
+    c.tvo = (unsigned)(lane & 31) * 4u;
+    c.n_addr[0] = c.lds_patch + (unsigned)(wave * 1024 + lane * 16);
+    c.n_addr[1] = c.n_addr[0] + Cfg::PATCH_BYTES;
+    {
+        const int frow = lane & 15, fq = lane >> 4;
+        const int ml = wm * 128 + frow;                                   // first pixel of this wave, the lane's row
+        const int pc = ((ml / W) + 1) * WS + (ml % W) + 1, xc = ml % W;    // its patch row at the centre tap, and its patch column - 1
+#pragma unroll
+        for (int d = 0; d < 3; ++d) c.a_dx[d] = c.lds_patch + (unsigned)((pc - WS + d - 1) * 64 + ((fq ^ Cfg::swz_key(xc + d)) << 4));
+        c.a_sc = c.lds_sc + (unsigned)(ml * 64 + ((fq ^ ((ml >> 1) & 2)) << 4));
+    }
+
+    // ---- prologue: table + raw patch of half-chunk 0 -> buffer 0, the first step's weights, the first two shortcut tiles ----
+    cg3_gtab(c.tvo, gsc, gsh, c.lds_tab);
+#pragma unroll
+    for (int r = 0; r < NROUND; ++r) cg3_glds16(c.vo[r], img, c.lds_patch + (r * 4) * 1024 + c.wave * 1024);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c.fb[0][j] = cg3_gload16(c.boff[j], wfrag);
+    if (n_sc > 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int n = 0; n < PSW; ++n) cg3_glds16(c.scv[n], a1base + t * KT, c.lds_sc + t * Cfg::SC_BYTES + n * 1024 + c.wave * (PSW * 1024));
+    }
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    cg3_wait<0, -1>();
+    // this wave's pieces of half-chunk 0, normalised in place (no MFMAs to hide behind yet: left to hipcc to interleave)
+#pragma unroll
+    for (int r = 0; r < NROUND; ++r) {
+        const unsigned tb = c.ntb[r];
+        u32x4 nv = *reinterpret_cast<const u32x4*>(smem + (c.n_addr[0] - c.lds_patch) + r * 4096);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(smem + (tb - c.lds_patch)), s1 = *reinterpret_cast<const f32x4*>(smem + (tb - c.lds_patch) + 16);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(smem + (tb - c.lds_patch) + 128), h1 = *reinterpret_cast<const f32x4*>(smem + (tb - c.lds_patch) + 144);
+        u32x4 ou;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const unsigned w_ = nv[p];
+            const float x0 = __uint_as_float(w_ << 16), x1 = __uint_as_float(w_ & 0xffff0000u);
+            const float sa = p < 2 ? s0[2 * p] : s1[2 * p - 4], sb = p < 2 ? s0[2 * p + 1] : s1[2 * p - 3];
+            const float ha = p < 2 ? h0[2 * p] : h1[2 * p - 4], hb = p < 2 ? h0[2 * p + 1] : h1[2 * p - 3];
+            const float t0 = __builtin_fmaf(x0, sa, ha), t1 = __builtin_fmaf(x1, sb, hb);
+            const float y0_ = t0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t0)), y1_ = t1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t1));
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const bf16x2_t pr_ = {(bf16)y0_, (bf16)y1_};
+            ou[p] = __builtin_bit_cast(unsigned, pr_);
+        }
+        if (!((c.nmask >> r) & 1u)) ou = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(smem + (c.n_addr[0] - c.lds_patch) + r * 4096) = ou;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c.fa[0][i] = *reinterpret_cast<const u32x4*>(smem + (c.a_dx[0] - c.lds_patch) + Cfg::aoff(i));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    using std::integral_constant;
+    auto half_chunk = [&](auto hp_tag, auto next_tag, int h) __attribute__((always_inline)) {
+        constexpr int HP = decltype(hp_tag)::value;
+        constexpr bool NEXT = decltype(next_tag)::value;
+        c.pnext = img + (h + 1) * KT; c.tsc = gsc + (h + 1) * KT; c.tsh = gsh + (h + 1) * KT;
+        const int kt = h * 9;
+#define NATINF_CG3_TAP(T)                                                                                             \
+        c.wnext = wfrag + (int64_t)((T < 8 || NEXT) ? kt + T + 1 : min(nk, NT - 1)) * 1024;                              \
+        CG3Tap<Cfg, T, HP, NEXT, 0>::run(acc, c);
+        NATINF_CG3_TAP(0) NATINF_CG3_TAP(1) NATINF_CG3_TAP(2) NATINF_CG3_TAP(3) NATINF_CG3_TAP(4)
+        NATINF_CG3_TAP(5) NATINF_CG3_TAP(6) NATINF_CG3_TAP(7) NATINF_CG3_TAP(8)
+#undef NATINF_CG3_TAP
+    };
+    for (int h = 0; h + 2 < n_half; h += 2) {
+        half_chunk(integral_constant<int, 0>{}, std::true_type{}, h);
+        half_chunk(integral_constant<int, 1>{}, std::true_type{}, h + 1);
+    }
+    half_chunk(integral_constant<int, 0>{}, std::true_type{}, n_half - 2);
+    half_chunk(integral_constant<int, 1>{}, std::false_type{}, n_half - 1);
+    // ---- 1x1 shortcut segment (nk is even: shortcut step s lives in register set s & 1, its tile in shortcut buffer s & 1) ----
+    for (int s = 0; s < n_sc; s += 2) {
+        c.wnext = wfrag + (int64_t)min(nk + s + 1, NT - 1) * 1024; c.scnext = a1base + min(s + 2, n_sc - 1) * KT;
+        CG3Sc<Cfg, 0, 0>::run(acc, c);
+        c.wnext = wfrag + (int64_t)min(nk + s + 2, NT - 1) * 1024; c.scnext = a1base + min(s + 3, n_sc - 1) * KT;
+        CG3Sc<Cfg, 1, 0>::run(acc, c);
+    }
+    // every request / read of the last step's look-ahead has landed, the last MFMAs' results are written (inline asm: hipcc does not see the writes
+    // it would pad for), and every wave is done with the tiles before the epilogue reuses them
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // the epilogue's arguments are fetched from the kernel-argument segment HERE (conv_gn.h: kept in scalar registers across the K
+    // loop they end up spilled into vector-register lanes)
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const unsigned __attribute__((address_space(4))) *kernarg_u32_t;
+    kernarg_u32_t gp = (kernarg_u32_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(gp));
+    GemmArgs ge;
+    {
+        unsigned* d = reinterpret_cast<unsigned*>(&ge);
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(GemmArgs) / 4; ++i) d[i] = gp[i];
+    }
+#else
+    const GemmArgs ge = g;
+#endif
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int tid_e = wave * 64 + lane_e;
+    tile_epilogue<WM, WN, 8, 8, typename Cfg::Epi, EPI, 1, false, true>(ge, smem, acc, m0, n0, 0, tid_e, lane_e, wm, wn);
+}
+
+}  // namespace ncsn

@@ -135,6 +135,9 @@ struct natinf_ncsnpp {
     std::vector<int> part_bm;            // see Ctx::part_bm
 };
 
+// k_conv_gn3 (conv_gn3.h / conv_gn3.hip: one wave per SIMD, 128 x 128 wave tiles, slot-table K loop) -- a translation unit of its own
+namespace ncsn_cg3 { bool configure(); int tile_rows(int shape); int tile_cols(int shape); void launch(const void* gemm_args, int shape, int epi, void* stream); }
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -289,7 +292,7 @@ bool configure_gemm_kernels() {
                                   GEMM_LDS_BYTES) == hipSuccess;
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_conv), hipFuncAttributeMaxDynamicSharedMemorySize, HeadConvCfg::LDS_BYTES) == hipSuccess &&
          set_lds<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4, 9>) &&
-         set_lds_epi_all() && set_lds_conv_gn<1>() && set_lds_conv_gn<2>() && set_lds_conv_gn<5>() && set_lds_conv_gn<6>() &&
+         set_lds_epi_all() && ncsn_cg3::configure() && set_lds_conv_gn<1>() && set_lds_conv_gn<2>() && set_lds_conv_gn<5>() && set_lds_conv_gn<6>() &&
 #ifdef NATINF_DEV
          set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4>) && set_lds<CfgD256x128>(&k_gemm_dma<4, 2, 4, 4>) &&
          set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4>) && set_lds<CfgR256x256>(&k_gemm_ring<2, 4, 8, 4, 4>) &&
@@ -338,12 +341,23 @@ int variant_bm(int v);
 // k_conv_gn instantiations: 32x32 and 16x16 images, 256 x 128 tiles -- 128 x 256 tiles for 16x16 layers whose N is a multiple of 256
 // (natinf_set_conv_gn_wide: A/B runs); packed epilogues 1 / 2 / 5 / 6 only
 int packed_epi(const GemmArgs& g, int bm);
+int g_cg3 = 0;                     // natinf_set_conv_gn_w128: bit 0 = 32x32 layers with N % 256 != 0 on 512 x 128 tiles, bit 1 = 32x32 layers with N % 256 == 0 on 256 x 256
+                                   // tiles, bit 2 = 16x16 layers with N % 256 == 0 on 256 x 256 tiles (one image per tile)
 int g_cg_wide = 3;                 // natinf_set_conv_gn_wide: bit 0 = 128 x 256 tiles at 16x16, bit 1 = at 32x32 (N % 256 == 0 layers: the 16 -> 32 up-sampling block)
 int g_fuse_up = 1;                 // natinf_set_fuse_up (read when a plan is BUILT): up blocks at 16x16 / 32x32 fetch their input up-sampled inside k_conv_gn2
 int g_cg_regw = 1;                 // natinf_set_conv_gn_regw: 1 = k_conv_gn2 (weights streamed through registers) where GemmArgs::b_frag is given
 // tile rows of the fused-convolution instantiation a launch takes: 128 x 256 tiles at 16x16 (N % 256 == 0) and at 8x8 (two images per tile), 256 x 128 elsewhere
+// the k_conv_gn3 shape a fused-convolution launch takes (-1: k_conv_gn2)
+inline int conv_gn3_shape(const GemmArgs& g) {
+    const int res = 1 << g.logW;
+    if (!g_cg3 || !g_cg_regw || !g.b_frag || g.N % 128) return -1;
+    if (res == 32) return g.N % 256 ? ((g_cg3 & 1) ? 0 : -1) : ((g_cg3 & 2) ? 1 : -1);
+    if (res == 16) return (g.N % 256 == 0 && (g_cg3 & 4)) ? 2 : -1;
+    return -1;
+}
 inline int conv_gn_bm(const GemmArgs& g) {
     const int res = 1 << g.logW;
+    if (const int sh3 = conv_gn3_shape(g); sh3 >= 0) return ncsn_cg3::tile_rows(sh3);
     if (res == 8) return g_cg8_tm4 ? 64 : 128;
     if (res == 4) return 64;
     if (res == 32) return ((g_cg_wide & 2) && g.N % 256 == 0 && g_cg_regw && g.b_frag) ? 128 : 256;      // (k_conv_gn2 only)
@@ -351,7 +365,7 @@ inline int conv_gn_bm(const GemmArgs& g) {
 }
 // rows of one GroupNorm-partial table row the launch writes (what the caller divides H*W by): a tile, or one SAMPLE of the two an 8x8 tile holds
 inline int conv_gn_part_rows(const GemmArgs& g) { const int res = 1 << g.logW; return res <= 8 ? res * res : conv_gn_bm(g); }
-inline bool conv_gn_regw(const GemmArgs& g) { return g_cg_regw && g.b_frag && g.N % ((conv_gn_bm(g) <= 128 && (1 << g.logW) != 4) ? 256 : 128) == 0; }      // (4x4: 64 x 128 tiles)
+inline bool conv_gn_regw(const GemmArgs& g) { return g_cg_regw && g.b_frag && (conv_gn3_shape(g) >= 0 || g.N % ((conv_gn_bm(g) <= 128 && (1 << g.logW) != 4) ? 256 : 128) == 0); }      // (4x4: 64 x 128 tiles)
 #ifdef NATINF_DEV
 constexpr bool HAVE_CONV_GN_V1 = true;              // k_conv_gn (weights through an LDS ring): superseded, development builds only
 #else
@@ -365,7 +379,7 @@ inline bool conv_gn_ok(const GemmArgs& g) {
     const int res = 1 << g.logW;
     if (g.logHW != 2 * g.logW || (res != 32 && res != 16 && res != 8 && res != 4) || g.N % 8) return false;
     if (res == 4 && (g.a0_C % (64 * CfgH4T::NG) || (g.a1 && g.a1_C % (64 * CfgH4T::NG)))) return false;          // two K groups per block: an even number of half-chunks / shortcut tiles EACH
-    if (res <= 8 ? (g.M % (res * res) || g.N % (res == 4 ? 128 : 256) || g.a0_up || g.a1_up || !conv_gn_regw(g) || (g.resid && g.rowvec)) : g.M % 256 != 0) return false;      // 8x8: whole images, k_conv_gn2 only;
+    if (res <= 8 ? (g.M % (res * res) || g.N % (res == 4 ? 128 : 256) || g.a0_up || g.a1_up || !conv_gn_regw(g) || (g.resid && g.rowvec)) : g.M % std::max(256, conv_gn_bm(g)) != 0) return false;      // 8x8: whole images, k_conv_gn2 only;
     // (its residual epilogues keep one set of column terms for both samples of a tile: no per-sample row vector there)
     if ((g.a0_up || g.a1_up || !HAVE_CONV_GN_V1) && !conv_gn_regw(g)) return false;          // up-sampled fetches: k_conv_gn2 only
     const int e = conv_gn_epi(g);
@@ -677,6 +691,7 @@ int launch_gemm(const GemmArgs& g0, hipStream_t s) {
                 case 2: launch_tiles<CFG>(&k_conv_gn2<RES, WIDE, 5>, g, s); break;                              \
                 default: launch_tiles<CFG>(&k_conv_gn2<RES, WIDE, 6>, g, s); break;                             \
             }
+            if (const int sh3 = conv_gn3_shape(g); sh3 >= 0) { ncsn_cg3::launch(&g, sh3, e, (void*)s); return conv_gn_part_rows(g); }
             if (conv_gn_regw(g)) {
                 if ((1 << g.logW) == 8 && g_cg8_tm4) {
                     switch (e4) {
@@ -1737,6 +1752,7 @@ int natinf_set_conv_gn8_tile(int one_image) {
     g_cg8_tm4 = one_image != 0; return NATINF_OK;
 }
 int natinf_set_fuse_head(int on) { g_fuse_head = on != 0; return NATINF_OK; }
+int natinf_set_conv_gn_w128(int mask) { if (mask < 0 || mask > 7) return NATINF_EINVAL; g_cg3 = mask; return NATINF_OK; }
 int natinf_set_conv_gn_wide(int mask) { if (mask < 0 || mask > 3) return NATINF_EINVAL; g_cg_wide = mask; return NATINF_OK; }
 int natinf_set_conv_gn_regw(int on) {
     if (!on && !HAVE_CONV_GN_V1) return NATINF_ESTATE;      // k_conv_gn (the LDS-ring form) exists in -DNATINF_DEV builds only
