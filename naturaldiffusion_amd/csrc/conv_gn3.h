@@ -46,16 +46,27 @@ struct ConvGn3Cfg {
     static constexpr int BAR = 40;                                              // tap 8 / shortcut steps: the block-wide barrier
     static constexpr int rd_a(int i) { return 10 + 2 * i; }                    // A fragment i of the next tap (taps 0..7)
     static constexpr int rd_a_late(int i) { return BAR + 2 + 2 * i; }          // ... of the step behind the barrier
-    static constexpr int DMA_TAB = 26;
-    static constexpr int dma_piece(int r) { return 28 + 3 * r; }               // tap 0: the raw patch of the next half-chunk, round r's piece
-    static constexpr int dma_sc(int n) { return BAR + 1 + 2 * n; }             // shortcut steps: piece n of tile s + 2
-    static_assert(dma_piece(NROUND - 1) < 64 && rd_a_late(7) < 64 && dma_sc(PSW - 1) < 64, "inside the step");
-    static constexpr int NREQ = 2 + NROUND;                                     // requests a wave issues at tap 0 behind the weight loads of tap 1
-    // normalisation rounds: global slot G = (T - 2) * 64 + S over taps 2..8; round r's four channel pairs occupy G in [gp(r), gp(r) + 36)
+    static constexpr int dma_sc(int n) { return BAR + 1 + 2 * n; }             // piece n of the shortcut tile two steps ahead
+    static_assert(rd_a_late(7) < 64 && dma_sc(PSW - 1) < 64, "inside the step");
+    // normalisation rounds: global slot G = (T - 2) * 64 + S over taps 2..8; the table rows of the half-chunk are read at G = 0, 1; round r's eight elements
+    // occupy the 34 gaps from gp(r), its store follows at gp(r) + 34; its patch bytes are read at gl(r) (round r > 0: behind the unpack stage of round r - 1)
+    static constexpr int RLEN = 34;
     static constexpr int G_END = 6 * 64 + BAR - 2;
-    static constexpr int STRIDE = (G_END - 1 - 38 - 12) / (NROUND - 1) > 37 ? (G_END - 1 - 38 - 12) / (NROUND - 1) : 37;
+    static constexpr int STRIDE = (G_END - 1 - RLEN - 2 - 12) / (NROUND - 1) > RLEN + 1 ? (G_END - 1 - RLEN - 2 - 12) / (NROUND - 1) : RLEN + 1;
     static constexpr int gp(int r) { return 12 + r * STRIDE; }
-    static_assert(gp(NROUND - 1) + 38 < G_END, "the rounds end in front of the barrier of tap 8");
+    static constexpr int gl(int r) { return r == 0 ? 2 : gp(r - 1) + 5; }
+    static_assert(gp(NROUND - 1) + RLEN + 2 < G_END, "the rounds end in front of the barrier of tap 8");
+    // The raw patch of the NEXT half-chunk arrives piece by piece, just in time: vector-memory operations retire in order, so every wait for a tap's weight
+    // fragments (slot 0 of every tap) also waits for every request issued before those loads -- a request can stay in flight for two taps at most,
+    // whatever its data is needed for.  Twelve requests at tap 0 (the first form) were therefore due ~1.4 taps later from EVERY block of the chip at once, and
+    // the half-chunks whose 64-byte rows are the first touch of their 128-byte lines stalled 2-5k clocks at tap 2 (tile timeline: odd half-chunks 13-17k clocks,
+    // even ones 11.3k).  Piece r is requested in tap td(r) = gl(r) / 64 (behind that tap's weight loads: it must have landed at the start of tap td(r) + 2, which
+    // is where its round reads it at the earliest): three requests in flight per wave at most, spread over six taps.
+    static constexpr int td(int r) { return gl(r) / 64; }
+    static constexpr int nd(int t) { int n = t == 0 ? 2 : 0; for (int r = 0; r < NROUND; ++r) n += td(r) == t; return n; }      // requests issued in tap t (the table: two)
+    static constexpr int DMA_TAB = 9;                                           // tap 0
+    static constexpr int dma_piece(int r) { int k = td(r) == 0 ? 1 : 0; for (int q = 0; q < r; ++q) k += td(q) == td(r); return 9 + 2 * k; }
+    static_assert(td(NROUND - 1) < 8 && dma_piece(NROUND - 1) < 40, "requests behind the weight loads, in front of the barrier");
 };
 
 // ---- instruction wrappers (volatile: the order of the K loop is the order written) ----
@@ -93,6 +104,16 @@ template <int VM, int LGKM> __device__ __forceinline__ void cg3_wait() {
 __device__ __forceinline__ void cg3_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void cg3_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
+// Development timeline (make EXTRA=-DNATINF_CG3_TIMELINE; tools/cg3_timeline.py): shader-clock stamps of wave 0 of blocks 0 and 300 at the section
+// boundaries of a tile -- [0] start, [1] requests issued, [2] patch landed, [3] K loop starts, [4 + h] half-chunk h starts, [40] shortcut segment starts,
+// [41] K loop done, [42] epilogue starts, [43] end.  The shipped kernels carry no stamps.
+#ifdef NATINF_CG3_TIMELINE
+#define NATINF_CG3_STAMP(i) do { if (g.dbg_ts && (blockIdx.x == 0 || blockIdx.x == 300) && threadIdx.x == 0) { unsigned long long t_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g.dbg_ts[(blockIdx.x ? 64 : 0) + (i)] = t_; } } while (0)
+#else
+#define NATINF_CG3_STAMP(i) do { } while (0)
+#endif
+
 // everything a step needs, in registers (the struct is taken apart by SROA: every member is accessed with compile-time indices)
 template <class Cfg>
 struct CG3Ctx {
@@ -102,13 +123,15 @@ struct CG3Ctx {
     unsigned scv[Cfg::PSW];                   // shortcut requests: the lane's source byte offset of piece n
     unsigned a_dx[3];                         // A fragment bases (dx = -1, 0, +1 at dy = -1) in patch buffer 0
     unsigned a_sc;                            // A fragment base in shortcut buffer 0
-    unsigned n_addr[2];                       // the lane's 16 bytes of its piece of round 0 in patch buffer 0 / 1
-    unsigned ntb[Cfg::NROUND];                // the lane's row of table 0 in round r: channel chunk (lane & 3) ^ 2 * (bit 2 of its patch column: the swizzle key)
+    // normalisation: the lane owns channel chunk (lane & 3) of patch row piece * 16 + (lane >> 2) -- the SAME eight channels in every round, so its rows of the
+    // (scale | shift) table are read once per half-chunk; the chunk sits in slot (lane & 3) ^ key of the row (key: the swizzle, bit 2 of the patch column)
+    unsigned nadr[Cfg::NROUND];               // the lane's 16 bytes of round r in patch buffer 0
+    unsigned ninf[Cfg::NROUND];               // 1.0f where the pixel of round r lies inside the image, +inf outside: y = t * rcp(2^t + ninf) is then 0 (the zero padding)
+    unsigned n_tab;                           // the lane's row of table 0
     unsigned tvo;                             // table request: (lane & 31) * 4
-    unsigned nmask;                           // bit r: the pixel of round r lies inside the image
     // normalisation rounds
     u32x4 nv, ns0, ns1, nh0, nh1, npk;
-    unsigned nin[2], nx[8], ne[8];
+    unsigned nx[8], ne[8];
     // wave-uniform
     const unsigned char* wnext;               // weight fragments of the NEXT K step
     const bf16* pnext;                        // raw patch source of the next half-chunk
@@ -117,13 +140,13 @@ struct CG3Ctx {
     unsigned lds_patch, lds_tab, lds_sc, wave;
 };
 
-// ---- the normalisation of one round (eight elements per lane = four channel pairs), STAGE BY STAGE over 36 MFMA gaps: unpack x 8 (gaps 0-3), fma x 8
-// ---- (4-7), exp2 x 8 (8-15), + 1 x 8 (16-19), rcp x 8 (20-27), mul x 8 (28-31), pack + mask x 4 (32-35): two plain vector instructions or one
+// ---- the normalisation of one round (eight elements per lane = four channel pairs), STAGE BY STAGE over 34 MFMA gaps: unpack x 8 (gaps 0-3), fma x 8
+// ---- (4-7), exp2 x 8 (8-15), + 1 x 8 (16-19), rcp x 8 (20-27), mul x 8 (28-31), pack x 4 (32-33): two plain vector instructions or one
 // ---- transcendental per gap (8 issue cycles beside the MFMA's 8).  Stage by stage, not element by element, because hipcc's hazard recogniser assumes
 // ---- a forwarding hazard between ANY inline-asm definition of a vector register and its first reader and does not count inline-asm statements as
 // ---- wait states: it puts an `s_nop 0` in front of the first statement that reads a register another statement wrote (unless a nop or a real
-// ---- instruction lies between them).  A dependent chain per element costs one nop per link (26 per round); eight elements a stage cost one per stage (7).
-template <int GG, int RPAR, class Cfg>
+// ---- instruction lies between them).  A dependent chain per element costs one nop per link (26 per round); eight elements a stage cost one per stage (6).
+template <int GG, int R, class Cfg>
 __device__ __forceinline__ void cg3_norm_gap(CG3Ctx<Cfg>& c) {
     if constexpr (GG < 4) {                                     // unpack pair GG: x[2 GG] = low half << 16, x[2 GG + 1] = high half
         asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(c.nx[2 * GG]) : "v"(c.nv[GG]));
@@ -138,41 +161,33 @@ __device__ __forceinline__ void cg3_norm_gap(CG3Ctx<Cfg>& c) {
             asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(c.nx[2 * P + 1]) : "v"(c.ns1[2 * P - 3]), "v"(c.nh1[2 * P - 3]));
         }
     } else if constexpr (GG < 16) asm volatile("v_exp_f32 %0, %1" : "=v"(c.ne[GG - 8]) : "v"(c.nx[GG - 8]));
-    else if constexpr (GG < 20) {
-        asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(c.ne[2 * (GG - 16)]));
-        asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(c.ne[2 * (GG - 16) + 1]));
+    else if constexpr (GG < 20) {                               // 2^t + 1 (+ inf for a pixel outside the image: its reciprocal, hence the element, is 0)
+        asm volatile("v_add_f32 %0, %1, %0" : "+v"(c.ne[2 * (GG - 16)]) : "v"(c.ninf[R]));
+        asm volatile("v_add_f32 %0, %1, %0" : "+v"(c.ne[2 * (GG - 16) + 1]) : "v"(c.ninf[R]));
     } else if constexpr (GG < 28) asm volatile("v_rcp_f32 %0, %0" : "+v"(c.ne[GG - 20]));
     else if constexpr (GG < 32) {                               // t / (1 + 2^t) = -log2 e * silu(v)
         asm volatile("v_mul_f32 %0, %0, %1" : "+v"(c.nx[2 * (GG - 28)]) : "v"(c.ne[2 * (GG - 28)]));
         asm volatile("v_mul_f32 %0, %0, %1" : "+v"(c.nx[2 * (GG - 28) + 1]) : "v"(c.ne[2 * (GG - 28) + 1]));
-    } else {                                                    // round to bf16 (RNE), pixels outside the image -> 0; ONE statement: no nop between the two
-        constexpr int P = GG - 32;
-        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_and_b32 %0, %0, %3" : "=&v"(c.npk[P]) : "v"(c.nx[2 * P]), "v"(c.nx[2 * P + 1]), "v"(c.nin[RPAR]));
+    } else {                                                    // round to bf16 (RNE)
+        constexpr int P = 2 * (GG - 32);
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(c.npk[P]) : "v"(c.nx[2 * P]), "v"(c.nx[2 * P + 1]));
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(c.npk[P + 1]) : "v"(c.nx[2 * P + 2]), "v"(c.nx[2 * P + 3]));
     }
 }
 
 // the normalisation work of global slot G (taps 2..8 of a half-chunk that has a successor): rounds R = 0 .. NROUND - 1 on patch buffer NB / table NB
 template <class Cfg, int NB, int G, int R = 0>
 __device__ __forceinline__ void cg3_norm_slot(CG3Ctx<Cfg>& c) {
+    if constexpr (R == 0) {                                     // the lane's rows of the half-chunk's table, once
+        if constexpr (G == 0) { c.ns0 = lds_read16<NB * Cfg::TAB_BYTES>(c.n_tab); c.ns1 = lds_read16<NB * Cfg::TAB_BYTES + 16>(c.n_tab); }
+        if constexpr (G == 1) { c.nh0 = lds_read16<NB * Cfg::TAB_BYTES + 128>(c.n_tab); c.nh1 = lds_read16<NB * Cfg::TAB_BYTES + 144>(c.n_tab); }
+    }
     if constexpr (R < Cfg::NROUND) {
         constexpr int GP = Cfg::gp(R);
-        // the loads of round R: round 0 at G = 1..3; round R > 0 inside round R - 1: its patch bytes behind that round's unpack stage (gaps 0-3), its table
-        // rows behind the fma stage (gaps 4-7)
-        constexpr int GL = R == 0 ? 1 : Cfg::gp(R - 1) + 5;
-        if constexpr (G == GL) c.nv = lds_read16<R * Cfg::NW * 1024>(c.n_addr[NB]);
-        if constexpr (G == GL + 4) {
-            // the inside mask of the round as a full word (v_bfe_i32 sign-extends the bit) and the lane's table row (chunk (lane & 3) ^ 2 * key)
-            asm volatile("v_bfe_i32 %0, %1, %2, 1" : "=v"(c.nin[R & 1]) : "v"(c.nmask), "n"(R));
-            c.ns0 = lds_read16<NB * Cfg::TAB_BYTES>(c.ntb[R]);
-            c.ns1 = lds_read16<NB * Cfg::TAB_BYTES + 16>(c.ntb[R]);
-        }
-        if constexpr (G == GL + 5) {
-            c.nh0 = lds_read16<NB * Cfg::TAB_BYTES + 128>(c.ntb[R]);
-            c.nh1 = lds_read16<NB * Cfg::TAB_BYTES + 144>(c.ntb[R]);
-        }
+        if constexpr (G == Cfg::gl(R)) c.nv = lds_read16<NB * Cfg::PATCH_BYTES>(c.nadr[R]);
         if constexpr (G == GP) cg3_wait_lgkm0();
-        if constexpr (G >= GP && G < GP + 36) cg3_norm_gap<G - GP, (R & 1)>(c);
-        if constexpr (G == GP + 36) cg3_lds_write16<R * Cfg::NW * 1024>(c.n_addr[NB], c.npk);
+        if constexpr (G >= GP && G < GP + Cfg::RLEN) cg3_norm_gap<G - GP, R>(c);
+        if constexpr (G == GP + Cfg::RLEN) cg3_lds_write16<NB * Cfg::PATCH_BYTES>(c.nadr[R], c.npk);
         cg3_norm_slot<Cfg, NB, G, R + 1>(c);
     }
 }
@@ -198,7 +213,7 @@ struct CG3Tap {
     template <int R>
     static __device__ __forceinline__ void requests(CG3Ctx<Cfg>& c) {
         if constexpr (R < Cfg::NROUND) {
-            if constexpr (S == Cfg::dma_piece(R))
+            if constexpr (T == Cfg::td(R) && S == Cfg::dma_piece(R))
                 cg3_glds16(c.vo[R], c.pnext, c.lds_patch + (HP ^ 1) * Cfg::PATCH_BYTES + (R * Cfg::NW) * 1024 + c.wave * 1024);
             requests<R + 1>(c);
         }
@@ -206,14 +221,18 @@ struct CG3Tap {
     static __device__ __forceinline__ void run(f32x4 (&acc)[8][8], CG3Ctx<Cfg>& c) {
         constexpr int P = (T + HP) & 1;
         if constexpr (S == 0) {
-            // the weight fragments of this step have landed (tap 1: the requests of tap 0 stay in flight); so have its A fragments
-            if constexpr (T == 1 && NEXT) cg3_wait<Cfg::NREQ, 0>(); else cg3_wait<0, 0>();
+            // the weight fragments of this step have landed (the requests issued behind them, in the tap before, stay in flight); so have its A fragments
+            if constexpr (T >= 1 && NEXT) cg3_wait<Cfg::nd(T - 1), 0>(); else cg3_wait<0, 0>();
         }
         if constexpr (S >= 1 && S <= 8) c.fb[P ^ 1][S - 1] = cg3_gload16(c.boff[S - 1], c.wnext);
         reads<0>(c);
-        if constexpr (T == 0 && NEXT) {
-            if constexpr (S == Cfg::DMA_TAB) cg3_gtab(c.tvo, c.tsc, c.tsh, c.lds_tab + (HP ^ 1) * Cfg::TAB_BYTES);
+        if constexpr (NEXT) {
+            if constexpr (T == 0 && S == Cfg::DMA_TAB) cg3_gtab(c.tvo, c.tsc, c.tsh, c.lds_tab + (HP ^ 1) * Cfg::TAB_BYTES);
             requests<0>(c);
+        } else if constexpr (T == 8 && S > Cfg::BAR && (S - Cfg::BAR - 1) % 2 == 0 && (S - Cfg::BAR - 1) / 2 < Cfg::PSW) {
+            // the last half-chunk: the SECOND shortcut tile -> shortcut buffer 1 (the first one came with the prologue; no shortcut segment: a dummy source)
+            constexpr int n = (S - Cfg::BAR - 1) / 2;
+            cg3_glds16(c.scv[n], c.scnext, c.lds_sc + Cfg::SC_BYTES + n * 1024 + c.wave * (Cfg::PSW * 1024));
         }
         if constexpr (T >= 2 && NEXT) cg3_norm_slot<Cfg, HP ^ 1, (T - 2) * 64 + S>(c);
         if constexpr (T == 8) {
@@ -231,7 +250,8 @@ struct CG3Tap {
 template <class Cfg, int P, int S>
 struct CG3Sc {
     static __device__ __forceinline__ void run(f32x4 (&acc)[8][8], CG3Ctx<Cfg>& c) {
-        if constexpr (S == 0) cg3_wait<0, 0>();                                     // this wave's pieces of tile s + 1 and the weights of step s have landed
+        if constexpr (S == 0) cg3_wait<Cfg::PSW, 0>();                              // the weights of step s have landed (the requests for tile s + 1, issued behind them, stay in flight)
+        if constexpr (S == Cfg::BAR - 1) cg3_wait<8, -1>();                          // this wave's pieces of tile s + 1 have landed (the weight loads of step s + 1 stay in flight)
         if constexpr (S >= 1 && S <= 8) c.fb[P ^ 1][S - 1] = cg3_gload16(c.boff[S - 1], c.wnext);
         if constexpr (S == Cfg::BAR) cg3_barrier();                                  // every wave's pieces of tile s + 1 are in LDS; nobody reads tile s any more
         if constexpr (S > Cfg::BAR && (S - Cfg::BAR - 1) % 2 == 0 && (S - Cfg::BAR - 1) / 2 < Cfg::PSW) {
@@ -258,6 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     lds_poison();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    NATINF_CG3_STAMP(0);
     const int wm = wave / WN, wn = wave % WN;
     const int nN = g.N / BN_, nM = g.M / BM_;
     const int tile = xcd_remap(blockIdx.x, nM * nN);
@@ -283,16 +304,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int prow = lane >> 2, pslot = lane & 3;
 #pragma unroll
     for (int j = 0; j < 8; ++j) c.boff[j] = (unsigned)(((n0 >> 4) + wn * 8 + j) * NT) * 1024u + (unsigned)lane * 16u;
-    // patch requests: piece r * 4 + wave, patch row pp = piece * 16 + (lane >> 2) = pixel (y0 - 1 + yy, xx - 1), clamped (halo / pad rows: any readable pixel)
-    c.nmask = 0;
+    // patch requests: piece r * 4 + wave, patch row pp = piece * 16 + (lane >> 2) = pixel (y0 - 1 + yy, xx - 1), clamped (halo / pad rows: any readable pixel);
+    // slot (lane & 3) of the row receives channel chunk (lane & 3) ^ key.  Normalisation: the lane owns chunk (lane & 3), i.e. slot (lane & 3) ^ key.
 #pragma unroll
     for (int r = 0; r < NROUND; ++r) {
         const int pp = (r * 4 + wave) * 16 + prow;
         const int yy = pp / WS, xx = pp - yy * WS;
         const int y = min(max(y0 - 1 + yy, 0), RES - 1), x = min(max(xx - 1, 0), RES - 1);
         c.vo[r] = (unsigned)(((y >> ush) * (W >> ush) + (x >> ush)) * g.a0_ld + ((pslot ^ Cfg::swz_key(xx)) << 3)) * 2u;
-        if ((unsigned)(y0 - 1 + yy) < (unsigned)RES && (unsigned)(xx - 1) < (unsigned)RES) c.nmask |= 1u << r;
-        c.ntb[r] = c.lds_tab + ((unsigned)((lane & 3) ^ Cfg::swz_key(xx)) << 5);
+        const bool inside = (unsigned)(y0 - 1 + yy) < (unsigned)RES && (unsigned)(xx - 1) < (unsigned)RES;
+        c.ninf[r] = inside ? 0x3f800000u : 0x7f800000u;
+        c.nadr[r] = c.lds_patch + (unsigned)((r * 4 + wave) * 1024 + prow * 64 + ((pslot ^ Cfg::swz_key(xx)) << 4));
     }
 #pragma unroll
     for (int n = 0; n < PSW; ++n) {
@@ -301,8 +323,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         c.scv[n] = (unsigned)(src * g.a1_ld + ((pslot ^ ((pp >> 1) & 2)) << 3)) * 2u;
     }
     c.tvo = (unsigned)(lane & 31) * 4u;
-    c.n_addr[0] = c.lds_patch + (unsigned)(wave * 1024 + lane * 16);
-    c.n_addr[1] = c.n_addr[0] + Cfg::PATCH_BYTES;
+    c.n_tab = c.lds_tab + ((unsigned)pslot << 5);
     {
         const int frow = lane & 15, fq = lane >> 4;
         const int ml = wm * 128 + frow;                                   // first pixel of this wave, the lane's row
@@ -312,31 +333,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         c.a_sc = c.lds_sc + (unsigned)(ml * 64 + ((fq ^ ((ml >> 1) & 2)) << 4));
     }
 
-    // ---- prologue: table + raw patch of half-chunk 0 -> buffer 0, the first step's weights, the first two shortcut tiles ----
+    // ---- prologue: the first shortcut tile, then table + raw patch of half-chunk 0 -> buffer 0 and the first step's weights ----
+    if (n_sc > 0) {
+#pragma unroll
+        for (int n = 0; n < PSW; ++n) cg3_glds16(c.scv[n], a1base, c.lds_sc + n * 1024 + c.wave * (PSW * 1024));
+    }
     cg3_gtab(c.tvo, gsc, gsh, c.lds_tab);
 #pragma unroll
     for (int r = 0; r < NROUND; ++r) cg3_glds16(c.vo[r], img, c.lds_patch + (r * 4) * 1024 + c.wave * 1024);
 #pragma unroll
     for (int j = 0; j < 8; ++j) c.fb[0][j] = cg3_gload16(c.boff[j], wfrag);
-    if (n_sc > 0) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int n = 0; n < PSW; ++n) cg3_glds16(c.scv[n], a1base + t * KT, c.lds_sc + t * Cfg::SC_BYTES + n * 1024 + c.wave * (PSW * 1024));
-    }
+    c.scnext = n_sc > 0 ? a1base + KT : reinterpret_cast<const bf16*>(wfrag);      // the second shortcut tile (requested in the last half-chunk); none: any readable address
     f32x4 acc[8][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    cg3_wait<0, -1>();
-    // this wave's pieces of half-chunk 0, normalised in place (no MFMAs to hide behind yet: left to hipcc to interleave)
-#pragma unroll
-    for (int r = 0; r < NROUND; ++r) {
-        const unsigned tb = c.ntb[r];
-        u32x4 nv = *reinterpret_cast<const u32x4*>(smem + (c.n_addr[0] - c.lds_patch) + r * 4096);
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(smem + (tb - c.lds_patch)), s1 = *reinterpret_cast<const f32x4*>(smem + (tb - c.lds_patch) + 16);
-        const f32x4 h0 = *reinterpret_cast<const f32x4*>(smem + (tb - c.lds_patch) + 128), h1 = *reinterpret_cast<const f32x4*>(smem + (tb - c.lds_patch) + 144);
+    NATINF_CG3_STAMP(1);
+    // this wave's pieces of half-chunk 0, normalised in place as they land (requests retire in order: round r waits for everything up to its piece; no MFMAs
+    // to hide behind yet, the arithmetic is left to hipcc to interleave)
+    auto norm0 = [&](auto r_tag, const f32x4& s0, const f32x4& s1, const f32x4& h0, const f32x4& h1) __attribute__((always_inline)) {
+        constexpr int R = decltype(r_tag)::value;
+        cg3_wait<NROUND - 1 - R + 8, -1>();
+        unsigned char* const pa = smem + (c.nadr[R] - c.lds_patch);
+        const u32x4 nv = *reinterpret_cast<const u32x4*>(pa);
+        const float ni = __uint_as_float(c.ninf[R]);
         u32x4 ou;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -345,26 +366,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float sa = p < 2 ? s0[2 * p] : s1[2 * p - 4], sb = p < 2 ? s0[2 * p + 1] : s1[2 * p - 3];
             const float ha = p < 2 ? h0[2 * p] : h1[2 * p - 4], hb = p < 2 ? h0[2 * p + 1] : h1[2 * p - 3];
             const float t0 = __builtin_fmaf(x0, sa, ha), t1 = __builtin_fmaf(x1, sb, hb);
-            const float y0_ = t0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t0)), y1_ = t1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t1));
+            const float y0_ = t0 * __builtin_amdgcn_rcpf(ni + __builtin_amdgcn_exp2f(t0)), y1_ = t1 * __builtin_amdgcn_rcpf(ni + __builtin_amdgcn_exp2f(t1));
             typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
             const bf16x2_t pr_ = {(bf16)y0_, (bf16)y1_};
             ou[p] = __builtin_bit_cast(unsigned, pr_);
         }
-        if (!((c.nmask >> r) & 1u)) ou = u32x4{0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4*>(smem + (c.n_addr[0] - c.lds_patch) + r * 4096) = ou;
+        *reinterpret_cast<u32x4*>(pa) = ou;
+    };
+    {
+        cg3_wait<NROUND + 8, -1>();                                        // the table
+        NATINF_CG3_STAMP(2);
+        const unsigned char* const tp = smem + (c.n_tab - c.lds_patch);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(tp), s1 = *reinterpret_cast<const f32x4*>(tp + 16);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(tp + 128), h1 = *reinterpret_cast<const f32x4*>(tp + 144);
+        using std::integral_constant;
+        norm0(integral_constant<int, 0>{}, s0, s1, h0, h1); norm0(integral_constant<int, 1>{}, s0, s1, h0, h1); norm0(integral_constant<int, 2>{}, s0, s1, h0, h1);
+        norm0(integral_constant<int, 3>{}, s0, s1, h0, h1); norm0(integral_constant<int, 4>{}, s0, s1, h0, h1); norm0(integral_constant<int, 5>{}, s0, s1, h0, h1);
+        if constexpr (NROUND > 6) { norm0(integral_constant<int, 6>{}, s0, s1, h0, h1); norm0(integral_constant<int, 7>{}, s0, s1, h0, h1); }
+        if constexpr (NROUND > 8) { norm0(integral_constant<int, 8>{}, s0, s1, h0, h1); norm0(integral_constant<int, 9>{}, s0, s1, h0, h1); }
+        static_assert(NROUND == 6 || NROUND == 8 || NROUND == 10, "rounds of the prologue");
     }
+    cg3_wait<0, -1>();                                                     // the first step's weights (and the first shortcut tile)
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 8; ++i) c.fa[0][i] = *reinterpret_cast<const u32x4*>(smem + (c.a_dx[0] - c.lds_patch) + Cfg::aoff(i));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
+    NATINF_CG3_STAMP(3);
     using std::integral_constant;
     auto half_chunk = [&](auto hp_tag, auto next_tag, int h) __attribute__((always_inline)) {
         constexpr int HP = decltype(hp_tag)::value;
         constexpr bool NEXT = decltype(next_tag)::value;
         c.pnext = img + (h + 1) * KT; c.tsc = gsc + (h + 1) * KT; c.tsh = gsh + (h + 1) * KT;
         const int kt = h * 9;
+        NATINF_CG3_STAMP(4 + (h < 36 ? h : 35));
 #define NATINF_CG3_TAP(T)                                                                                             \
         c.wnext = wfrag + (int64_t)((T < 8 || NEXT) ? kt + T + 1 : min(nk, NT - 1)) * 1024;                              \
         CG3Tap<Cfg, T, HP, NEXT, 0>::run(acc, c);
@@ -378,6 +414,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     half_chunk(integral_constant<int, 0>{}, std::true_type{}, n_half - 2);
     half_chunk(integral_constant<int, 1>{}, std::false_type{}, n_half - 1);
+    NATINF_CG3_STAMP(40);
     // ---- 1x1 shortcut segment (nk is even: shortcut step s lives in register set s & 1, its tile in shortcut buffer s & 1) ----
     for (int s = 0; s < n_sc; s += 2) {
         c.wnext = wfrag + (int64_t)min(nk + s + 1, NT - 1) * 1024; c.scnext = a1base + min(s + 2, n_sc - 1) * KT;
@@ -385,6 +422,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         c.wnext = wfrag + (int64_t)min(nk + s + 2, NT - 1) * 1024; c.scnext = a1base + min(s + 3, n_sc - 1) * KT;
         CG3Sc<Cfg, 1, 0>::run(acc, c);
     }
+    NATINF_CG3_STAMP(41);
     // every request / read of the last step's look-ahead has landed, the last MFMAs' results are written (inline asm: hipcc does not see the writes
     // it would pad for), and every wave is done with the tiles before the epilogue reuses them
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_barrier" ::: "memory");
@@ -407,7 +445,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int lane_e;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
     const int tid_e = wave * 64 + lane_e;
+    NATINF_CG3_STAMP(42);
     tile_epilogue<WM, WN, 8, 8, typename Cfg::Epi, EPI, 1, false, true>(ge, smem, acc, m0, n0, 0, tid_e, lane_e, wm, wn);
+    NATINF_CG3_STAMP(43);
 }
 
 }  // namespace ncsn
