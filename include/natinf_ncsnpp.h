@@ -153,6 +153,9 @@ int natinf_set_conv_gn_wide(int mask);
  * 32x32 images, N % 256 == 0, 256 x 256 tiles; bit 2: 16x16 images, N % 256 == 0, 256 x 256 tiles (one image per tile).  The convolution sums are the
  * bytes k_conv_gn2 gives (same K order, same normalisation arithmetic); GroupNorm partial rows then cover 512 / 256 pixels (natinf_debug_conv_gn: rows). */
 int natinf_set_conv_gn_w128(int mask);
+/* Smallest K (9 * cin + shortcut channels) at which a launch of shape 0 (32x32, 512 x 128 tiles), 1 (32x32, 256 x 256) or 2 (16x16, 256 x 256) takes k_conv_gn3
+ * (defaults 2304 / 0 / 2560: with one block per CU a tile's prologue and epilogue are exposed, so short-K launches stay on k_conv_gn2); 0 = every K (tests, A/B runs). */
+int natinf_set_conv_gn_w128_min_k(int shape, int k);
 int natinf_set_conv_gn_regw(int on);
 /* 1 (default; read when a plan is built): the up-sampling blocks at 16x16 / 32x32 read their half-resolution input inside the fused
  * convolution (nearest up-sampling in the patch fetch and in the residual fetch); 0: through the separate GroupNorm-apply + up-sample pass. */

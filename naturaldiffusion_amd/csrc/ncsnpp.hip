@@ -341,19 +341,24 @@ int variant_bm(int v);
 // k_conv_gn instantiations: 32x32 and 16x16 images, 256 x 128 tiles -- 128 x 256 tiles for 16x16 layers whose N is a multiple of 256
 // (natinf_set_conv_gn_wide: A/B runs); packed epilogues 1 / 2 / 5 / 6 only
 int packed_epi(const GemmArgs& g, int bm);
-int g_cg3 = 0;                     // natinf_set_conv_gn_w128: bit 0 = 32x32 layers with N % 256 != 0 on 512 x 128 tiles, bit 1 = 32x32 layers with N % 256 == 0 on 256 x 256
+int g_cg3 = 7;                     // natinf_set_conv_gn_w128: bit 0 = 32x32 layers with N % 256 != 0 on 512 x 128 tiles, bit 1 = 32x32 layers with N % 256 == 0 on 256 x 256
                                    // tiles, bit 2 = 16x16 layers with N % 256 == 0 on 256 x 256 tiles (one image per tile)
 int g_cg_wide = 3;                 // natinf_set_conv_gn_wide: bit 0 = 128 x 256 tiles at 16x16, bit 1 = at 32x32 (N % 256 == 0 layers: the 16 -> 32 up-sampling block)
 int g_fuse_up = 1;                 // natinf_set_fuse_up (read when a plan is BUILT): up blocks at 16x16 / 32x32 fetch their input up-sampled inside k_conv_gn2
 int g_cg_regw = 1;                 // natinf_set_conv_gn_regw: 1 = k_conv_gn2 (weights streamed through registers) where GemmArgs::b_frag is given
 // tile rows of the fused-convolution instantiation a launch takes: 128 x 256 tiles at 16x16 (N % 256 == 0) and at 8x8 (two images per tile), 256 x 128 elsewhere
-// the k_conv_gn3 shape a fused-convolution launch takes (-1: k_conv_gn2)
+// the k_conv_gn3 shape a fused-convolution launch takes (-1: k_conv_gn2).  One block per CU exposes a tile's prologue and epilogue (~28k clocks), which the two
+// co-resident blocks of k_conv_gn2 partly hide: k_conv_gn3 is ahead where the K loop is long (same-process A/B at B = 512, profiles/r05/cg3_v2_ab.log: 1.04-1.08 at
+// K >= 2,304 on 512 x 128 tiles, 1.035-1.04 on 256 x 256 tiles at 32x32, 1.01-1.06 at K >= 2,816 at 16x16) and behind at short K (0.92-0.98 at K = 1,152 .. 1,536)
+int g_cg3_min_k[3] = {2304, 0, 2560};      // natinf_set_conv_gn_w128_min_k: smallest K (9 cin + shortcut channels) per shape that takes k_conv_gn3
 inline int conv_gn3_shape(const GemmArgs& g) {
     const int res = 1 << g.logW;
     if (!g_cg3 || !g_cg_regw || !g.b_frag || g.N % 128) return -1;
-    if (res == 32) return g.N % 256 ? ((g_cg3 & 1) ? 0 : -1) : ((g_cg3 & 2) ? 1 : -1);
-    if (res == 16) return (g.N % 256 == 0 && (g_cg3 & 4)) ? 2 : -1;
-    return -1;
+    int sh = -1;
+    if (res == 32) sh = g.N % 256 ? ((g_cg3 & 1) ? 0 : -1) : ((g_cg3 & 2) ? 1 : -1);
+    else if (res == 16) sh = (g.N % 256 == 0 && (g_cg3 & 4)) ? 2 : -1;
+    if (sh >= 0 && 9 * g.a0_C + (g.a1 ? g.a1_C : 0) < g_cg3_min_k[sh]) sh = -1;
+    return sh;
 }
 inline int conv_gn_bm(const GemmArgs& g) {
     const int res = 1 << g.logW;
@@ -1753,6 +1758,7 @@ int natinf_set_conv_gn8_tile(int one_image) {
 }
 int natinf_set_fuse_head(int on) { g_fuse_head = on != 0; return NATINF_OK; }
 int natinf_set_conv_gn_w128(int mask) { if (mask < 0 || mask > 7) return NATINF_EINVAL; g_cg3 = mask; return NATINF_OK; }
+int natinf_set_conv_gn_w128_min_k(int shape, int k) { if (shape < 0 || shape > 2 || k < 0) return NATINF_EINVAL; g_cg3_min_k[shape] = k; return NATINF_OK; }
 int natinf_set_conv_gn_wide(int mask) { if (mask < 0 || mask > 3) return NATINF_EINVAL; g_cg_wide = mask; return NATINF_OK; }
 int natinf_set_conv_gn_regw(int on) {
     if (!on && !HAVE_CONV_GN_V1) return NATINF_ESTATE;      // k_conv_gn (the LDS-ring form) exists in -DNATINF_DEV builds only

@@ -72,6 +72,7 @@ def test_conv_gn_matches_torch(res, B, cin, N, c1, resid, parts):
     rd = r.bfloat16().to(dev) if resid else None
     wide = res in (16, 32) and N % 256 == 0                # 128-pixel x 256-channel tiles (default) -- the 256 x 128 ones are tested as well
     wf = torch.zeros_like(wd)                              # receives the fragment-major copy of the weights (k_conv_gn2)
+    lib.natinf_set_conv_gn_w128(0)                      # this file is about k_conv_gn2 (k_conv_gn3, which takes the long-K launches by default: tests/test_gpu_conv_gn3.py)
     assert lib.natinf_set_conv_gn_regw(0) != 0          # k_conv_gn (weights through an LDS ring): -DNATINF_DEV builds only
     assert lib.natinf_set_conv_gn8_tile(0) != 0         # the two-images-per-tile form of the 8x8 level: -DNATINF_DEV builds only
     for use_wide, regw in (((1, 1), (0, 1)) if wide else ((1, 1),)):
@@ -92,6 +93,7 @@ def test_conv_gn_matches_torch(res, B, cin, N, c1, resid, parts):
         if parts:                                           # (sum, sum of squares) per tile and 4-channel quad, of the fp32 results
             want = torch.stack([ref.reshape(M // rows, rows, N // 4, 4).sum(dim=(1, 3)), (ref ** 2).reshape(M // rows, rows, N // 4, 4).sum(dim=(1, 3))], dim=-1)
             assert ((part.cpu() - want).abs().max() / want.abs().max()).item() <= 5e-3
+    lib.natinf_set_conv_gn_w128(7)                      # (the library's default; a failed case leaves 0 behind: only this file's later cases see it)
 
 def test_ragged_channel_counts_are_refused_in_the_shipped_build():
     """k_conv_gn2 needs whole 128- (or 256-) channel tiles; the LDS-ring kernel that took ragged N is a -DNATINF_DEV kernel now."""

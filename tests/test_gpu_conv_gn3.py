@@ -57,6 +57,8 @@ def _run(res, B, cin, N, c1, t, up_flags, mask, rows, parts):
     out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
     part = torch.zeros(M // rows, N // 4, 2, device=dev) if parts else None
     check(lib.natinf_set_conv_gn_w128(mask), "knob")
+    for sh in range(3):
+        check(lib.natinf_set_conv_gn_w128_min_k(sh, 0), "min_k")               # every K: the library's defaults keep short-K launches on k_conv_gn2
     check(lib.natinf_debug_conv_gn_up(up_flags), "up")
     try:
         check(lib.natinf_debug_conv_gn(res, B, N, cin, c1, ptr(xd), ptr(scd), ptr(shd), ptr(wd), ptr(wf), ptr(a1d), ptr(bd), ptr(rd), 0.70710678, ptr(out),
@@ -64,11 +66,13 @@ def _run(res, B, cin, N, c1, t, up_flags, mask, rows, parts):
         torch.cuda.synchronize()
     finally:
         lib.natinf_set_conv_gn_w128(_DEFAULT_MASK)
+        for sh, k in enumerate(_DEFAULT_MIN_K):
+            lib.natinf_set_conv_gn_w128_min_k(sh, k)
         lib.natinf_debug_conv_gn_up(0)
     return out.cpu(), (part.cpu() if parts else None)
 
 
-_DEFAULT_MASK = 0
+_DEFAULT_MASK, _DEFAULT_MIN_K = 7, (2304, 0, 2560)          # (csrc/ncsnpp.hip: g_cg3, g_cg3_min_k)
 
 
 @pytest.mark.parametrize("res,B,cin,N,c1,resid,parts,up", [
@@ -104,11 +108,32 @@ def test_conv_gn3_matches_torch_and_conv_gn2_bit_for_bit(res, B, cin, N, c1, res
         assert ((part3 - want).abs().max() / want.abs().max()).item() <= 5e-3
 
 
-def test_conv_gn3_is_reproducible_and_leaves_its_neighbours_alone():
-    """Two runs give the same bytes; rows beyond the output (a guard band around `out`) stay untouched."""
-    from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
+def test_conv_gn3_is_reproducible():
+    """Two runs give the same bytes."""
     res, B, cin, N, c1 = 32, 2, 128, 128, 128
     t, _ = _case(res, B, cin, N, c1, True, 0, 5)
     a, _ = _run(res, B, cin, N, c1, t, 0, 7, 512, False)
     b, _ = _run(res, B, cin, N, c1, t, 0, 7, 512, False)
     assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+def test_the_default_rule_sends_long_k_launches_to_conv_gn3():
+    """natinf_set_conv_gn_w128_min_k defaults (2304 / 0 / 2560): the GroupNorm partial rows tell which kernel ran -- 512 / 256 pixels per row for k_conv_gn3,
+    256 / 128 for k_conv_gn2."""
+    for res, B, cin, N, c1, rows in ((32, 1, 128, 128, 0, 256), (32, 1, 256, 128, 0, 512), (32, 1, 128, 256, 0, 256), (16, 2, 256, 256, 0, 128), (16, 2, 256, 256, 256, 256)):
+        t, ref = _case(res, B, cin, N, c1, False, 0, 77 + res + cin + c1)
+        from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
+        dev, M = "cuda", B * res * res
+        wd = _pack(t["w"] * (-1.0 / LOG2E), t["w1"]).bfloat16().to(dev)
+        xd = t["x"].bfloat16().to(dev).contiguous()
+        scd, shd, bd = (t["scale"] * -LOG2E).to(dev), (t["shift"] * -LOG2E).to(dev), t["bias"].to(dev)
+        a1d = t["a1"].bfloat16().to(dev).contiguous() if c1 else None
+        wf = torch.zeros_like(wd)
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        part = torch.full((M // 128, N // 4, 2), -1.0, device=dev)              # (room for the smallest rows; unwritten rows keep -1)
+        check(lib.natinf_debug_conv_gn(res, B, N, cin, c1, ptr(xd), ptr(scd), ptr(shd), ptr(wd), ptr(wf), ptr(a1d), ptr(bd), None, 0.70710678, ptr(out), ptr(part), 1,
+                                       stream_ptr()), "conv_gn")
+        torch.cuda.synchronize()
+        written = int((part[:, 0, 1] >= 0).sum().item())                        # (a sum of squares is never negative)
+        assert written == M // rows, (res, cin, N, c1, written, M // rows)
+        assert ((out.float().cpu() - ref).abs().max() / ref.abs().max()).item() <= 1e-2

@@ -17,6 +17,8 @@ ts = torch.zeros(128, dtype=torch.int64, device=dev)
 f = lib.natinf_debug_cg3_timeline; f.restype = C.c_int; f.argtypes = [C.c_void_p]
 check(f(ptr(ts)), "timeline")
 check(lib.natinf_set_conv_gn_w128(7), "knob")
+for sh in range(3):
+    check(lib.natinf_set_conv_gn_w128_min_k(sh, 0), "min_k")
 args = (res, B, N, cin, c1, ptr(x), ptr(sc), ptr(sh), ptr(w), ptr(wf), ptr(a1), ptr(bias), None, 0.7071, ptr(out), ptr(part))
 for _ in range(3):
     check(lib.natinf_debug_conv_gn(*args, 1, stream_ptr()), "run"); torch.cuda.synchronize()
