@@ -423,12 +423,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         CG3Sc<Cfg, 1, 0>::run(acc, c);
     }
     NATINF_CG3_STAMP(41);
-    // every request / read of the last step's look-ahead has landed, the last MFMAs' results are written (inline asm: hipcc does not see the writes
-    // it would pad for), and every wave is done with the tiles before the epilogue reuses them
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    // the epilogue's arguments are fetched from the kernel-argument segment HERE (conv_gn.h: kept in scalar registers across the K
-    // loop they end up spilled into vector-register lanes)
+    // the epilogue's arguments are fetched from the kernel-argument segment HERE (conv_gn.h: kept in scalar registers across the K loop they end up spilled
+    // into vector-register lanes) -- and IN FRONT of the drain below, pinned by an empty statement that reads them: hipcc otherwise issues the scalar loads
+    // behind its ~190 accumulator reads and waits a full round trip for them with nothing else to do (one block per CU)
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef const unsigned __attribute__((address_space(4))) *kernarg_u32_t;
     kernarg_u32_t gp = (kernarg_u32_t)__builtin_amdgcn_kernarg_segment_ptr();
@@ -439,14 +436,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (unsigned i = 0; i < sizeof(GemmArgs) / 4; ++i) d[i] = gp[i];
     }
+    asm volatile("" :: "s"(ge.c), "s"(ge.bias_n), "s"(ge.rowvec), "s"(ge.resid), "s"(ge.gn_part), "s"(ge.c_ld), "s"(ge.rowvec_ld), "s"(ge.resid_ld), "s"(ge.gn_quads),
+                 "s"(ge.log_rows_per_sample), "s"(ge.scale), "s"(ge.M), "s"(ge.N));
 #else
     const GemmArgs ge = g;
 #endif
+    // every request / read of the last step's look-ahead has landed, the last MFMAs' results are written (inline asm: hipcc does not see the writes
+    // it would pad for), and every wave is done with the tiles before the epilogue reuses them
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     int lane_e;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
     const int tid_e = wave * 64 + lane_e;
     NATINF_CG3_STAMP(42);
-    tile_epilogue<WM, WN, 8, 8, typename Cfg::Epi, EPI, 1, false, true>(ge, smem, acc, m0, n0, 0, tid_e, lane_e, wm, wn);
+    static_assert(EPI == 1 || EPI == 2 || EPI == 5 || EPI == 6, "packed epilogues: plain / + GroupNorm partials / + bf16 residual / both");
+    packed_tile_epilogue<WM, WN, 8, 8, typename Cfg::Epi, ACT_NONE, EPI == 2 || EPI == 6, EPI == 5 || EPI == 6, false, false, 1, false, true, true>(ge, smem, acc, m0, n0, 0, tid_e, lane_e, wm, wn);
     NATINF_CG3_STAMP(43);
 }
 

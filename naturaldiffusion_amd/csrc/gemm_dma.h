@@ -137,7 +137,9 @@ struct SlabCopy<NSW, NSW, RPS, PROW, EDGE> {
 // the tile's own partial sums, same additions in the same order as k_gn_finalize (bit-identical tables).
 // PAIR (k_conv_gn2: k_pack_frag interleaves the weight rows of n-tiles 2 p, 2 p + 1 -- row r of tile 2 p + h = channel 32 p + 8 (r >> 2) + 4 h + (r & 3)): the four
 // rows 4 q + e a lane holds of both tiles are EIGHT consecutive channels 32 p + 8 q .. + 7 -- 16-byte residual loads and 16-byte slab writes instead of 8-byte ones.
-template <int WM, int WN, int TM, int TN, class Cfg, int ACT, bool GN, bool RES, bool DEQ = false, bool OUT8 = false, int NSAMP = 1, bool FIN = false, bool PAIR = false>
+// SCALE_ALWAYS (k_conv_gn3: one block per CU, nothing hides the epilogue): the output scale is applied without the wave-uniform `scale != 1` branch around it -- 64 taken-or-not
+// branches per tile cost more than 64 packed multiplies by 1.0 (exact: the same bytes).
+template <int WM, int WN, int TM, int TN, class Cfg, int ACT, bool GN, bool RES, bool DEQ = false, bool OUT8 = false, int NSAMP = 1, bool FIN = false, bool PAIR = false, bool SCALE_ALWAYS = false>
 __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned char* smem, f32x4 (&acc)[TM][TN],
                                                      int m0, int n0, int z, int tid, int lane, int wm, int wn)
 {
@@ -245,7 +247,10 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += (float)x[e];
         }
-        if (scale != 1.0f) {                                              // (wave-uniform; the transformer engines' GEMMs all have scale 1)
+        if constexpr (SCALE_ALWAYS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= scale;
+        } else if (scale != 1.0f) {                                       // (wave-uniform; the transformer engines' GEMMs all have scale 1)
             asm volatile("");                                             // (a real branch, as above)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= scale;
