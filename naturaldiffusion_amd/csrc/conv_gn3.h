@@ -15,6 +15,8 @@
 //     the gap that produced it, and the table / patch reads of round r + 1 issued inside the tail of round r;
 //   * ONE block-wide barrier per half-chunk (in tap 8, behind the last normalisation store): it publishes the normalised patch of half-chunk
 //     h + 1 and frees the buffer of h for the raw patch of h + 2; the 1x1 shortcut tiles have two LDS buffers of their own (requested two steps ahead);
+//     (the segment with its A fragments loaded straight from global memory into four register sets -- no LDS, no barrier, two steps of lead -- was built and
+//     measured 4-7 % SLOWER per launch than the LDS tiles: sixteen half-line loads per step and wave through the vector-memory return path; not kept);
 //   * no run-time branch inside the loop: every wave normalises NROUND pieces (the pad pieces read a clamped pixel and are never read back).
 // Same K order, same normalisation arithmetic, one accumulation chain per output element: the convolution sums are the same bytes as k_conv_gn2's
 // (tests/test_gpu_conv_gn.py compares them bit for bit); the GroupNorm partial sums of the OUTPUT are grouped by 512- / 256-pixel tiles.
@@ -245,19 +247,21 @@ struct CG3Tap {
     }
 };
 
-// ---- one step of the 1x1 shortcut segment: tile s (register set P = s & 1) is multiplied; behind the barrier tile s + 2 is requested into the
-// ---- buffer tile s was read from, and the A fragments of tile s + 1 are read from the other one
+// ---- one step of the 1x1 shortcut segment: tile s (register set P = s & 1) is multiplied.  Barrier 1 (slot 1): every wave holds its A fragments of tile s, so
+// ---- tile s + 2 may be requested into that buffer right behind the weight loads (1.5 steps before its fragments are read instead of 1: a step is ~1,100 clocks and
+// ---- every second tile is the first touch of its 128-byte lines); barrier 2 (slot BAR): every wave's pieces of tile s + 1 have landed -- its fragments are read behind it.
 template <class Cfg, int P, int S>
 struct CG3Sc {
     static __device__ __forceinline__ void run(f32x4 (&acc)[8][8], CG3Ctx<Cfg>& c) {
-        if constexpr (S == 0) cg3_wait<Cfg::PSW, 0>();                              // the weights of step s have landed (the requests for tile s + 1, issued behind them, stay in flight)
-        if constexpr (S == Cfg::BAR - 1) cg3_wait<8, -1>();                          // this wave's pieces of tile s + 1 have landed (the weight loads of step s + 1 stay in flight)
+        if constexpr (S == 0) cg3_wait<Cfg::PSW, 0>();                              // the weights of step s have landed (the requests for tile s + 1, issued behind them, stay in flight); so have its A fragments
+        if constexpr (S == 1) cg3_barrier();
         if constexpr (S >= 1 && S <= 8) c.fb[P ^ 1][S - 1] = cg3_gload16(c.boff[S - 1], c.wnext);
-        if constexpr (S == Cfg::BAR) cg3_barrier();                                  // every wave's pieces of tile s + 1 are in LDS; nobody reads tile s any more
-        if constexpr (S > Cfg::BAR && (S - Cfg::BAR - 1) % 2 == 0 && (S - Cfg::BAR - 1) / 2 < Cfg::PSW) {
-            constexpr int n = (S - Cfg::BAR - 1) / 2;
+        if constexpr (S >= 9 && (S - 9) % 2 == 0 && (S - 9) / 2 < Cfg::PSW) {
+            constexpr int n = (S - 9) / 2;
             cg3_glds16(c.scv[n], c.scnext, c.lds_sc + P * Cfg::SC_BYTES + n * 1024 + c.wave * (Cfg::PSW * 1024));
         }
+        if constexpr (S == Cfg::BAR - 1) cg3_wait<8 + Cfg::PSW, -1>();              // this wave's pieces of tile s + 1 have landed (the weight loads and requests of this step stay in flight)
+        if constexpr (S == Cfg::BAR) cg3_barrier();
         if constexpr (S > Cfg::BAR + 1 && (S - Cfg::BAR - 2) % 2 == 0 && (S - Cfg::BAR - 2) / 2 < 8) {
             constexpr int i = (S - Cfg::BAR - 2) / 2;
             c.fa[P ^ 1][i] = lds_read16<(P ^ 1) * Cfg::SC_BYTES + i * 1024>(c.a_sc);
@@ -422,6 +426,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         c.wnext = wfrag + (int64_t)min(nk + s + 2, NT - 1) * 1024; c.scnext = a1base + min(s + 3, n_sc - 1) * KT;
         CG3Sc<Cfg, 1, 0>::run(acc, c);
     }
+    // The last step's look-ahead loads (clamped: nobody multiplies them) may still be in flight and, to hipcc, are DEAD: it may put the epilogue's first values into
+    // their destination registers at once -- and the load then lands on top of them.  (Seen with a form of the shortcut segment that read its A fragments from global
+    // memory: the residual epilogues, whose address arithmetic is hoisted up here, gave wrong tiles at B = 512 and right ones at B = 1.)  So: wait for everything,
+    // THEN read every register a load may have been writing.
+    cg3_wait<0, 0>();
+#define NATINF_CG3_PIN8(a) asm volatile("" :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
+    NATINF_CG3_PIN8(c.fb[0]) NATINF_CG3_PIN8(c.fb[1]) NATINF_CG3_PIN8(c.fa[0]) NATINF_CG3_PIN8(c.fa[1])
+#undef NATINF_CG3_PIN8
     NATINF_CG3_STAMP(41);
     // the epilogue's arguments are fetched from the kernel-argument segment HERE (conv_gn.h: kept in scalar registers across the K loop they end up spilled
     // into vector-register lanes) -- and IN FRONT of the drain below, pinned by an empty statement that reads them: hipcc otherwise issues the scalar loads

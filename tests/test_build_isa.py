@@ -19,7 +19,7 @@ BUILD = CSRC / "build"
 def listings():
     subprocess.check_call(["make", "-C", str(CSRC), "-j4"], stdout=subprocess.DEVNULL)       # no-op when up to date
     out = {}
-    for stem in ("ni_step", "ncsnpp"):
+    for stem in ("ni_step", "ncsnpp", "conv_gn3"):
         p = BUILD / f"{stem}-hip-amdgcn-amd-amdhsa-gfx950.s"
         assert p.exists(), f"{p} missing: the Makefile builds with -save-temps=obj"
         out[stem] = p.read_text()
@@ -214,7 +214,7 @@ def test_no_dpp_source_reads_a_packed_fp32_result(listings):
     spec = importlib.util.spec_from_file_location("scan_pk_hazard", Path(__file__).resolve().parent.parent / "tools" / "scan_pk_hazard.py")
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    for stem in ("ni_step", "ncsnpp"):
+    for stem in ("ni_step", "ncsnpp", "conv_gn3"):
         hits = mod.scan(str(BUILD / f"{stem}-hip-amdgcn-amd-amdhsa-gfx950.s"), 8)
         bad = {k: v[:2] for k, v in hits.items() if k[1] in ("dpp", "lane")}
         assert not bad, bad
@@ -267,3 +267,44 @@ def test_w128_gemm_loops_are_the_written_instruction_stream(listings):
         waits = [ln.strip() for ln in loop.split("\n") if "s_waitcnt" in ln and "vmcnt" in ln]
         assert waits and (fp8 or all("vmcnt(0)" not in wt for wt in waits)), waits
     assert seen == 15
+
+
+def test_conv_gn3_loops_are_the_written_instruction_stream(listings):
+    """k_conv_gn3 (conv_gn3.h): twelve kernels (three tile shapes x four packed epilogues), none with a spilled register or a byte of scratch memory, accumulators in all
+    256 AGPRs.  Its steady-state loop is two half-chunks of nine taps, every instruction a volatile asm statement of the slot table: 1,152 MFMAs, 144 weight-fragment loads,
+    144 A-fragment reads + the normalisation's reads (4 table rows + NROUND patch pieces per half-chunk), NROUND stores, NROUND + 2 LDS-DMA requests per half-chunk, two
+    barriers -- and no register copy, no scratch access, no lane-parked scalar inside it.  Per half-chunk and round the normalisation is 8 unpack, 8 fma, 8 exp2, 8 add,
+    8 rcp, 8 mul, 4 pack; hipcc's hazard recogniser adds one `s_nop 0` per stage boundary (an inline-asm definition read by the next statement), not one per instruction."""
+    code = listings["conv_gn3"]
+    ks = _kernels(code)
+    code = code[:code.index("amdhsa.kernels:")]
+    w = {n: v for n, v in ks.items() if "k_conv_gn3" in n}
+    assert len(w) == 12 and all(v["scratch"] == 0 and v["spill"] == 0 for v in w.values()), w
+    seen = 0
+    for m in re.finditer(r"^(_ZN\w*10k_conv_gn3ILi(\d+)ELi(\d)ELi(\d)ELi(\d)E\w+):\s*; @", code, flags=re.M):
+        res, wm = int(m.group(2)), int(m.group(3))
+        nround = 10 if (res, wm) == (32, 4) else 6
+        end = re.compile(r"^\.Lfunc_end\d+:", flags=re.M).search(code, m.end()).start()
+        body = code[m.end():end]
+        assert re.search(r"; NumAgprs: 256", code[end:end + 3000])
+        # the first loop with MFMAs inside: the two-half-chunk loop (prologue loops, if any, hold none)
+        loop = None
+        for lm in re.finditer(r"Inner Loop Header", body):
+            seg = body[lm.start():body.index("s_cbranch_scc", lm.start())]
+            if "v_mfma" in seg:
+                loop = seg
+                break
+        assert loop is not None, m.group(1)
+        ins = [ln.strip().split()[0] for ln in loop.split("\n") if ln.strip() and not ln.strip().startswith((";", "."))]
+        n_mfma = sum(i.startswith("v_mfma") for i in ins)
+        assert n_mfma == 2 * 9 * 64, (m.group(1), n_mfma)
+        assert ins.count("global_load_dwordx4") == 2 * 9 * 8
+        assert ins.count("ds_read_b128") == 2 * (9 * 8 + 4 + nround) and ins.count("ds_write_b128") == 2 * nround
+        assert ins.count("global_load_lds_dwordx4") == 2 * nround and ins.count("global_load_lds_dword") == 4 and ins.count("s_barrier") == 2
+        for op, per_round in (("v_exp_f32", 8), ("v_rcp_f32", 8), ("v_fma_f32", 8), ("v_mul_f32", 8), ("v_add_f32", 8), ("v_cvt_pk_bf16_f32", 4)):
+            assert ins.count(op) == 2 * nround * per_round, (m.group(1), op, ins.count(op))
+        assert not [i for i in ins if i.startswith(("v_mov", "v_accvgpr", "scratch_", "v_readlane", "v_writelane"))], m.group(1)
+        # compiler-inserted wait states: the stage boundaries of the rounds (+ the LDS-DMA statements' own `s_nop 0` behind their M0 write)
+        assert ins.count("s_nop") <= 2 * (nround * 9 + nround + 2), (m.group(1), ins.count("s_nop"))
+        seen += 1
+    assert seen == 12
