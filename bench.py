@@ -50,8 +50,8 @@ one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
                     DiT-XL/2 engine, 8 class-conditional latents, CFG 4 (the conditional and unconditional calls of a step as ONE forward of 16), 24 steps, one fused
                     ``natinf_step_f32prod`` launch per step -- then the AutoencoderKL decoder engine (8 x 256x256 images) and the PNG
                     row.  value = images/s; dit_ms = mean DiT forward (16 samples); vae_ms = decode of the 8 latents; synthetic weights.
-  roofline          the dominant kernel, ``k_conv_gn2`` at 32x32 / 16x16 (3x3 convolution with GroupNorm-apply + SiLU fused into its
-                    operand path; MFMA-bound): achieved = algorithmic flops per launch (2*M*N*K of the launches, from the engine's own
+  roofline          the dominant kernel class, ``k_conv_gn2`` / ``k_conv_gn3`` at 32x32 / 16x16 (3x3 convolution with GroupNorm-apply + SiLU fused into its
+                    operand path; k_conv_gn3 -- one wave per SIMD, 128 x 128 wave tiles -- takes the long-K launches; MFMA-bound): achieved = algorithmic flops per launch (2*M*N*K of the launches, from the engine's own
                     launch table) / mean launch duration, measured with HIP events on the engine's stream over an instrumented ONE-stream
                     replica of the timed region (one kernel on the GPU at a time); traffic = HBM bytes per launch from the newest
                     committed rocprofv3 PMC summary (profiles/rNN/*_hbm_traffic.json: bench.py cannot run rocprofv3 on itself);
@@ -409,7 +409,7 @@ def bench_cifar(args, world, rank, dev):
         gemm_flops = GFLOP_PER_IMAGE_FORWARD * 1e9 * Bz * fwd - cg_flops - c8_flops          # the rest: the k_gemm_* launches, the fused attention, the head
         all_ms = cg_ms + c8_ms + gemm_ms + other_ms
         ach = cg_flops / (cg_ms * 1e-3) / 1e12
-        line["roofline"] = {"kernel": "k_conv_gn2<32|16>", "bound": "mfma", "achieved": r4(ach), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+        line["roofline"] = {"kernel": "k_conv_gn2+k_conv_gn3<32|16>", "bound": "mfma", "achieved": r4(ach), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": r4(ach / MFMA_BF16_PEAK_TFLOPS), "traffic": profiled_traffic("k_conv_gn", exclude=("k_conv_gn2<8", "k_conv_gn2<4")),
                             "launches": int(cg_n), "mean_launch_ms": r4(cg_ms / cg_n), "flops_per_launch": r4(cg_flops / cg_n), "share": r4(cg_ms / all_ms)}
         if c8_n:

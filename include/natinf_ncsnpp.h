@@ -154,7 +154,7 @@ int natinf_set_conv_gn_wide(int mask);
  * bytes k_conv_gn2 gives (same K order, same normalisation arithmetic); GroupNorm partial rows then cover 512 / 256 pixels (natinf_debug_conv_gn: rows). */
 int natinf_set_conv_gn_w128(int mask);
 /* Smallest K (9 * cin + shortcut channels) at which a launch of shape 0 (32x32, 512 x 128 tiles), 1 (32x32, 256 x 256) or 2 (16x16, 256 x 256) takes k_conv_gn3
- * (defaults 2304 / 0 / 2560: with one block per CU a tile's prologue and epilogue are exposed, so short-K launches stay on k_conv_gn2); 0 = every K (tests, A/B runs). */
+ * (defaults 2304 / 0 / 2304: with one block per CU a tile's prologue and epilogue are exposed, so short-K launches stay on k_conv_gn2); 0 = every K (tests, A/B runs). */
 int natinf_set_conv_gn_w128_min_k(int shape, int k);
 int natinf_set_conv_gn_regw(int on);
 /* 1 (default; read when a plan is built): the up-sampling blocks at 16x16 / 32x32 read their half-resolution input inside the fused
@@ -189,6 +189,10 @@ int natinf_set_attn_proj(int on);
 int natinf_set_attn_waves8(int on);
 /* 1 (default; read when a plan is built): GroupNorm-apply and the q | k | v projections of the 16x16 attention block run as ONE launch (k_qkv256:
  * the block input is read once, the normalised tensor is never stored); 0: k_gn_apply + the q | k GEMM + the batched V^T GEMM. */
+/* 1 (default; read when a plan is built): the whole 16x16 attention block -- GroupNorm-apply + q | k | v projections, scores, softmax, P V, output projection, skip
+ * and the GroupNorm partials of its output -- is ONE launch (csrc/attn_blk256.h: q stays in registers; k and V^T are written and re-read through L2 by the same block);
+ * 0: k_qkv256 + k_attn256 (A/B runs).  Needs natinf_set_attn_qkv, natinf_set_attn_proj, natinf_set_attn_waves8 and natinf_set_attn256 at 1. */
+int natinf_set_attn_block(int on);
 int natinf_set_attn_qkv(int on);
 /* Tile of the fused kernel on the 8x8 level: 1 (default) = 64 pixels x 256 channels (one image per tile, wave tile 64 x 64, two blocks per CU at
  * B = 512), 0 = 128 x 256 (two images per tile, one block per CU; 0.6 % slower per forward: a -DNATINF_DEV kernel -- NATINF_ESTATE in the shipped

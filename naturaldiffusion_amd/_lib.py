@@ -69,6 +69,7 @@ SIGNATURES = {
     "natinf_set_gemm_w128": (C.c_int, [_i32]),
     "natinf_set_fuse_gn": (C.c_int, [_i32]),
     "natinf_set_conv_gn_wide": (C.c_int, [_i32]),
+    "natinf_set_attn_block": (C.c_int, [_i32]),
     "natinf_set_conv_gn_w128": (C.c_int, [_i32]),
     "natinf_set_conv_gn_w128_min_k": (C.c_int, [_i32, _i32]),
     "natinf_set_conv_gn_regw": (C.c_int, [_i32]),

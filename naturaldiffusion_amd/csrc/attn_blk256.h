@@ -1,0 +1,327 @@
+// attn_blk256.h -- k_attn_blk256: the WHOLE 16x16 attention block of NCSN++ / ddpm (AttnBlockpp, layerspp.py:75-91: h = GroupNorm(x); q, k, v = NIN(h);
+// softmax(q k^T / sqrt(C)) v; NIN_3; (x + .) / sqrt 2) as ONE launch: k_qkv256 (attn_qkv.h) and k_attn256<true, 8> (attn256.h) in one kernel, phase after phase.
+//
+// Both kernels already worked on the same geometry -- one 8-wave block per sample, a wave = 32 tokens -- and between them q | k (134 MB at B = 512) and V^T (67 MB)
+// went to HBM and came back: 226 MB written and 272 MB re-read per launch pair, each launch bound by memory at ~4.2 TB/s (72 + 84 us).  Here
+//   * q never leaves the registers.  k_qkv256's q tiles leave a lane with EIGHT consecutive channels 32 t + 8 q' .. + 7 of token tau(g, r) = 8 (r >> 2) + 4 g + (r & 3):
+//     that IS the B operand of S^T = K Q^T for K step t (lane (r, q'): eight K values of query column r) -- for the wave's queries taken in the order tau instead of
+//     16 g + r.  The attention phases do not care which query a column is; the output rows (projection, residual, store) use tau too.
+//   * k and V^T are still written (one block cannot keep 256 KB on chip) and re-read by the SAME block right away: the stores are complete behind `s_waitcnt vmcnt(0)`
+//     (one XCD's L2; the block's own L1 holds no line of them: nothing of this launch read them before), a barrier publishes them to the other waves, and the LDS-DMA
+//     of the attention phases finds them in L2 -- HBM sees the writes only.
+// Arithmetic, tile loops, swizzles, projection and GroupNorm partials: the two kernels' own (see their headers).  One block per CU (256 registers), 64 KB of LDS.
+#pragma once
+#include "attn_qkv.h"
+#include "attn256.h"
+
+namespace ncsn {
+
+// x: [B*256][x_ld] bf16 (raw block input: normalised for q | k | v, and the residual of the output); gsc / gsh: GroupNorm (scale | shift) tables [B][256] fp32;
+// wf: k_pack_qkv_w's output; bqk: [512] (q then k), bv: [256]; qk: [B*256][512] scratch (only the k half, columns 256.., is written); vT: [B][256][256] scratch;
+// w3f: k_pack_attn_w3's output, b3: [256]; o: [B*256][o_ld]; gn_part (may be null): float2 [B][gn_quads].  grid = B, 512 threads, A256_LDS_BYTES.
+__global__ __launch_bounds__(512, 1) void k_attn_blk256(const bf16* __restrict__ x, int x_ld, const float* __restrict__ gsc, const float* __restrict__ gsh,
+                                                       const bf16* __restrict__ wf, const float* __restrict__ bqk, const float* __restrict__ bv,
+                                                       bf16* __restrict__ qk, bf16* __restrict__ vT, float scale, const bf16* __restrict__ w3f, const float* __restrict__ b3,
+                                                       bf16* __restrict__ o, int o_ld, float out_scale, float2* __restrict__ gn_part, int gn_quads)
+{
+    constexpr int T = 256, C = 256, KT = A256_KT, NKT = T / KT;
+    static_assert(2 * QKV_STAGE + QKV_BIAS_BYTES <= A256_LDS_BYTES, "the projection phase's stages and biases inside the attention phases' LDS");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_poison();
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const int tok0 = wave * 32;
+
+    // ================= phase 1: GroupNorm-apply + q | k | v projections (k_qkv256) =================
+    auto issue_w = [&](int i) __attribute__((always_inline)) {     // weight tile i: n-tiles 2 i, 2 i + 1, all eight K steps
+        unsigned char* st = smem + (i & 1) * QKV_STAGE;
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        const bf16* base = wf + (int64_t)i * (QKV_STAGE / 2);
+#pragma unroll
+        for (int j = 0; j < QKV_STAGE / 8192; ++j) {
+            const int p = wave * (QKV_STAGE / 8192) + j;
+            __builtin_amdgcn_global_load_lds(base + p * 512 + l * 8, (lds_void*)(st + p * 1024), 16, 0, 0);
+        }
+    };
+    issue_w(0);
+    float* const sBias = reinterpret_cast<float*>(smem + 2 * QKV_STAGE);      // [512 q | k][256 v]
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    const unsigned lds_bias = (unsigned)(uintptr_t)((lds_u8*)smem) + 2 * QKV_STAGE;
+    if (tid < 192) reinterpret_cast<float4*>(sBias)[tid] = tid < 128 ? reinterpret_cast<const float4*>(bqk)[tid] : reinterpret_cast<const float4*>(bv)[tid - 128];
+
+    bf16x8 qf[2][8];                                              // the wave's queries as B operands: query tau(g, r), channels 32 c + 8 q .. + 7 (filled by the q tiles)
+    {
+        bf16x8 hf[2][8];                                          // the wave's 32 tokens x 256 channels, normalised, in operand layout (attn_qkv.h)
+        {
+            const bf16* xb = x + ((int64_t)b * T + tok0 + 8 * (r >> 2) + (r & 3)) * x_ld + 8 * q;
+            bf16x8 raw[2][8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) raw[g][kc] = *reinterpret_cast<const bf16x8*>(xb + (int64_t)(4 * g) * x_ld + 32 * kc);
+            const float* sc = gsc + (int64_t)b * C + 8 * q;
+            const float* sh = gsh + (int64_t)b * C + 8 * q;
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                const float4 s0 = *reinterpret_cast<const float4*>(sc + 32 * kc), s1 = *reinterpret_cast<const float4*>(sc + 32 * kc + 4);
+                const float4 h0 = *reinterpret_cast<const float4*>(sh + 32 * kc), h1 = *reinterpret_cast<const float4*>(sh + 32 * kc + 4);
+                const float s[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) hf[g][kc][j] = (bf16)((float)raw[g][kc][j] * s[j] + h[j]);
+            }
+        }
+        int le;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(le));
+        const int re = le & 15, qe = le >> 4;
+        // a q | k tile (two n-tiles = one 32-channel group with interleaved rows: the lane ends up with EIGHT consecutive channels of its token)
+        auto qk_tile = [&](int t, bf16x8 (&w)[2]) __attribute__((always_inline)) {
+            // tile t has landed.  Younger than its requests are only the two stores of tile t - 1 -- where that tile stored: the q tiles (and hence tile 8's predecessor) do not
+            if (t <= 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue_w(t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* sW = smem + (t & 1) * QKV_STAGE;
+            f32x4 a[2][2];
+#pragma unroll
+            for (int ntl = 0; ntl < 2; ++ntl) {
+                a[ntl][0] = f32x4{0.f, 0.f, 0.f, 0.f}; a[ntl][1] = a[ntl][0];
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) {
+                    const bf16x8 fa = *reinterpret_cast<const bf16x8*>(sW + (ntl * 8 + kc) * 1024 + le * 16);
+                    a[ntl][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, hf[0][kc], a[ntl][0], 0, 0, 0);
+                    a[ntl][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, hf[1][kc], a[ntl][1], 0, 0, 0);
+                }
+            }
+            const int n = 32 * t + 8 * qe;
+            f32x4 b0, b1;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(b0), "=&v"(b1) : "v"(lds_bias + (unsigned)n * 4u) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1) :: "memory");
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { w[g][i] = (bf16)(a[0][g][i] + b0[i]); w[g][4 + i] = (bf16)(a[1][g][i] + b1[i]); }
+        };
+        // q: tiles 0..7 stay in registers (K step t of the scores); unrolled: qf is indexed by the tile
+#define NATINF_BLK_Q(t) { bf16x8 w[2]; qk_tile(t, w); qf[0][t] = w[0]; qf[1][t] = w[1]; }
+        NATINF_BLK_Q(0) NATINF_BLK_Q(1) NATINF_BLK_Q(2) NATINF_BLK_Q(3) NATINF_BLK_Q(4) NATINF_BLK_Q(5) NATINF_BLK_Q(6) NATINF_BLK_Q(7)
+#undef NATINF_BLK_Q
+        // k: tiles 8..15 -> [q | k] columns 256..
+#pragma unroll 1
+        for (int t = 8; t < 16; ++t) {
+            bf16x8 w[2];
+            qk_tile(t, w);
+            const int n = 32 * t + 8 * qe;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) *reinterpret_cast<bf16x8*>(qk + ((int64_t)b * T + tok0 + 8 * (re >> 2) + 4 * g + (re & 3)) * (2 * C) + n) = w[g];
+        }
+        // v: tiles 16..23 -> V^T (the same registers as the A operand)
+#pragma unroll 1
+        for (int t = 16; t < QKV_TILES; ++t) {
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + 1 < QKV_TILES) issue_w(t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* sW = smem + (t & 1) * QKV_STAGE;
+#pragma unroll
+            for (int ntl = 0; ntl < QKV_NTL; ++ntl) {
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) {
+                    const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sW + (ntl * 8 + kc) * 1024 + le * 16);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[0][kc], fb, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[1][kc], fb, a1, 0, 0, 0);
+                }
+                const int ch = 16 * (QKV_NTL * t + ntl - 32) + re;
+                float bb;
+                asm volatile("ds_read_b32 %0, %1" : "=v"(bb) : "v"(lds_bias + (unsigned)(512 + ch) * 4u) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb) :: "memory");
+                bf16x8 w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { w[i] = (bf16)(a0[i] + bb); w[4 + i] = (bf16)(a1[i] + bb); }
+                *reinterpret_cast<bf16x8*>(vT + ((int64_t)b * C + ch) * T + tok0 + 8 * qe) = w;
+            }
+        }
+    }
+    // every store of k and V^T is complete (vmcnt counts a store until it is written), every wave's: the block re-reads them through L2
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ================= phases 2-4: scores, softmax, P V, output projection (k_attn256<true, 8>) =================
+    constexpr int NP = 4;                                         // 1-KiB DMA pieces per wave and 32-KB tile (8 waves)
+    const bf16* kbase = qk + (int64_t)b * T * (2 * C) + C;
+    const bf16* vbase = vT + (int64_t)b * A256_D * T;
+    constexpr int qk_ld = 2 * C;
+    auto issue = [&](int i) __attribute__((always_inline)) {
+        unsigned char* st = smem + (i & 1) * A256_STAGE;
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        if (i >= 2 * NKT) {                                       // W3 tile i - 8
+            const bf16* base = w3f + (int64_t)(i - 2 * NKT) * (A256_STAGE / 2);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const int p = wave * NP + j;
+                __builtin_amdgcn_global_load_lds(base + p * 512 + l * 8, (lds_void*)(st + p * 1024), 16, 0, 0);
+            }
+        } else if (i < NKT) {
+            const bf16* base = kbase + (int64_t)(i * KT) * qk_ld;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const int p = wave * NP + j, row = 2 * p + (l >> 5), ch = l & 31;
+                const int h = (row & 3) | (((row >> 3) & 3) << 2);
+                __builtin_amdgcn_global_load_lds(base + row * qk_ld + ((ch ^ h) << 3), (lds_void*)(st + p * 1024), 16, 0, 0);
+            }
+        } else {
+            const bf16* base = vbase + (i - NKT) * KT;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const int p = wave * NP + j, d = 8 * p + (l >> 3), ch = l & 7;
+                __builtin_amdgcn_global_load_lds(base + d * T + ((ch ^ ((d >> 1) & 7)) << 3), (lds_void*)(st + p * 1024), 16, 0, 0);
+            }
+        }
+    };
+    issue(0);
+
+    f32x4 acc[2][16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { acc[0][t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int krow = 8 * (r >> 2) + (r & 3);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        issue(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* sK = smem + (kt & 1) * A256_STAGE;
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int row = 32 * (tl >> 1) + 4 * (tl & 1) + krow;
+                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(sK + row * 512 + (((4 * c + q) ^ r) << 4));
+                acc[0][4 * kt + tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, qf[0][c], acc[0][4 * kt + tl], 0, 0, 0);
+                acc[1][4 * kt + tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, qf[1][c], acc[1][4 * kt + tl], 0, 0, 0);
+            }
+    }
+    float inv[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mx = fmaxf(mx, acc[g][t][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float p = __expf((acc[g][t][i] - mx) * scale); acc[g][t][i] = p; sum += p; }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        inv[g] = 1.0f / sum;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    bf16x8 pf[2][8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { pf[g][c][i] = (bf16)(acc[g][2 * c][i] * inv[g]); pf[g][c][4 + i] = (bf16)(acc[g][2 * c + 1][i] * inv[g]); }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 oacc[2][16];
+#pragma unroll
+    for (int dt = 0; dt < 16; ++dt) { oacc[0][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc[1][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int vt = 0; vt < NKT; ++vt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        issue(NKT + vt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* sV = smem + ((NKT + vt) & 1) * A256_STAGE;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int dt = 0; dt < 16; ++dt) {
+                const bf16x8 fv = *reinterpret_cast<const bf16x8*>(sV + (16 * dt + r) * 128 + (((4 * cc + q) ^ (r >> 1)) << 4));
+                oacc[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pf[0][2 * vt + cc], oacc[0][dt], 0, 0, 0);
+                oacc[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pf[1][2 * vt + cc], oacc[1][dt], 0, 0, 0);
+            }
+    }
+    bf16x8 of[2][8];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { of[g][kc][i] = (bf16)oacc[g][2 * kc][i]; of[g][kc][4 + i] = (bf16)oacc[g][2 * kc + 1][i]; }
+    __builtin_amdgcn_sched_barrier(0);
+    int le;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(le));
+    const int re = le & 15, qe = le >> 4;
+    float2* const sred = reinterpret_cast<float2*>(smem);
+    float2 part[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < 4) issue(2 * NKT + t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* sW = smem + (t & 1) * A256_STAGE;
+        f32x4 a3[2][4];
+#pragma unroll
+        for (int ntl = 0; ntl < 4; ++ntl) { a3[0][ntl] = f32x4{0.f, 0.f, 0.f, 0.f}; a3[1][ntl] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ntl = 0; ntl < 4; ++ntl)
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(sW + (ntl * 8 + kc) * 1024 + le * 16);
+                a3[0][ntl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, of[0][kc], a3[0][ntl], 0, 0, 0);
+                a3[1][ntl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, of[1][kc], a3[1][ntl], 0, 0, 0);
+            }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int n = 64 * t + 32 * pr + 8 * qe;
+            const float4 b0 = *reinterpret_cast<const float4*>(b3 + n), b1 = *reinterpret_cast<const float4*>(b3 + n + 4);
+            float s0 = 0.f, ss0 = 0.f, s1 = 0.f, ss1 = 0.f;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int64_t row = (int64_t)b * T + tok0 + 8 * (re >> 2) + 4 * g + (re & 3);      // query tau(g, re)
+                const bf16x8 rx = *reinterpret_cast<const bf16x8*>(x + row * x_ld + n);
+                const f32x4 lo = a3[g][2 * pr], hi = a3[g][2 * pr + 1];
+                float v[8] = {lo[0] + b0.x, lo[1] + b0.y, lo[2] + b0.z, lo[3] + b0.w, hi[0] + b1.x, hi[1] + b1.y, hi[2] + b1.z, hi[3] + b1.w};
+                bf16x8 w;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { v[i] = (v[i] + (float)rx[i]) * out_scale; w[i] = (bf16)v[i]; }
+                *reinterpret_cast<bf16x8*>(o + row * o_ld + n) = w;
+                s0 += (v[0] + v[1]) + (v[2] + v[3]);  ss0 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                s1 += (v[4] + v[5]) + (v[6] + v[7]);  ss1 += (v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]);
+            }
+            part[4 * t + 2 * pr] = make_float2(dpp_row_sum(s0), dpp_row_sum(ss0));
+            part[4 * t + 2 * pr + 1] = make_float2(dpp_row_sum(s1), dpp_row_sum(ss1));
+        }
+    }
+    if (gn_part) {
+        __syncthreads();
+        if (re == 0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sred[wave * 64 + 8 * (k >> 1) + 2 * qe + (k & 1)] = part[k];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float s = 0.f, ss = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { s += sred[w * 64 + tid].x; ss += sred[w * 64 + tid].y; }
+            gn_part[(int64_t)b * gn_quads + tid] = make_float2(s, ss);
+        }
+    }
+}
+
+}  // namespace ncsn

@@ -41,6 +41,7 @@
 #include "attn_fused.h"
 #include "attn256.h"
 #include "attn_qkv.h"
+#include "attn_blk256.h"
 #include "flash_attn.h"
 
 using namespace ncsn;
@@ -233,6 +234,7 @@ using CfgG32 = ConvGnCfg<32>; using CfgG16 = ConvGnCfg<16>; using CfgG16W = Conv
 #endif
 int g_fuse_head = 1;               // natinf_set_fuse_head (read when a plan is BUILT): GroupNorm + SiLU + the 128 -> 3 output convolution as ONE launch (head_conv.h)
 int g_cg8_tm4 = 1;                 // natinf_set_conv_gn8_tile: 1 = 8x8 level on 64-pixel x 256-channel tiles (one image per tile, two blocks per CU), 0 = 128 x 256 (two images per tile; -DNATINF_DEV builds)
+int g_attn_blk = 1;                // natinf_set_attn_block (read when a plan is BUILT): the whole 16x16 attention block -- k_qkv256 + k_attn256<true, 8> -- as ONE launch (attn_blk256.h: q stays in registers)
 int g_attn_qkv = 1;                // natinf_set_attn_qkv (read when a plan is BUILT): GroupNorm-apply + the q | k | v projections of the 16x16 attention as ONE launch (attn_qkv.h)
 int g_attn_w8 = 1;                 // natinf_set_attn_waves8: k_attn256<true> as one 8-wave block per sample (1) or two 4-wave blocks (0)
 int g_attn_proj = 1;               // natinf_set_attn_proj (read when a plan is BUILT): the 16x16 attention's output projection + skip + GroupNorm partials inside k_attn256
@@ -317,6 +319,7 @@ bool configure_gemm_kernels() {
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<false>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<true>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_blk256), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
          set_lds<AttnCfg<2, 4>>(&k_attn_fused<2, 4>) && set_lds<AttnCfg<3, 6>>(&k_attn_fused<3, 6>) &&
          set_lds<AttnCfg<3, 5>>(&k_attn_fused<3, 5>) &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess &&
@@ -349,8 +352,8 @@ int g_cg_regw = 1;                 // natinf_set_conv_gn_regw: 1 = k_conv_gn2 (w
 // tile rows of the fused-convolution instantiation a launch takes: 128 x 256 tiles at 16x16 (N % 256 == 0) and at 8x8 (two images per tile), 256 x 128 elsewhere
 // the k_conv_gn3 shape a fused-convolution launch takes (-1: k_conv_gn2).  One block per CU exposes a tile's prologue and epilogue (~28k clocks), which the two
 // co-resident blocks of k_conv_gn2 partly hide: k_conv_gn3 is ahead where the K loop is long (same-process A/B at B = 512, profiles/r05/cg3_v2_ab.log: 1.04-1.08 at
-// K >= 2,304 on 512 x 128 tiles, 1.035-1.04 on 256 x 256 tiles at 32x32, 1.01-1.06 at K >= 2,816 at 16x16) and behind at short K (0.92-0.98 at K = 1,152 .. 1,536)
-int g_cg3_min_k[3] = {2304, 0, 2560};      // natinf_set_conv_gn_w128_min_k: smallest K (9 cin + shortcut channels) per shape that takes k_conv_gn3
+// K >= 2,304 on 512 x 128 tiles, 1.035-1.04 on 256 x 256 tiles at 32x32, 1.01-1.06 at K >= 2,816 at 16x16; inside the network, rocprofv3 trace of both in one process, profiles/r05/cg3_in_network_ab_by_shape.txt: 1.08-1.15 at K >= 2,304 at 32x32, 1.02-1.09 at K >= 2,304 at 16x16) and level or behind at short K (0.97-0.99 at K = 1,152 .. 1,536)
+int g_cg3_min_k[3] = {2304, 0, 2304};      // natinf_set_conv_gn_w128_min_k: smallest K (9 cin + shortcut channels) per shape that takes k_conv_gn3
 inline int conv_gn3_shape(const GemmArgs& g) {
     const int res = 1 << g.logW;
     if (!g_cg3 || !g_cg_regw || !g.b_frag || g.N % 128) return -1;
@@ -629,8 +632,8 @@ int launch_gemm(const GemmArgs& g0, hipStream_t s) {
     }
     if (g_record) {
         char line[160];
-        snprintf(line, sizeof(line), "%d %d %d %d %d %d %s/e%d\n", g.M, g.N, g.taps * g.a0_C, g.a1 ? g.a1_C : 0, g.taps, g.batch, variant_name(v),
-                 v == V_CONV_GN ? conv_gn_epi(g) : effective_epi(v, g));
+        snprintf(line, sizeof(line), "%d %d %d %d %d %d %s/e%d\n", g.M, g.N, g.taps * g.a0_C, g.a1 ? g.a1_C : 0, g.taps, g.batch,
+                 v == V_CONV_GN && conv_gn3_shape(g) >= 0 ? "conv_gn3" : variant_name(v), v == V_CONV_GN ? conv_gn_epi(g) : effective_epi(v, g));
         *g_record += line;
         return v == V_CONV_GN ? conv_gn_part_rows(g) : variant_bm(v);
     }
@@ -971,13 +974,18 @@ struct Builder {
         TRef h = new_act(m.res, C);
         if (!fuse_qkv) emit_gn_apply(x, sc, sh, h, nullptr, ACT_NONE, RS_NONE);
         const int64_t qk = arena.alloc((int64_t)T * 2 * C * 2), vT = arena.alloc((int64_t)C * T * 2);
+        // k_attn_blk256: projections, attention and output projection of a sample in ONE launch (needs the three fusions it is made of)
+        const bool blk = fuse_qkv && g_attn256 && g_attn_proj && g_attn_w8 && g_attn_blk;
+        int64_t wqkvf = -1;
+        const int64_t sc_q = sc, sh_q = sh;
         if (fuse_qkv) {
-            const int64_t wqkvf = wres((int64_t)3 * C * C * 2);
+            wqkvf = wres((int64_t)3 * C * C * 2);
             const int64_t s0 = pw[0], s1 = pw[1], s2 = pw[2];
             E.packs.push_back([=](const PackCtx& p) {
                 hipLaunchKernelGGL(k_pack_qkv_w, dim3(3 * 256), dim3(256), 0, p.stream, p.params + s0, p.params + s1, p.params + s2, reinterpret_cast<bf16*>(p.packed + wqkvf));
             });
             const int64_t sc_ = sc, sh_ = sh;
+            if (!blk)
             op(CLS_GEMM, [=](const Ctx& c) {
                 if (g_record) return;
                 hipLaunchKernelGGL(k_qkv256, dim3((unsigned)c.B), dim3(512), QKV_LDS_BYTES, c.stream, (const bf16*)c.act(x), x.ld, c.at<float>(sc_), c.at<float>(sh_),
@@ -1018,7 +1026,12 @@ struct Builder {
             // 16x16 attention: scores, softmax and P V of a sample in one block (attn_fused.h, two-phase: V^T follows K through LDS)
             op(CLS_GEMM, [=](const Ctx& c) {
                 if (g_record) return;                    // natinf_ncsnpp_describe_gemms: GEMM launches only, nothing touches memory
-                if (proj) {
+                if (blk) {
+                    hipLaunchKernelGGL(k_attn_blk256, dim3((unsigned)c.B), dim3(512), A256_LDS_BYTES, c.stream, (const bf16*)c.act(x), x.ld, c.at<float>(sc_q), c.at<float>(sh_q),
+                                       c.w<bf16>(wqkvf), c.w<float>(bqk), c.w<float>(bv), c.at<bf16>(qk), c.at<bf16>(vT), 1.0f / sqrtf((float)C), c.w<bf16>(w3f), c.w<float>(b3),
+                                       c.act(out), out.ld, rs_attn, po_attn.valid ? c.at<float2>(po_attn.off) : (float2*)nullptr, po_attn.quads);
+                    if (po_attn.valid) c.part_bm[po_attn.id] = 256;
+                } else if (proj) {
                     if (g_attn_w8) {
                         hipLaunchKernelGGL((k_attn256<true, 8>), dim3((unsigned)c.B), dim3(512), A256_LDS_BYTES, c.stream, c.at<bf16>(qk), 2 * C, C, c.at<bf16>(vT), c.act(out), out.ld,
                                            1.0f / sqrtf((float)C), c.w<bf16>(w3f), c.w<float>(b3), (const bf16*)c.act(x), x.ld, rs_attn,
@@ -1743,6 +1756,7 @@ int natinf_set_attn256(int on) {
     g_attn256 = on != 0; return NATINF_OK;
 }
 int natinf_set_conv_gn_warm(int mask) { if (mask < 0 || mask > 15) return NATINF_EINVAL; g_cg_warm = mask; return NATINF_OK; }
+int natinf_set_attn_block(int on) { g_attn_blk = on != 0; return NATINF_OK; }
 int natinf_set_attn_qkv(int on) { g_attn_qkv = on != 0; return NATINF_OK; }
 int natinf_set_attn_waves8(int on) { g_attn_w8 = on != 0; return NATINF_OK; }
 int natinf_set_attn_proj(int on) { g_attn_proj = on != 0; return NATINF_OK; }

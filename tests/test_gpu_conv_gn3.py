@@ -72,7 +72,7 @@ def _run(res, B, cin, N, c1, t, up_flags, mask, rows, parts):
     return out.cpu(), (part.cpu() if parts else None)
 
 
-_DEFAULT_MASK, _DEFAULT_MIN_K = 7, (2304, 0, 2560)          # (csrc/ncsnpp.hip: g_cg3, g_cg3_min_k)
+_DEFAULT_MASK, _DEFAULT_MIN_K = 7, (2304, 0, 2304)          # (csrc/ncsnpp.hip: g_cg3, g_cg3_min_k)
 
 
 @pytest.mark.parametrize("res,B,cin,N,c1,resid,parts,up", [
@@ -118,9 +118,9 @@ def test_conv_gn3_is_reproducible():
 
 
 def test_the_default_rule_sends_long_k_launches_to_conv_gn3():
-    """natinf_set_conv_gn_w128_min_k defaults (2304 / 0 / 2560): the GroupNorm partial rows tell which kernel ran -- 512 / 256 pixels per row for k_conv_gn3,
+    """natinf_set_conv_gn_w128_min_k defaults (2304 / 0 / 2304): the GroupNorm partial rows tell which kernel ran -- 512 / 256 pixels per row for k_conv_gn3,
     256 / 128 for k_conv_gn2."""
-    for res, B, cin, N, c1, rows in ((32, 1, 128, 128, 0, 256), (32, 1, 256, 128, 0, 512), (32, 1, 128, 256, 0, 256), (16, 2, 256, 256, 0, 128), (16, 2, 256, 256, 256, 256)):
+    for res, B, cin, N, c1, rows in ((32, 1, 128, 128, 0, 256), (32, 1, 256, 128, 0, 512), (32, 1, 128, 256, 0, 256), (16, 2, 128, 256, 0, 128), (16, 2, 256, 256, 0, 256)):
         t, ref = _case(res, B, cin, N, c1, False, 0, 77 + res + cin + c1)
         from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
         dev, M = "cuda", B * res * res
