@@ -9,23 +9,26 @@
 //   * k and V^T are still written (one block cannot keep 256 KB on chip) and re-read by the SAME block right away: the stores are complete behind `s_waitcnt vmcnt(0)`
 //     (one XCD's L2; the block's own L1 holds no line of them: nothing of this launch read them before), a barrier publishes them to the other waves, and the LDS-DMA
 //     of the attention phases finds them in L2 -- HBM sees the writes only.
-// Arithmetic, tile loops, swizzles, projection and GroupNorm partials: the two kernels' own (see their headers).  One block per CU (256 registers), 64 KB of LDS.
+// Arithmetic, tile loops, swizzles, projection and GroupNorm partials: the two kernels' own (see their headers).  One block per CU (256 registers), 67 KB of LDS;
+// the projection phase's weight tiles come three tiles ahead (four 16-KB stages: what k_qkv256's four co-resident blocks hide, one block must prefetch).
 #pragma once
 #include "attn_qkv.h"
 #include "attn256.h"
 
 namespace ncsn {
 
+constexpr int ABLK_STAGES = 4, ABLK_LDS_BYTES = ABLK_STAGES * A256_STAGE + QKV_BIAS_BYTES;      // four 32-KB stages (K / V^T / W3 tiles three ahead), the projection phase's biases behind them
+
 // x: [B*256][x_ld] bf16 (raw block input: normalised for q | k | v, and the residual of the output); gsc / gsh: GroupNorm (scale | shift) tables [B][256] fp32;
 // wf: k_pack_qkv_w's output; bqk: [512] (q then k), bv: [256]; qk: [B*256][512] scratch (only the k half, columns 256.., is written); vT: [B][256][256] scratch;
-// w3f: k_pack_attn_w3's output, b3: [256]; o: [B*256][o_ld]; gn_part (may be null): float2 [B][gn_quads].  grid = B, 512 threads, A256_LDS_BYTES.
+// w3f: k_pack_attn_w3's output, b3: [256]; o: [B*256][o_ld]; gn_part (may be null): float2 [B][gn_quads].  grid = B, 512 threads, ABLK_LDS_BYTES.
 __global__ __launch_bounds__(512, 1) void k_attn_blk256(const bf16* __restrict__ x, int x_ld, const float* __restrict__ gsc, const float* __restrict__ gsh,
                                                        const bf16* __restrict__ wf, const float* __restrict__ bqk, const float* __restrict__ bv,
                                                        bf16* __restrict__ qk, bf16* __restrict__ vT, float scale, const bf16* __restrict__ w3f, const float* __restrict__ b3,
                                                        bf16* __restrict__ o, int o_ld, float out_scale, float2* __restrict__ gn_part, int gn_quads)
 {
     constexpr int T = 256, C = 256, KT = A256_KT, NKT = T / KT;
-    static_assert(2 * QKV_STAGE + QKV_BIAS_BYTES <= A256_LDS_BYTES, "the projection phase's stages and biases inside the attention phases' LDS");
+    static_assert(4 * QKV_STAGE <= ABLK_STAGES * A256_STAGE && QKV_TILES == 24, "the projection phase's four stages inside the attention phases' LDS; its biases behind them");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     lds_poison();
     typedef __attribute__((address_space(3))) void lds_void;
@@ -35,8 +38,13 @@ __global__ __launch_bounds__(512, 1) void k_attn_blk256(const bf16* __restrict__
     const int tok0 = wave * 32;
 
     // ================= phase 1: GroupNorm-apply + q | k | v projections (k_qkv256) =================
+    // One block per CU here (the attention phases need 256 registers), so the weight tiles -- an L2 round trip each, 2-4k clocks against ~1k clocks of MFMAs per
+    // tile -- come THREE tiles ahead through four 16-KB stages (k_qkv256 hides them behind four co-resident blocks instead).  Requests, loads and stores retire in
+    // issue order: the wait for tile t leaves everything issued behind its requests in flight -- the stores of tiles t - 3 .. t - 1 (two per tile; the q tiles store
+    // nothing) and the requests of tiles t + 1, t + 2 (two per wave and tile).
+    constexpr int NST = 4, AHEAD = NST - 1;
     auto issue_w = [&](int i) __attribute__((always_inline)) {     // weight tile i: n-tiles 2 i, 2 i + 1, all eight K steps
-        unsigned char* st = smem + (i & 1) * QKV_STAGE;
+        unsigned char* st = smem + (i & (NST - 1)) * QKV_STAGE;
         int l;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
         const bf16* base = wf + (int64_t)i * (QKV_STAGE / 2);
@@ -46,10 +54,10 @@ __global__ __launch_bounds__(512, 1) void k_attn_blk256(const bf16* __restrict__
             __builtin_amdgcn_global_load_lds(base + p * 512 + l * 8, (lds_void*)(st + p * 1024), 16, 0, 0);
         }
     };
-    issue_w(0);
-    float* const sBias = reinterpret_cast<float*>(smem + 2 * QKV_STAGE);      // [512 q | k][256 v]
+    issue_w(0); issue_w(1); issue_w(2);
+    float* const sBias = reinterpret_cast<float*>(smem + ABLK_STAGES * A256_STAGE);     // [512 q | k][256 v], behind the attention phases' stages
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
-    const unsigned lds_bias = (unsigned)(uintptr_t)((lds_u8*)smem) + 2 * QKV_STAGE;
+    const unsigned lds_bias = (unsigned)(uintptr_t)((lds_u8*)smem) + ABLK_STAGES * A256_STAGE;
     if (tid < 192) reinterpret_cast<float4*>(sBias)[tid] = tid < 128 ? reinterpret_cast<const float4*>(bqk)[tid] : reinterpret_cast<const float4*>(bv)[tid - 128];
 
     bf16x8 qf[2][8];                                              // the wave's queries as B operands: query tau(g, r), channels 32 c + 8 q .. + 7 (filled by the q tiles)
@@ -78,15 +86,20 @@ __global__ __launch_bounds__(512, 1) void k_attn_blk256(const bf16* __restrict__
         int le;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(le));
         const int re = le & 15, qe = le >> 4;
-        // a q | k tile (two n-tiles = one 32-channel group with interleaved rows: the lane ends up with EIGHT consecutive channels of its token)
-        auto qk_tile = [&](int t, bf16x8 (&w)[2]) __attribute__((always_inline)) {
-            // tile t has landed.  Younger than its requests are only the two stores of tile t - 1 -- where that tile stored: the q tiles (and hence tile 8's predecessor) do not
-            if (t <= 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        // tile t has landed for every wave, and everyone is done with the stage tile t + 3 goes into (tile t - 1's)
+        auto tile_begin = [&](auto t_tag) __attribute__((always_inline)) {
+            constexpr int t = decltype(t_tag)::value;
+            constexpr int stores = 2 * ((t - 3 >= 8) + (t - 2 >= 8) + (t - 1 >= 8)), ahead = 2 * ((t + 1 < QKV_TILES) + (t + 2 < QKV_TILES));
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(stores + ahead) : "memory");
             __builtin_amdgcn_s_barrier();
-            issue_w(t + 1);
+            if constexpr (t + AHEAD < QKV_TILES) issue_w(t + AHEAD);
             __builtin_amdgcn_sched_barrier(0);
-            const unsigned char* sW = smem + (t & 1) * QKV_STAGE;
+        };
+        // a q | k tile (two n-tiles = one 32-channel group with interleaved rows: the lane ends up with EIGHT consecutive channels of its token)
+        auto qk_tile = [&](auto t_tag, bf16x8 (&w)[2]) __attribute__((always_inline)) {
+            constexpr int t = decltype(t_tag)::value;
+            tile_begin(t_tag);
+            const unsigned char* sW = smem + (t & (NST - 1)) * QKV_STAGE;
             f32x4 a[2][2];
 #pragma unroll
             for (int ntl = 0; ntl < 2; ++ntl) {
@@ -107,27 +120,21 @@ __global__ __launch_bounds__(512, 1) void k_attn_blk256(const bf16* __restrict__
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { w[g][i] = (bf16)(a[0][g][i] + b0[i]); w[g][4 + i] = (bf16)(a[1][g][i] + b1[i]); }
         };
-        // q: tiles 0..7 stay in registers (K step t of the scores); unrolled: qf is indexed by the tile
-#define NATINF_BLK_Q(t) { bf16x8 w[2]; qk_tile(t, w); qf[0][t] = w[0]; qf[1][t] = w[1]; }
+        using std::integral_constant;
+        // q: tiles 0..7 stay in registers (K step t of the scores)
+#define NATINF_BLK_Q(t) { bf16x8 w[2]; qk_tile(integral_constant<int, t>{}, w); qf[0][t] = w[0]; qf[1][t] = w[1]; }
         NATINF_BLK_Q(0) NATINF_BLK_Q(1) NATINF_BLK_Q(2) NATINF_BLK_Q(3) NATINF_BLK_Q(4) NATINF_BLK_Q(5) NATINF_BLK_Q(6) NATINF_BLK_Q(7)
 #undef NATINF_BLK_Q
         // k: tiles 8..15 -> [q | k] columns 256..
-#pragma unroll 1
-        for (int t = 8; t < 16; ++t) {
-            bf16x8 w[2];
-            qk_tile(t, w);
-            const int n = 32 * t + 8 * qe;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) *reinterpret_cast<bf16x8*>(qk + ((int64_t)b * T + tok0 + 8 * (re >> 2) + 4 * g + (re & 3)) * (2 * C) + n) = w[g];
-        }
+#define NATINF_BLK_K(t) { bf16x8 w[2]; qk_tile(integral_constant<int, t>{}, w); const int n = 32 * t + 8 * qe;                                   \
+            _Pragma("unroll") for (int g = 0; g < 2; ++g) *reinterpret_cast<bf16x8*>(qk + ((int64_t)b * T + tok0 + 8 * (re >> 2) + 4 * g + (re & 3)) * (2 * C) + n) = w[g]; }
+        NATINF_BLK_K(8) NATINF_BLK_K(9) NATINF_BLK_K(10) NATINF_BLK_K(11) NATINF_BLK_K(12) NATINF_BLK_K(13) NATINF_BLK_K(14) NATINF_BLK_K(15)
+#undef NATINF_BLK_K
         // v: tiles 16..23 -> V^T (the same registers as the A operand)
-#pragma unroll 1
-        for (int t = 16; t < QKV_TILES; ++t) {
-            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (t + 1 < QKV_TILES) issue_w(t + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned char* sW = smem + (t & 1) * QKV_STAGE;
+        auto v_tile = [&](auto t_tag) __attribute__((always_inline)) {
+            constexpr int t = decltype(t_tag)::value;
+            tile_begin(t_tag);
+            const unsigned char* sW = smem + (t & (NST - 1)) * QKV_STAGE;
 #pragma unroll
             for (int ntl = 0; ntl < QKV_NTL; ++ntl) {
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
@@ -146,7 +153,9 @@ __global__ __launch_bounds__(512, 1) void k_attn_blk256(const bf16* __restrict__
                 for (int i = 0; i < 4; ++i) { w[i] = (bf16)(a0[i] + bb); w[4 + i] = (bf16)(a1[i] + bb); }
                 *reinterpret_cast<bf16x8*>(vT + ((int64_t)b * C + ch) * T + tok0 + 8 * qe) = w;
             }
-        }
+        };
+        v_tile(integral_constant<int, 16>{}); v_tile(integral_constant<int, 17>{}); v_tile(integral_constant<int, 18>{}); v_tile(integral_constant<int, 19>{});
+        v_tile(integral_constant<int, 20>{}); v_tile(integral_constant<int, 21>{}); v_tile(integral_constant<int, 22>{}); v_tile(integral_constant<int, 23>{});
     }
     // every store of k and V^T is complete (vmcnt counts a store until it is written), every wave's: the block re-reads them through L2
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(512, 1) void k_attn_blk256(const bf16* __restrict__
     const bf16* vbase = vT + (int64_t)b * A256_D * T;
     constexpr int qk_ld = 2 * C;
     auto issue = [&](int i) __attribute__((always_inline)) {
-        unsigned char* st = smem + (i & 1) * A256_STAGE;
+        unsigned char* st = smem + (i & (ABLK_STAGES - 1)) * A256_STAGE;
         int l;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
         if (i >= 2 * NKT) {                                       // W3 tile i - 8
@@ -185,7 +194,10 @@ __global__ __launch_bounds__(512, 1) void k_attn_blk256(const bf16* __restrict__
             }
         }
     };
-    issue(0);
+    // the twelve tiles (four of K, four of V^T, four of W3) come THREE ahead through four stages: an L2 round trip is 2-4k clocks, a tile 1-2k clocks of MFMAs, and one
+    // block per CU has nothing else to run meanwhile.  Phases 2-3 issue no other vector-memory operation: the wait for tile i leaves the eight requests of tiles
+    // i + 1, i + 2 in flight; the projection phase (residual loads, stores) waits for everything.
+    issue(0); issue(1); issue(2);
 
     f32x4 acc[2][16];
 #pragma unroll
@@ -193,11 +205,11 @@ __global__ __launch_bounds__(512, 1) void k_attn_blk256(const bf16* __restrict__
     const int krow = 8 * (r >> 2) + (r & 3);
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        issue(kt + 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // (the raw barrier: __syncthreads() carries a fence that waits vmcnt(0) -- for the two tiles in flight too)
+        issue(kt + 3);
         __builtin_amdgcn_sched_barrier(0);
-        const unsigned char* sK = smem + (kt & 1) * A256_STAGE;
+        const unsigned char* sK = smem + (kt & 3) * A256_STAGE;
 #pragma unroll
         for (int tl = 0; tl < 4; ++tl)
 #pragma unroll
@@ -241,11 +253,11 @@ __global__ __launch_bounds__(512, 1) void k_attn_blk256(const bf16* __restrict__
     for (int dt = 0; dt < 16; ++dt) { oacc[0][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc[1][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int vt = 0; vt < NKT; ++vt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        issue(NKT + vt + 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // (the raw barrier: __syncthreads() carries a fence that waits vmcnt(0) -- for the two tiles in flight too)
+        issue(NKT + vt + 3);
         __builtin_amdgcn_sched_barrier(0);
-        const unsigned char* sV = smem + ((NKT + vt) & 1) * A256_STAGE;
+        const unsigned char* sV = smem + ((NKT + vt) & 3) * A256_STAGE;
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
@@ -272,9 +284,9 @@ __global__ __launch_bounds__(512, 1) void k_attn_blk256(const bf16* __restrict__
     for (int t = 0; t < 4; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t + 1 < 4) issue(2 * NKT + t + 1);
+        if (t + 3 < 4) issue(2 * NKT + t + 3);
         __builtin_amdgcn_sched_barrier(0);
-        const unsigned char* sW = smem + (t & 1) * A256_STAGE;
+        const unsigned char* sW = smem + ((2 * NKT + t) & 3) * A256_STAGE;
         f32x4 a3[2][4];
 #pragma unroll
         for (int ntl = 0; ntl < 4; ++ntl) { a3[0][ntl] = f32x4{0.f, 0.f, 0.f, 0.f}; a3[1][ntl] = f32x4{0.f, 0.f, 0.f, 0.f}; }

@@ -319,7 +319,7 @@ bool configure_gemm_kernels() {
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<false>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<true>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
-         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_blk256), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_blk256), hipFuncAttributeMaxDynamicSharedMemorySize, ABLK_LDS_BYTES) == hipSuccess &&
          set_lds<AttnCfg<2, 4>>(&k_attn_fused<2, 4>) && set_lds<AttnCfg<3, 6>>(&k_attn_fused<3, 6>) &&
          set_lds<AttnCfg<3, 5>>(&k_attn_fused<3, 5>) &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess &&
@@ -1027,7 +1027,7 @@ struct Builder {
             op(CLS_GEMM, [=](const Ctx& c) {
                 if (g_record) return;                    // natinf_ncsnpp_describe_gemms: GEMM launches only, nothing touches memory
                 if (blk) {
-                    hipLaunchKernelGGL(k_attn_blk256, dim3((unsigned)c.B), dim3(512), A256_LDS_BYTES, c.stream, (const bf16*)c.act(x), x.ld, c.at<float>(sc_q), c.at<float>(sh_q),
+                    hipLaunchKernelGGL(k_attn_blk256, dim3((unsigned)c.B), dim3(512), ABLK_LDS_BYTES, c.stream, (const bf16*)c.act(x), x.ld, c.at<float>(sc_q), c.at<float>(sh_q),
                                        c.w<bf16>(wqkvf), c.w<float>(bqk), c.w<float>(bv), c.at<bf16>(qk), c.at<bf16>(vT), 1.0f / sqrtf((float)C), c.w<bf16>(w3f), c.w<float>(b3),
                                        c.act(out), out.ld, rs_attn, po_attn.valid ? c.at<float2>(po_attn.off) : (float2*)nullptr, po_attn.quads);
                     if (po_attn.valid) c.part_bm[po_attn.id] = 256;
