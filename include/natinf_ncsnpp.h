@@ -94,7 +94,8 @@ int natinf_debug_gemm(int variant, int M, int N, int K0, int K1, int taps, int l
 int natinf_debug_quant_fp8_rows(const float* w, void* q, float* row_scale, int rows, int cols, natinf_stream_t stream);
 /* a_mx (optional): E8M0 block scales of a8 (then a_scale is normally NULL), stored K-tile major: the byte of (row r, 32-block
  * kb) at [(kb / 4) * M * 4 + r * 4 + kb % 4], readable up to 256-row granularity (allocate ceil(M / 256) * 256 rows per
- * plane).  c_mode 0 bf16, 1 fp32, 3 = fp8 e4m3 bytes [M][N] + block scales c_mx in the same layout (N % 128 == 0). */
+ * plane).  c_mode 0 bf16, 1 fp32, 3 = fp8 e4m3 bytes [M][N] + block scales c_mx in the same layout (N % 128 == 0);
+ * c_mode | (2 << 8) applies the tanh-GELU first (3 | 2 << 8 = the fc1 epilogue of the MMDiT engine's fp8 path). */
 /* One plain GEMM C[M][N] = A[M][K] B[N][K]^T (bf16 operands) with the fused epilogue terms, any of which may be NULL: column bias,
  * row bias, per-sample row vector and gate ([samples][N], sample = row >> log_rows_per_sample), bf16 / fp32 residual [M][N], scale,
  * activation (0 none, 1 SiLU, 2 tanh-GELU); output bf16 or fp32 [M][N]; gn_part (optional) receives (sum, sum of squares) per
@@ -137,8 +138,8 @@ int natinf_set_gemm_half_issue(int on);
  * 0 = by the pre-round-4 rules; a value >= 10 sets the four-wave tile's ratio to value / 10 (tuning runs). */
 int natinf_set_gemm_round_model(int on);
 /* A/B switch for tuning: 1 (default) = plain GEMMs that took the 256 x 256 tile of eight waves (two per SIMD, 128 x 64 wave tiles) take the 256 x 256 x 64 tile of FOUR
- * waves (one per SIMD, 128 x 128 wave tiles, accumulators in AGPRs: csrc/gemm_w128.h) -- bf16 and e4m3 operands alike, except the e4m3 GEMMs that write e4m3 + E8M0 behind a
- * tanh-GELU --; 2 = those too; 0 = the eight-wave tiles as before round 4. */
+ * waves (one per SIMD, 128 x 128 wave tiles, accumulators in AGPRs: csrc/gemm_w128.h) -- bf16 and e4m3 operands alike, the e4m3 GEMMs that write e4m3 + E8M0 behind a
+ * tanh-GELU (fc1 of the MMDiT) included since round 5; 2 = all but those (the round-4 rule); 0 = the eight-wave tiles as before round 4. */
 int natinf_set_gemm_w128(int on);
 /* Tuning: row-tiles per raster group of launches with >= 8 column tiles (default 8; 0 = plain row-major tile order). */
 int natinf_set_gemm_raster(int rows);

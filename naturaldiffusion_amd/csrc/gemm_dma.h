@@ -234,7 +234,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
             if constexpr (DEQ) v[e] = __builtin_fmaf(acc[i][j][e] * rsc[i], dn[j][e], ct[sc_][j][e]);
             else v[e] = acc[i][j][e] + ct[sc_][j][e];
         }
-        if constexpr (DEQ) {
+        if constexpr (DEQ && !OUT8) {                                     // (OUT8 -- fc1 --: no row bias, scale 1: fp8_epi() checks it)
             if (g.bias_m) {                                               // (wave-uniform: only the V^T GEMMs carry a row bias)
                 asm volatile("");                                         // (a real branch: without it hipcc if-converts this into an add + four selects per value on EVERY launch)
 #pragma unroll
@@ -250,12 +250,12 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
         if constexpr (SCALE_ALWAYS) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= scale;
-        } else if (scale != 1.0f) {                                       // (wave-uniform; the transformer engines' GEMMs all have scale 1)
+        } else if (!OUT8 && scale != 1.0f) {                              // (wave-uniform; the transformer engines' GEMMs all have scale 1)
             asm volatile("");                                             // (a real branch, as above)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= scale;
         }
-        if constexpr (ACT != ACT_NONE) apply_act4(v, ACT);
+        if constexpr (ACT != ACT_NONE && !(OUT8 && ACT == ACT_GELU_TANH)) apply_act4(v, ACT);      // (OUT8 + GELU: eight values at once below)
         if constexpr (GN) {
             gs[sm][j] += (v[0] + v[1]) + (v[2] + v[3]);
             gq[sm][j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
@@ -304,13 +304,19 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
                 float v0[4], v1[4];
                 value(i, 2 * b, v0);
                 value(i, 2 * b + 1, v1);
+                if constexpr (ACT == ACT_GELU_TANH) {
+                    float v8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    gelu_tanh_fast8(v8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] = v8[e]; v1[e] = v8[4 + e]; }
+                }
                 float amax = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
                                    fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
                 amax = group4_max_nonneg(amax);
                 float inv;
                 const unsigned e8 = mx_scale_of(amax, inv);
-                *reinterpret_cast<unsigned*>(wbase + i * 16 * PROW + (2 * b) * 16) = pack_fp8x4(v0[0] * inv, v0[1] * inv, v0[2] * inv, v0[3] * inv);
-                *reinterpret_cast<unsigned*>(wbase + i * 16 * PROW + (2 * b + 1) * 16) = pack_fp8x4(v1[0] * inv, v1[1] * inv, v1[2] * inv, v1[3] * inv);
+                *reinterpret_cast<unsigned*>(wbase + i * 16 * PROW + (2 * b) * 16) = pack_fp8x4<false>(v0[0] * inv, v0[1] * inv, v0[2] * inv, v0[3] * inv);
+                *reinterpret_cast<unsigned*>(wbase + i * 16 * PROW + (2 * b + 1) * 16) = pack_fp8x4<false>(v1[0] * inv, v1[1] * inv, v1[2] * inv, v1[3] * inv);
                 e8pair |= e8 << (8 * b);
             }
             // the wave's 64 columns are blocks (wn & 1) * 2 + {0, 1} of their 128-column group: two adjacent scale bytes

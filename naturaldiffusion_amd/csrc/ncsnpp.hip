@@ -474,7 +474,7 @@ int fp8_epi(const GemmArgs& g) {
     if (g.c_mode == OUT_F32 && g.resid_f32 && !g.bias_m && g.act == ACT_NONE && g.resid_f32_ld % 4 == 0 && g.c_ld % 4 == 0) return 3;
     if (g.resid_f32 || g.gate) return 0;
     if (g.c_mode == OUT_BF16 && g.act == ACT_NONE) return 1;
-    if (g.c_mode == OUT_FP8_MX && g.act == ACT_GELU_TANH && g.c_mx && g.N % 32 == 0) return 2;
+    if (g.c_mode == OUT_FP8_MX && g.act == ACT_GELU_TANH && g.c_mx && g.N % 32 == 0 && !g.bias_m && g.scale == 1.0f) return 2;      // (its epilogue carries neither term)
     return 0;
 }
 extern int g_w128;
@@ -486,9 +486,11 @@ bool w128_fp8_ok(const GemmArgs& g) {
 }
 template <bool MXA>
 void launch_gemm_fp8_t(const GemmArgs& g, hipStream_t s) {
-    // (the e4m3 + E8M0 epilogue with its tanh-GELU -- fc1 -- stays on the eight-wave tile unless natinf_set_gemm_w128(2): with ONE block per CU nothing multiplies while
-    // a block runs that epilogue; same-process A/B at K = 1,536: 1,100-1,130 TFLOP/s against 1,300-1,520, where the bf16 / fp32 epilogues gain 6-38 %)
-    if (g_w128 && w128_fp8_ok(g) && (fp8_epi(g) != 2 || g_w128 == 2)) {
+    // (round 5: the e4m3 + E8M0 epilogue with its tanh-GELU -- fc1 -- takes the four-wave tile too: with the GELU issued stage by stage for eight values at a time
+    // (gelu_tanh_fast8) (32768, 6144, 1536) runs 1,756-1,759 TFLOP/s there against 1,641-1,697 on the eight-wave tile, same process (tools/ab_fc1_w128.py).  Round 4 kept it on
+    // the eight-wave tile on a figure -- 1,100-1,130 against 1,300-1,520 -- that the debug entry had measured on the fp32-SLAB epilogue in e4m3 mode (no activation
+    // passed: fp8_epi() = 0), not on this one.  natinf_set_gemm_w128(2) = the round-4 rule, for A/B runs.)
+    if (g_w128 && w128_fp8_ok(g) && (fp8_epi(g) != 2 || g_w128 != 2)) {
         switch (fp8_epi(g)) {
             case 1: launch_tiles<W128F8Cfg>(&k_gemm_w128_fp8<MXA, 1>, g, s); break;
             case 2: launch_tiles<W128F8Cfg>(&k_gemm_w128_fp8<MXA, 2>, g, s); break;
@@ -1730,7 +1732,9 @@ int natinf_debug_gemm_fp8(int M, int N, int K, const void* a8, const float* a_sc
     if (!configured) { if (!configure_gemm_kernels()) return NATINF_ENODEV; configured = true; }
     GemmArgs g = gemm_defaults();
     g.a0 = (const bf16*)a8; g.a0_C = K; g.a0_ld = K; g.M = M; g.N = N; g.b = (const bf16*)b8; g.b_ld = K;
-    g.deq_m = a_scale; g.deq_n = b_scale; g.bias_n = bias_n; g.c = c; g.c_ld = N; g.c_mode = c_mode;
+    const int act = c_mode >> 8; c_mode &= 0xff;                         // bits 8+: activation (2 = tanh-GELU: with c_mode 3 the fc1 epilogue of the MMDiT engine)
+    if (act != ACT_NONE && act != ACT_GELU_TANH) return NATINF_EINVAL;
+    g.deq_m = a_scale; g.deq_n = b_scale; g.bias_n = bias_n; g.c = c; g.c_ld = N; g.c_mode = c_mode; g.act = act;
     g.a_mx = (const uint8_t*)a_mx; g.a_mx_ld = M; g.c_mx = (uint8_t*)c_mx; g.c_mx_ld = M;       // K-tile-major planes of M rows
     if ((c_mode == OUT_FP8_MX && (!c_mx || N % 32)) || c_mode < 0 || c_mode > OUT_FP8_MX || c_mode == OUT_F32_NCHW) return NATINF_EINVAL;
     for (int i = 0; i < iters; ++i) launch_gemm_fp8(g, (hipStream_t)stream);

@@ -127,6 +127,29 @@ __device__ __forceinline__ float gelu_tanh_fast(float v) {
     const float t = v * __builtin_fmaf(v * v, -0.10294324f, -2.3022082f);
     return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
+// Eight values at once, STAGE BY STAGE (round 5): the same operations per element as gelu_tanh_fast -- the same bytes -- but every stage is issued for all eight values
+// before the next one starts (the one-statement pins order the stages; hipcc otherwise emits each element as one serial chain exp2 -> s_nop -> add -> rcp -> s_nop -> mul
+// through a single register, which a lone wave per SIMD pays in full: nothing else fills the transcendental unit's latency there).
+__device__ __forceinline__ void pin8(float (&x)[8]) {
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+}
+__device__ __forceinline__ void gelu_tanh_fast8(float (&v)[8]) {
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = v[k] * __builtin_fmaf(v[k] * v[k], -0.10294324f, -2.3022082f);
+    pin8(t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = __builtin_amdgcn_exp2f(t[k]);
+    pin8(t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = 1.0f + t[k];
+    pin8(t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = __builtin_amdgcn_rcpf(t[k]);
+    pin8(t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= t[k];
+}
 __device__ __forceinline__ float apply_act(float v, int act) {
     return act == ACT_SILU ? silu_f(v) : (act == ACT_GELU_TANH ? gelu_tanh_f(v) : (act == ACT_RELU ? fmaxf(v, 0.f) : v));
 }
@@ -152,9 +175,13 @@ __device__ __forceinline__ float group4_max_nonneg(float a) {
     u = t[0] > t[1] ? t[0] : t[1];
     return __uint_as_float(u);
 }
+// CLAMP = false: the caller guarantees |value| <= 448 (block-scaled values: mx_scale_of's 2^-e maps the block maximum into (224, 448], exactly -- a power of two)
+template <bool CLAMP = true>
 __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {      // values already scaled; clamp: the cvt does not saturate
-    a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);      // (one v_med3_f32 per value)
-    c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+    if constexpr (CLAMP) {
+        a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);      // (one v_med3_f32 per value)
+        c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+    }
     int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
     w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
     return (unsigned)w;
