@@ -147,6 +147,8 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
     static_assert(!OUT8 || (!GN && !RES && TN % 2 == 0), "fp8 output: plain column terms only");
     static_assert(!PAIR || (TN % 2 == 0 && !OUT8 && !DEQ), "interleaved n-tile pairs: bf16 output");
     static_assert(NSAMP == 1 || ((NSAMP == 2 || NSAMP == 4) && WM == 1 && TM % NSAMP == 0 && !DEQ && !OUT8), "several samples per tile: one wave row, bf16 output");
+    // the activation over two accumulator tiles at a time (gelu_tanh_fast8 / silu_fast8: the same operations per element, issued stage by stage)
+    constexpr bool ACT8 = (ACT == ACT_GELU_TANH || ACT == ACT_SILU) && !GN && TN % 2 == 0 && NSAMP == 1;
     const int r = lane & 15, q = lane >> 4;
     // first column, inside the wave's TN * 16, of the four consecutive columns lane group q holds of accumulator tile j
     auto ncol = [&](int j) __attribute__((always_inline)) { return PAIR ? 32 * (j >> 1) + 8 * q + 4 * (j & 1) : 16 * j + 4 * q; };
@@ -255,11 +257,18 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= scale;
         }
-        if constexpr (ACT != ACT_NONE && !(OUT8 && ACT == ACT_GELU_TANH)) apply_act4(v, ACT);      // (OUT8 + GELU: eight values at once below)
+        // (tanh-GELU / SiLU: eight values -- two accumulator tiles -- at once, stage by stage, where the call sites below pair the tiles: ACT8)
+        if constexpr (ACT != ACT_NONE && !ACT8) apply_act4(v, ACT);
         if constexpr (GN) {
             gs[sm][j] += (v[0] + v[1]) + (v[2] + v[3]);
             gq[sm][j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
         }
+    };
+    auto act8 = [&](float (&v0)[4], float (&v1)[4]) __attribute__((always_inline)) {
+        float v8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if constexpr (ACT == ACT_GELU_TANH) gelu_tanh_fast8(v8); else silu_fast8(v8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v0[e] = v8[e]; v1[e] = v8[4 + e]; }
     };
     constexpr int EB = OUT8 ? 1 : 2;                   // bytes per output element
     unsigned char* wbase = smem + (wm * TM * 16 + r) * PROW + (wn * TN * 16 + q * 4) * EB;
@@ -273,6 +282,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
                 float v0[4], v1[4];
                 value(i, 2 * p, v0);
                 value(i, 2 * p + 1, v1);
+                if constexpr (ACT8) act8(v0, v1);
                 bf16x4_t o0, o1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { o0[e] = (bf16)v0[e]; o1[e] = (bf16)v1[e]; }
@@ -284,6 +294,20 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             fetch_rowvec(i);
+            if constexpr (ACT8) {
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    float v0[4], v1[4];
+                    value(i, j, v0);
+                    value(i, j + 1, v1);
+                    act8(v0, v1);
+                    bf16x4_t o0, o1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o0[e] = (bf16)v0[e]; o1[e] = (bf16)v1[e]; }
+                    *reinterpret_cast<uint2*>(wbase + i * 16 * PROW + j * 32) = __builtin_bit_cast(uint2, o0);
+                    *reinterpret_cast<uint2*>(wbase + i * 16 * PROW + (j + 1) * 32) = __builtin_bit_cast(uint2, o1);
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float v[4];
@@ -292,6 +316,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
                 *reinterpret_cast<uint2*>(wbase + i * 16 * PROW + j * 32) = __builtin_bit_cast(uint2, o);
+            }
             }
         }
     } else {
@@ -304,12 +329,7 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
                 float v0[4], v1[4];
                 value(i, 2 * b, v0);
                 value(i, 2 * b + 1, v1);
-                if constexpr (ACT == ACT_GELU_TANH) {
-                    float v8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    gelu_tanh_fast8(v8);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v0[e] = v8[e]; v1[e] = v8[4 + e]; }
-                }
+                if constexpr (ACT8) act8(v0, v1);
                 float amax = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
                                    fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
                 amax = group4_max_nonneg(amax);

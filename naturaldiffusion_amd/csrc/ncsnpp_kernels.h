@@ -150,6 +150,21 @@ __device__ __forceinline__ void gelu_tanh_fast8(float (&v)[8]) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] *= t[k];
 }
+// (SiLU the same way: v * rcp(1 + __expf(-v)), the operations of apply_act4 / apply_act8)
+__device__ __forceinline__ void silu_fast8(float (&v)[8]) {
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = __expf(-v[k]);
+    pin8(t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = 1.0f + t[k];
+    pin8(t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = __builtin_amdgcn_rcpf(t[k]);
+    pin8(t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= t[k];
+}
 __device__ __forceinline__ float apply_act(float v, int act) {
     return act == ACT_SILU ? silu_f(v) : (act == ACT_GELU_TANH ? gelu_tanh_f(v) : (act == ACT_RELU ? fmaxf(v, 0.f) : v));
 }
@@ -191,11 +206,9 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // and v_rcp_f32 instead of the 15-instruction IEEE division -- 1 ulp, far inside the bf16 output rounding.
 __device__ __forceinline__ void apply_act8(float (&v)[8], int act) {
     if (act == ACT_SILU) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = v[q] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[q]));
+        silu_fast8(v);                                   // (stage by stage: the same operations per element)
     } else if (act == ACT_GELU_TANH) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = gelu_tanh_fast(v[q]);
+        gelu_tanh_fast8(v);
     } else if (act == ACT_RELU) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
