@@ -30,6 +30,7 @@
 #include "ncsnpp_kernels.h"
 #include "gemm_dma.h"
 #include "gemm_w128.h"
+#include "conv_ring.h"
 #include "conv_gn.h"
 #include "conv_gn2.h"
 #include "head_conv.h"
@@ -137,6 +138,7 @@ struct natinf_ncsnpp {
 };
 
 // k_conv_gn3 (conv_gn3.h / conv_gn3.hip: one wave per SIMD, 128 x 128 wave tiles, slot-table K loop) -- a translation unit of its own
+bool configure_conv_ring();          // inception_engine.inc: the k_conv_ring instantiations' LDS sizes
 namespace ncsn_cg3 { bool configure(); int tile_rows(int shape); int tile_cols(int shape); void launch(const void* gemm_args, int shape, int epi, void* stream); }
 
 namespace {
@@ -294,7 +296,7 @@ bool configure_gemm_kernels() {
                                   GEMM_LDS_BYTES) == hipSuccess;
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_conv), hipFuncAttributeMaxDynamicSharedMemorySize, HeadConvCfg::LDS_BYTES) == hipSuccess &&
          set_lds<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4, 9>) &&
-         set_lds_epi_all() && ncsn_cg3::configure() && set_lds_conv_gn<1>() && set_lds_conv_gn<2>() && set_lds_conv_gn<5>() && set_lds_conv_gn<6>() &&
+         set_lds_epi_all() && ncsn_cg3::configure() && ::configure_conv_ring() && set_lds_conv_gn<1>() && set_lds_conv_gn<2>() && set_lds_conv_gn<5>() && set_lds_conv_gn<6>() &&
 #ifdef NATINF_DEV
          set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4>) && set_lds<CfgD256x128>(&k_gemm_dma<4, 2, 4, 4>) &&
          set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4>) && set_lds<CfgR256x256>(&k_gemm_ring<2, 4, 8, 4, 4>) &&
