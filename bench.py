@@ -743,7 +743,7 @@ def bench_fid50k(args, world, rank, dev, steps=1, warmup=0):
             st.append(s_.mean_cov())
         line["d_matrices"] = r4(frechet_distance(st[0][0], st[0][1], st[1][0], st[1][1]))
         inc_tf = INCEPTION_GFLOP_PER_IMAGE * 1e9 * len(mats) * n_local / per["inception"] / 1e12
-        line["roofline"] = {"kernel": "inception pool3 engine (im2col + k_gemm_*, hi+lo filter terms)", "bound": "mfma", "achieved": r4(inc_tf), "peak": MFMA_BF16_PEAK_TFLOPS,
+        line["roofline"] = {"kernel": "inception pool3 engine (k_conv_ring implicit GEMMs, fp16 activations + one fp16 filter term)", "bound": "mfma", "achieved": r4(inc_tf), "peak": MFMA_BF16_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": r4(inc_tf / MFMA_BF16_PEAK_TFLOPS), "traffic": None}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "fid50k":
         # bounded CPU sample of the same job: 16 images x 18 steps through the oracle denoiser + recurrence, then the Inception oracle on them

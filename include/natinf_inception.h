@@ -29,9 +29,10 @@ enum { NATINF_INCEPTION_U8_HWC = 0,     /* images: uint8 [B][H][W][3], the tenso
 
 int natinf_inception_create(natinf_inception_t* out, int in_h, int in_w);    /* input image size (32 x 32 for CIFAR10) */
 int natinf_inception_destroy(natinf_inception_t h);
-/* A/B switch, read by natinf_inception_create: 1 (default) = every convolution behind the stem is one implicit-GEMM launch (csrc/conv_ring.h: the activation tensor
- * is the A operand, a K-tile = one tap x 32 channels); 0 = the round-3 / 4 plan (an im2col pass + a GEMM per convolution).  The parameter order and the features'
- * meaning are the same; packed_bytes / workspace_bytes differ (ask the handle). */
+/* A/B switch, read by natinf_inception_create: 2 (default) = every convolution is one implicit-GEMM launch (csrc/conv_ring.h: the activation tensor is the A
+ * operand, a K-tile = one tap x 32 channels) on HALF-PRECISION activations and one half-precision filter term (rows scaled by a power of two); 1 = the same launches
+ * on bf16 activations with the filters as two bf16 terms; 0 = the round-3 / 4 plan (bf16, two terms, an im2col pass + a GEMM per convolution).  The parameter order
+ * and the features' meaning are the same; packed_bytes / workspace_bytes differ (ask the handle). */
 int natinf_set_inception_conv(int mode);
 int64_t natinf_inception_param_count(natinf_inception_t h);
 int64_t natinf_inception_packed_bytes(natinf_inception_t h);

@@ -13,7 +13,14 @@
 //     weight rows -- the B columns are packed in K-loop order, as for k_gemm_ring;
 //   * channel counts that are no multiple of 32 (48, 80) are padded by their PRODUCER: its filter rows and bias beyond the real outputs are zero, so the pad
 //     channels hold relu(0) = 0 and this kernel never looks at a channel count.
-// Epilogue: the shared tile epilogue (bias + ReLU, bf16 NHWC into a channel slice of the concat buffer).
+//   * F16 (the Inception engine's default since round 5, natinf_set_inception_conv(2)): activations and filters are IEEE half precision and the filters ONE term.
+//     Why the two-term bf16 filters existed: a bf16-rounded filter is off by the same amount for every image, which shifts the feature means -- what a Frechet
+//     distance measures (0.095 of 0.099 on 2,000 images with one bf16 term).  A half-precision filter has eleven significant bits instead of eight: the same shift
+//     is 8x smaller, its square 64x -- where two bf16 terms put it -- for HALF the matrix work; half-precision activations round 8x finer than bf16 ones as well.
+//     Range: every filter row is scaled by a power of two so that its largest element lies in [0.5, 1) (exact; the epilogue multiplies the column back:
+//     GemmArgs::deq_n), so a row keeps 2^-14 of its maximum as NORMAL numbers whatever BatchNorm folded into it; activations behind a ReLU stay far below 65,504.
+// Epilogue: bias (+ the column scale) + ReLU in the accumulator registers, 16-bit values through one LDS slab, 16-byte row stores into a channel slice of the
+// concat buffer (NHWC).
 #pragma once
 #include "gemm_dma.h"
 
@@ -27,7 +34,52 @@ struct ConvGeom {
     const void* zeros;                // >= 16 zero bytes
 };
 
-template <int WM, int WN, int TM, int TN, int NS>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+
+// relu(acc * deq_n + bias_n) -> 16-bit -> LDS slab [BM][BN * 2 + 16 bytes] -> 16-byte row stores.  N % 8 == 0; rows >= M and columns >= N are not stored.
+template <int WM, int WN, int TM, int TN, bool F16>
+__device__ __forceinline__ void conv_ring_epilogue(const GemmArgs& g, unsigned char* smem, f32x4 (&acc)[TM][TN], int m0, int n0, int tid, int lane, int wm, int wn)
+{
+    constexpr int BM_ = WM * TM * 16, BN_ = WN * TN * 16, THREADS = WM * WN * 64, PROW = BN_ * 2 + 16;
+    const int r = lane & 15, q = lane >> 4;
+    float bs[TN][4], sc[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 16 + j * 16 + q * 4;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (n < g.N) {
+            if (g.bias_n) b = gload_f4(g.bias_n + n);
+            if (g.deq_n) d = gload_f4(g.deq_n + n);
+        }
+        bs[j][0] = b.x; bs[j][1] = b.y; bs[j][2] = b.z; bs[j][3] = b.w; sc[j][0] = d.x; sc[j][1] = d.y; sc[j][2] = d.z; sc[j][3] = d.w;
+    }
+    unsigned char* wbase = smem + (wm * TM * 16 + r) * PROW + (wn * TN * 16 + q * 4) * 2;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(acc[i][j][e], sc[j][e], bs[j][e]), 0.f);
+            uint2 o;
+            if constexpr (F16) { f16x4_t h; for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e]; o = __builtin_bit_cast(uint2, h); }
+            else { bf16x4_t h; for (int e = 0; e < 4; ++e) h[e] = (bf16)v[e]; o = __builtin_bit_cast(uint2, h); }
+            *reinterpret_cast<uint2*>(wbase + i * 16 * PROW + j * 32) = o;
+        }
+    __syncthreads();
+    constexpr int CPR = BN_ * 2 / 16, RPS = THREADS / CPR, NSW = BM_ / RPS;
+    static_assert(THREADS % CPR == 0 && BM_ % RPS == 0, "whole rows per sweep");
+    const int cchunk = tid % CPR, rsub = tid / CPR, n = n0 + cchunk * 8;
+    if (n < g.N) {
+        const unsigned char* src = smem + rsub * PROW + cchunk * 16;
+        unsigned short* dst = reinterpret_cast<unsigned short*>(g.c) + (int64_t)(m0 + rsub) * g.c_ld + n;
+        if (m0 + BM_ <= g.M) SlabCopy<0, NSW, RPS, PROW, false>::run(src, dst, g.c_ld, m0 + rsub, g.M);
+        else SlabCopy<0, NSW, RPS, PROW, true>::run(src, dst, g.c_ld, m0 + rsub, g.M);
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int NS, bool F16 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void k_conv_ring(const GemmArgs g, const ConvGeom cv)
 {
     using Cfg = RingCfg<WM, WN, TM, TN, NS>;
@@ -122,12 +174,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_conv_ring(const GemmArgs g,
         for (int i = 0; i < TM; ++i) {
             const bf16x8 fa = *reinterpret_cast<const bf16x8*>(ta + i * 16 * ROW);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fb[j]), __builtin_bit_cast(f16x8, fa), acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[i][j], 0, 0, 0);
+            }
         }
     }
     __syncthreads();               // every wave is done with the ring before the epilogue reuses it
-    tile_epilogue<WM, WN, TM, TN, typename Cfg::Epi, 0>(g, smem, acc, m0, n0, 0, tid, lane, wm, wn);
+    static_assert(BM_ * (BN_ * 2 + 16) <= Cfg::LDS_BYTES, "the 16-bit slab fits the ring");
+    conv_ring_epilogue<WM, WN, TM, TN, F16>(g, smem, acc, m0, n0, tid, lane, wm, wn);
 }
 
 }  // namespace ncsn
