@@ -208,6 +208,32 @@ def test_validation_grid_is_one_row_of_eight(tmp_path):
     assert Image.open(tmp_path / "g.png").size == (8 * 18 + 2, 18 + 2)
 
 
+def test_png_writer_gives_the_pixels_back(tmp_path):
+    """write_png_rgb (the band-parallel deflate of round 5): a reader (PIL) decodes every file to the array it was given -- one band, several bands, ragged band
+    heights, a one-pixel image -- and the stream passes PIL's integrity check (CRCs, Adler-32 of the concatenated bands)."""
+    import numpy as np
+    from PIL import Image
+    from naturaldiffusion_amd.ValidateNaturalInference import write_png_rgb, save_image_grid
+    import torch
+    r = np.random.RandomState(3)
+    for shape, threads in (((260, 2066, 3), 8), ((1, 1, 3), 8), ((17, 5, 3), 8), ((300, 33, 3), 3), ((64, 64, 3), 1), ((131, 7, 3), 16)):
+        a = r.randint(0, 256, shape).astype(np.uint8)
+        if shape[0] > 100:
+            a[: shape[0] // 2] = 7                                          # a compressible half: exercises real deflate blocks next to stored ones
+        write_png_rgb(a, tmp_path / "a.png", threads=threads)
+        Image.open(tmp_path / "a.png").verify()
+        assert np.array_equal(np.array(Image.open(tmp_path / "a.png").convert("RGB")), a), (shape, threads)
+    with pytest.raises(ValueError):
+        write_png_rgb(np.zeros((4, 4), np.uint8), tmp_path / "b.png")
+    # through save_image_grid: the values torchvision's save_image(normalize=True, value_range=(-1, 1)) would write
+    x = torch.linspace(-1.2, 1.2, 8 * 3 * 16 * 16).reshape(8, 3, 16, 16)
+    save_image_grid(x, tmp_path / "g.png")
+    got = np.array(Image.open(tmp_path / "g.png").convert("RGB"))
+    want = (((x.clamp(-1, 1) + 1) * 0.5) * 255 + 0.5).clamp(0, 255).to(torch.uint8)
+    assert np.array_equal(got[2:18, 2:18], want[0].permute(1, 2, 0).numpy()) and np.array_equal(got[2:18, 20:36], want[1].permute(1, 2, 0).numpy())
+    assert (got[:2] == 0).all() and (got[:, :2] == 0).all()
+
+
 def test_generation_pipeline_host_logic(tmp_path):
     """Round 4 host pieces that need no GPU: how `generate_sharded` / `natural_inference_tx` pick their lanes, the reference-statistics argument of the FID
     functions, the FidBlocked result, the handle-sharing ABI's argument checks, the per-workload defaults of bench.py."""
