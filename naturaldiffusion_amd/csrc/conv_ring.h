@@ -68,14 +68,25 @@ __device__ __forceinline__ void conv_ring_epilogue(const GemmArgs& g, unsigned c
             *reinterpret_cast<uint2*>(wbase + i * 16 * PROW + j * 32) = o;
         }
     __syncthreads();
-    constexpr int CPR = BN_ * 2 / 16, RPS = THREADS / CPR, NSW = BM_ / RPS;
-    static_assert(THREADS % CPR == 0 && BM_ % RPS == 0, "whole rows per sweep");
-    const int cchunk = tid % CPR, rsub = tid / CPR, n = n0 + cchunk * 8;
-    if (n < g.N) {
-        const unsigned char* src = smem + rsub * PROW + cchunk * 16;
-        unsigned short* dst = reinterpret_cast<unsigned short*>(g.c) + (int64_t)(m0 + rsub) * g.c_ld + n;
-        if (m0 + BM_ <= g.M) SlabCopy<0, NSW, RPS, PROW, false>::run(src, dst, g.c_ld, m0 + rsub, g.M);
-        else SlabCopy<0, NSW, RPS, PROW, true>::run(src, dst, g.c_ld, m0 + rsub, g.M);
+    constexpr int CPR = BN_ * 2 / 16;
+    if constexpr (THREADS % CPR == 0) {
+        constexpr int RPS = THREADS / CPR, NSW = BM_ / RPS;
+        static_assert(BM_ % RPS == 0, "whole rows per sweep");
+        const int cchunk = tid % CPR, rsub = tid / CPR, n = n0 + cchunk * 8;
+        if (n < g.N) {
+            const unsigned char* src = smem + rsub * PROW + cchunk * 16;
+            unsigned short* dst = reinterpret_cast<unsigned short*>(g.c) + (int64_t)(m0 + rsub) * g.c_ld + n;
+            if (m0 + BM_ <= g.M) SlabCopy<0, NSW, RPS, PROW, false>::run(src, dst, g.c_ld, m0 + rsub, g.M);
+            else SlabCopy<0, NSW, RPS, PROW, true>::run(src, dst, g.c_ld, m0 + rsub, g.M);
+        }
+    } else {                                                            // (192-column tiles: 24 chunks per row do not divide the block)
+        static_assert((BM_ * CPR) % THREADS == 0, "whole sweeps");
+#pragma unroll
+        for (int sw = 0; sw < BM_ * CPR / THREADS; ++sw) {
+            const int e = sw * THREADS + tid, row = e / CPR, cchunk = e - row * CPR, n = n0 + cchunk * 8;
+            if (m0 + row < g.M && n < g.N)
+                gstore_u4(reinterpret_cast<unsigned short*>(g.c) + (int64_t)(m0 + row) * g.c_ld + n, *reinterpret_cast<const uint4*>(smem + row * PROW + cchunk * 16));
+        }
     }
 }
 
