@@ -30,7 +30,11 @@ struct AttnCfg {
 };
 
 // qk: [B*256][qk_ld] bf16 with q at column 0 and k at column k_off (+ head*hd); vT: [B][H*hd][256]; o: [B*256][o_ld]
-template <int NQK, int ND, bool TWO_PHASE = false>
+// VROW (round 5, the DiT engine): v comes ROW-MAJOR -- `vT` then points at the v columns of the same [B*256][qk_ld] buffer the q | k | v projection wrote as ONE
+// GEMM -- and is transposed on its way into LDS (eight 2-byte LDS writes per 16-byte load, lanes along the keys: the 64 keys of a wave-instruction fill the 32
+// banks twice).  What it replaces is a launch: the batched V^T = W_v h^T GEMM, 24.6 us of a 245-us DiT-XL/2 block at Validate's batch of 16, whose output columns now
+// ride in the q | k GEMM's one under-filled round of tiles.  Same LDS image, same arithmetic behind it.
+template <int NQK, int ND, bool TWO_PHASE = false, bool VROW = false>
 __global__ __launch_bounds__(512) void k_attn_fused(const bf16* __restrict__ qk, int qk_ld, int k_off, const bf16* __restrict__ vT,
                                                     bf16* __restrict__ o, int o_ld, int H, int hd, float scale)
 {
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(512) void k_attn_fused(const bf16* __restrict__ qk,
     const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
     const bf16* qbase = qk + (int64_t)b * T * qk_ld + hh * hd;
     const bf16* kbase = qbase + k_off;
-    const bf16* vbase = vT + ((int64_t)b * H + hh) * hd * T;
+    const bf16* vbase = VROW ? vT + (int64_t)b * T * qk_ld + hh * hd : vT + ((int64_t)b * H + hh) * hd * T;
     // (zero fill by assignment, not `cond ? *p : zero4`: hipcc turns that select of two lvalues into a select of ADDRESSES and
     // parks the zero vector in scratch memory)
 
@@ -56,6 +60,21 @@ __global__ __launch_bounds__(512) void k_attn_fused(const bf16* __restrict__ qk,
         *reinterpret_cast<uint4*>(sK + row * KSTR + ch * 16) = v;
     }
     auto load_vT = [&]() __attribute__((always_inline)) {
+        if constexpr (VROW) {
+            // key k of a 32-key chunk sits at position 8 * (2 * (m & 1) + half) + 4 * (m >> 1) + i of its chunk, m = k >> 3, half = (k >> 2) & 1, i = k & 3
+            // (the image the loop below builds from V^T rows); channels [hd, ND * 16) are zero rows
+            for (int idx = tid; idx < T * ND * 2; idx += 512) {
+                const int key = idx & (T - 1), d0 = (idx >> 8) * 8;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (d0 < hd) v = *reinterpret_cast<const uint4*>(vbase + (int64_t)key * qk_ld + d0);
+                const int kk = key & 31, m = kk >> 3, pos = 8 * (2 * (m & 1) + ((kk >> 2) & 1)) + 4 * (m >> 1) + (kk & 3);
+                unsigned short* dst = reinterpret_cast<unsigned short*>(sV + d0 * VSTR + ((key & ~31) + pos) * 2);
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[e * (VSTR / 2)] = (unsigned short)(w[e >> 1] >> (16 * (e & 1)));
+            }
+            return;
+        }
         for (int idx = tid; idx < ND * 16 * 32; idx += 512) {                      // V^T rows, keys permuted inside 32-key chunks
             const int d = idx >> 5, m8 = idx & 31, c = m8 >> 2, m = m8 & 3;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);

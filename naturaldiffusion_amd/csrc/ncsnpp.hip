@@ -139,6 +139,7 @@ struct natinf_ncsnpp {
 
 // k_conv_gn3 (conv_gn3.h / conv_gn3.hip: one wave per SIMD, 128 x 128 wave tiles, slot-table K loop) -- a translation unit of its own
 bool configure_conv_ring();          // inception_engine.inc: the k_conv_ring instantiations' LDS sizes
+namespace { bool configure_dit_attention(); }      // dit_engine.inc: the row-major-v forms of k_attn_fused
 namespace ncsn_cg3 { bool configure(); int tile_rows(int shape); int tile_cols(int shape); void launch(const void* gemm_args, int shape, int epi, void* stream); }
 
 namespace {
@@ -296,7 +297,7 @@ bool configure_gemm_kernels() {
                                   GEMM_LDS_BYTES) == hipSuccess;
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_conv), hipFuncAttributeMaxDynamicSharedMemorySize, HeadConvCfg::LDS_BYTES) == hipSuccess &&
          set_lds<CfgR128x128>(&k_gemm_ring<2, 2, 4, 4, 4, 9>) &&
-         set_lds_epi_all() && ncsn_cg3::configure() && ::configure_conv_ring() && set_lds_conv_gn<1>() && set_lds_conv_gn<2>() && set_lds_conv_gn<5>() && set_lds_conv_gn<6>() &&
+         set_lds_epi_all() && ncsn_cg3::configure() && ::configure_conv_ring() && configure_dit_attention() && set_lds_conv_gn<1>() && set_lds_conv_gn<2>() && set_lds_conv_gn<5>() && set_lds_conv_gn<6>() &&
 #ifdef NATINF_DEV
          set_lds<CfgD256x256>(&k_gemm_dma<2, 4, 8, 4>) && set_lds<CfgD256x128>(&k_gemm_dma<4, 2, 4, 4>) &&
          set_lds<CfgD128x128>(&k_gemm_dma<2, 2, 4, 4>) && set_lds<CfgR256x256>(&k_gemm_ring<2, 4, 8, 4, 4>) &&
@@ -443,14 +444,18 @@ int choose_variant(const GemmArgs& g) {
     // (2664, 6144, 1536) the rule below took 256 x 256 tiles -- 264 of them: a second round for eight tiles, 77 us -- where 1,008 tiles of 128 x 128 run as two rounds of
     // two blocks per CU in 55 us; at (2664, 4608, 1536) it took 128 x 128 (756 tiles, two rounds, 52 us) where 198 tiles of 256 x 256 are ONE round (43 us).  Measured
     // cost of a round at K = 1,536: 25-28 us (128 x 128, two blocks per CU) against 37-43 us (256 x 256): ratio 1.5 (tools/scan_small_m_gemm.py).
-    if (g_round_model && g.taps == 1 && !g.gn_part && g.batch == 1 && g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) < 2 * NUM_CU) {
-        const int64_t r256 = (mt256 * (g.N / 256) + NUM_CU - 1) / NUM_CU, r128 = (mt128 * nt128 + 2 * NUM_CU - 1) / (2 * NUM_CU);
+    // (round 5: the four-wave tile multiplies its 256 columns as two 128-column halves and skips a half that lies beyond N, so N % 128 == 0 is enough for it --
+    // DiT-XL/2's q | k | v projection, N = 3,456 = 13.5 tiles, had fallen to 128 x 128 tiles: 50.7 us against 30 us)
+    const int64_t nt256 = (g.N + 255) / 256;
+    const bool n_ok256 = g.N % 256 == 0 || (w128 && g.N % 128 == 0);
+    if (g_round_model && g.taps == 1 && !g.gn_part && g.batch == 1 && n_ok256 && K0 + K1 >= 1024 && mt256 * nt256 < 2 * NUM_CU) {
+        const int64_t r256 = (mt256 * nt256 + NUM_CU - 1) / NUM_CU, r128 = (mt128 * nt128 + 2 * NUM_CU - 1) / (2 * NUM_CU);
         // (a round of the four-wave 256 x 256 tile costs ~1.3 rounds of 128 x 128 tiles, not 1.5: DiT-XL/2's fc1 at B = 16, (4096, 4608, 1152), is 288 tiles = two rounds of
         // ~28 us against three rounds of two 128 x 128 blocks per CU in 74.6 us; natinf_set_gemm_round_model(v >= 10) sets the ratio to v / 10 for A/B runs)
         const int64_t c256 = w128 ? g_round_model_w128 : 15;
         if (mt128 * nt128 >= NUM_CU / 2) return c256 * r256 < 10 * r128 ? (w128 ? V_W128 : half ? V_DMA_256x256_H : V_DMA_256x256_P) : V_DMA_128x128_P;
     }
-    if (g.N % 256 == 0 && K0 + K1 >= 1024 && mt256 * (g.N / 256) * g.batch >= NUM_CU) return w128 ? V_W128 : half ? V_DMA_256x256_H : V_DMA_256x256_P;
+    if (n_ok256 && K0 + K1 >= 1024 && mt256 * nt256 * g.batch >= NUM_CU) return w128 ? V_W128 : half ? V_DMA_256x256_H : V_DMA_256x256_P;
     if (g_pref_512 && g.N <= 128 && K0 + K1 >= 1024 && ((g.M + 511) / 512) * g.batch >= 2 * NUM_CU &&
         (!g.gn_part || (g.taps == 9 && (1 << g.logHW) % 512 == 0)))           // GroupNorm partials: a tile inside one sample
         return half ? V_DMA_512x128_H : V_DMA_512x128;

@@ -108,6 +108,25 @@ def test_w128_tile_equals_the_eight_wave_tile():
         assert torch.equal(auto[0], old[0])
 
 
+def test_w128_tile_with_a_half_tile_of_columns():
+    """N % 256 == 128 on the four-wave tile (round 5: DiT-XL/2's q | k | v projection, (4096, 3456, 1152) = 13.5 column tiles; the kernel skips the half that lies
+    beyond N): forced and as the automatic choice, against the fp32 reference and -- the same K steps in the same order -- the 128 x 128 tiles' bytes"""
+    from naturaldiffusion_amd._lib import lib, check
+    for (M, N, K) in ((4096, 3456, 1152), (1024, 384, 1024)):
+        for terms, act in ((("bias_n",), 0), (("bias_n",), 2)):
+            forced = _run(V_W128, M, N, K, 30, terms, act, False)
+            auto = _run(0, M, N, K, 30, terms, act, False)
+            check(lib.natinf_set_gemm_w128(0), "set")
+            try:
+                old = _run(0, M, N, K, 30, terms, act, False)
+            finally:
+                check(lib.natinf_set_gemm_w128(1), "set")
+            ref = forced[1]
+            assert torch.isfinite(forced[0].float()).all()
+            assert (forced[0].float() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
+            assert torch.equal(forced[0], old[0]) and torch.equal(auto[0], old[0])
+
+
 def test_w128_splitk_with_the_gated_fp32_residual_epilogue():
     """an under-filled long-K GEMM with the transformer engines' residual epilogue (DiT-XL/2's fc2 at 16 samples: 80 tiles of 256 x 256, 72 K-tiles): K slices on
     k_gemm_w128<9> + k_splitk_reduce_f32 against the fp32 reference and against the unsplit launch; deterministic; the in-place form (residual == output) is what the
