@@ -34,6 +34,14 @@ int natinf_inception_destroy(natinf_inception_t h);
  * on bf16 activations with the filters as two bf16 terms; 0 = the round-3 / 4 plan (bf16, two terms, an im2col pass + a GEMM per convolution).  The parameter order
  * and the features' meaning are the same; packed_bytes / workspace_bytes differ (ask the handle). */
 int natinf_set_inception_conv(int mode);
+/* The engine's convolution kernel on caller-supplied operands (tests): out[b, oy, ox, n] = relu(col_scale[n] * sum_{ky, kx, c} x[b, oy*stride - ph + ky, ox*stride - pw + kx, c]
+ * * w[n, (ky*kw + kx)*cin_p + c] + bias[n]), zero padding.  x: 16-bit [B][H][W][x_ld] (bf16, or IEEE half when f16 = 1), cin_p % 32 == 0 channels read per pixel;
+ * w_packed: 16-bit [cout][passes * kh*kw*cin_p] (passes = 2: the second block of columns is a second filter term over the same taps); bias / col_scale: fp32 [cout] or NULL;
+ * zeros: >= 16 zero bytes on the device (what padding taps fetch); out: 16-bit [B*Ho*Wo][out_ld], cout % 8 == 0.  tile: 0 = 256 x 64, 1 = 256 x 128, 2 = 128 x 128,
+ * 3 = 128 x 192 (f16 only). */
+int natinf_debug_conv_ring(int tile, int f16, int B, int H, int W, int cin_p, int x_ld, int cout, int kh, int kw, int stride, int ph, int pw, int passes,
+                           const void* x, const void* w_packed, const float* bias, const float* col_scale, const void* zeros, void* out, int out_ld,
+                           natinf_stream_t stream);
 int64_t natinf_inception_param_count(natinf_inception_t h);
 int64_t natinf_inception_packed_bytes(natinf_inception_t h);
 int64_t natinf_inception_workspace_bytes(natinf_inception_t h, int max_batch);

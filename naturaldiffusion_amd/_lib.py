@@ -112,6 +112,7 @@ SIGNATURES = {
     "natinf_inception_create": (C.c_int, [_p, _i32, _i32]),
     "natinf_inception_destroy": (C.c_int, [_p]),
     "natinf_set_inception_conv": (C.c_int, [_i32]),
+    "natinf_debug_conv_ring": (C.c_int, [_i32] * 14 + [_p, _p, _p, _p, _p, _p, _i32, _p]),
     "natinf_inception_param_count": (_i64, [_p]),
     "natinf_inception_packed_bytes": (_i64, [_p]),
     "natinf_inception_workspace_bytes": (_i64, [_p, _i32]),

@@ -98,6 +98,65 @@ def test_implicit_gemm_plans_against_the_im2col_plan(params, dev):
     assert lib.natinf_set_inception_conv(3) != 0                                  # unknown mode: refused
 
 
+CONV_CASES = [   # (B, H, W, cin, cout, kh, kw, stride, ph, pw): the engine's geometries and ragged relatives
+    (2, 35, 35, 48, 64, 5, 5, 1, 2, 2),       # 48 channels (padded to 64), 5 x 5, padding 2
+    (3, 17, 17, 160, 192, 1, 7, 1, 0, 3),     # 1 x 7
+    (3, 17, 17, 128, 128, 7, 1, 1, 3, 0),     # 7 x 1
+    (2, 35, 35, 288, 384, 3, 3, 2, 0, 0),     # stride 2, no padding
+    (1, 9, 13, 32, 40, 3, 3, 1, 1, 1),        # non-square, N = 40: ragged column tile
+    (5, 8, 8, 448, 384, 3, 3, 1, 1, 1),       # long K
+    (2, 21, 19, 96, 96, 3, 3, 2, 1, 1),       # stride 2 WITH padding (not in the network)
+    (4, 12, 12, 64, 200, 1, 1, 1, 0, 0),      # 1 x 1, N = 200
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("f16", [0, 1])
+def test_conv_ring_against_torch_conv2d(case, f16, dev):
+    """k_conv_ring on its own (natinf_debug_conv_ring), every tile shape, bf16 with two filter terms and half precision with one + column scales, against
+    torch.nn.functional.conv2d in fp32 on the SAME 16-bit operands: what is left is the fp32 summation order and the 16-bit rounding of the output."""
+    from naturaldiffusion_amd._lib import lib, check, ptr, stream_ptr
+    B, H, W, cin, cout, kh, kw, stride, ph, pw = case
+    dt = torch.float16 if f16 else torch.bfloat16
+    g = torch.Generator().manual_seed(H * 131 + cin)
+    cin_p = (cin + 31) // 32 * 32
+    x = torch.zeros(B, H, W, cin_p)
+    x[..., :cin] = torch.randn(B, H, W, cin, generator=g)
+    x = x.to(dt)
+    w = torch.randn(cout, cin, kh, kw, generator=g) * (1.0 / (cin * kh * kw) ** 0.5)
+    bias = torch.randn(cout, generator=g) * 0.2
+    # pack: [cout][(ky*kw + kx)*cin_p + c]; bf16: hi | lo terms; half: one term, rows scaled by a power of two
+    wk = torch.zeros(cout, kh, kw, cin_p)
+    wk[..., :cin] = w.permute(0, 2, 3, 1)
+    wk = wk.reshape(cout, kh * kw * cin_p)
+    if f16:
+        scale = torch.exp2(torch.floor(torch.log2(wk.abs().amax(dim=1).clamp_min(1e-30))) + 1)
+        packed = (wk / scale[:, None]).to(dt)
+        w_eff = packed.float() * scale[:, None]
+        passes, col_scale = 1, scale.float().cuda()
+    else:
+        hi = wk.to(dt); lo = (wk - hi.float()).to(dt)
+        packed = torch.cat([hi, lo], dim=1)
+        w_eff = hi.float() + lo.float()
+        passes, col_scale = 2, None
+    w_eff4 = w_eff.reshape(cout, kh, kw, cin_p)[..., :cin].permute(0, 3, 1, 2).contiguous()
+    ref = torch.relu(torch.nn.functional.conv2d(x.float()[..., :cin].permute(0, 3, 1, 2).double(), w_eff4.double(), bias.double(), stride=stride, padding=(ph, pw)))
+    ref = ref.permute(0, 2, 3, 1).float()                                        # [B][Ho][Wo][cout]
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    xd, pd, bd = x.cuda().contiguous(), packed.cuda().contiguous(), bias.cuda()
+    zeros = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    for tile in ((0, 1, 2, 3) if f16 else (0, 1, 2)):
+        out_ld = cout + 8                                                        # a channel slice of a wider buffer
+        out = torch.full((B * Ho * Wo, out_ld), 7.0, dtype=dt, device="cuda")
+        check(lib.natinf_debug_conv_ring(tile, f16, B, H, W, cin_p, cin_p, cout, kh, kw, stride, ph, pw, passes, ptr(xd), ptr(pd), ptr(bd),
+                                         ptr(col_scale) if col_scale is not None else None, ptr(zeros), ptr(out), out_ld, stream_ptr()), "conv_ring")
+        got = out[:, :cout].float().cpu().reshape(B, Ho, Wo, cout)
+        tol = (2.0 ** -10 if f16 else 2.0 ** -7) * ref.abs().max().item()
+        assert torch.isfinite(got).all() and (got - ref).abs().max().item() <= tol, (case, f16, tile, (got - ref).abs().max().item(), tol)
+        assert (out[:, cout:].float() == 7.0).all()                              # nothing written beyond the slice
+    assert lib.natinf_debug_conv_ring(3, 0, B, H, W, cin_p, cin_p, cout, kh, kw, stride, ph, pw, 2, ptr(xd), ptr(pd), None, None, ptr(zeros), ptr(out), out_ld, None) != 0
+
+
 def test_features_do_not_depend_on_the_batch(params, dev):
     """calc_fid scores FID_BATCH (500) images per engine call where the reference feeds 50: an image's pool3 features are the same bytes either way (also for a
     ragged last batch), so the statistics -- and the FID -- are those of the reference's batching"""
