@@ -10,7 +10,9 @@
  * Mixed_5b-5d (FIDInceptionA), Mixed_6a, Mixed_6b-6e (FIDInceptionC), Mixed_7a, Mixed_7b (FIDInceptionE_1), Mixed_7c (FIDInceptionE_2),
  * global average pool.  BatchNorm (eval, eps 1e-3) is folded into the filters when the weights are packed.
  *
- * Arithmetic: bf16 operands on the matrix cores, fp32 accumulation, bias + ReLU in fp32, activations stored as bf16; features fp32.
+ * Arithmetic (default plan; natinf_set_inception_conv below): IEEE-half operands on the matrix cores -- activations, and filters as one half-precision term per
+ * power-of-two-scaled row --, fp32 accumulation, column scale + bias + ReLU in fp32, activations stored as half; features fp32.  Plans 0 / 1: bf16 operands, filters as
+ * two bf16 terms, activations stored as bf16.
  */
 #ifndef NATINF_INCEPTION_H
 #define NATINF_INCEPTION_H
