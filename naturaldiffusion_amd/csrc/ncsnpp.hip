@@ -323,8 +323,7 @@ bool configure_gemm_kernels() {
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<true>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_blk256), hipFuncAttributeMaxDynamicSharedMemorySize, ABLK_LDS_BYTES) == hipSuccess &&
-         set_lds<AttnCfg<2, 4>>(&k_attn_fused<2, 4>) && set_lds<AttnCfg<3, 6>>(&k_attn_fused<3, 6>) &&
-         set_lds<AttnCfg<3, 5>>(&k_attn_fused<3, 5>) &&
+         // (k_attn_fused<2,4> / <3,5> / <3,6> with v as V^T: superseded by the row-major-v forms of the DiT engine, configure_dit_attention)
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess &&
 #ifdef NATINF_DEV
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64_v2<0>), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess &&

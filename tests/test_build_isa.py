@@ -163,13 +163,14 @@ def test_no_development_kernels_in_the_shipped_library(listings):
     assert not abl, abl
     # superseded kernels nothing selects (round-2 review, weak #14): the LDS-ring conv_gn, the LDS-resident-patch conv, the 8-phase GEMM,
     # the unpipelined / spread-issue DMA tiles, the every-wave-issues 256x256 / 512x128 pipelines and the ring shapes without a caller
+    assert not [n for n in ks if re.search(r"k_attn_fused<\d, \d, false, false>", n)]      # (round 5: the DiT engine's attention takes v row-major; the V^T forms have no caller)
     dead = [n for n in ks if re.search(r"k_conv_gn<|k_conv_patch|k_gemm_8ph|k_gemm_dma<\d, \d, \d, \d, [01], |k_gemm_dma<2, 4, 8, 4, 2, |"
                                        r"k_gemm_dma<4, 2, 8, 4, 2, |k_gemm_dma<4, 2, 4, 4|k_gemm_dma<2, 2, 8, 4|k_gemm_ring<2, 4, |k_gemm_ring<4, 2, |"
                                        r"k_gemm_ring<2, 2, 4, 4, 4, 0>", n)]
     assert not dead, dead
     tiles = [n for n in ks if re.search(r"k_gemm_|k_conv_gn|k_conv_patch", n)]
     assert len(tiles) <= 88, len(tiles)                                        # the matmul tile families: 117 instantiations in round 2; round 4 added k_gemm_w128 (six epilogues) and k_gemm_w128_fp8 (2 x 4)
-    assert len(ks) < 150, len(ks)                                              # all kernels (146 in round 2; round 3 added the Inception, head and vectorised LayerNorm kernels; round 4 the w128 GEMMs and the 1,152-column LayerNorm; round 5 k_attn_blk256 and the Inception engine's k_conv_ring: three tiles x bf16 / fp16, its fp16 pack and pool)
+    assert len(ks) < 160, len(ks)                                              # all kernels (146 in round 2; round 3 added the Inception, head and vectorised LayerNorm kernels; round 4 the w128 GEMMs and the 1,152-column LayerNorm; round 5 k_attn_blk256 and the Inception engine's k_conv_ring: four tiles x bf16 / fp16, its fp16 pack, the row-walking pools: precision x max / average x stride)
     code = listings["ncsnpp"]
     assert "s_memtime" not in code[:code.index("amdhsa.kernels:")]           # tile-timeline stamps: -DNATINF_DEV builds only
 
