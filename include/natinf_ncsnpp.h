@@ -171,8 +171,11 @@ int natinf_set_fuse_gn8(int on);
  * 256-channel tile; per-sample tables, row vectors and GroupNorm partials); 0: GroupNorm-apply pass + split-K implicit GEMM + reduce pass +
  * statistics pass. */
 int natinf_set_fuse_gn4(int on);
-/* 1 (default; read when a plan is built): at 8x8 / 4x4, where a tile of the fused convolution holds whole samples and every output channel, its
- * epilogue writes the GroupNorm (scale | shift) table of the tensor's consumer itself; 0: a k_gn_finalize launch per table, as at 16x16 / 32x32. */
+/* 1 (default; read when a plan is built): where a tile of the fused convolution holds whole samples and every output channel, its epilogue writes the GroupNorm
+ * (scale | shift) table of the tensor's single consumer itself instead of a k_gn_finalize launch behind it -- at 8x8 / 4x4 (k_conv_gn2's 64-pixel x 256-channel
+ * tiles) and, since round 5, at 16x16 (k_conv_gn3's 256 x 256 tile IS one sample; when a tuning knob routes the launch to another kernel the consumer's op launches
+ * k_gn_finalize after all).  The tables are the same bytes either way.  0: a k_gn_finalize launch per table, as at 32x32; 2: 8x8 / 4x4 only (the round-4 plan);
+ * 3: 16x16 only. */
 int natinf_set_fuse_fin(int on);
 /* Bit mask by resolution (1: 4x4, 2: 8x8; bits 4 / 8 -- 16x16 / 32x32 -- are accepted and ignored: measured +-0 there, compiled out; read at launch) of the fused-convolution launches whose first blocks request the
  * whole weight matrix once at kernel start, so that the K loop's one-tap-ahead weight stream hits L2 inside a forward pass (where every layer's

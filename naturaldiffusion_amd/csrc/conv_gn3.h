@@ -462,7 +462,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tid_e = wave * 64 + lane_e;
     NATINF_CG3_STAMP(42);
     static_assert(EPI == 1 || EPI == 2 || EPI == 5 || EPI == 6, "packed epilogues: plain / + GroupNorm partials / + bf16 residual / both");
-    packed_tile_epilogue<WM, WN, 8, 8, typename Cfg::Epi, ACT_NONE, EPI == 2 || EPI == 6, EPI == 5 || EPI == 6, false, false, 1, false, true, true>(ge, smem, acc, m0, n0, 0, tid_e, lane_e, wm, wn);
+    // FIN (round 5): at 16x16 the 256 x 256 tile IS one sample with every channel, so its epilogue can write the consumer's GroupNorm table itself (GemmArgs::fin_*, when the plan
+    // asked for it) -- no k_gn_finalize launch behind this one, and no cross-block protocol either: the "last-arriving block" of a 16x16 sample is its only block
+    constexpr bool FIN16 = RES == 16 && WM == 2 && WN == 2 && (EPI == 2 || EPI == 6);
+    packed_tile_epilogue<WM, WN, 8, 8, typename Cfg::Epi, ACT_NONE, EPI == 2 || EPI == 6, EPI == 5 || EPI == 6, false, false, 1, FIN16, true, true>(ge, smem, acc, m0, n0, 0, tid_e, lane_e, wm, wn);
     NATINF_CG3_STAMP(43);
 }
 

@@ -395,7 +395,9 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
             }
         }
         if constexpr (FIN) {
-            static_assert(WM == 1 && BN_ <= THREADS, "one channel per thread, one wave row");
+            // (round 5: also the 256 x 256 tile of k_conv_gn3 at 16x16 -- ONE sample, every channel, two wave rows: a quad's partial is the wave rows' sum in the
+            // order the gn_part writer above adds them, so the table is the one k_gn_finalize computes from that single tile row)
+            static_assert((WM == 1 || NSAMP == 1) && BN_ <= THREADS, "one channel per thread; several samples per tile: one wave row");
             const int n = n0 + tid;
             if (g.fin_scale && tid < BN_ && n < g.N) {
                 constexpr int HWS = BM_ / NSAMP;                       // rows of a sample
@@ -405,7 +407,14 @@ __device__ __forceinline__ void packed_tile_epilogue(const GemmArgs& g, unsigned
                 for (int sm = 0; sm < NSAMP; ++sm) {
                     if (m0 + sm * HWS >= g.M) break;
                     float s = 0.f, qq = 0.f;
-                    for (int i = 0; i < qpg; ++i) { const float2 v = sred[sm * (BN_ / 4) + q0 + i]; s += v.x; qq += v.y; }
+                    for (int i = 0; i < qpg; ++i) {
+                        if constexpr (NSAMP == 1 && WM > 1) {
+                            float ps = 0.f, pq = 0.f;
+#pragma unroll
+                            for (int w = 0; w < WM; ++w) { ps += sred[w * (BN_ / 4) + q0 + i].x; pq += sred[w * (BN_ / 4) + q0 + i].y; }
+                            s += ps; qq += pq;
+                        } else { const float2 v = sred[sm * (BN_ / 4) + q0 + i]; s += v.x; qq += v.y; }
+                    }
                     const float mean = s * inv;
                     float var = qq * inv - mean * mean;
                     var = var < 0.f ? 0.f : var;

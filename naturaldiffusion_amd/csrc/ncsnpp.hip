@@ -244,7 +244,7 @@ int g_attn_proj = 1;               // natinf_set_attn_proj (read when a plan is 
 int g_attn256 = 1;                 // natinf_set_attn256: 1 = k_attn256 (K / V^T streamed through a two-stage LDS ring, two blocks per CU), 0 = k_attn_fused<8,16,true>
 int g_fuse_gn8 = 1;                // natinf_set_fuse_gn8 (read when a plan is BUILT): the 8x8 level on the fused kernel too (two images per 128-pixel tile)
 int g_cg_warm = 15;                // natinf_set_conv_gn_warm: bit mask by resolution (1: 4x4, 2: 8x8, 4: 16x16, 8: 32x32) of the fused-convolution launches that warm L2 with their weights
-int g_fuse_fin = 1;                // natinf_set_fuse_fin (read when a plan is BUILT): at 8x8 / 4x4 the fused convolution's epilogue writes the GroupNorm table of its
+int g_fuse_fin = 3;                // natinf_set_fuse_fin (read when a plan is BUILT): at 8x8 / 4x4 the fused convolution's epilogue writes the GroupNorm table of its
                                    // output's consumer itself (whole samples x all channels per tile) instead of a k_gn_finalize launch behind it
 int g_fuse_gn4 = 1;                // natinf_set_fuse_gn4 (read when a plan is BUILT): the 4x4 level on the fused kernel too (four images per 64-pixel tile) instead of
                                    // k_gn_apply + split-K GEMM + k_splitk_reduce + k_gn_stats
@@ -557,6 +557,7 @@ inline int effective_epi(int v, const GemmArgs& g) { const int e = packed_epi(g,
 // natinf_ncsnpp_forward clears it on entry and reports it on exit -- per calling thread, so two engines on two threads do not see
 // each other's, and a description pass (g_record) never sets it
 thread_local int g_launch_error = 0;
+thread_local bool g_fin_written = false;      // set by launch_gemm: the launch that just ran wrote the consumer's GroupNorm table (GemmArgs::fin_*) -- k_conv_gn3 at 16x16
 int g_splitk = 1;                  // natinf_set_gemm_splitk: 0 = never split K
 float* g_dbg_splitk_ws = nullptr; int g_dbg_splitk_max = 0;        // natinf_debug_set_splitk_workspace
 // Split-K for launches that cannot fill the chip otherwise (the 8x8 and 4x4 levels: 32,768 / 8,192 rows x 256 columns, K = 2,304 ..
@@ -707,7 +708,11 @@ int launch_gemm(const GemmArgs& g0, hipStream_t s) {
                 case 2: launch_tiles<CFG>(&k_conv_gn2<RES, WIDE, 5>, g, s); break;                              \
                 default: launch_tiles<CFG>(&k_conv_gn2<RES, WIDE, 6>, g, s); break;                             \
             }
-            if (const int sh3 = conv_gn3_shape(g); sh3 >= 0) { ncsn_cg3::launch(&g, sh3, e, (void*)s); return conv_gn_part_rows(g); }
+            if (const int sh3 = conv_gn3_shape(g); sh3 >= 0) {
+                ncsn_cg3::launch(&g, sh3, e, (void*)s);
+                g_fin_written = sh3 == 2 && g.fin_scale && (e == 2 || e == 6) && g.N == 256;      // (k_conv_gn3<16, 2, 2, 2 | 6>: FIN16, conv_gn3.h)
+                return conv_gn_part_rows(g);
+            }
             if (conv_gn_regw(g)) {
                 if ((1 << g.logW) == 8 && g_cg8_tm4) {
                     switch (e4) {
@@ -920,8 +925,10 @@ struct Builder {
             if (skws >= 0) { g.splitk_ws = c.at<float>(skws); g.splitk_max = SK_MAX; }
             g.c = c.act(t); g.c_ld = t.ld;
             if (pt.valid) { g.gn_part = c.at<float>(pt.off); g.gn_quads = pt.quads; set_fin(g, pt, c); }
+            g_fin_written = false;
             const int bm = launch_gemm(g, c.stream);
             if (pt.valid) c.part_bm[pt.id] = bm;
+            if (pt.fin && pt.fin->check) pt.fin->done = g_fin_written;
         });
         if (!fuse) arena.release(h.off);
         int64_t sc1 = own_sc, sh1 = own_sh;               // GroupNorm_1's table: the same buffers again, or the one Conv_0's epilogue wrote
@@ -949,8 +956,10 @@ struct Builder {
             if (skws >= 0) { g.splitk_ws = c.at<float>(skws); g.splitk_max = SK_MAX; }
             g.c = c.act(out); g.c_ld = out.ld;
             if (po.valid) { g.gn_part = c.at<float>(po.off); g.gn_quads = po.quads; set_fin(g, po, c); }
+            g_fin_written = false;
             const int bm = launch_gemm(g, c.stream);
             if (po.valid) c.part_bm[po.id] = bm;
+            if (po.fin && po.fin->check) po.fin->done = g_fin_written;
         });
         if (skws >= 0) arena.release(skws);
         if (fuse1) arena.release(t.off); else arena.release(u.off);
@@ -1187,7 +1196,9 @@ struct Builder {
     // Fin: the producer's epilogue writes its consumer's GroupNorm table (GemmArgs::fin_*).  The table buffers are allocated with the Part -- in front
     // of the producing launch, so they cannot alias anything that launch still reads -- and the consumer fills in its gamma / beta when it is emitted
     // (the producer's op reads the struct when it RUNS).  Only the first single-source consumer claims it; anyone else takes k_gn_finalize.
-    struct Fin { int64_t sc = -1, sh = -1, gamma = -1, beta = -1; int C = 0; float out_mul = 1.0f; bool claimed = false; };
+    // check (round 5, the 16x16 level): whether the producer's launch wrote the table is only known when it RUNS (k_conv_gn3's 256 x 256 tile does, the k_conv_gn2 tiles a
+    // tuning knob may select instead do not): the producer's op records it in `done`, and the consumer's op launches k_gn_finalize into the same buffers when it is false
+    struct Fin { int64_t sc = -1, sh = -1, gamma = -1, beta = -1; int C = 0; float out_mul = 1.0f; bool claimed = false, check = false, done = false; };
     struct Part { int64_t off = -1; int quads = 0, id = -1, res = 0; bool valid = false; std::shared_ptr<Fin> fin; };
     static void set_fin(GemmArgs& g, const Part& p, const Ctx& c) {
         if (!p.fin || !p.fin->claimed) return;
@@ -1209,9 +1220,14 @@ struct Builder {
     Part register_output(const TRef& out, bool fused8 = false) {
         Part p;
         if (fusable(out.res) || (out.res <= 8 && fused8)) p = new_part(out.res, out.C);
-        if (p.valid && out.res <= 8 && fused8 && g_fuse_fin && out.C == 256) {      // (the fused kernel's 64-pixel x 256-channel tile: whole samples, every channel)
+        if (p.valid && out.res <= 8 && fused8 && (g_fuse_fin & 1) && out.C == 256) {      // (the fused kernel's 64-pixel x 256-channel tile: whole samples, every channel)
             p.fin = std::make_shared<Fin>();
             p.fin->sc = arena.alloc((int64_t)out.C * 4); p.fin->sh = arena.alloc((int64_t)out.C * 4); p.fin->C = out.C;
+        }
+        // 16x16 (round 5): k_conv_gn3's 256 x 256 tile = ONE sample x every channel (fused8 here: "the producer is the fused convolution")
+        if (p.valid && out.res == 16 && fused8 && (g_fuse_fin & 2) && out.C == 256 && !ddpm) {
+            p.fin = std::make_shared<Fin>();
+            p.fin->sc = arena.alloc((int64_t)out.C * 4); p.fin->sh = arena.alloc((int64_t)out.C * 4); p.fin->C = out.C; p.fin->check = true;
         }
         parts[{out.off, out.coff}] = p;
         return p;
@@ -1235,6 +1251,15 @@ struct Builder {
             Fin& f = *p0.fin;
             f.gamma = gn.gamma; f.beta = gn.beta; f.out_mul = out_mul; f.claimed = true;
             sc = f.sc; sh = f.sh;
+            if (f.check) {                                                              // ... unless the launch that ran was not the one that can (see Fin)
+                const std::shared_ptr<Fin> fp = p0.fin;
+                const int64_t fsc = f.sc, fsh = f.sh;
+                op(CLS_OTHER, [=](const Ctx& c) {
+                    if (fp->done) return;
+                    hipLaunchKernelGGL(k_gn_finalize, dim3(c.B), dim3(256), 0, c.stream, c.at<float2>(p0.off), HW / c.part_bm[p0.id], p0.quads, (const float2*)nullptr, 0, 0, C, HW,
+                                       c.w<float>(gn.gamma), c.w<float>(gn.beta), c.at<float>(fsc), c.at<float>(fsh), GN_EPS, out_mul);
+                });
+            }
             return true;
         }
         const int64_t sc_ = sc, sh_ = sh;
@@ -1512,6 +1537,7 @@ const natinf_ncsnpp& reference_engine() {
         int* knobs[] = {&g_fuse_gn, &g_fuse_up, &g_fuse_head, &g_fuse_gn8, &g_fuse_gn4, &g_fuse_fin, &g_attn_qkv, &g_attn_proj, &g_attn256};
         int saved[sizeof(knobs) / sizeof(knobs[0])];
         for (size_t i = 0; i < sizeof(knobs) / sizeof(knobs[0]); ++i) { saved[i] = *knobs[i]; *knobs[i] = 1; }
+        g_fuse_fin = 3;                                      // (a bit mask: both levels' producer-written tables)
         natinf_ncsnpp* r = make_engine(0);
         for (size_t i = 0; i < sizeof(knobs) / sizeof(knobs[0]); ++i) *knobs[i] = saved[i];
         return r;
@@ -1770,7 +1796,12 @@ int natinf_set_attn_block(int on) { g_attn_blk = on != 0; return NATINF_OK; }
 int natinf_set_attn_qkv(int on) { g_attn_qkv = on != 0; return NATINF_OK; }
 int natinf_set_attn_waves8(int on) { g_attn_w8 = on != 0; return NATINF_OK; }
 int natinf_set_attn_proj(int on) { g_attn_proj = on != 0; return NATINF_OK; }
-int natinf_set_fuse_fin(int on) { g_fuse_fin = on != 0; return NATINF_OK; }
+int natinf_set_fuse_fin(int on) {              // 1 = every level that can (the default), 0 = none, 2 = 8x8 / 4x4 only (the round-4 plan), 3 = 16x16 only
+    if (on < 0 || on > 3) return NATINF_EINVAL;
+    static const int mask[4] = {0, 3, 1, 2};    // g_fuse_fin: bit 0 = 8x8 / 4x4 (k_conv_gn2), bit 1 = 16x16 (k_conv_gn3)
+    g_fuse_fin = mask[on];
+    return NATINF_OK;
+}
 int natinf_set_gemm_round_model(int on) { g_round_model = on != 0; g_round_model_w128 = on >= 10 ? on : 13; return NATINF_OK; }
 int natinf_set_gemm_w128(int on) { g_w128 = on < 0 ? 0 : (on > 2 ? 2 : on); return NATINF_OK; }
 int natinf_set_fuse_gn4(int on) { g_fuse_gn4 = on != 0; return NATINF_OK; }

@@ -319,6 +319,37 @@ def test_odd_batches_default_plan_against_the_unfused_plan(dev, flat, B):
     assert _rel(y.cpu(), ref.cpu()) < 2e-2
 
 
+@pytest.mark.parametrize("B", [2, 67])
+def test_producer_written_tables_at_16x16_are_the_finalize_kernels_bytes(dev, flat, B):
+    """natinf_set_fuse_fin: 1 (default) = at 16x16 k_conv_gn3's 256 x 256 tile -- ONE sample, every channel -- writes its consumer's GroupNorm table in its
+    epilogue; 2 = the round-4 plan (a k_gn_finalize launch per 16x16 table).  Same sums in the same order: the network's output is the same bytes.  Then the
+    run-time fallback: with natinf_set_conv_gn_w128(0) every 16x16 launch takes k_conv_gn2, whose tiles cannot write the table -- the plan that claimed
+    producer-written tables must launch k_gn_finalize itself and still give the bytes of the plan that never claimed them."""
+    from naturaldiffusion_amd.ncsnpp import NCSNppEngine
+    from naturaldiffusion_amd._lib import lib
+    g = torch.Generator().manual_seed(300 + B)
+    x = torch.randn(B, 3, 32, 32, generator=g).to(dev)
+    labels = (torch.rand(B, generator=g) * 999).to(dev)
+    new = NCSNppEngine(flat, max_batch=B, device=dev)
+    try:
+        assert lib.natinf_set_fuse_fin(2) == 0
+        old = NCSNppEngine(flat, max_batch=B, device=dev)
+    finally:
+        lib.natinf_set_fuse_fin(1)
+    y_new, y_old = new(x, labels).clone(), old(x, labels).clone()
+    assert torch.isfinite(y_new).all() and torch.equal(y_new, y_old)
+    assert torch.equal(new(x, labels), y_new)                                  # (the tables are rewritten every forward)
+    try:
+        assert lib.natinf_set_conv_gn_w128(0) == 0                             # k_conv_gn2 everywhere: no launch writes a 16x16 table
+        z_new, z_old = new(x, labels).clone(), old(x, labels).clone()
+    finally:
+        lib.natinf_set_conv_gn_w128(7)
+    # (against y_new only close: k_conv_gn2's 128-row tiles give TWO partial rows per 16x16 sample, so the statistics are summed in another order)
+    assert torch.equal(z_new, z_old) and _rel(z_new.cpu(), y_new.cpu()) < 2e-2
+    assert torch.equal(new(x, labels), y_new)                                  # back on k_conv_gn3: the producer writes again
+    assert lib.natinf_set_fuse_fin(4) != 0
+
+
 def test_natural_inference_tx_two_stream_pipeline(dev, flat, repo_root):
     """CIFAR10NaturalInference.natural_inference_tx(streams=2, the default): consecutive batches on two HIP streams (two engine handles) against the
     reference's one-after-the-other order.  Same noise order, same launches per batch: bit-identical images, run after run (it was not, until the DPP
