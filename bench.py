@@ -26,8 +26,9 @@ one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
                     fc2 GEMMs, bf16 elsewhere.  Fields: value (images/s), ms_per_step, frac (all 2*MAC flops of the forward / wall time
                     / 2,500 TFLOP/s), roofline {k_flash_attn64_v2 timed IN the engine: HIP events around each launch of one 28-step batch: ms,
                     TFLOP/s, frac of the bf16 peak; iso_ms = the same kernel in a back-to-back loop, which this power-capped part clocks
-                    lower}, gemm {per image-stream projection shape (M = 32,768): TFLOP/s and frac of ITS operand type's dense peak
-                    (bf16 2,500 / fp8 5,000); frac = sum(flops_i / peak_i) / sum(time_i)}, cpu (the MMDiT oracle on one sequence through 2
+                    lower}, gemm {per image-stream projection role (qk, vT, out, fc1, fc2; 4,096 tokens x 8 sequences), timed IN the engine by natinf_gemm_profile --
+                    the kernel with the epilogue the engine gives it: [TFLOP/s, frac of ITS operand type's dense peak (bf16 2,500 / fp8 5,000), mean launch us];
+                    frac = sum(flops_i / peak_i) / sum(time_i); iso_fc1 = fc1 with that same epilogue in an isolated back-to-back loop, TFLOP/s}, cpu (the MMDiT oracle on one sequence through 2
                     of 24 blocks, extrapolated: images/s), acc (28-step NI through a 4-block / 256-wide MMDiT: relative RMS of the final
                     latents vs the fp32 oracle -- PARITY UNPINNED, the oracle restates the published architecture).
   fid50k            BASELINE config 3 (``--workload fid50k`` alone): the 50,000-image FID job of reference
@@ -154,9 +155,11 @@ def timed_region(one_step, steps, warmup, world, sync, dist, dev):
     and the outputs of the LAST TWO steps (one per lane of a two-stream run)."""
     import torch
 
+    grouped = dist.is_available() and dist.is_initialized()      # world > 1, or one rank under --force-pg (the RCCL rehearsal of a one-GPU box)
+
     def barrier():
         sync()
-        if world > 1:
+        if grouped:
             dist.barrier()
         sync()
     outs = []
@@ -168,7 +171,7 @@ def timed_region(one_step, steps, warmup, world, sync, dist, dev):
         outs = (outs + [one_step(i)])[-2:]
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
@@ -195,6 +198,9 @@ def main():
     ap.add_argument("--fid-samples", type=int, default=50000, help="fid50k: images of the whole job (reference: 50,000)")
     ap.add_argument("--fid-share-of", type=int, default=0, help="fid50k on ONE GPU: run rank 0's share of a job sharded this many ways (default 8; 1 = the whole job)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process-group backend (gloo: the selftest workload on CPU)")
+    ap.add_argument("--force-pg", action="store_true",
+                    help="initialise the process group even with ONE rank and run every collective of the N > 1 path through it (barriers, the max-over-ranks "
+                         "all-reduce of a device tensor, fid50k's 33.6 MB fp64 all-reduce): with --backend nccl the RCCL rehearsal a one-GPU box can do")
     ap.add_argument("--same-device", action="store_true",
                     help="functional test of the N > 1 path on a ONE-GPU box: every rank uses cuda:0 (gloo backend only: RCCL refuses two ranks on one device)")
     ap.add_argument("--selftest-fail-rank", type=int, default=-1, help="selftest: this rank exits non-zero (launcher error-path test)")
@@ -224,8 +230,15 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    grouped = world > 1 or args.force_pg
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:            # --force-pg without a launcher: a one-rank rendezvous of our own
+            import socket
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        os.environ.setdefault("RANK", str(rank)); os.environ.setdefault("WORLD_SIZE", str(world))
         if args.backend == "gloo":
             dist.init_process_group("gloo")
         else:
@@ -270,9 +283,11 @@ def main():
             line["validate"] = slim({k: v for k, v in sub.items() if k not in strip and k not in ("dtype", "cpu_baseline", "dit_forwards")})
             release()
         line.update(tail)
+    if grouped:
+        line.setdefault("config", {})["process_group"] = f"{dist.get_backend()} x{world}"
     if rank == 0:
         print(json.dumps(line, separators=(",", ":")), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 
@@ -601,39 +616,56 @@ def bench_sd3(args, world, rank, dev, fp8=False, steps=2, warmup=1, flat=None):
         o = torch.empty(Bs, Tp, D, device=dev, dtype=torch.bfloat16)
         t_fa_iso = timed(lambda: check(lib.natinf_attention_hd64_bf16(ptr(q), ptr(q) + 2 * D, 2 * D, Tp * 2 * D, ptr(vT), ptr(o), D, Tp * D, Bs, H, Tp, T, 0.125,
                                                                        stream_ptr()), "attention"))
-        # the same kernel where it actually runs: one more 28-step batch with an event pair around every k_flash_attn64 launch of the engine
+        # the same kernels where they actually run: one more 28-step batch with an event pair around every k_flash_attn64 launch AND every matmul-shaped launch
+        # of the engine (natinf_gemm_profile: the kernel with the epilogue the engine gives it, on its stream, between its real neighbours)
         import ctypes
         check(lib.natinf_attention_profile(1), "attention_profile")
+        check(lib.natinf_gemm_profile(1), "gemm_profile")
         one_step(); torch.cuda.synchronize()
         ms_tot, n_l = ctypes.c_double(), ctypes.c_int64()
         check(lib.natinf_attention_profile_read(ctypes.byref(ms_tot), ctypes.byref(n_l)), "attention_profile_read")
         check(lib.natinf_attention_profile(0), "attention_profile")
+        check(lib.natinf_gemm_profile(0), "gemm_profile")
+        gbuf = ctypes.create_string_buffer(1 << 16)
+        check(min(0, lib.natinf_gemm_profile_read(gbuf, len(gbuf))), "gemm_profile_read")
         t_fa = ms_tot.value / max(1, n_l.value) * 1e-3
         fa_flops = 4.0 * T * T * 64 * H * Bs
         line["roofline"] = {"kernel": "k_flash_attn64_v2<1,64>", "bound": "mfma", "achieved": r4(fa_flops / t_fa / 1e12), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": r4(fa_flops / t_fa / 1e12 / MFMA_BF16_PEAK_TFLOPS), "traffic": None, "mean_launch_ms": r4(t_fa * 1e3), "launches": int(n_l.value),
                             "flops_per_launch": r4(fa_flops), "iso_ms": r4(t_fa_iso * 1e3), "flop_share": r4(L * fa_flops / (flops_fwd_seq * Bs))}
-        M = Bs * tx
-        shapes = [("qk", 2 * D, D), ("v_out", D, D), ("fc1", 4 * D, D), ("fc2", D, 4 * D)]
-        tot_t, tot_f, tot_ideal, per = 0.0, 0.0, 0.0, {}
-        for name, N_, K_ in shapes:
-            if fp8 and name != "v_out":
-                a8 = torch.randint(0, 255, (M, K_), device=dev, dtype=torch.uint8); b8 = torch.randint(0, 255, (N_, K_), device=dev, dtype=torch.uint8)
-                a8 &= 0x77; b8 &= 0x77                                                 # finite e4m3 patterns
-                sa, sb = torch.ones(M, device=dev), torch.ones(N_, device=dev)
-                c = torch.empty(M, N_, device=dev, dtype=torch.bfloat16)
-                t_ = timed(lambda: check(lib.natinf_debug_gemm_fp8(M, N_, K_, ptr(a8), ptr(sa), None, ptr(b8), ptr(sb), None, ptr(c), None, 0, 1, stream_ptr()), "gemm_fp8"))
-                pk_ = MFMA_FP8_PEAK_TFLOPS
-            else:
-                a = torch.randn(M, K_, device=dev).bfloat16(); b = torch.randn(N_, K_, device=dev).bfloat16()
-                c = torch.empty(M, N_, device=dev, dtype=torch.bfloat16)
-                t_ = timed(lambda: check(lib.natinf_debug_gemm(0, M, N_, K_, 0, 1, 0, 1, ptr(a), None, ptr(b), None, ptr(c), 0, 1.0, 1, stream_ptr()), "gemm"))
-                pk_ = MFMA_BF16_PEAK_TFLOPS
-            f_ = 2.0 * M * N_ * K_
-            per[name] = [r4(f_ / t_ / 1e12), r4(f_ / t_ / 1e12 / pk_)]             # [TFLOP/s, fraction of the operand type's dense peak]
+        # image-stream projections (4,096 tokens x 8 sequences per launch) by role; a row of the table: "M N K K1 taps batch kernel/eEPI launches total_ms"
+        role = {(tx, 2 * D, D): "qk", (D, tx, D): "vT", (tx, D, D): "out", (tx, 4 * D, D): "fc1", (tx, D, 4 * D): "fc2"}
+        tot_t, tot_f, tot_ideal, per, kernels = 0.0, 0.0, 0.0, {}, set()
+        for row in gbuf.value.decode().splitlines():
+            f = row.split()
+            M_, N_, K_, bt, kern, nl, ms = int(f[0]), int(f[1]), int(f[2]), int(f[5]), f[6], int(f[7]), float(f[8])
+            if bt == 1 and M_ == Bs * tx:
+                M_, bt = tx, Bs                                               # (a flat launch over all sequences)
+            name = role.get((M_, N_, K_))
+            if name is None or bt != Bs:
+                continue                                                      # text stream (333 tokens), embedders, modulation, proj_out: < 4 % of the forward's flops
+            pk_ = MFMA_FP8_PEAK_TFLOPS if "fp8" in kern else MFMA_BF16_PEAK_TFLOPS
+            f_, t_ = 2.0 * M_ * N_ * K_ * bt, ms / nl * 1e-3
+            per[name] = [r4(f_ / t_ / 1e12), r4(f_ / t_ / 1e12 / pk_), r4(t_ * 1e6)]      # [TFLOP/s, fraction of ITS operand type's dense peak, mean launch us] -- in the engine
+            kernels.add(kern)
             tot_t += t_; tot_f += f_; tot_ideal += f_ / (pk_ * 1e12)
-        line["roofline_gemm"] = {"kernel": "k_gemm_w128_fp8+k_gemm_w128" if fp8 else "k_gemm_w128", "achieved": r4(tot_f / tot_t / 1e12), "peak": r4(tot_f / tot_ideal / 1e12),
-                                 "frac": r4(tot_ideal / tot_t), "shapes": per}
+        line["roofline_gemm"] = {"kernel": "+".join(sorted(kernels)), "where": "in-engine (HIP events around every launch of one 28-step batch)",
+                                 "achieved": r4(tot_f / tot_t / 1e12), "peak": r4(tot_f / tot_ideal / 1e12), "frac": r4(tot_ideal / tot_t), "shapes": per}
+        # isolated back-to-back loop of fc1 WITH the engine's epilogue (tanh-GELU; fp8: + e4m3 output with E8M0 block scales), for the isolated-vs-engine gap
+        M = Bs * tx
+        N_, K_ = 4 * D, D
+        if fp8:
+            a8 = torch.randint(0, 255, (M, K_), device=dev, dtype=torch.uint8); b8 = torch.randint(0, 255, (N_, K_), device=dev, dtype=torch.uint8)
+            a8 &= 0x77; b8 &= 0x77                                                     # finite e4m3 patterns
+            sa, sb = torch.ones(M, device=dev), torch.ones(N_, device=dev)
+            c8 = torch.empty(M, N_, device=dev, dtype=torch.uint8); cmx = torch.empty(N_ // 32, (M + 255) // 256 * 256, device=dev, dtype=torch.uint8)
+            t_ = timed(lambda: check(lib.natinf_debug_gemm_fp8(M, N_, K_, ptr(a8), ptr(sa), None, ptr(b8), ptr(sb), None, ptr(c8), ptr(cmx), 3 | (2 << 8), 1, stream_ptr()), "gemm_fp8"))
+        else:
+            a = torch.randn(M, K_, device=dev).bfloat16(); b = torch.randn(N_, K_, device=dev).bfloat16()
+            c = torch.empty(M, N_, device=dev, dtype=torch.bfloat16); bias = torch.zeros(N_, device=dev)
+            t_ = timed(lambda: check(lib.natinf_debug_gemm_fused(0, M, N_, K_, ptr(a), ptr(b), ptr(bias), None, None, None, 30, None, None, 1.0, 2, ptr(c), 0, None, None, 0,
+                                                                  stream_ptr()), "gemm_fused"))
+        line["roofline_gemm"]["iso_fc1"] = r4(2.0 * M * N_ * K_ / t_ / 1e12)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the MMDiT oracle (fp32, eager PyTorch) on ONE sequence through TWO blocks at full width, extrapolated to the
         # ---- 24 blocks x 2 sequences (CFG) x 28 steps of an image -- a full forward on the CPU would take minutes
@@ -729,6 +761,8 @@ def bench_fid50k(args, world, rank, dev, steps=1, warmup=0):
             "fid": ("blocked" if blocked else {k: r4(v["fid"]) for k, v in res.items()}),
             "config": {"workload": f"CIFAR10 FID job {total} images / {share_of} shares, dpmsolverpp2s_018.npz + coeffgen.ddim_vp_continuous(19 nodes), B={args.batch}, "
                                    "Inception pool3 engine in 500s, one statistics all-reduce", "nfe": 18, "streams": len(lanes), "sharding": f"batch x{share_of}"}}
+    if dist.is_available() and dist.is_initialized():
+        line["collective"] = f"{dist.get_backend()} x{dist.get_world_size()}"        # what carried s.allreduce (absent: no process group, nothing to reduce over)
     if blocked:
         line["frechet_vs_synthetic_ref"] = {k: r4(v["fid"]) for k, v in res.items()}
     # untimed sanity figure that needs no asset: the two matrices integrate the same ODE from the same noise with the same network, so their image

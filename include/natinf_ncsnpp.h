@@ -221,6 +221,15 @@ int natinf_debug_timestamps(void* dev_buf16);
 int natinf_ncsnpp_profile(natinf_ncsnpp_t h, int enable);
 int natinf_ncsnpp_profile_read(natinf_ncsnpp_t h, double* ms_by_class /*[4]*/, int64_t* launches_by_class /*[4]*/);
 
+/* Per-shape timing of the matmul-shaped launches WHERE THEY RUN (every engine of the library: NCSN++, DiT, MMDiT, VAE, Inception): while enabled, each
+ * launch -- bf16 or fp8, with the epilogue the engine gives it, on the stream it runs on -- is bracketed by a HIP event pair.  natinf_gemm_profile_read waits
+ * for the recorded events and writes one line per distinct launch description since the previous read, in first-seen order:
+ *   "M N K K_shortcut taps batch kernel/eEPILOGUE launches total_ms\n"   (the first seven fields are natinf_ncsnpp_describe_gemms' line)
+ * and returns the number of bytes written (negative: error; NATINF_EINVAL when `cap` is too small -- the records are consumed either way).
+ * Process-global switch, one host thread at a time (as natinf_attention_profile).  bench.py's `sd3*.gemm` objects are these numbers. */
+int natinf_gemm_profile(int enable);
+int natinf_gemm_profile_read(char* buf, int cap);
+
 /* After a forward on a KEEP_ACTIVATIONS handle: copy the output of all_modules[module_idx]
  * (module_idx >= 2) as fp32 NCHW into `out` (capacity in elements).  Same B / workspace as the forward. */
 int natinf_ncsnpp_debug_tap(natinf_ncsnpp_t h, int module_idx, float* out, int64_t capacity_elems,

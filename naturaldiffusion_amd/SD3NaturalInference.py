@@ -210,9 +210,13 @@ def sd_natural_inference_tx(pipe=None, device="cuda", noises: Optional[torch.Ten
             tr = getattr(pipe, "transformer", None)
             latent_shape = (tr.in_ch, 2 * tr.grid, 2 * tr.grid) if hasattr(tr, "in_ch") and hasattr(tr, "grid") else (16, 128, 128)
         finals = []
+        # an index-less "cuda" (this function's default) is THIS rank's current device -- where `_load_pipe` and the engine live after the launcher's
+        # `torch.cuda.set_device(local_rank)` -- never a literal cuda:0: rank r's Philox noise and history slabs belong next to rank r's transformer
+        dev_r = torch.device(device)
+        if dev_r.type == "cuda" and dev_r.index is None:
+            dev_r = torch.device("cuda", torch.cuda.current_device())
         for weight_name in weight_names:
-            lat, idx = sd_generate_sharded(pipe, sample_count, n, rank, world, seed, num_step, weight_name, device if str(device) != "cuda" else "cuda:0",
-                                           latent_shape=tuple(latent_shape))
+            lat, idx = sd_generate_sharded(pipe, sample_count, n, rank, world, seed, num_step, weight_name, dev_r, latent_shape=tuple(latent_shape))
             finals.append((lat, idx))
             if decode:
                 for s0 in range(0, lat.shape[0], n):

@@ -9,7 +9,7 @@
 //   * k and V^T are still written (one block cannot keep 256 KB on chip) and re-read by the SAME block right away: the stores are complete behind `s_waitcnt vmcnt(0)`
 //     (one XCD's L2; the block's own L1 holds no line of them: nothing of this launch read them before), a barrier publishes them to the other waves, and the LDS-DMA
 //     of the attention phases finds them in L2 -- HBM sees the writes only.
-// Arithmetic, tile loops, swizzles, projection and GroupNorm partials: the two kernels' own (see their headers).  One block per CU (256 registers), 67 KB of LDS;
+// Arithmetic, tile loops, swizzles, projection and GroupNorm partials: the two kernels' own (see their headers).  One block per CU (256 registers), 134 KB of LDS (ABLK_LDS_BYTES: four 32-KB stages + the biases);
 // the projection phase's weight tiles come three tiles ahead (four 16-KB stages: what k_qkv256's four co-resident blocks hide, one block must prefetch).
 #pragma once
 #include "attn_qkv.h"
@@ -18,6 +18,29 @@
 namespace ncsn {
 
 constexpr int ABLK_STAGES = 4, ABLK_LDS_BYTES = ABLK_STAGES * A256_STAGE + QKV_BIAS_BYTES;      // four 32-KB stages (K / V^T / W3 tiles three ahead), the projection phase's biases behind them
+
+// Sum over the wave's 32 queries of a lane's two per-query values (a: query tau(0, r), b: tau(1, r)) IN THE ORDER k_attn256<true, 8> ADDS THEM, so that the GroupNorm
+// partial sums of the block's output -- and with them every later module of the network -- are the two-launch plan's bytes (round-5 review, item 5; advisor note).
+// k_attn256's lane r holds queries u = 16 g + r and adds (g = 0) + (g = 1) first, then dpp_row_sum's tree over r: u ^ 16, then u ^ 1, u ^ 2, u ^ 4, u ^ 8.  Here
+// u = tau(g, r) = 8 (r >> 2) + 4 g + (r & 3): bit 4 of u is bit 3 of r, bit 2 of u is g, bit 3 of u is bit 2 of r -- so the same tree is r ^ 8 (row_ror:8) on each of the
+// two values, the two quad stages on each, THEN a + b, then the half-row mirror (quads are uniform by then: r ^ 4).  fp32 addition commutes, the tree is what must match.
+__device__ __forceinline__ float dpp_row_sum_tau(float a, float b) {
+    asm volatile("s_nop 4" : "+v"(a), "+v"(b));            // (the inputs may be packed-fp32 results: dpp_row_sum's note in gemm_dma.h)
+    a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x128, 0xF, 0xF, true));
+    b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x128, 0xF, 0xF, true));
+    asm volatile("" : "+v"(a), "+v"(b));
+    a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));
+    b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0xB1, 0xF, 0xF, true));
+    asm volatile("" : "+v"(a), "+v"(b));
+    a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x4E, 0xF, 0xF, true));
+    b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x4E, 0xF, 0xF, true));
+    asm volatile("" : "+v"(a), "+v"(b));
+    float v = a + b;
+    asm volatile("s_nop 1" : "+v"(v));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    asm volatile("" : "+v"(v));
+    return v;
+}
 
 // x: [B*256][x_ld] bf16 (raw block input: normalised for q | k | v, and the residual of the output); gsc / gsh: GroupNorm (scale | shift) tables [B][256] fp32;
 // wf: k_pack_qkv_w's output; bqk: [512] (q then k), bv: [256]; qk: [B*256][512] scratch (only the k half, columns 256.., is written); vT: [B][256][256] scratch;
@@ -302,7 +325,7 @@ __global__ __launch_bounds__(512, 1) void k_attn_blk256(const bf16* __restrict__
         for (int pr = 0; pr < 2; ++pr) {
             const int n = 64 * t + 32 * pr + 8 * qe;
             const float4 b0 = *reinterpret_cast<const float4*>(b3 + n), b1 = *reinterpret_cast<const float4*>(b3 + n + 4);
-            float s0 = 0.f, ss0 = 0.f, s1 = 0.f, ss1 = 0.f;
+            float s0[2], ss0[2], s1[2], ss1[2];                 // per g: dpp_row_sum_tau adds them in k_attn256's order
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const int64_t row = (int64_t)b * T + tok0 + 8 * (re >> 2) + 4 * g + (re & 3);      // query tau(g, re)
@@ -313,11 +336,11 @@ __global__ __launch_bounds__(512, 1) void k_attn_blk256(const bf16* __restrict__
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { v[i] = (v[i] + (float)rx[i]) * out_scale; w[i] = (bf16)v[i]; }
                 *reinterpret_cast<bf16x8*>(o + row * o_ld + n) = w;
-                s0 += (v[0] + v[1]) + (v[2] + v[3]);  ss0 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                s1 += (v[4] + v[5]) + (v[6] + v[7]);  ss1 += (v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]);
+                s0[g] = (v[0] + v[1]) + (v[2] + v[3]);  ss0[g] = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                s1[g] = (v[4] + v[5]) + (v[6] + v[7]);  ss1[g] = (v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]);
             }
-            part[4 * t + 2 * pr] = make_float2(dpp_row_sum(s0), dpp_row_sum(ss0));
-            part[4 * t + 2 * pr + 1] = make_float2(dpp_row_sum(s1), dpp_row_sum(ss1));
+            part[4 * t + 2 * pr] = make_float2(dpp_row_sum_tau(s0[0], s0[1]), dpp_row_sum_tau(ss0[0], ss0[1]));
+            part[4 * t + 2 * pr + 1] = make_float2(dpp_row_sum_tau(s1[0], s1[1]), dpp_row_sum_tau(ss1[0], ss1[1]));
         }
     }
     if (gn_part) {

@@ -126,7 +126,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     auto lds_addr = [](const unsigned char* p) __attribute__((always_inline)) { return (unsigned)(uintptr_t)((lds_u8*)const_cast<unsigned char*>(p)); };
     auto glds16 = [](unsigned voff, const void* sbase, unsigned lds_dst) __attribute__((always_inline)) {
+        NATINF_M0_ASM_BEGIN
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+        NATINF_M0_ASM_END
     };
     unsigned off_b[PB];
     {
@@ -157,7 +159,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gn(const GemmArgs g)
         if (j0 == 0) {
             const float* src = (lane < 32 ? gsc : gsh - 32) + (unsigned)(hc * KT + lane);
             const unsigned dst = lds_tab + buf * Cfg::TAB_BYTES;
+            NATINF_M0_ASM_BEGIN
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(src), "s"(dst) : "memory", "m0");
+            NATINF_M0_ASM_END
         }
         const bf16* base = img + hc * KT;
         int l = lane;

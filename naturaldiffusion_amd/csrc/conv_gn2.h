@@ -167,7 +167,9 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
     // why: hipcc drains vmcnt in front of any LDS access it can see while an LDS-DMA is in flight).
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     auto glds16 = [](unsigned voff, const void* sbase, unsigned lds_dst) __attribute__((always_inline)) {
+        NATINF_M0_ASM_BEGIN
         asm volatile(NATINF_PAD_PRE "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" NATINF_PAD_POST :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+        NATINF_M0_ASM_END
     };
     // (LDS byte addresses straight from the array: a cast of a generic pointer carries a null check against the shared aperture, which
     // hipcc has mis-selected into a vector compare on an SGPR-only operand in some variants of this kernel)
@@ -206,8 +208,10 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
             for (int im = 0; im < NIMG; ++im) {
                 const unsigned dst = lds_tab + buf * Cfg::TAB_BYTES + im * Cfg::TAB_IMG_BYTES;
                 const int64_t io = (int64_t)min(im, nval - 1) * g.gn_ld;
+                NATINF_M0_ASM_BEGIN
                 if (l < 32) asm volatile(NATINF_PAD_PRE "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" NATINF_PAD_POST :: "v"(toff), "s"(gsc + io + hc * KT), "s"(dst) : "memory", "m0");
                 else        asm volatile(NATINF_PAD_PRE "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" NATINF_PAD_POST :: "v"(toff), "s"(gsh + io + hc * KT), "s"(dst) : "memory", "m0");
+                NATINF_M0_ASM_END
             }
         }
         const bf16* base = img + hc * KT;
@@ -332,7 +336,8 @@ __global__ __launch_bounds__(256 * NGV, NGV > 1 ? 1 : 2) void k_conv_gn2(const G
         // the lane's row of the table: channel chunk (l & 3) ^ 2 * (bit 2 of the patch column).  Recomputed from the slot address (bits 4-9 = the lane) per
         // round: a register held across the K loop for it is the one hipcc spills (and its reload drains the weight stream)
         // (several images per tile: the piece's image, hence its table, is wave-uniform -- pieces do not straddle images)
-        const unsigned timg = NIMG > 1 ? (unsigned)((J * NW + wave) / (IMGP / 16)) * Cfg::TAB_IMG_BYTES : 0u;
+        constexpr int PIECES_PER_IMG = NIMG > 1 ? IMGP / 16 : 1;                 // (one image per tile: IMGP = 0, and the arm below is dead -- no division by it)
+        const unsigned timg = NIMG > 1 ? (unsigned)((J * NW + wave) / PIECES_PER_IMG) * Cfg::TAB_IMG_BYTES : 0u;
         const unsigned tbase = lds_tab + timg + ((((nb >> 4) & 3u) ^ ((nm >> (7 + J)) & 2u)) << 5);
         ns0 = lds_read16<BUF * Cfg::TAB_BYTES>(tbase); ns1 = lds_read16<BUF * Cfg::TAB_BYTES + 16>(tbase);
         nh0 = lds_read16<BUF * Cfg::TAB_BYTES + 128>(tbase); nh1 = lds_read16<BUF * Cfg::TAB_BYTES + 144>(tbase);

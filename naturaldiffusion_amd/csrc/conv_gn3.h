@@ -81,11 +81,14 @@ __device__ __forceinline__ u32x4 cg3_gload16(unsigned voff, const void* sbase) {
     return v;
 }
 __device__ __forceinline__ void cg3_glds16(unsigned voff, const void* sbase, unsigned lds_dst) {
+    NATINF_M0_ASM_BEGIN
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+    NATINF_M0_ASM_END
 }
 // the (scale | shift) table of a half-chunk: scale by lanes 0-31, shift by lanes 32-63, 4 bytes per lane -> 256 consecutive bytes of LDS (two requests)
 __device__ __forceinline__ void cg3_gtab(unsigned toff, const float* sc, const float* sh, unsigned lds_dst) {
     unsigned long long save;
+    NATINF_M0_ASM_BEGIN
     asm volatile("s_mov_b32 m0, %4\n\t"
                  "s_mov_b64 %0, exec\n\t"
                  "s_mov_b32 exec_lo, -1\n\t"
@@ -95,6 +98,7 @@ __device__ __forceinline__ void cg3_gtab(unsigned toff, const float* sc, const f
                  "global_load_lds_dword %1, %3\n\t"
                  "s_mov_b64 exec, %0"
                  : "=&s"(save) : "v"(toff), "s"(sc), "s"(sh), "s"(lds_dst) : "memory", "m0", "scc");
+    NATINF_M0_ASM_END
 }
 template <int OFF> __device__ __forceinline__ void cg3_lds_write16(unsigned addr, const u32x4& v) {
     asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(OFF) : "memory");

@@ -18,7 +18,8 @@
 //     distance measures (0.095 of 0.099 on 2,000 images with one bf16 term).  A half-precision filter has eleven significant bits instead of eight: the same shift
 //     is 8x smaller, its square 64x -- where two bf16 terms put it -- for HALF the matrix work; half-precision activations round 8x finer than bf16 ones as well.
 //     Range: every filter row is scaled by a power of two so that its largest element lies in [0.5, 1) (exact; the epilogue multiplies the column back:
-//     GemmArgs::deq_n), so a row keeps 2^-14 of its maximum as NORMAL numbers whatever BatchNorm folded into it; activations behind a ReLU stay far below 65,504.
+//     GemmArgs::deq_n), so a row keeps 2^-14 of its maximum as NORMAL numbers whatever BatchNorm folded into it; activations behind a ReLU stayed far below 65,504 on the synthetic weights (2,000 images; parity with pytorch_fid's fp32 module is UNPINNED),
+//     and the epilogue saturates at 65,504 instead of overflowing to inf should real weights ever exceed it.
 // Epilogue: bias (+ the column scale) + ReLU in the accumulator registers, 16-bit values through one LDS slab, 16-byte row stores into a channel slice of the
 // concat buffer (NHWC).
 #pragma once
@@ -63,7 +64,9 @@ __device__ __forceinline__ void conv_ring_epilogue(const GemmArgs& g, unsigned c
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(acc[i][j][e], sc[j][e], bs[j][e]), 0.f);
             uint2 o;
-            if constexpr (F16) { f16x4_t h; for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e]; o = __builtin_bit_cast(uint2, h); }
+            // IEEE half saturates here, it does not overflow: a value above 65,504 would become inf, then NaN features and a NaN FID without a word (round-5 advisor note).
+            // With the ReLU's lower bound this is one v_med3_f32 per value; finite inputs give finite activations in every layer.
+            if constexpr (F16) { f16x4_t h; for (int e = 0; e < 4; ++e) h[e] = (_Float16)fminf(v[e], 65504.f); o = __builtin_bit_cast(uint2, h); }
             else { bf16x4_t h; for (int e = 0; e < 4; ++e) h[e] = (bf16)v[e]; o = __builtin_bit_cast(uint2, h); }
             *reinterpret_cast<uint2*>(wbase + i * 16 * PROW + j * 32) = o;
         }

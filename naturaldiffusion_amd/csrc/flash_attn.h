@@ -263,7 +263,9 @@ __global__ __launch_bounds__(256, KT == 64 ? 3 : 2) void k_flash_attn64_v2(const
     }
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
     auto glds = [](unsigned vo, const void* sbase, unsigned dst) __attribute__((always_inline)) {
+        NATINF_M0_ASM_BEGIN
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo), "s"(sbase), "s"(dst) : "memory", "m0");
+        NATINF_M0_ASM_END
     };
     auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
         const unsigned st = lds0 + buf * STAGE + wave * (NPW * 1024);

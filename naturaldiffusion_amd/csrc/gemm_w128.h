@@ -45,12 +45,18 @@ __device__ __forceinline__ void w128_mfma(f32x4& acc, const u32x4& b, const u32x
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(b), "v"(a));
 }
 __device__ __forceinline__ void w128_glds(unsigned vo, const void* sbase, unsigned dst) {       // prologue form: destination set right in front
+    NATINF_M0_ASM_BEGIN
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo), "s"(sbase), "s"(dst) : "memory", "m0");
+    NATINF_M0_ASM_END
 }
 // K-loop form: M0 is set ONE MFMA EARLIER (w128_m0_set / w128_m0_next: the MFMA in between is the wait state the hardware asks for between a write of M0 and an
 // LDS-DMA instruction), so that a request costs its gap one instruction, not four.  Nothing else in the loop touches M0 (the loop holds no compiler-generated code).
+NATINF_M0_ASM_BEGIN
 __device__ __forceinline__ void w128_m0_set(unsigned dst) { asm volatile("s_mov_b32 m0, %0" :: "s"(dst) : "memory", "m0"); }
+NATINF_M0_ASM_END
+NATINF_M0_ASM_BEGIN
 __device__ __forceinline__ void w128_m0_next() { asm volatile("s_add_u32 m0, m0, 0x1000" ::: "memory", "m0", "scc"); }
+NATINF_M0_ASM_END
 // The requests are BUFFER loads: address = descriptor base + the lane's offset inside an 8-row piece (ONE register per operand) + the piece's scalar offset -- fourteen
 // lane registers fewer than global_load_lds with an offset per piece (the fp8 kernel spilled them, and hipcc put a vmcnt(0) behind every reload).  A piece whose rows
 // lie beyond the matrix is pointed at the last valid 8-row group (M % 8 == 0, N % 8 == 0): every address is in bounds, the epilogue masks the rows.
@@ -69,7 +75,9 @@ __device__ __forceinline__ void w128_bufdma(unsigned vo, const w128_rsrc& rs, un
     asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(vo), "s"(rs), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void w128_bufdma_at(unsigned vo, const w128_rsrc& rs, unsigned soff, unsigned dst) {       // prologue form: destination set right in front
+    NATINF_M0_ASM_BEGIN
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(vo), "s"(rs), "s"(soff), "s"(dst) : "memory", "m0");
+    NATINF_M0_ASM_END
 }
 
 // The slot table of one iteration (slot S = the instructions issued in front of MFMA S; MFMA S = K step S / 64, A fragment (S / 8) % 8, B fragment S % 8).
@@ -114,7 +122,7 @@ struct W128Step {
             static_assert(P == 0 || SCH::dma(P - 1, WV) < at, "requests in piece order, at most one per slot");
             static_assert(at > (P < 8 ? SCH::WAIT1 + 1 : SCH::WAIT2 + 1) && at >= 2 && at < 128, "behind the barrier that frees its half");
             if constexpr (S == at - 1) { if constexpr (P == 0) w128_m0_set(ad.da); else w128_m0_next(); }
-            if constexpr (S == at) w128_bufdma(P < 8 ? dm.voa : dm.vob, P < 8 ? dm.ra : dm.rb, P < 8 ? dm.soa[P] : dm.sob[P - 8]);
+            if constexpr (S == at) w128_bufdma(P < 8 ? dm.voa : dm.vob, P < 8 ? dm.ra : dm.rb, (P < 8 ? dm.soa : dm.sob)[P & 7]);
             dma<P + 1>(ad, dm);
         }
     }
@@ -375,7 +383,7 @@ struct W128F8Step {
         if constexpr (P < 16) {
             constexpr int at = w128f8::dma(P);
             if constexpr (S == at - 1) { if constexpr (P == 0) w128_m0_set(ad.d[PAR]); else w128_m0_next(); }
-            if constexpr (S == at) w128_bufdma(P < 8 ? dm.voa : dm.vob, P < 8 ? dm.ra : dm.rb, P < 8 ? dm.soa[P] : dm.sob[P - 8]);
+            if constexpr (S == at) w128_bufdma(P < 8 ? dm.voa : dm.vob, P < 8 ? dm.ra : dm.rb, (P < 8 ? dm.soa : dm.sob)[P & 7]);
             dma<P + 1>(ad, dm);
         }
     }

@@ -71,6 +71,8 @@ struct Ctx {                     // per-forward launch context
     const float* x; const float* labels; float* out;
     int* part_bm;                // [n_parts] block-tile rows (BM) of the GEMM variant that wrote each partial table
     hipStream_t stream2 = nullptr; hipEvent_t* ev = nullptr;      // MMDiT engine: the text stream's own HIP stream and the fork / join events (null: everything on `stream`)
+    unsigned char* fin_done = nullptr;   // [n_parts] per FORWARD, like part_bm: the launch that wrote partial table i also wrote its consumer's GroupNorm table (see Fin).  Not plan
+                                         // state: a description pass (scratch array) or a second thread's forward on a shared plan cannot flip it under a running forward
     bf16* act(const TRef& t) const { return reinterpret_cast<bf16*>(ws + t.off * B) + t.coff; }
     template <class T> T* at(int64_t off) const { return reinterpret_cast<T*>(ws + off * B); }
     template <class T> const T* w(int64_t off) const { return reinterpret_cast<const T*>(wp + off); }
@@ -135,6 +137,7 @@ struct natinf_ncsnpp {
     bool attr_set = false;
     int last_B = 0; unsigned char* last_ws = nullptr;
     std::vector<int> part_bm;            // see Ctx::part_bm
+    std::vector<unsigned char> fin_done; // see Ctx::fin_done
 };
 
 // k_conv_gn3 (conv_gn3.h / conv_gn3.hip: one wave per SIMD, 128 x 128 wave tiles, slot-table K loop) -- a translation unit of its own
@@ -490,13 +493,14 @@ bool w128_fp8_ok(const GemmArgs& g) {
     return g.taps == 1 && !g.a1 && g.a0_C % 256 == 0 && g.N % 8 == 0 && g.M % 8 == 0 && (!g.a_mx || g.M % 256 == 0) &&
            (int64_t)g.M * g.a0_ld < (int64_t)1 << 32 && (int64_t)g.N * g.b_ld < (int64_t)1 << 32;
 }
+bool fp8_on_w128(const GemmArgs& g) { return g_w128 && w128_fp8_ok(g) && (fp8_epi(g) != 2 || g_w128 != 2); }      // the four-wave tile takes this launch
 template <bool MXA>
 void launch_gemm_fp8_t(const GemmArgs& g, hipStream_t s) {
     // (round 5: the e4m3 + E8M0 epilogue with its tanh-GELU -- fc1 -- takes the four-wave tile too: with the GELU issued stage by stage for eight values at a time
     // (gelu_tanh_fast8) (32768, 6144, 1536) runs 1,756-1,759 TFLOP/s there against 1,641-1,697 on the eight-wave tile, same process (tools/ab_fc1_w128.py).  Round 4 kept it on
     // the eight-wave tile on a figure -- 1,100-1,130 against 1,300-1,520 -- that the debug entry had measured on the fp32-SLAB epilogue in e4m3 mode (no activation
     // passed: fp8_epi() = 0), not on this one.  natinf_set_gemm_w128(2) = the round-4 rule, for A/B runs.)
-    if (g_w128 && w128_fp8_ok(g) && (fp8_epi(g) != 2 || g_w128 != 2)) {
+    if (fp8_on_w128(g)) {
         switch (fp8_epi(g)) {
             case 1: launch_tiles<W128F8Cfg>(&k_gemm_w128_fp8<MXA, 1>, g, s); break;
             case 2: launch_tiles<W128F8Cfg>(&k_gemm_w128_fp8<MXA, 2>, g, s); break;
@@ -512,8 +516,33 @@ void launch_gemm_fp8_t(const GemmArgs& g, hipStream_t s) {
         default: launch_tiles<CfgD256x256>(&k_gemm_fp8<MXA, 0>, g, s); break;
     }
 }
+// natinf_gemm_profile(1): every matmul-shaped launch of every engine -- launch_gemm and launch_gemm_fp8, i.e. the kernel WITH the epilogue it runs in the network, on
+// the stream it runs on, between its real neighbours -- is bracketed by a HIP event pair and tagged with the line natinf_ncsnpp_describe_gemms would print for it.
+// natinf_gemm_profile_read sums them per tag.  (Round-5 review, item 2: the SD3 bench line quoted isolated loops of debug entries with the plain epilogue.)
+// One host thread at a time, like natinf_attention_profile; the events serialise nothing, but two HIP streams still overlap: a launch's span then includes what it
+// shared the chip with -- bench.py reads the image-stream shapes, whose launches are 10-100x the text stream's.
+struct GemmProf {
+    struct Rec { hipEvent_t a, b; std::string tag; };
+    bool on = false; std::vector<Rec> ev; std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    bool begin(Rec& r, hipStream_t s) {
+        r.a = r.b = nullptr;
+        if (!pool.empty()) { r.a = pool.back().first; r.b = pool.back().second; pool.pop_back(); }
+        else if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { r.a = r.b = nullptr; (void)hipGetLastError(); return false; }
+        (void)hipEventRecord(r.a, s);
+        return true;
+    }
+    void end(Rec& r, hipStream_t s) { (void)hipEventRecord(r.b, s); ev.push_back(std::move(r)); }
+} g_gemm_prof;
 void launch_gemm_fp8(const GemmArgs& g, hipStream_t s) {
+    GemmProf::Rec r;
+    const bool prof = g_gemm_prof.on && !g_record && g_gemm_prof.begin(r, s);
+    if (prof) {
+        char line[160];
+        snprintf(line, sizeof(line), "%d %d %d %d %d %d %s%s/e%d", g.M, g.N, g.taps * g.a0_C, 0, g.taps, g.batch, fp8_on_w128(g) ? "w128_fp8" : "fp8_256x256", g.a_mx ? "_mxa" : "", fp8_epi(g));
+        r.tag = line;
+    }
     if (g.a_mx) launch_gemm_fp8_t<true>(g, s); else launch_gemm_fp8_t<false>(g, s);
+    if (prof) g_gemm_prof.end(r, s);
 }
 
 // Which epilogue a launch can take (see tile_epilogue in gemm_dma.h): 0 = the general fp32-slab one; 1..6 = packed, when only
@@ -589,8 +618,21 @@ int w128_splitk_slices(const GemmArgs& g) {
     while (S > 1 && g.a0_C / BK / S < 16) --S;
     return S;
 }
+int launch_gemm_run(const GemmArgs& g0, hipStream_t s);
 // returns the block-tile row count of the variant used
 int launch_gemm(const GemmArgs& g0, hipStream_t s) {
+    if (!g_gemm_prof.on || g_record) return launch_gemm_run(g0, s);
+    GemmProf::Rec r;
+    std::string tag;
+    g_record = &tag; (void)launch_gemm_run(g0, s); g_record = nullptr;          // description pass: the tag, nothing launched
+    while (!tag.empty() && tag.back() == '\n') tag.pop_back();
+    if (!g_gemm_prof.begin(r, s)) return launch_gemm_run(g0, s);
+    r.tag = std::move(tag);
+    const int bm = launch_gemm_run(g0, s);
+    g_gemm_prof.end(r, s);
+    return bm;
+}
+int launch_gemm_run(const GemmArgs& g0, hipStream_t s) {
     if (g_force_variant == V_AUTO) {
         const int S8 = w128_splitk_slices(g0);
         if (S8 > 1) {
@@ -928,7 +970,7 @@ struct Builder {
             g_fin_written = false;
             const int bm = launch_gemm(g, c.stream);
             if (pt.valid) c.part_bm[pt.id] = bm;
-            if (pt.fin && pt.fin->check) pt.fin->done = g_fin_written;
+            if (pt.fin && pt.fin->check) c.fin_done[pt.id] = g_fin_written;
         });
         if (!fuse) arena.release(h.off);
         int64_t sc1 = own_sc, sh1 = own_sh;               // GroupNorm_1's table: the same buffers again, or the one Conv_0's epilogue wrote
@@ -959,7 +1001,7 @@ struct Builder {
             g_fin_written = false;
             const int bm = launch_gemm(g, c.stream);
             if (po.valid) c.part_bm[po.id] = bm;
-            if (po.fin && po.fin->check) po.fin->done = g_fin_written;
+            if (po.fin && po.fin->check) c.fin_done[po.id] = g_fin_written;
         });
         if (skws >= 0) arena.release(skws);
         if (fuse1) arena.release(t.off); else arena.release(u.off);
@@ -1197,8 +1239,8 @@ struct Builder {
     // of the producing launch, so they cannot alias anything that launch still reads -- and the consumer fills in its gamma / beta when it is emitted
     // (the producer's op reads the struct when it RUNS).  Only the first single-source consumer claims it; anyone else takes k_gn_finalize.
     // check (round 5, the 16x16 level): whether the producer's launch wrote the table is only known when it RUNS (k_conv_gn3's 256 x 256 tile does, the k_conv_gn2 tiles a
-    // tuning knob may select instead do not): the producer's op records it in `done`, and the consumer's op launches k_gn_finalize into the same buffers when it is false
-    struct Fin { int64_t sc = -1, sh = -1, gamma = -1, beta = -1; int C = 0; float out_mul = 1.0f; bool claimed = false, check = false, done = false; };
+    // tuning knob may select instead do not): the producer's op records it in Ctx::fin_done (per forward), and the consumer's op launches k_gn_finalize into the same buffers when it is false
+    struct Fin { int64_t sc = -1, sh = -1, gamma = -1, beta = -1; int C = 0; float out_mul = 1.0f; bool claimed = false, check = false; };
     struct Part { int64_t off = -1; int quads = 0, id = -1, res = 0; bool valid = false; std::shared_ptr<Fin> fin; };
     static void set_fin(GemmArgs& g, const Part& p, const Ctx& c) {
         if (!p.fin || !p.fin->claimed) return;
@@ -1255,7 +1297,7 @@ struct Builder {
                 const std::shared_ptr<Fin> fp = p0.fin;
                 const int64_t fsc = f.sc, fsh = f.sh;
                 op(CLS_OTHER, [=](const Ctx& c) {
-                    if (fp->done) return;
+                    if (c.fin_done[p0.id]) return;
                     hipLaunchKernelGGL(k_gn_finalize, dim3(c.B), dim3(256), 0, c.stream, c.at<float2>(p0.off), HW / c.part_bm[p0.id], p0.quads, (const float2*)nullptr, 0, 0, C, HW,
                                        c.w<float>(gn.gamma), c.w<float>(gn.beta), c.at<float>(fsc), c.at<float>(fsh), GN_EPS, out_mul);
                 });
@@ -1495,6 +1537,7 @@ struct Builder {
         }
         E.n_params = poff;
         E.part_bm.assign(n_parts > 0 ? n_parts : 1, 128);
+        E.fin_done.assign(n_parts > 0 ? n_parts : 1, 0);
         E.ws_per_image = arena.peak;
         E.packed_bytes = wtop;
         // parameter offsets for describe(): recompute by module in order
@@ -1562,7 +1605,8 @@ int64_t natinf_ncsnpp_workspace_bytes(natinf_ncsnpp_t h, int max_batch) {
 
 // every switch a plan builder reads (layout of the packed weights included), one byte each
 static uint64_t plan_signature() {
-    const int k[] = {g_fuse_head, g_cg8_tm4, g_attn_qkv, g_attn_w8, g_attn_proj, g_attn256, g_fuse_gn8, g_fuse_fin, g_fuse_gn4, g_fuse_gn, g_cg_wide, g_fuse_up, g_cg_regw};
+    const int k[] = {g_fuse_head, g_cg8_tm4, g_attn_qkv, g_attn_w8, g_attn_proj, g_attn256, g_fuse_gn8, g_fuse_fin, g_fuse_gn4, g_fuse_gn, g_cg_wide, g_fuse_up, g_cg_regw,
+                     g_attn_blk, g_cg3 /* read by the plan builders too (which launches exist; which tables a producer may write): no pack offset depends on them today */};
     uint64_t h = 1469598103934665603ull;
     for (int v : k) h = (h ^ (uint64_t)(v & 0xff)) * 1099511628211ull;
     return h;
@@ -1629,6 +1673,7 @@ int natinf_ncsnpp_forward(natinf_ncsnpp_t h, const float* x, const float* labels
         h->attr_set = true;
     }
     Ctx c{B, reinterpret_cast<unsigned char*>(workspace), h->packed, (hipStream_t)stream, x, labels, out, h->part_bm.data()};
+    c.fin_done = h->fin_done.data();
     g_launch_error = 0;
     if (!h->prof) {
         for (const auto& f : h->ops) f(c);
@@ -1656,7 +1701,9 @@ int natinf_ncsnpp_describe_gemms(natinf_ncsnpp_t h, int B, char* buf, int cap) {
     g_record = &out;
     std::vector<int> scratch_bm(h->part_bm.size(), 128);
     // (a non-null fake workspace base: launches are only described, but "is this pointer set" decides the kernel variant)
+    std::vector<unsigned char> scratch_done(h->part_bm.size(), 0);
     Ctx c{B, reinterpret_cast<unsigned char*>(4096), reinterpret_cast<const unsigned char*>(4096), nullptr, nullptr, nullptr, nullptr, scratch_bm.data()};
+    c.fin_done = scratch_done.data();
     for (size_t i = 0; i < h->ops.size(); ++i)
         if (h->op_cls[i] == CLS_GEMM || h->op_cls[i] == CLS_CONV_GN || h->op_cls[i] == CLS_CONV_GN8) h->ops[i](c);          // GEMM ops only compute pointers and call launch_gemm
     g_record = nullptr;
@@ -1838,6 +1885,34 @@ int natinf_set_gemm_variant(int variant) {
     return NATINF_OK;
 }
 
+int natinf_gemm_profile(int enable) { g_gemm_prof.on = enable != 0; return NATINF_OK; }
+int natinf_gemm_profile_read(char* buf, int cap) {
+    if (!buf || cap <= 0) return NATINF_EINVAL;
+    std::map<std::string, std::pair<double, int64_t>> by;
+    std::vector<std::string> order;
+    int rc = NATINF_OK;
+    for (auto& e : g_gemm_prof.ev) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e.b) != hipSuccess || hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) { (void)hipGetLastError(); rc = NATINF_ELAUNCH; }
+        else {
+            auto it = by.find(e.tag);
+            if (it == by.end()) { order.push_back(e.tag); it = by.emplace(e.tag, std::make_pair(0.0, (int64_t)0)).first; }
+            it->second.first += ms; it->second.second += 1;
+        }
+        g_gemm_prof.pool.emplace_back(e.a, e.b);
+    }
+    g_gemm_prof.ev.clear();
+    if (rc != NATINF_OK) return rc;
+    std::string out;
+    for (auto& t : order) {
+        char tail[64];
+        snprintf(tail, sizeof(tail), " %lld %.6f\n", (long long)by[t].second, by[t].first);
+        out += t + tail;
+    }
+    if ((int)out.size() + 1 > cap) return NATINF_EINVAL;
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return (int)out.size();
+}
 int natinf_ncsnpp_profile(natinf_ncsnpp_t h, int enable) {
     if (!h) return NATINF_EINVAL;
     h->prof = enable != 0;

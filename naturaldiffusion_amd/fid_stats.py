@@ -31,10 +31,11 @@ class ActivationStats:
         self.s2 += a.t() @ a
 
     def all_reduce(self, group=None) -> None:
-        """sum the statistics of all ranks in place (one flat buffer, one collective; a no-op without a process group or at world size 1).
+        """sum the statistics of all ranks in place (one flat buffer, one collective; a no-op without a process group -- an initialised group of ONE
+        rank does run the collective: that is how a one-GPU box rehearses the RCCL path, ``bench.py --force-pg``).
         RCCL reduces device tensors in place; under gloo (CPU tests, two ranks on one GPU) the buffer goes through the host."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()):
             return
         flat = torch.cat([self.n.reshape(1), self.s1, self.s2.reshape(-1)])
         dev = flat.device

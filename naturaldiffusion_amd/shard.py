@@ -26,8 +26,9 @@ def rank_batches(sample_count: int, batch: int, rank: int, world: int) -> Iterat
 
 
 def max_over_ranks(seconds: float, device=None) -> float:
+    """no process group: the value itself; an initialised group (of any size, one rank included) runs the all-reduce"""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(seconds)
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -73,27 +73,29 @@ def test_conv_gn_matches_torch(res, B, cin, N, c1, resid, parts):
     wide = res in (16, 32) and N % 256 == 0                # 128-pixel x 256-channel tiles (default) -- the 256 x 128 ones are tested as well
     wf = torch.zeros_like(wd)                              # receives the fragment-major copy of the weights (k_conv_gn2)
     lib.natinf_set_conv_gn_w128(0)                      # this file is about k_conv_gn2 (k_conv_gn3, which takes the long-K launches by default: tests/test_gpu_conv_gn3.py)
-    assert lib.natinf_set_conv_gn_regw(0) != 0          # k_conv_gn (weights through an LDS ring): -DNATINF_DEV builds only
-    assert lib.natinf_set_conv_gn8_tile(0) != 0         # the two-images-per-tile form of the 8x8 level: -DNATINF_DEV builds only
-    for use_wide, regw in (((1, 1), (0, 1)) if wide else ((1, 1),)):
-        lib.natinf_set_conv_gn_wide(3 if use_wide else 0)
-        rows = res * res if res <= 8 else (128 if (wide and use_wide) else 256)      # (8x8 / 4x4: one partial row per SAMPLE)
-        part = torch.zeros(M // rows, N // 4, 2, device=dev) if parts else None
-        out.zero_()
-        try:
-            check(lib.natinf_debug_conv_gn(res, B, N, cin, c1, ptr(xd), ptr(scd), ptr(shd), ptr(wd), ptr(wf) if regw else None, ptr(a1d), ptr(bd),
-                                           ptr(rd), out_scale, ptr(out), ptr(part), 1, stream_ptr()), "conv_gn")
-            torch.cuda.synchronize()
-        finally:
-            lib.natinf_set_conv_gn_wide(3)
-        got = out.float().cpu()
-        assert torch.isfinite(got).all()
-        err = ((got - ref).abs().max() / ref.abs().max()).item()
-        assert err <= 1e-2, (err, use_wide, regw)
-        if parts:                                           # (sum, sum of squares) per tile and 4-channel quad, of the fp32 results
-            want = torch.stack([ref.reshape(M // rows, rows, N // 4, 4).sum(dim=(1, 3)), (ref ** 2).reshape(M // rows, rows, N // 4, 4).sum(dim=(1, 3))], dim=-1)
-            assert ((part.cpu() - want).abs().max() / want.abs().max()).item() <= 5e-3
-    lib.natinf_set_conv_gn_w128(7)                      # (the library's default; a failed case leaves 0 behind: only this file's later cases see it)
+    try:
+        assert lib.natinf_set_conv_gn_regw(0) != 0          # k_conv_gn (weights through an LDS ring): -DNATINF_DEV builds only
+        assert lib.natinf_set_conv_gn8_tile(0) != 0         # the two-images-per-tile form of the 8x8 level: -DNATINF_DEV builds only
+        for use_wide, regw in (((1, 1), (0, 1)) if wide else ((1, 1),)):
+            lib.natinf_set_conv_gn_wide(3 if use_wide else 0)
+            rows = res * res if res <= 8 else (128 if (wide and use_wide) else 256)      # (8x8 / 4x4: one partial row per SAMPLE)
+            part = torch.zeros(M // rows, N // 4, 2, device=dev) if parts else None
+            out.zero_()
+            try:
+                check(lib.natinf_debug_conv_gn(res, B, N, cin, c1, ptr(xd), ptr(scd), ptr(shd), ptr(wd), ptr(wf) if regw else None, ptr(a1d), ptr(bd),
+                                               ptr(rd), out_scale, ptr(out), ptr(part), 1, stream_ptr()), "conv_gn")
+                torch.cuda.synchronize()
+            finally:
+                lib.natinf_set_conv_gn_wide(3)
+            got = out.float().cpu()
+            assert torch.isfinite(got).all()
+            err = ((got - ref).abs().max() / ref.abs().max()).item()
+            assert err <= 1e-2, (err, use_wide, regw)
+            if parts:                                           # (sum, sum of squares) per tile and 4-channel quad, of the fp32 results
+                want = torch.stack([ref.reshape(M // rows, rows, N // 4, 4).sum(dim=(1, 3)), (ref ** 2).reshape(M // rows, rows, N // 4, 4).sum(dim=(1, 3))], dim=-1)
+                assert ((part.cpu() - want).abs().max() / want.abs().max()).item() <= 5e-3
+    finally:
+        lib.natinf_set_conv_gn_w128(7)                  # the library's default, restored on the failure path too (round-5 advisor note)
 
 def test_ragged_channel_counts_are_refused_in_the_shipped_build():
     """k_conv_gn2 needs whole 128- (or 256-) channel tiles; the LDS-ring kernel that took ragged N is a -DNATINF_DEV kernel now."""
