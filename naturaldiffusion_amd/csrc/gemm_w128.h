@@ -80,6 +80,17 @@ __device__ __forceinline__ void w128_bufdma_at(unsigned vo, const w128_rsrc& rs,
     NATINF_M0_ASM_END
 }
 
+// The direct fp32 residual-stream epilogue (EPI 7 here, 3 in the fp8 kernel: out = resid + gate * (acc + bias), in place) is the slow one of this tile, measured in round 6
+// (tools/w128_e7_timeline.py, profiles/r06/w128_e7_timeline.log): 43k shader clocks per tile against 12.5k for the packed bf16 epilogue -- each half tile is one round trip for
+// 128 KB of residual per CU that ALL CUs ask for at the same moment (32 MB per half tile and round; 64 MB read + 64 MB written per round at ~3.5 TB/s).  In the MMDiT engine
+// the attention output projection (4096 x 1536 x 1536 x 8) runs at 233 us = 662 TFLOP/s where q | k with the packed epilogue runs at 1,217.  Two remedies were built,
+// measured and removed (profiles/r06/resid_warm_*.log, stagger_bf16.log; same bytes both):
+//  * touching the residual tile once at kernel start (one dword per 128-byte line into a junk register, in front of the first operand requests): 233 -> 257 us, fc2
+//    525 -> 554 us -- in-order return puts an HBM round trip under load in front of K-tile 0, and the lines are gone again when the epilogue asks (32 CUs x 256 KB per
+//    XCD against 4 MB of L2);
+//  * a phase stagger (the first round's blocks sleep 0 / 1 / 2 x 8 or 16 us by CU, so that a third of the chip is in its epilogue while two thirds multiply): the epilogues
+//    do get shorter (-17 .. -24 us per launch), and the last group's sleep costs exactly that (+-0 at 8 us, +8 us at 16 us per launch; three rounds per launch).
+// What is left is fewer bytes (a 16-bit residual stream, as the reference's fp16 pipeline has) or the residual under the K loop (registers: DESIGN.md section 4c).
 // The slot table of one iteration (slot S = the instructions issued in front of MFMA S; MFMA S = K step S / 64, A fragment (S / 8) % 8, B fragment S % 8).
 // MODE 0: steady state; 1: second-to-last tile (nothing left to request; the last tile is awaited with vmcnt(0)); 2: last tile (K step 1's reads only).
 // A schedule SCH names the slots: K step 1's fragment reads (rd1: 0..7 = A, 8..15 = B), the two "half is free" barriers, the sixteen requests (piece p: 0..7 = A,
@@ -290,7 +301,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     if constexpr (EPI == 7) {                                            // direct fp32 residual stream: no LDS, the whole half tile's residual in one round trip
         direct_f32_epilogue<2, 2, 8, 4, false, 8>(g, accL, m0, n0, z, lane, wm, wn);
+        NATINF_TS(6);
         if (n0 + 128 < g.N) direct_f32_epilogue<2, 2, 8, 4, false, 8>(g, accH, m0, n0 + 128, z, lane, wm, wn);
+#ifdef NATINF_DEV
+        if (g.dbg_ts) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (timeline runs: stamp 7 is "the tile's stores have been acknowledged")
+#endif
+        NATINF_TS(7);
         return;
     }
     __syncthreads();

@@ -1753,6 +1753,7 @@ int natinf_debug_gemm_fused(int variant, int M, int N, int K, const void* a, con
     g.scale = scale; g.act = act; g.c = c; g.c_ld = N; g.c_mode = c_f32 ? OUT_F32 : OUT_BF16;
     g.gn_part = gn_part; g.gn_quads = N / 4; g.epi_fp32_slab = fp32_slab != 0;
     g.splitk_ws = g_dbg_splitk_ws; g.splitk_max = g_dbg_splitk_max;
+    g.dbg_ts = g_dbg_ts;
     const int saved = g_force_variant;
     g_force_variant = variant;
     const int bm = launch_gemm(g, (hipStream_t)stream);

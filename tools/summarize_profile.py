@@ -7,14 +7,14 @@ tag, rnd = sys.argv[1], sys.argv[2]
 src = ROOT / "gpurun_out" / f"profile_{tag}"
 dst = ROOT / "profiles" / rnd
 dst.mkdir(parents=True, exist_ok=True)
-shutil.copy(glob.glob(str(src / "stats/*/*_kernel_stats.csv"))[0], dst / f"{tag}_kernel_stats.csv")
+shutil.copy(sorted(glob.glob(str(src / "stats/**/*kernel_stats.csv"), recursive=True))[-1], dst / f"{tag}_kernel_stats.csv")
 shutil.copy(str(src) + ".bench.json", dst / f"{tag}_bench.json")
 def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("ncsn::", "").replace("void ", "")
     return n.split("(")[0][:48]
 traffic = defaultdict(lambda: dict(launches=0, fetch_kb=0.0, write_kb=0.0))
 for kind, key in (("fetch", "fetch_kb"), ("write", "write_kb")):
-    f = glob.glob(str(src / kind / "*/*_counter_collection.csv"))[0]
+    f = sorted(glob.glob(str(src / kind / "**/*_counter_collection.csv"), recursive=True))[-1]
     seen = defaultdict(int)
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
