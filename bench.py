@@ -9,13 +9,13 @@ what every field means is written HERE.
 Top level (default workload = BASELINE config 2).  One "step" = one pass of the hot path over one batch: 15-step Natural
 Inference with ``weights/step_15_weight_173.npz`` on 512 CIFAR10-shaped samples = 15 NCSN++ forwards in the HIP engine (bf16
 MFMA operands, fp32 accumulate) + 15 fused ``ni_step`` launches (fp64 history, the reference's arithmetic).  Inputs (noise,
-weights, coefficient rows) are resident in HBM before the timed region.  ``value`` is TWO-STREAM THROUGHPUT: consecutive steps
-alternate between two HIP streams (two engine handles sharing one copy of the packed weights, two history buffers) -- the order
+weights, coefficient rows) are resident in HBM before the timed region.  ``value`` is MULTI-STREAM THROUGHPUT: consecutive steps
+rotate over ``--streams`` HIP streams (three since round 6, two before: that many engine handles sharing one copy of the packed weights, one history buffer each) -- the order
 ``CIFAR10NaturalInference.natural_inference_tx`` / ``generate_sharded`` run their batches in; the images are bit-identical to the
 one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
   single_stream     {value, ms_per_step}: the same K steps one batch after the other on ONE stream (the reference's order; the
                     like-for-like number for rounds 1-2, whose headline was this).  ``--streams 1`` makes it the headline.
-  pipeline          {value}: images/s of the same K batches through the production pipeline (``generate_sharded`` on the same two lanes): Philox noise by
+  pipeline          {value}: images/s of the same K batches through the production pipeline (``generate_sharded`` on the same lanes): Philox noise by
                     global index drawn inside the timed span, the 15 steps, ``to_pixel``, and the ONE copy of the uint8 images to the host -- everything the
                     reference's per-batch loop contains (:290, :308-309) that the contract's "inputs resident in HBM" region leaves out.
   sd3, sd3_fp8      BASELINE configs 4 / 5 (``--workload sd3 [--fp8]`` alone): 28-step SD3-form NI at 1024x1024, 4 images x CFG per
@@ -150,9 +150,9 @@ def launch_ranks(args):
         raise SystemExit(p.returncode or 1)
 
 
-def timed_region(one_step, steps, warmup, world, sync, dist, dev):
+def timed_region(one_step, steps, warmup, world, sync, dist, dev, keep=2):
     """W untimed steps, then exactly K steps between (synchronize, barrier, synchronize) brackets; returns the max over ranks (s)
-    and the outputs of the LAST TWO steps (one per lane of a two-stream run)."""
+    and the outputs of the last ``keep`` steps (one per lane of a multi-stream run)."""
     import torch
 
     grouped = dist.is_available() and dist.is_initialized()      # world > 1, or one rank under --force-pg (the RCCL rehearsal of a one-GPU box)
@@ -168,7 +168,7 @@ def timed_region(one_step, steps, warmup, world, sync, dist, dev):
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
-        outs = (outs + [one_step(i)])[-2:]
+        outs = (outs + [one_step(i)])[-keep:]
     barrier()
     dt = time.perf_counter() - t0
     if grouped:
@@ -184,7 +184,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 8 for cifar10, 2 for sd3, 1 for fid50k, 3 for validate)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 1; 0 for fid50k)")
     ap.add_argument("--no-single-stream", dest="single_stream_extra", action="store_false", help="skip the extra one-stream timing of the CIFAR10 workload")
-    ap.add_argument("--streams", type=int, default=2, help="CIFAR10 / fid50k: HIP streams the consecutive batches alternate between (default 2; 1 = one batch after the other)")
+    ap.add_argument("--streams", type=int, default=3, help="CIFAR10 / fid50k: HIP streams (lanes) the consecutive batches rotate over (default 3 since round 6: +1 % over 2 in same-box A/Bs, profiles/r06/streams_ab.txt; 1 = one batch after the other)")
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--weights", default=str(ROOT / "weights" / "step_15_weight_173.npz"))
     ap.add_argument("--workload", choices=["cifar10", "sd3", "fid50k", "validate", "selftest"], default="cifar10",
@@ -362,14 +362,14 @@ def bench_cifar(args, world, rank, dev):
         dt1, outs = timed_region(one_step, args.steps, args.warmup, world, torch.cuda.synchronize, dist, dev)
         assert all(torch.isfinite(o).all() for o in outs)
     if n_str > 1:
-        dt, outs = timed_region(one_step_streams, args.steps, max(args.warmup, n_str), world, torch.cuda.synchronize, dist, dev)   # every lane warmed
+        dt, outs = timed_region(one_step_streams, args.steps, max(args.warmup, n_str), world, torch.cuda.synchronize, dist, dev, keep=n_str)   # every lane warmed
         torch.cuda.synchronize()
-        assert all(torch.isfinite(o).all() for o in outs)                  # the last step of BOTH lanes
+        assert all(torch.isfinite(o).all() for o in outs)                  # the last step of EVERY lane
     else:
         dt = dt1
     imgs = world * Bz * args.steps
     line = {
-        "metric": "images/sec at 15-step Natural Inference (CIFAR10 32x32, NCSN++)" + (", two-stream throughput" if n_str > 1 else ""),
+        "metric": "images/sec at 15-step Natural Inference (CIFAR10 32x32, NCSN++)" + (f", {n_str}-stream throughput" if n_str > 1 else ""),
         "value": round(imgs / dt, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",

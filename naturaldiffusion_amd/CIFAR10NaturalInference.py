@@ -176,7 +176,7 @@ def _lane_models(model_fn, streams: int, n_batches: int):
 
 @torch.no_grad()
 def generate_sharded(model_fn, weight_path, sample_count: int, batch_size: int, rank: int = 0, world: int = 1,
-                     seed: int = 888, device="cuda:0", streams: int = 2, to_cpu: bool = True, coeff=None):
+                     seed: int = 888, device="cuda:0", streams: int = 3, to_cpu: bool = True, coeff=None):
     """Batch-sharded generation (BASELINE config 3): this rank generates the images whose
     global index is rank, rank+world, ... in batches of ``batch_size`` -- no collective on the data path -- on the two-lane pipeline
     of ``natural_inference_tx`` (``BatchLanes``): Philox noise keyed by the GLOBAL image index drawn on the lane's own stream, uint8 images
@@ -372,12 +372,12 @@ def natural_inference_tx(batch_size: int = 500,
                          ckpt_filename: Optional[str] = None,
                          weight_path: Optional[str] = None,
                          sample_count: int = 50 * 1000, seed: int = 888, device: str = "cuda:0",
-                         compute_fid: bool = True, flat_params: Optional[torch.Tensor] = None, streams: int = 2):
+                         compute_fid: bool = True, flat_params: Optional[torch.Tensor] = None, streams: int = 3):
     """Reference :242-317: generate ``sample_count`` CIFAR10 images with the NI matrix at ``weight_path``
     and score them.  ``flat_params`` lets a caller supply weights directly (engine order) instead of the
     score_sde checkpoint.
 
-    ``streams`` (default 2): the batches are independent trajectories (reference loop :287-309); consecutive batches go to two HIP streams
+    ``streams`` (default 3 since round 6; 2 before): the batches are independent trajectories (reference loop :287-309); consecutive batches rotate over that many HIP streams
     (one engine handle + history buffer each), so that the under-occupied launches of one batch -- the 4x4 level, the per-sample GroupNorm
     tables, every launch's last round of blocks -- run under the other batch's convolutions: -6 % per batch at 512 images on one MI355X.
     The noise is drawn in the reference's order and every batch runs the same launches: the images are bit-identical to ``streams=1``,
