@@ -296,22 +296,30 @@ def bench_selftest(args, world, rank):
     ranks, rank 0 prints the line.  tests/test_bench_launcher.py drives ``python bench.py --gpus 2 --workload selftest --backend gloo``."""
     import torch
     import torch.distributed as dist
-    if world > 1:
+    grouped = world > 1 or args.force_pg
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:            # --force-pg without a launcher: a one-rank rendezvous of our own (as main() does for the GPU workloads)
+            import socket
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        os.environ.setdefault("RANK", str(rank)); os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group(args.backend if args.backend == "gloo" else "gloo")
     if rank == args.selftest_fail_rank:
         raise SystemExit(3)
     a = torch.ones(64, 64)
     dt, _ = timed_region(lambda i: (a @ a).sum() + rank, args.steps, args.warmup, world, lambda: None, dist, torch.device("cpu"))
     tot = torch.tensor([float(rank + 1)])
-    if world > 1:
+    if grouped:
         dist.all_reduce(tot)
     if rank == 0:
         print(json.dumps({"metric": "selftest steps/sec (launcher + rendezvous + timing skeleton, no kernels)", "value": round(world * args.steps / dt, 2),
                           "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "selftest", "backend": "gloo", "rank_sum": float(tot[0])}}), flush=True)
-    if world > 1:
+                          "config": {"workload": "selftest", "backend": "gloo", "rank_sum": float(tot[0]),
+                                     "process_group": (f"{dist.get_backend()} x{dist.get_world_size()}" if grouped else None)}}), flush=True)
+    if grouped:
         dist.destroy_process_group()
 
 

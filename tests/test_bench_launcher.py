@@ -45,3 +45,12 @@ def test_rank_count_mismatch_is_refused():
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "selftest", "--gpus", "2"], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=120)
     assert p.returncode != 0 and "ranks" in p.stderr
+
+
+def test_force_pg_runs_the_collectives_through_a_group_of_one_rank():
+    """--force-pg (round 6): the process group is initialised with ONE rank -- a rendezvous of bench.py's own when no launcher set one up -- and the timed region's barriers,
+    its max-over-ranks all-reduce and the workload's all-reduce run through it.  On a GPU box with --backend nccl this is the RCCL rehearsal (tests/test_gpu_rccl_world1.py)."""
+    p = _run("--gpus", "1", "--force-pg")
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["process_group"] == "gloo x1" and line["config"]["rank_sum"] == 1.0

@@ -174,3 +174,29 @@ def test_splitk_matches_fp32_reference_and_the_unsplit_launch(M, N, K, lrs, term
         assert (got[..., 1] - q).abs().max().item() <= 2e-3 * q.max().item()
     again = _run(0, M, N, K, lrs, terms, splitk=4)
     assert torch.equal(again[0], out)                                  # slices are summed in a fixed order
+
+
+def test_gemm_profile_tags_every_launch_where_it_runs():
+    """natinf_gemm_profile / natinf_gemm_profile_read (round 6; include/natinf_ncsnpp.h): while enabled, every matmul-shaped launch is bracketed by a HIP event pair on its
+    stream and tagged with its launch description; the read sums per tag, in first-seen order, and consumes the records.  The results must not depend on the switch."""
+    from naturaldiffusion_amd._lib import lib, check
+    ref = _run(V_W128, 512, 256, 256, 30, {"bias_n"}, seed=3)[0].clone()
+    buf = C.create_string_buffer(1 << 14)
+    try:
+        check(lib.natinf_gemm_profile(1), "profile on")
+        for _ in range(3):
+            got = _run(V_W128, 512, 256, 256, 30, {"bias_n"}, seed=3)[0]
+        _run(V_DMA128P, 300, 136, 192, 30, {"bias_n", "resid_f32"}, c_f32=True)
+        torch.cuda.synchronize()
+    finally:
+        check(lib.natinf_gemm_profile(0), "profile off")
+    n = lib.natinf_gemm_profile_read(buf, len(buf))
+    assert n > 0, n
+    rows = [r.split() for r in buf.value.decode().splitlines()]
+    assert [r[:3] for r in rows] == [["512", "256", "256"], ["300", "136", "192"]], rows            # first-seen order, one row per distinct description
+    assert rows[0][6].startswith("w128_256x256/e") and int(rows[0][7]) == 3 and float(rows[0][8]) > 0.0
+    assert rows[1][6] == "dma128x128p/e7" and int(rows[1][7]) == 1 and float(rows[1][8]) > 0.0      # the direct fp32 residual epilogue, named
+    assert lib.natinf_gemm_profile_read(buf, len(buf)) == 0 and buf.value == b""                    # consumed
+    assert torch.equal(got, ref)
+    _run(V_W128, 512, 256, 256, 30, {"bias_n"}, seed=3)                                              # switched off: nothing is recorded
+    assert lib.natinf_gemm_profile_read(buf, len(buf)) == 0
