@@ -30,7 +30,7 @@ one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
                     the kernel with the epilogue the engine gives it: [TFLOP/s, frac of ITS operand type's dense peak (bf16 2,500 / fp8 5,000), mean launch us];
                     frac = sum(flops_i / peak_i) / sum(time_i); iso_fc1 = fc1 with that same epilogue in an isolated back-to-back loop, TFLOP/s}, cpu (the MMDiT oracle on one sequence through 2
                     of 24 blocks, extrapolated: images/s), acc (28-step NI through a 4-block / 256-wide MMDiT: relative RMS of the final
-                    latents vs the fp32 oracle -- PARITY UNPINNED, the oracle restates the published architecture).
+                    latents vs the fp32 oracle, both precisions, in the `sd3` object only -- PARITY UNPINNED, the oracle restates the published architecture).
   fid50k            BASELINE config 3 (``--workload fid50k`` alone): the 50,000-image FID job of reference
                     src/CIFAR10NaturalInference.py:281-312 for BOTH coefficient-matrix equivalents -- DPM-Solver++(2S)
                     (results/dpmsolverpp/dpmsolverpp2s_018.npz) and DDIM on the continuous VP grid (coeffgen.ddim_vp_continuous over
@@ -58,7 +58,7 @@ one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
                     committed rocprofv3 PMC summary (profiles/rNN/*_hbm_traffic.json: bench.py cannot run rocprofv3 on itself);
                     share = its part of the engine's device time.
   roofline_conv_gn8 the same kernel's 8x8 / 4x4 instantiations; roofline_gemm: every other matmul-shaped launch (k_gemm_*, the 16x16
-                    attention block's k_qkv256 / k_attn256, k_head_conv); roofline_whole_denoiser: all flops / all device time.
+                    attention block k_attn_blk256, k_head_conv); roofline_whole_denoiser: all flops / all device time.
   roofline_ni_step  ``k_step_f64hist`` (HBM-bound): algorithmic bytes per launch / mean launch duration.
   cpu_baseline      the CPU oracle (eager-PyTorch restatement of the reference path: fp32 NCSN++ + fp64 recurrence) on this host:
                     64 images x 15 steps; ``config1`` = BASELINE config 1 (8 images x 5 steps) images/s; threads = min(32, physical):
@@ -94,7 +94,10 @@ INCEPTION_GFLOP_PER_IMAGE = 11.42      # pool3 path at 299x299 (DESIGN.md sectio
 
 def r4(x):
     """4 significant digits: the line is numbers, keep them short"""
-    return None if x is None else float(f"{float(x):.4g}")
+    if x is None:
+        return None
+    f = float(f"{float(x):.4g}")
+    return int(f) if f == int(f) and abs(f) >= 100 else f          # (1236 instead of 1236.0: ~100 bytes of the line)
 
 
 def ni_step_bytes_per_element(C, s_x=4, s_h=8):
@@ -112,16 +115,14 @@ def profiled_traffic(match, exclude=None):
     """HBM bytes per launch from the newest committed rocprofv3 PMC summary (profiles/rNN/*_hbm_traffic.json:
     separate FETCH_SIZE / WRITE_SIZE passes over this very command, gfx950 x2 read correction applied by
     tools/summarize_profile.py).  bench.py cannot run rocprofv3 itself; returns None when no summary exists."""
-    files = sorted(ROOT.glob("profiles/r*/*_hbm_traffic.json"))
-    if not files:
-        return None
-    tab = json.loads(files[-1].read_text())
     excl = (exclude,) if isinstance(exclude, str) else tuple(exclude or ())
-    rows = [v for k, v in tab.items() if match in k and not any(e in k for e in excl)]
-    n = sum(v["launches"] for v in rows)
-    if not n:
-        return None
-    return r4(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in rows) / n)
+    for f in sorted(ROOT.glob("profiles/r*/*_hbm_traffic.json"), reverse=True):      # newest round first; within it the first summary that holds the kernel (SD3 / CIFAR10 / Inception runs are separate files)
+        tab = json.loads(f.read_text())
+        rows = [v for k, v in tab.items() if match in k and not any(e in k for e in excl)]
+        n = sum(v["launches"] for v in rows)
+        if n:
+            return r4(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in rows) / n)
+    return None
 
 
 def launch_ranks(args):
@@ -259,7 +260,7 @@ def main():
         line = bench_cifar(args, world, rank, dev)
         tail = {k: line.pop(k) for k in list(line) if k.startswith(("config", "roofline", "cpu_baseline", "accuracy"))}
         strip = ("metric", "unit", "n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "config", "warmup", "steps")
-        drop = ("bound", "peak", "unit", "traffic", "flops_per_launch", "launches", "flop_share", "sample", "kind")       # constants of the sub-objects: in the docstring
+        drop = ("bound", "peak", "unit", "traffic", "flops_per_launch", "launches", "flop_share", "sample", "kind", "where")       # constants of the sub-objects: in the docstring
 
         def slim(o):
             return {k: slim(v) for k, v in o.items() if k not in drop} if isinstance(o, dict) else o
@@ -271,7 +272,7 @@ def main():
             flat = synthetic_mmdit_flat(grid=64, seed=0, **SD3_MEDIUM)
             for key, fp8 in (("sd3", False), ("sd3_fp8", True)):
                 sub = bench_sd3(args, world, rank, dev, fp8=fp8, steps=args.sd3_steps, warmup=1, flat=flat)
-                line[key] = slim({k: v for k, v in sub.items() if k not in strip and k != "dtype"})
+                line[key] = slim({k: v for k, v in sub.items() if k not in strip and k != "dtype" and not (fp8 and k == "acc")})      # (acc carries both precisions: once, in "sd3")
                 release()
             del flat
         if not args.no_fid50k:
@@ -440,7 +441,7 @@ def bench_cifar(args, world, rank, dev):
             line["roofline_conv_gn8"] = {"kernel": "k_conv_gn2<8|4>", "achieved": r4(ach8), "frac": r4(ach8 / MFMA_BF16_PEAK_TFLOPS), "launches": int(c8_n),
                                          "mean_launch_ms": r4(c8_ms / c8_n), "share": r4(c8_ms / all_ms)}
         ach_g = gemm_flops / (gemm_ms * 1e-3) / 1e12
-        line["roofline_gemm"] = {"kernel": "k_gemm_*+k_qkv256+k_attn256+k_head_conv", "achieved": r4(ach_g), "frac": r4(ach_g / MFMA_BF16_PEAK_TFLOPS),
+        line["roofline_gemm"] = {"kernel": "k_gemm_*+k_attn_blk256+k_head_conv", "achieved": r4(ach_g), "frac": r4(ach_g / MFMA_BF16_PEAK_TFLOPS),
                                  "launches": int(gemm_n), "mean_launch_ms": r4(gemm_ms / gemm_n), "share": r4(gemm_ms / all_ms),
                                  "other_share": r4(other_ms / all_ms)}
         whole = (cg_flops + c8_flops + gemm_flops) / (all_ms * 1e-3) / 1e12
@@ -450,7 +451,7 @@ def bench_cifar(args, world, rank, dev):
         tot_bytes = sum(bpe[k] * E for k, _, _ in ev)
         ach_gbs = tot_bytes / (tot_ms * 1e-3) / 1e9
         line["roofline_ni_step"] = {"kernel": "k_step_f64hist", "bound": "hbm", "achieved": r4(ach_gbs), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": r4(ach_gbs / HBM_PEAK_GBS), "traffic": profiled_traffic("k_step_f64hist"), "launches": len(ev),
+                                    "frac": r4(ach_gbs / HBM_PEAK_GBS), "traffic": profiled_traffic("k_step_f64hist"),
                                     "mean_launch_ms": r4(tot_ms / len(ev)), "bytes_per_launch": r4(tot_bytes / len(ev))}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -657,7 +658,11 @@ def bench_sd3(args, world, rank, dev, fp8=False, steps=2, warmup=1, flat=None):
             per[name] = [r4(f_ / t_ / 1e12), r4(f_ / t_ / 1e12 / pk_), r4(t_ * 1e6)]      # [TFLOP/s, fraction of ITS operand type's dense peak, mean launch us] -- in the engine
             kernels.add(kern)
             tot_t += t_; tot_f += f_; tot_ideal += f_ / (pk_ * 1e12)
-        line["roofline_gemm"] = {"kernel": "+".join(sorted(kernels)), "where": "in-engine (HIP events around every launch of one 28-step batch)",
+        by_name = {}
+        for kn in sorted(kernels):                                            # "w128_256x256/e1" ... -> "w128_256x256/e1+4+7+8" (the line stays short)
+            nm, ep = kn.split("/e")
+            by_name.setdefault(nm, []).append(ep)
+        line["roofline_gemm"] = {"kernel": ",".join(f"{nm}/e{'+'.join(ep)}" for nm, ep in by_name.items()), "where": "in-engine (HIP events around every launch of one 28-step batch)",
                                  "achieved": r4(tot_f / tot_t / 1e12), "peak": r4(tot_f / tot_ideal / 1e12), "frac": r4(tot_ideal / tot_t), "shapes": per}
         # isolated back-to-back loop of fc1 WITH the engine's epilogue (tanh-GELU; fp8: + e4m3 output with E8M0 block scales), for the isolated-vs-engine gap
         M = Bs * tx
@@ -785,7 +790,7 @@ def bench_fid50k(args, world, rank, dev, steps=1, warmup=0):
             st.append(s_.mean_cov())
         line["d_matrices"] = r4(frechet_distance(st[0][0], st[0][1], st[1][0], st[1][1]))
         inc_tf = INCEPTION_GFLOP_PER_IMAGE * 1e9 * len(mats) * n_local / per["inception"] / 1e12
-        line["roofline"] = {"kernel": "inception pool3 engine (k_conv_ring implicit GEMMs, fp16 activations + one fp16 filter term)", "bound": "mfma", "achieved": r4(inc_tf), "peak": MFMA_BF16_PEAK_TFLOPS,
+        line["roofline"] = {"kernel": "inception pool3 engine", "bound": "mfma", "achieved": r4(inc_tf), "peak": MFMA_BF16_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": r4(inc_tf / MFMA_BF16_PEAK_TFLOPS), "traffic": None}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "fid50k":
         # bounded CPU sample of the same job: 16 images x 18 steps through the oracle denoiser + recurrence, then the Inception oracle on them
@@ -854,7 +859,7 @@ def bench_validate(args, world, rank, dev, steps=3, warmup=1):
             "dit_ms": r4(dit_ms), "dit_forwards": len(t_acc["ev"]) // (steps + warmup), "vae_ms": r4(vae_ms),
             "config": {"workload": "ValidateNaturalInference.natural_inference('ddim', 24): DiT-XL/2 engine, CFG 4 (cond + uncond as one forward of 16), natinf_step_f32prod, "
                                    "AutoencoderKL decoder engine 8 x 256x256 + PNG row", "nfe": 2 * nstep, "images_per_gpu": n},
-            "roofline": {"kernel": "DiT-XL/2 forward B=16 (k_gemm_* + k_attn_fused)", "bound": "mfma", "achieved": r4(dit_fl / (dit_ms * 1e-3) / 1e12),
+            "roofline": {"kernel": "DiT-XL/2 forward B=16", "bound": "mfma", "achieved": r4(dit_fl / (dit_ms * 1e-3) / 1e12),
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": r4(dit_fl / (dit_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS), "traffic": None}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "validate":
         from oracle import dit_oracle as DO
