@@ -66,6 +66,12 @@ int natinf_mmdit_forward(natinf_mmdit_t h, const float* latents, const float* ti
 int natinf_attention_hd64_bf16(const void* q, const void* k, int ld_qk, int64_t qk_bs, const void* vT, void* o, int ld_o,
                                int64_t o_bs, int B, int H, int Tp, int T, float scale, natinf_stream_t stream);
 
+/* 1 (read when an engine is CREATED): the image tokens' residual stream x [Tx][D] is kept in IEEE half instead of fp32 -- the reference's SD3 pipeline is
+ * fp16 end to end (src/SD3NaturalInference.py:175-176) --: every update x += gate * (W h + b) is computed in fp32 from the half row and rounded to half once
+ * (2^-11 per update); the attention output projection / fc2 epilogues and the LayerNorm-modulate passes move half the bytes.  The text stream (ctx_tokens rows)
+ * stays fp32.  0: both streams fp32; a negative value: the library's default (1 since round 6).  Workspace bytes per sequence differ: query natinf_mmdit_workspace_bytes after creating the engine. */
+int natinf_set_mmdit_stream16(int on);
+
 /* Measurement hook: while enabled, every k_flash_attn64 launch of this process (engine forwards and natinf_attention_hd64_bf16
  * alike) is bracketed by a HIP event pair on its own stream.  natinf_attention_profile_read synchronises on them and returns the
  * summed duration (ms) and the launch count since the last read.  Not thread-safe; for bench.py / tools. */

@@ -120,6 +120,7 @@ SIGNATURES = {
     "natinf_inception_forward": (C.c_int, [_p, _p, _i32, _p, _i32, _p, _i64, _p]),
     "natinf_gemm_profile": (C.c_int, [_i32]),
     "natinf_gemm_profile_read": (C.c_int, [_p, _i32]),
+    "natinf_set_mmdit_stream16": (C.c_int, [_i32]),
     "natinf_attention_profile": (C.c_int, [_i32]),
     "natinf_set_mmdit_text_stream": (C.c_int, [_i32]),
     "natinf_set_flash_mode": (C.c_int, [_i32]),

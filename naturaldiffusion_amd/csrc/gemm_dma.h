@@ -651,34 +651,56 @@ __device__ __forceinline__ void direct_f32_epilogue(const GemmArgs& g, f32x4 (&a
         gt[j][0] = gv.x; gt[j][1] = gv.y; gt[j][2] = gv.z; gt[j][3] = gv.w;
     }
     const float scale = g.scale;
-    const float* rb = g.resid_f32 + (int64_t)z * g.c_bs + n0 + wn * TN * 16 + q * 4;
-    float* cb = reinterpret_cast<float*>(g.c) + (int64_t)z * g.c_bs + n0 + wn * TN * 16 + q * 4;
+    const int64_t eoff = (int64_t)z * g.c_bs + n0 + wn * TN * 16 + q * 4;                        // element offset of the lane's first column (fp32 and half streams alike)
     constexpr int HI = HI_ > 0 ? HI_ : (DEQ ? (TM > 2 ? 2 : TM) : (TM > 4 ? TM / 2 : TM));      // residual row-tiles in flight (register budget)
+    typedef _Float16 f16x4_ds __attribute__((ext_vector_type(4)));
+    // F16 (GemmArgs::stream_f16, kernel-uniform): the stream's rows are IEEE half -- 8 bytes per lane and access instead of 16, half the bytes of the epilogue that
+    // bounds these launches (gemm_w128.h); the update itself stays fp32 with ONE rounding to half
+    auto sweep = [&](auto f16_tag) __attribute__((always_inline)) {
+        constexpr bool F16 = decltype(f16_tag)::value;
+        const float* rb = g.resid_f32 + eoff;
+        float* cb = reinterpret_cast<float*>(g.c) + eoff;
+        const _Float16* rbh = reinterpret_cast<const _Float16*>(g.resid_f32) + eoff;
+        _Float16* cbh = reinterpret_cast<_Float16*>(g.c) + eoff;
 #pragma unroll
-    for (int h = 0; h < TM / HI; ++h) {
-        f32x4 rs[HI][TN];
+        for (int h = 0; h < TM / HI; ++h) {
+            f32x4 rs[F16 ? 1 : HI][F16 ? 1 : TN];
+            uint2 rh[F16 ? HI : 1][F16 ? TN : 1];
 #pragma unroll
-        for (int i = 0; i < HI; ++i) {
-            const int m = min(m0 + wm * TM * 16 + (h * HI + i) * 16 + r, g.M - 1);
+            for (int i = 0; i < HI; ++i) {
+                const int m = min(m0 + wm * TM * 16 + (h * HI + i) * 16 + r, g.M - 1);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                rs[i][j] = n_ok[j] ? *reinterpret_cast<const f32x4*>(rb + (int64_t)m * g.resid_f32_ld + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int i = 0; i < HI; ++i) {
-            const int m = m0 + wm * TM * 16 + (h * HI + i) * 16 + r;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float a0 = DEQ ? acc[h * HI + i][j][e] * (rsc[h * HI + i] * dn[j][e]) : acc[h * HI + i][j][e];
-                    v[e] = ((a0 + ct[j][e]) * gt[j][e] + rs[i][j][e]) * scale;
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (F16) rh[i][j] = n_ok[j] ? *reinterpret_cast<const uint2*>(rbh + (int64_t)m * g.resid_f32_ld + j * 16) : make_uint2(0u, 0u);
+                    else rs[i][j] = n_ok[j] ? *reinterpret_cast<const f32x4*>(rb + (int64_t)m * g.resid_f32_ld + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                if (m < g.M && n_ok[j]) *reinterpret_cast<f32x4*>(cb + (int64_t)m * g.c_ld + j * 16) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < HI; ++i) {
+                const int m = m0 + wm * TM * 16 + (h * HI + i) * 16 + r;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x4 v;
+                    f16x4_ds xh;
+                    if constexpr (F16) xh = __builtin_bit_cast(f16x4_ds, rh[i][j]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a0 = DEQ ? acc[h * HI + i][j][e] * (rsc[h * HI + i] * dn[j][e]) : acc[h * HI + i][j][e];
+                        float x_;
+                        if constexpr (F16) x_ = (float)xh[e]; else x_ = rs[i][j][e];
+                        v[e] = ((a0 + ct[j][e]) * gt[j][e] + x_) * scale;
+                    }
+                    if (m < g.M && n_ok[j]) {
+                        if constexpr (F16) {
+                            const f16x4_ds o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                            *reinterpret_cast<uint2*>(cbh + (int64_t)m * g.c_ld + j * 16) = __builtin_bit_cast(uint2, o);
+                        } else *reinterpret_cast<f32x4*>(cb + (int64_t)m * g.c_ld + j * 16) = v;
+                    }
+                }
             }
         }
-    }
+    };
+    if (g.stream_f16) sweep(std::integral_constant<bool, true>{}); else sweep(std::integral_constant<bool, false>{});
 }
 
 // EPI (kernel template parameter, chosen on the host by packed_epi()): 0 = fp32-slab epilogue with every fused term as a run-time

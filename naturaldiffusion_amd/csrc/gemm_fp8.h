@@ -129,17 +129,20 @@ __global__ __launch_bounds__(512, 2) void k_gemm_fp8(const GemmArgs g)
 // q = round(v / s), s = max|v| / 448 (the e4m3 maximum; values are clamped, v_cvt_pk_fp8_f32 does not saturate)
 __global__ __launch_bounds__(256) void k_ln_modulate_fp8(const float* __restrict__ x, const float* __restrict__ shift,
                                                          const float* __restrict__ scale, int mod_ld, uint8_t* __restrict__ h,
-                                                         float* __restrict__ row_scale, int D, int64_t rows, int rows_per_sample)
+                                                         float* __restrict__ row_scale, int D, int64_t rows, int rows_per_sample, int x_f16 = 0)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + row * D;
+    const _Float16* xh = reinterpret_cast<const _Float16*>(x) + row * D;      // (x_f16: the residual stream is IEEE half, read through the same pointer)
     float v[24];                                                    // D <= 1536, D % 128 == 0: two adjacent columns per lane and step
     const int n = D >> 6;
     float s = 0.f;
     for (int i = 0; i < n; i += 2) {
-        const float2 u = *reinterpret_cast<const float2*>(xr + 64 * i + 2 * lane);
+        float2 u;
+        if (x_f16) { u.x = (float)xh[64 * i + 2 * lane]; u.y = (float)xh[64 * i + 2 * lane + 1]; }
+        else u = *reinterpret_cast<const float2*>(xr + 64 * i + 2 * lane);
         v[i] = u.x; v[i + 1] = u.y; s += u.x + u.y;
     }
 #pragma unroll
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256) void k_ln_modulate_fp8(const float* __restrict
 }
 
 // The same for D = NC * 256 with 16-byte loads and 4-byte stores (k_ln_modulate_v4's access pattern, dit_engine.inc)
-template <int NC>
+template <int NC, bool XH = false>                                      // XH: x is IEEE half (the MMDiT engine's 16-bit image stream): 8-byte loads of four columns
 __global__ __launch_bounds__(256) void k_ln_modulate_fp8_v4(const float* __restrict__ x, const float* __restrict__ shift,
                                                             const float* __restrict__ scale, int mod_ld, uint8_t* __restrict__ h,
                                                             float* __restrict__ row_scale, int64_t rows, int rows_per_sample)
@@ -181,10 +184,18 @@ __global__ __launch_bounds__(256) void k_ln_modulate_fp8_v4(const float* __restr
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float4* xr = reinterpret_cast<const float4*>(x + row * D) + lane;
+    const uint2* xh = reinterpret_cast<const uint2*>(reinterpret_cast<const _Float16*>(x) + row * D) + lane;
     float4 v[NC];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NC; ++i) { v[i] = xr[64 * i]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+    for (int i = 0; i < NC; ++i) {
+        if constexpr (XH) {
+            typedef _Float16 f16x4_ln8 __attribute__((ext_vector_type(4)));
+            const f16x4_ln8 hv = __builtin_bit_cast(f16x4_ln8, xh[64 * i]);
+            v[i] = make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
+        } else v[i] = xr[64 * i];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float mean = s / (float)D;
@@ -217,13 +228,19 @@ __global__ __launch_bounds__(256) void k_ln_modulate_fp8_v4(const float* __restr
     for (int i = 0; i < NC; ++i) out[64 * i] = pack_fp8x4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
 }
 inline void launch_ln_modulate_fp8(const float* x, const float* shift, const float* scale, int mod_ld, uint8_t* h, float* row_scale, int D, int64_t rows,
-                                   int rows_per_sample, hipStream_t s)
+                                   int rows_per_sample, hipStream_t s, bool x_f16 = false)
 {
     const dim3 grid((unsigned)((rows + 3) / 4));
     const bool al = mod_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(scale)) % 16 == 0;
+    if (x_f16) {
+        if (D == 1536 && al) hipLaunchKernelGGL((k_ln_modulate_fp8_v4<6, true>), grid, dim3(256), 0, s, x, shift, scale, mod_ld, h, row_scale, rows, rows_per_sample);
+        else if (D == 256 && al) hipLaunchKernelGGL((k_ln_modulate_fp8_v4<1, true>), grid, dim3(256), 0, s, x, shift, scale, mod_ld, h, row_scale, rows, rows_per_sample);
+        else hipLaunchKernelGGL(k_ln_modulate_fp8, grid, dim3(256), 0, s, x, shift, scale, mod_ld, h, row_scale, D, rows, rows_per_sample, 1);
+        return;
+    }
     if (D == 1536 && al) hipLaunchKernelGGL(k_ln_modulate_fp8_v4<6>, grid, dim3(256), 0, s, x, shift, scale, mod_ld, h, row_scale, rows, rows_per_sample);
     else if (D == 256 && al) hipLaunchKernelGGL(k_ln_modulate_fp8_v4<1>, grid, dim3(256), 0, s, x, shift, scale, mod_ld, h, row_scale, rows, rows_per_sample);
-    else hipLaunchKernelGGL(k_ln_modulate_fp8, grid, dim3(256), 0, s, x, shift, scale, mod_ld, h, row_scale, D, rows, rows_per_sample);
+    else hipLaunchKernelGGL(k_ln_modulate_fp8, grid, dim3(256), 0, s, x, shift, scale, mod_ld, h, row_scale, D, rows, rows_per_sample, 0);
 }
 
 // weights: W fp32 [N][K] -> fp8 bytes [N][K] + one scale per output channel

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace ncsn {
 
@@ -115,6 +116,9 @@ struct GemmArgs {
     int a0_up; int a1_up;
     // split-K (launch_gemm decides; small-M, long-K launches): `splitk_ws` = fp32 workspace for splitk_max * M * N partial sums
     float* splitk_ws; int splitk_max; int splitk;
+    // direct residual-stream epilogue (EPI 7 / fp8 EPI 3) on a 16-bit stream: resid_f32 and c point at IEEE-half rows (same element strides); the arithmetic stays
+    // fp32, one rounding to half per update (the MMDiT engine's image stream, natinf_set_mmdit_stream16: the reference's SD3 pipeline is fp16)
+    int stream_f16;
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }

@@ -8,8 +8,9 @@ memory and the stream.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
@@ -69,7 +70,8 @@ def flatten_state_dict(sd: Dict[str, torch.Tensor], grid: int, layers: int, head
 
 class MMDiTEngine:
     def __init__(self, flat_params: torch.Tensor, max_batch: int, grid: int = 64, ctx_tokens: int = 333, layers: int = 24,
-                 heads: int = 24, joint_dim: int = 4096, pooled_dim: int = 2048, in_ch: int = 16, device="cuda:0", fp8: bool = False):
+                 heads: int = 24, joint_dim: int = 4096, pooled_dim: int = 2048, in_ch: int = 16, device="cuda:0", fp8: bool = False,
+                 stream16: Optional[bool] = None):
         _lib.require_gpu()
         if min(layers, heads, joint_dim, pooled_dim, in_ch, grid, ctx_tokens) <= 0 or heads > 24 or joint_dim % 8 or pooled_dim % 8 \
                 or in_ch % 2 or (grid * grid) % 8:
@@ -79,7 +81,17 @@ class MMDiTEngine:
         self.device = torch.device(device)
         self.max_batch, self.grid, self.ctx_tokens, self.joint_dim, self.pooled_dim, self.in_ch = int(max_batch), grid, ctx_tokens, joint_dim, pooled_dim, in_ch
         self._h = C.c_void_p()
-        check(lib.natinf_mmdit_create(C.byref(self._h), layers, heads, joint_dim, pooled_dim, in_ch, grid, ctx_tokens, FP8 if fp8 else 0), "natinf_mmdit_create")
+        # ``stream16`` (None = the library's default; the environment variable NATINF_MMDIT_STREAM16 = 0 / 1 overrides that default for A/B runs): the image
+        # tokens' residual stream in IEEE half instead of fp32 (include/natinf_mmdit.h, natinf_set_mmdit_stream16: read when the engine is created)
+        if stream16 is None and os.environ.get("NATINF_MMDIT_STREAM16") is not None:
+            stream16 = bool(int(os.environ["NATINF_MMDIT_STREAM16"]))
+        if stream16 is not None:
+            check(lib.natinf_set_mmdit_stream16(int(bool(stream16))), "natinf_set_mmdit_stream16")
+        try:
+            check(lib.natinf_mmdit_create(C.byref(self._h), layers, heads, joint_dim, pooled_dim, in_ch, grid, ctx_tokens, FP8 if fp8 else 0), "natinf_mmdit_create")
+        finally:
+            if stream16 is not None:
+                lib.natinf_set_mmdit_stream16(-1)
         n = lib.natinf_mmdit_param_count(self._h)
         if flat_params.numel() != n:
             raise ValueError(f"expected {n} parameters, got {flat_params.numel()}")
