@@ -700,7 +700,57 @@ __device__ __forceinline__ void direct_f32_epilogue(const GemmArgs& g, f32x4 (&a
             }
         }
     };
-    if (g.stream_f16) sweep(std::integral_constant<bool, true>{}); else sweep(std::integral_constant<bool, false>{});
+    // Half stream, 16-byte form (the wave's TN column tiles all inside N; TN even): the lanes q, q ^ 1 of a row -- rows of sixteen lanes that hold columns 4 q .. 4 q + 3
+    // of EVERY column tile -- trade halves with v_permlane16_swap (gfx950: the odd rows of one register against the even rows of another), so that the even lane
+    // owns eight consecutive columns of tile 2 p and the odd lane eight of tile 2 p + 1: one 16-byte access per lane and tile pair, 64 contiguous bytes per row and
+    // instruction -- the fp32 form's access shape at half its count (the 8-byte form above moves 32-byte segments).
+    auto sweep16 = [&]() __attribute__((always_inline)) {
+        static_assert(TN % 2 == 0 || TN == 1, "tile pairs");
+        const int jt_off = (q & 1) * 16 + (q >> 1) * 8 - q * 4;            // the lane's eight columns start at tile 2 p + (q & 1), column (q >> 1) * 8 (eoff already holds q * 4)
+        const _Float16* rbh = reinterpret_cast<const _Float16*>(g.resid_f32) + eoff + jt_off;
+        _Float16* cbh = reinterpret_cast<_Float16*>(g.c) + eoff + jt_off;
+        constexpr int NP = TN / 2 > 0 ? TN / 2 : 1;
+#pragma unroll
+        for (int h = 0; h < TM / HI; ++h) {
+            uint4 rq[HI][NP];
+#pragma unroll
+            for (int i = 0; i < HI; ++i) {
+                const int m = min(m0 + wm * TM * 16 + (h * HI + i) * 16 + r, g.M - 1);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) rq[i][p] = *reinterpret_cast<const uint4*>(rbh + (int64_t)m * g.resid_f32_ld + p * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < HI; ++i) {
+                const int m = m0 + wm * TM * 16 + (h * HI + i) * 16 + r;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    // even lane: (x, y) = its tile-2p columns, (z, w) = the odd lane's; odd lane: (x, y) = the even lane's tile-2p+1 columns, (z, w) = its own.
+                    // odd.x <-> even.z, odd.y <-> even.w: afterwards (x, y) = the lane's columns of tile 2 p, (z, w) = of tile 2 p + 1, on every lane
+                    auto s0 = __builtin_amdgcn_permlane16_swap(rq[i][p].x, rq[i][p].z, false, false);
+                    auto s1 = __builtin_amdgcn_permlane16_swap(rq[i][p].y, rq[i][p].w, false, false);
+                    const f16x4_ds x0 = __builtin_bit_cast(f16x4_ds, make_uint2(s0[0], s1[0])), x1 = __builtin_bit_cast(f16x4_ds, make_uint2(s0[1], s1[1]));
+                    f16x4_ds o0, o1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a0 = DEQ ? acc[h * HI + i][2 * p][e] * (rsc[h * HI + i] * dn[2 * p][e]) : acc[h * HI + i][2 * p][e];
+                        const float a1 = DEQ ? acc[h * HI + i][2 * p + 1][e] * (rsc[h * HI + i] * dn[2 * p + 1][e]) : acc[h * HI + i][2 * p + 1][e];
+                        o0[e] = (_Float16)(((a0 + ct[2 * p][e]) * gt[2 * p][e] + (float)x0[e]) * scale);
+                        o1[e] = (_Float16)(((a1 + ct[2 * p + 1][e]) * gt[2 * p + 1][e] + (float)x1[e]) * scale);
+                    }
+                    const uint2 u0 = __builtin_bit_cast(uint2, o0), u1 = __builtin_bit_cast(uint2, o1);
+                    auto t0 = __builtin_amdgcn_permlane16_swap(u0.x, u1.x, false, false);          // the same trade back: (x, y, z, w) = the lane's eight consecutive columns
+                    auto t1 = __builtin_amdgcn_permlane16_swap(u0.y, u1.y, false, false);
+                    if (m < g.M) *reinterpret_cast<uint4*>(cbh + (int64_t)m * g.c_ld + p * 32) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                }
+            }
+        }
+    };
+    if (g.stream_f16) {
+        bool wide = false;
+        if constexpr (TN % 2 == 0) wide = n0 + (wn + 1) * TN * 16 <= g.N && g.resid_f32_ld % 8 == 0 && g.c_ld % 8 == 0;      // (wave-uniform)
+        if (wide) { if constexpr (TN % 2 == 0) sweep16(); }
+        else sweep(std::integral_constant<bool, true>{});
+    } else sweep(std::integral_constant<bool, false>{});
 }
 
 // EPI (kernel template parameter, chosen on the host by packed_epi()): 0 = fp32-slab epilogue with every fused term as a run-time

@@ -90,8 +90,8 @@ __device__ __forceinline__ void w128_bufdma_at(unsigned vo, const w128_rsrc& rs,
 //    XCD against 4 MB of L2);
 //  * a phase stagger (the first round's blocks sleep 0 / 1 / 2 x 8 or 16 us by CU, so that a third of the chip is in its epilogue while two thirds multiply): the epilogues
 //    do get shorter (-17 .. -24 us per launch), and the last group's sleep costs exactly that (+-0 at 8 us, +8 us at 16 us per launch; three rounds per launch).
-// What helped is fewer bytes: the MMDiT engine keeps its image stream in IEEE half (natinf_set_mmdit_stream16, GemmArgs::stream_f16: gemm_dma.h direct_f32_epilogue) -- -1.8 % bf16 /
-// -2.4 % fp8 per forward; the residual under the K loop needs registers that are not there.
+// What helped is fewer bytes: the MMDiT engine keeps its image stream in IEEE half (natinf_set_mmdit_stream16, GemmArgs::stream_f16: gemm_dma.h direct_f32_epilogue, 16-byte accesses through v_permlane16_swap) -- -3.3 % bf16 /
+// -5.2 % fp8 per forward; the residual under the K loop needs registers that are not there.
 // The slot table of one iteration (slot S = the instructions issued in front of MFMA S; MFMA S = K step S / 64, A fragment (S / 8) % 8, B fragment S % 8).
 // MODE 0: steady state; 1: second-to-last tile (nothing left to request; the last tile is awaited with vmcnt(0)); 2: last tile (K step 1's reads only).
 // A schedule SCH names the slots: K step 1's fragment reads (rd1: 0..7 = A, 8..15 = B), the two "half is free" barriers, the sixteen requests (piece p: 0..7 = A,
