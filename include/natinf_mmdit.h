@@ -71,6 +71,9 @@ int natinf_attention_hd64_bf16(const void* q, const void* k, int ld_qk, int64_t 
  * (2^-11 per update); the attention output projection / fc2 epilogues and the LayerNorm-modulate passes move half the bytes.  The text stream (ctx_tokens rows)
  * stays fp32.  0: both streams fp32; a negative value: the library's default (1 since round 6).  Workspace bytes per sequence differ: query natinf_mmdit_workspace_bytes after creating the engine. */
 int natinf_set_mmdit_stream16(int on);
+/* 1 (default): the text stream's fc1 (bias + tanh-GELU: no per-sequence term, operands contiguous over the sequences) runs as ONE GEMM over B * ctx_tokens rows; 0: batched
+ * per sequence like the text stream's other GEMMs (A/B runs).  Read at every forward. */
+int natinf_set_mmdit_text_flat(int on);
 
 /* Measurement hook: while enabled, every k_flash_attn64 launch of this process (engine forwards and natinf_attention_hd64_bf16
  * alike) is bracketed by a HIP event pair on its own stream.  natinf_attention_profile_read synchronises on them and returns the
