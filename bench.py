@@ -20,7 +20,8 @@ one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
                     reference's per-batch loop contains (:290, :308-309) that the contract's "inputs resident in HBM" region leaves out.
   sd3, sd3_fp8      BASELINE configs 4 / 5 (``--workload sd3 [--fp8]`` alone): 28-step SD3-form NI at 1024x1024, 4 images x CFG per
                     GPU = ONE batched MMDiT forward of 8 sequences (4,096 image + 333 text tokens; inside it the text stream's launches run on a HIP
-                    stream of the engine's own, joined with the image stream at every joint attention: same bytes) per step + one fused
+                    stream of the engine's own, joined with the image stream at every joint attention: same bytes; the image tokens' residual stream in IEEE half since
+                    round 6 -- the reference's pipeline is fp16 --, natinf_set_mmdit_stream16) per step + one fused
                     ``natinf_step_f16chain`` launch; a step = one 4-image batch through all 28 steps; SD3-medium-shaped synthetic
                     weights (2.03 B parameters).  fp8 = e4m3 operands (v_mfma_f32_16x16x128_f8f6f4) for the image-stream q|k, v, fc1,
                     fc2 GEMMs, bf16 elsewhere.  Fields: value (images/s), ms_per_step, frac (all 2*MAC flops of the forward / wall time
