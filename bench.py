@@ -15,7 +15,7 @@ rotate over ``--streams`` HIP streams (three since round 6, two before: that man
 one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
   single_stream     {value, ms_per_step}: the same K steps one batch after the other on ONE stream (the reference's order; the
                     like-for-like number for rounds 1-2, whose headline was this).  ``--streams 1`` makes it the headline.
-  pipeline          {value}: images/s of the same K batches through the production pipeline (``generate_sharded`` on the same lanes): Philox noise by
+  pipeline          {value}: images/s of the same K batches (K x 512 images) through the production pipeline (``generate_sharded`` on the same lanes): Philox noise by
                     global index drawn inside the timed span, the 15 steps, ``to_pixel``, and the ONE copy of the uint8 images to the host -- everything the
                     reference's per-batch loop contains (:290, :308-309) that the contract's "inputs resident in HBM" region leaves out.
   sd3, sd3_fp8      BASELINE configs 4 / 5 (``--workload sd3 [--fp8]`` alone): 28-step SD3-form NI at 1024x1024, 4 images x CFG per
@@ -86,9 +86,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the first HIP call
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
-MFMA_FP8_PEAK_TFLOPS = 5000.0
-HBM_PEAK_GBS = 8000.0                # HBM3E spec, same guide
+MFMA_BF16_PEAK_TFLOPS = 2500         # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_FP8_PEAK_TFLOPS = 5000
+HBM_PEAK_GBS = 8000                  # HBM3E spec, same guide
 GFLOP_PER_IMAGE_FORWARD = 21.69307136  # 2*MAC of conv/linear/attention matmuls (oracle.flops_per_image)
 INCEPTION_GFLOP_PER_IMAGE = 11.42      # pool3 path at 299x299
 
@@ -278,7 +278,7 @@ def main():
             del flat
         if not args.no_fid50k:
             sub = bench_fid50k(args, world, rank, dev, steps=1, warmup=0)
-            line["fid50k"] = slim({k: v for k, v in sub.items() if k not in strip and k not in ("dtype", "cpu_baseline", "batches", "last_batch", "frechet_vs_synthetic_ref")})
+            line["fid50k"] = slim({k: v for k, v in sub.items() if k not in strip and k not in ("dtype", "cpu_baseline", "batches", "last_batch", "frechet_vs_synthetic_ref", "ms_per_step")})
             release()
         if not args.no_validate and world == 1:
             sub = bench_validate(args, world, rank, dev, steps=3, warmup=1)
@@ -394,8 +394,9 @@ def bench_cifar(args, world, rank, dev):
         generate_sharded(pl, None, 2 * Bz, Bz, device=dev, coeff=(C, Bm, node))                   # slabs of the lanes' first use
         torch.cuda.synchronize(); tp = time.perf_counter()
         im, _ = generate_sharded(pl, None, args.steps * Bz, Bz, device=dev, coeff=(C, Bm, node), to_cpu=True)
-        line["pipeline"] = {"value": round(args.steps * Bz / (time.perf_counter() - tp), 2), "images": int(im.shape[0])}
-    line["config"] = {"workload": f"CIFAR10 NI 15-step {os.path.basename(args.weights)} B={Bz}/GPU NCSN++ 61.8M bf16 MFMA, ni_step fp64 history",
+        assert int(im.shape[0]) == args.steps * Bz
+        line["pipeline"] = {"value": round(args.steps * Bz / (time.perf_counter() - tp), 2)}
+    line["config"] = {"workload": f"CIFAR10 NI 15-step {os.path.basename(args.weights)} B={Bz}/GPU NCSN++ 61.8M bf16, ni_step fp64 history",
                       "nfe": n_step, "batch_per_gpu": Bz, "streams": n_str, "sharding": f"batch x{world}, no collective"}
 
     if rank == 0 and not args.no_roofline:
