@@ -29,6 +29,10 @@ typedef struct natinf_dit* natinf_dit_t;
 
 /* hidden % 64 == 0, hidden <= 1536, hidden % heads == 0, (hidden / heads) % 8 == 0 */
 int natinf_dit_create(natinf_dit_t* out, int depth, int hidden, int heads, int flags);
+/* 1 (read when an engine is CREATED): the residual stream x [256 tokens][hidden] is kept in IEEE half instead of fp32; every update
+ * x += gate * (W h + b) is computed in fp32 from the half row and rounded to half once (the MMDiT engine's natinf_set_mmdit_stream16,
+ * include/natinf_mmdit.h).  0: fp32; a negative value: the library's default (1 since round 6). */
+int natinf_set_dit_stream16(int on);
 int natinf_dit_destroy(natinf_dit_t h);
 int64_t natinf_dit_param_count(natinf_dit_t h);           /* incl. the frozen pos_embed */
 int64_t natinf_dit_packed_bytes(natinf_dit_t h);

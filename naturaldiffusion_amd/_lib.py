@@ -121,6 +121,7 @@ SIGNATURES = {
     "natinf_gemm_profile": (C.c_int, [_i32]),
     "natinf_gemm_profile_read": (C.c_int, [_p, _i32]),
     "natinf_set_mmdit_stream16": (C.c_int, [_i32]),
+    "natinf_set_dit_stream16": (C.c_int, [_i32]),
     "natinf_set_mmdit_text_flat": (C.c_int, [_i32]),
     "natinf_attention_profile": (C.c_int, [_i32]),
     "natinf_set_mmdit_text_stream": (C.c_int, [_i32]),

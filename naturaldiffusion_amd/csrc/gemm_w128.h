@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // (deterministic) and applies out = (resid + gate[sample] * (sum + bias)) * scale, four columns per thread.  resid may be out (same element, same thread).
 __global__ __launch_bounds__(256) void k_splitk_reduce_f32(const float* __restrict__ part, int S, int64_t slice_stride, int M, int N, const float* __restrict__ bias_n,
                                                             const float* __restrict__ gate, int gate_ld, int log_rows_per_sample, int z_samples,
-                                                            const float* resid, int resid_ld, int64_t c_bs, float scale, float* c, int c_ld)
+                                                            const float* resid, int resid_ld, int64_t c_bs, float scale, float* c, int c_ld, int stream_f16 = 0)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, per = (int64_t)M * (N >> 2);
     const int z = blockIdx.y;
@@ -346,6 +346,17 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_f32(const float* __restri
     for (int sl = 1; sl < S; ++sl) { const f32x4 u = *reinterpret_cast<const f32x4*>(p + sl * slice_stride); v += u; }
     if (bias_n) { const f32x4 b = *reinterpret_cast<const f32x4*>(bias_n + n); v += b; }
     if (gate) { const f32x4 gt = *reinterpret_cast<const f32x4*>(gate + (int64_t)((m >> log_rows_per_sample) + z * z_samples) * gate_ld + n); v *= gt; }
+    typedef _Float16 f16x4_sk __attribute__((ext_vector_type(4)));
+    if (stream_f16) {                                                 // (GemmArgs::stream_f16: resid and c are IEEE-half rows -- the transformer engines' 16-bit residual stream)
+        if (resid) {
+            const f16x4_sk rs = *reinterpret_cast<const f16x4_sk*>(reinterpret_cast<const _Float16*>(resid) + (int64_t)z * c_bs + (int64_t)m * resid_ld + n);
+            v += f32x4{(float)rs[0], (float)rs[1], (float)rs[2], (float)rs[3]};
+        }
+        v *= scale;
+        const f16x4_sk o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        *reinterpret_cast<f16x4_sk*>(reinterpret_cast<_Float16*>(c) + (int64_t)z * c_bs + (int64_t)m * c_ld + n) = o;
+        return;
+    }
     if (resid) { const f32x4 rs = *reinterpret_cast<const f32x4*>(resid + (int64_t)z * c_bs + (int64_t)m * resid_ld + n); v += rs; }
     v *= scale;
     *reinterpret_cast<f32x4*>(c + (int64_t)z * c_bs + (int64_t)m * c_ld + n) = v;

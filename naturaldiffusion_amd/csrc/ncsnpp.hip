@@ -610,7 +610,7 @@ int splitk_slices(const GemmArgs& g) {
 int w128_splitk_slices(const GemmArgs& g) {
     // (batch 1 only: the workspace contract is splitk_max * M * N floats; a batched launch would need batch times that)
     if (!g_splitk || !g_w128 || !g.splitk_ws || g.splitk_max < 2 || g.batch != 1 || !w128_ok(g) || g.a0_C < 3072) return 1;
-    if (g.c_mode != OUT_F32 || !g.resid_f32 || g.resid || g.rowvec || g.bias_m || g.gn_part || g.act != ACT_NONE || g.epi_fp32_slab || g.N % 4 || g.c_ld % 4 || g.resid_f32_ld % 4 || g.stream_f16) return 1;      // (the reduce pass reads and writes an fp32 stream)
+    if (g.c_mode != OUT_F32 || !g.resid_f32 || g.resid || g.rowvec || g.bias_m || g.gn_part || g.act != ACT_NONE || g.epi_fp32_slab || g.N % 4 || g.c_ld % 4 || g.resid_f32_ld % 4) return 1;
     const int64_t tiles = (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.batch;
     if (tiles * 2 > NUM_CU) return 1;
     int S = (int)(NUM_CU / tiles);
@@ -650,7 +650,7 @@ int launch_gemm_run(const GemmArgs& g0, hipStream_t s) {
             const int64_t per = (int64_t)g0.M * (g0.N / 4);
             hipLaunchKernelGGL(k_splitk_reduce_f32, dim3((unsigned)((per + 255) / 256), (unsigned)g0.batch), dim3(256), 0, s, g0.splitk_ws, S8, (int64_t)g0.batch * g0.M * g0.N, g0.M, g0.N,
                                g0.bias_n, g0.gate, g0.gate_ld, g0.log_rows_per_sample, g0.z_samples, g0.resid_f32, g0.resid_f32_ld, g0.c_bs, g0.scale,
-                               reinterpret_cast<float*>(g0.c), g0.c_ld);
+                               reinterpret_cast<float*>(g0.c), g0.c_ld, g0.stream_f16);
             return 256;
         }
     }

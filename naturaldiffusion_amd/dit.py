@@ -51,14 +51,25 @@ def flatten_state_dict(sd: Dict[str, torch.Tensor], depth: int, hidden: int) -> 
 
 class DiTEngine:
     def __init__(self, flat_params: torch.Tensor, max_batch: int, depth: int = 28, hidden: int = 1152, heads: int = 16,
-                 device="cuda:0", unfused_attention: bool = False):
+                 device="cuda:0", unfused_attention: bool = False, stream16=None):
         _lib.require_gpu()
         if depth <= 0 or hidden <= 0 or heads <= 0 or hidden % 64 or hidden > 1536 or hidden % heads or (hidden // heads) % 8:
             raise ValueError("hidden must be a multiple of 64 (<= 1536) and of heads, head_dim a multiple of 8")
         self.device = torch.device(device)
         self.max_batch = int(max_batch)
         self._h = C.c_void_p()
-        check(lib.natinf_dit_create(C.byref(self._h), depth, hidden, heads, UNFUSED_ATTENTION if unfused_attention else 0), "natinf_dit_create")
+        # ``stream16`` (None = the library's default; NATINF_DIT_STREAM16 = 0 / 1 in the environment overrides that default for A/B runs): the residual stream in
+        # IEEE half instead of fp32 (include/natinf_dit.h, natinf_set_dit_stream16: read when the engine is created)
+        import os
+        if stream16 is None and os.environ.get("NATINF_DIT_STREAM16") is not None:
+            stream16 = bool(int(os.environ["NATINF_DIT_STREAM16"]))
+        if stream16 is not None:
+            check(lib.natinf_set_dit_stream16(int(bool(stream16))), "natinf_set_dit_stream16")
+        try:
+            check(lib.natinf_dit_create(C.byref(self._h), depth, hidden, heads, UNFUSED_ATTENTION if unfused_attention else 0), "natinf_dit_create")
+        finally:
+            if stream16 is not None:
+                lib.natinf_set_dit_stream16(-1)
         n = lib.natinf_dit_param_count(self._h)
         if flat_params.numel() != n:
             raise ValueError(f"expected {n} parameters, got {flat_params.numel()}")
