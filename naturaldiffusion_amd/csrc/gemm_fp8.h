@@ -227,13 +227,68 @@ __global__ __launch_bounds__(256) void k_ln_modulate_fp8_v4(const float* __restr
 #pragma unroll
     for (int i = 0; i < NC; ++i) out[64 * i] = pack_fp8x4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
 }
+// The half stream in 16-byte accesses (D = NC8 * 512; SD3: 1536), as k_ln_modulate_h8 (dit_engine.inc): eight consecutive columns per lane and 512-column chunk, one
+// 16-byte load of x and one 8-byte store of e4m3 bytes per chunk (32 us alone; ~49 us mean inside a forward, beside the text stream's launches, like the four-column form).
+template <int NC8>
+__global__ __launch_bounds__(256) void k_ln_modulate_fp8_h8(const float* __restrict__ x, const float* __restrict__ shift, const float* __restrict__ scale, int mod_ld,
+                                                            uint8_t* __restrict__ h, float* __restrict__ row_scale, int64_t rows, int rows_per_sample)
+{
+    constexpr int D = NC8 * 512;
+    typedef _Float16 f16x8_ln8 __attribute__((ext_vector_type(8)));
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint4* xh = reinterpret_cast<const uint4*>(reinterpret_cast<const _Float16*>(x) + row * D) + lane;
+    float v[NC8][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC8; ++i) {
+        const f16x8_ln8 hv = __builtin_bit_cast(f16x8_ln8, xh[64 * i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = (float)hv[e];
+        s += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)D;
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC8; ++i) {
+        float d[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = v[i][e] - mean;
+        qq += ((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) + ((d[4] * d[4] + d[5] * d[5]) + (d[6] * d[6] + d[7] * d[7]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o);
+    const float rstd = 1.0f / sqrtf(qq / (float)D + 1e-6f);
+    const int64_t b = row / rows_per_sample;
+    const float4* sh = reinterpret_cast<const float4*>(shift + b * mod_ld) + 2 * lane;
+    const float4* sc = reinterpret_cast<const float4*>(scale + b * mod_ld) + 2 * lane;
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC8; ++i) {
+        const float4 g0 = sc[128 * i], g1 = sc[128 * i + 1], t0 = sh[128 * i], t1 = sh[128 * i + 1];
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, tt[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[i][e] = (v[i][e] - mean) * rstd * (1.0f + gg[e]) + tt[e]; amax = fmaxf(amax, fabsf(v[i][e])); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const float qs = amax > 0.f ? amax / 448.0f : 1.0f, inv = 1.0f / qs;
+    if (lane == 0) row_scale[row] = qs;
+    uint2* out = reinterpret_cast<uint2*>(h + row * D) + lane;
+#pragma unroll
+    for (int i = 0; i < NC8; ++i)
+        out[64 * i] = make_uint2(pack_fp8x4(v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv), pack_fp8x4(v[i][4] * inv, v[i][5] * inv, v[i][6] * inv, v[i][7] * inv));
+}
 inline void launch_ln_modulate_fp8(const float* x, const float* shift, const float* scale, int mod_ld, uint8_t* h, float* row_scale, int D, int64_t rows,
                                    int rows_per_sample, hipStream_t s, bool x_f16 = false)
 {
     const dim3 grid((unsigned)((rows + 3) / 4));
     const bool al = mod_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(scale)) % 16 == 0;
     if (x_f16) {
-        if (D == 1536 && al) hipLaunchKernelGGL((k_ln_modulate_fp8_v4<6, true>), grid, dim3(256), 0, s, x, shift, scale, mod_ld, h, row_scale, rows, rows_per_sample);
+        if (D == 1536 && al) hipLaunchKernelGGL(k_ln_modulate_fp8_h8<3>, grid, dim3(256), 0, s, x, shift, scale, mod_ld, h, row_scale, rows, rows_per_sample);
         else if (D == 256 && al) hipLaunchKernelGGL((k_ln_modulate_fp8_v4<1, true>), grid, dim3(256), 0, s, x, shift, scale, mod_ld, h, row_scale, rows, rows_per_sample);
         else hipLaunchKernelGGL(k_ln_modulate_fp8, grid, dim3(256), 0, s, x, shift, scale, mod_ld, h, row_scale, D, rows, rows_per_sample, 1);
         return;
