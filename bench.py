@@ -49,7 +49,7 @@ one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
                     fid = "blocked"; d_matrices = Frechet distance between the two matrices' image statistics (same network, same
                     noise: a sanity figure that needs no asset).
   validate          SURVEY 8f N2 + N4 (``--workload validate`` alone): ``ValidateNaturalInference.natural_inference("ddim", 24)`` --
-                    DiT-XL/2 engine, 8 class-conditional latents, CFG 4 (the conditional and unconditional calls of a step as ONE forward of 16), 24 steps, one fused
+                    DiT-XL/2 engine (residual stream in IEEE half since round 6: natinf_set_dit_stream16), 8 class-conditional latents, CFG 4 (the conditional and unconditional calls of a step as ONE forward of 16), 24 steps, one fused
                     ``natinf_step_f32prod`` launch per step -- then the AutoencoderKL decoder engine (8 x 256x256 images) and the PNG
                     row.  value = images/s; dit_ms = mean DiT forward (16 samples); vae_ms = decode of the 8 latents; synthetic weights.
   roofline          the dominant kernel class, ``k_conv_gn2`` / ``k_conv_gn3`` at 32x32 / 16x16 (3x3 convolution with GroupNorm-apply + SiLU fused into its
