@@ -193,9 +193,11 @@ int natinf_set_attn_proj(int on);
 int natinf_set_attn_waves8(int on);
 /* 1 (default; read when a plan is built): GroupNorm-apply and the q | k | v projections of the 16x16 attention block run as ONE launch (k_qkv256:
  * the block input is read once, the normalised tensor is never stored); 0: k_gn_apply + the q | k GEMM + the batched V^T GEMM. */
-/* 1 (default; read when a plan is built): the whole 16x16 attention block -- GroupNorm-apply + q | k | v projections, scores, softmax, P V, output projection, skip
+/* (read when a plan is built; a negative value: the library's default = 2 since round 6)  1: the whole 16x16 attention block -- GroupNorm-apply + q | k | v projections, scores, softmax, P V, output projection, skip
  * and the GroupNorm partials of its output -- is ONE launch (csrc/attn_blk256.h: q stays in registers; k and V^T are written and re-read through L2 by the same block);
- * 0: k_qkv256 + k_attn256 (A/B runs).  Needs natinf_set_attn_qkv, natinf_set_attn_proj, natinf_set_attn_waves8 and natinf_set_attn256 at 1. */
+ * 0: k_qkv256 + k_attn256 (A/B runs); 2 (round 6): k_attn_blk256_v2 -- q k^T and P V taken against the normalised tokens h themselves (folded matrices Wq Wk^T and Wv W3,
+ * exact in real arithmetic): two projections instead of four, h resident in LDS (read row-wise and, for P V, transposed: ds_read_b64_tr_b16), nothing written between the
+ * phases.  Needs natinf_set_attn_qkv, natinf_set_attn_proj, natinf_set_attn_waves8 and natinf_set_attn256 at 1. */
 int natinf_set_attn_block(int on);
 int natinf_set_attn_qkv(int on);
 /* Tile of the fused kernel on the 8x8 level: 1 (default) = 64 pixels x 256 channels (one image per tile, wave tile 64 x 64, two blocks per CU at

@@ -31,10 +31,11 @@ namespace ncsn {
 constexpr int QKV_STAGE = 16384, QKV_NTL = 2, QKV_TILES = 48 / QKV_NTL, QKV_BIAS_BYTES = 768 * 4, QKV_LDS_BYTES = 2 * QKV_STAGE + QKV_BIAS_BYTES;
 
 // w0 / w1 / w2: the NIN weights of q, k, v, each [256 in][256 out] fp32 (layers.py:546-555) -> wf[nt][kc][lane][j] = W_(nt / 16)[32 kc + 8 (lane >> 4) + j][16 (nt % 16) + (lane & 15)]
-__global__ __launch_bounds__(256) void k_pack_qkv_w(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2, bf16* __restrict__ wf)
+// (n_mats = 1: the q tiles only -- k_attn_blk256_v2's folded Wqk: w1 / w2 are not read)
+__global__ __launch_bounds__(256) void k_pack_qkv_w(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2, bf16* __restrict__ wf, int n_mats = 3)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 3 * 256 * 256) return;
+    if (idx >= n_mats * 256 * 256) return;
     const int j = idx & 7, lane = (idx >> 3) & 63, kc = (idx >> 9) & 7, nt = idx >> 12;
     const float* w = nt < 16 ? w0 : (nt < 32 ? w1 : w2);
     const int r = lane & 15;

@@ -240,7 +240,9 @@ using CfgG32 = ConvGnCfg<32>; using CfgG16 = ConvGnCfg<16>; using CfgG16W = Conv
 #endif
 int g_fuse_head = 1;               // natinf_set_fuse_head (read when a plan is BUILT): GroupNorm + SiLU + the 128 -> 3 output convolution as ONE launch (head_conv.h)
 int g_cg8_tm4 = 1;                 // natinf_set_conv_gn8_tile: 1 = 8x8 level on 64-pixel x 256-channel tiles (one image per tile, two blocks per CU), 0 = 128 x 256 (two images per tile; -DNATINF_DEV builds)
-int g_attn_blk = 1;                // natinf_set_attn_block (read when a plan is BUILT): the whole 16x16 attention block -- k_qkv256 + k_attn256<true, 8> -- as ONE launch (attn_blk256.h: q stays in registers)
+constexpr int ATTN_BLK_DEFAULT = 2;
+int g_attn_blk = ATTN_BLK_DEFAULT;  // natinf_set_attn_block (read when a plan is BUILT): the whole 16x16 attention block as ONE launch -- 1: k_qkv256 + k_attn256<true, 8> in one kernel (attn_blk256.h: q stays in
+                                   // registers, k / V^T through L2); 2 (default since round 6): k_attn_blk256_v2 -- q k^T and P V against h itself, h resident in LDS (forward -3.3 % at B = 512); 0: two launches
 int g_attn_qkv = 1;                // natinf_set_attn_qkv (read when a plan is BUILT): GroupNorm-apply + the q | k | v projections of the 16x16 attention as ONE launch (attn_qkv.h)
 int g_attn_w8 = 1;                 // natinf_set_attn_waves8: k_attn256<true> as one 8-wave block per sample (1) or two 4-wave blocks (0)
 int g_attn_proj = 1;               // natinf_set_attn_proj (read when a plan is BUILT): the 16x16 attention's output projection + skip + GroupNorm partials inside k_attn256
@@ -326,6 +328,7 @@ bool configure_gemm_kernels() {
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<true>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn256<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, A256_LDS_BYTES) == hipSuccess &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_blk256), hipFuncAttributeMaxDynamicSharedMemorySize, ABLK_LDS_BYTES) == hipSuccess &&
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_blk256_v2), hipFuncAttributeMaxDynamicSharedMemorySize, ABLK2_LDS_BYTES) == hipSuccess &&
          // (k_attn_fused<2,4> / <3,5> / <3,6> with v as V^T: superseded by the row-major-v forms of the DiT engine, configure_dit_attention)
          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn64), hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES) == hipSuccess &&
 #ifdef NATINF_DEV
@@ -1078,6 +1081,23 @@ struct Builder {
                 hipLaunchKernelGGL(k_pack_attn_w3, dim3(256), dim3(256), 0, p.stream, p.params + src, reinterpret_cast<bf16*>(p.packed + w3f));
             });
         }
+        // k_attn_blk256_v2 (natinf_set_attn_block(2)): q k^T and P V against h itself -- the folded matrices Wqk = Wq Wk^T, Wvo = Wv W3 and their bias vectors, computed in
+        // fp32 at load time (k_attn_fold_w) and packed like the q tiles / W3 of the four-projection plans
+        const bool blk2 = blk && g_attn_blk == 2;
+        int64_t wqf2 = -1, wvof2 = -1, cq2 = -1, bo2 = -1;
+        if (blk2) {
+            const int64_t fq = wres((int64_t)C * C * 4), fv = wres((int64_t)C * C * 4);
+            cq2 = wres((int64_t)C * 4); bo2 = wres((int64_t)C * 4);
+            wqf2 = wres((int64_t)C * C * 2); wvof2 = wres((int64_t)C * C * 2);
+            const int64_t w0_ = pw[0], w1_ = pw[1], w2_ = pw[2], w3_ = pw[3], b0_ = pb[0], b2_ = pb[2], b3_ = pb[3], cq_ = cq2, bo_ = bo2, wq_ = wqf2, wv_ = wvof2;
+            E.packs.push_back([=](const PackCtx& p) {
+                float* fqp = reinterpret_cast<float*>(p.packed + fq); float* fvp = reinterpret_cast<float*>(p.packed + fv);
+                hipLaunchKernelGGL(k_attn_fold_w, dim3(257), dim3(256), 0, p.stream, p.params + w0_, p.params + w1_, p.params + w2_, p.params + w3_, p.params + b0_, p.params + b2_,
+                                   p.params + b3_, fqp, reinterpret_cast<float*>(p.packed + cq_), fvp, reinterpret_cast<float*>(p.packed + bo_));
+                hipLaunchKernelGGL(k_pack_qkv_w, dim3(256), dim3(256), 0, p.stream, (const float*)fqp, (const float*)fqp, (const float*)fqp, reinterpret_cast<bf16*>(p.packed + wq_), 1);
+                hipLaunchKernelGGL(k_pack_attn_w3, dim3(256), dim3(256), 0, p.stream, (const float*)fvp, reinterpret_cast<bf16*>(p.packed + wv_));
+            });
+        }
         const Part po_attn = proj ? register_output(out) : Part();
         const float rs_attn = res_scale;
         TRef O = new_act(m.res, C);
@@ -1085,7 +1105,12 @@ struct Builder {
             // 16x16 attention: scores, softmax and P V of a sample in one block (attn_fused.h, two-phase: V^T follows K through LDS)
             op(CLS_GEMM, [=](const Ctx& c) {
                 if (g_record) return;                    // natinf_ncsnpp_describe_gemms: GEMM launches only, nothing touches memory
-                if (blk) {
+                if (blk2) {
+                    hipLaunchKernelGGL(k_attn_blk256_v2, dim3((unsigned)c.B), dim3(512), ABLK2_LDS_BYTES, c.stream, (const bf16*)c.act(x), x.ld, c.at<float>(sc_q), c.at<float>(sh_q),
+                                       c.w<bf16>(wqf2), c.w<float>(cq2), 1.0f / sqrtf((float)C), c.w<bf16>(wvof2), c.w<float>(bo2),
+                                       c.act(out), out.ld, rs_attn, po_attn.valid ? c.at<float2>(po_attn.off) : (float2*)nullptr, po_attn.quads);
+                    if (po_attn.valid) c.part_bm[po_attn.id] = 256;
+                } else if (blk) {
                     hipLaunchKernelGGL(k_attn_blk256, dim3((unsigned)c.B), dim3(512), ABLK_LDS_BYTES, c.stream, (const bf16*)c.act(x), x.ld, c.at<float>(sc_q), c.at<float>(sh_q),
                                        c.w<bf16>(wqkvf), c.w<float>(bqk), c.w<float>(bv), c.at<bf16>(qk), c.at<bf16>(vT), 1.0f / sqrtf((float)C), c.w<bf16>(w3f), c.w<float>(b3),
                                        c.act(out), out.ld, rs_attn, po_attn.valid ? c.at<float2>(po_attn.off) : (float2*)nullptr, po_attn.quads);
@@ -1606,7 +1631,7 @@ int64_t natinf_ncsnpp_workspace_bytes(natinf_ncsnpp_t h, int max_batch) {
 // every switch a plan builder reads (layout of the packed weights included), one byte each
 static uint64_t plan_signature() {
     const int k[] = {g_fuse_head, g_cg8_tm4, g_attn_qkv, g_attn_w8, g_attn_proj, g_attn256, g_fuse_gn8, g_fuse_fin, g_fuse_gn4, g_fuse_gn, g_cg_wide, g_fuse_up, g_cg_regw,
-                     g_attn_blk, g_cg3 /* read by the plan builders too (which launches exist; which tables a producer may write): no pack offset depends on them today */};
+                     g_attn_blk /* (2: the folded attention weights are packed too) */, g_cg3 /* read by the plan builders (which launches exist; which tables a producer may write) */};
     uint64_t h = 1469598103934665603ull;
     for (int v : k) h = (h ^ (uint64_t)(v & 0xff)) * 1099511628211ull;
     return h;
@@ -1840,7 +1865,7 @@ int natinf_set_attn256(int on) {
     g_attn256 = on != 0; return NATINF_OK;
 }
 int natinf_set_conv_gn_warm(int mask) { if (mask < 0 || mask > 15) return NATINF_EINVAL; g_cg_warm = mask; return NATINF_OK; }
-int natinf_set_attn_block(int on) { g_attn_blk = on != 0; return NATINF_OK; }
+int natinf_set_attn_block(int on) { g_attn_blk = on < 0 ? ATTN_BLK_DEFAULT : (on > 2 ? 2 : on); return NATINF_OK; }
 int natinf_set_attn_qkv(int on) { g_attn_qkv = on != 0; return NATINF_OK; }
 int natinf_set_attn_waves8(int on) { g_attn_w8 = on != 0; return NATINF_OK; }
 int natinf_set_attn_proj(int on) { g_attn_proj = on != 0; return NATINF_OK; }
