@@ -59,7 +59,8 @@ one-after-the-other order.  ``ms_per_step`` = time / K, an inverse throughput.
                     committed rocprofv3 PMC summary (profiles/rNN/*_hbm_traffic.json: bench.py cannot run rocprofv3 on itself);
                     share = its part of the engine's device time.
   roofline_conv_gn8 the same kernel's 8x8 / 4x4 instantiations; roofline_gemm: every other matmul-shaped launch (k_gemm_*, the 16x16
-                    attention block k_attn_blk256, k_head_conv); roofline_whole_denoiser: all flops / all device time.
+                    attention block k_attn_blk256(_v2), k_head_conv; the flops are the REFERENCE's -- four projections per attention block: the v2 kernel multiplies two of folded matrices);
+                    roofline_whole_denoiser: all flops / all device time.
   roofline_ni_step  ``k_step_f64hist`` (HBM-bound): algorithmic bytes per launch / mean launch duration.
   cpu_baseline      the CPU oracle (eager-PyTorch restatement of the reference path: fp32 NCSN++ + fp64 recurrence) on this host:
                     64 images x 15 steps; ``config1`` = BASELINE config 1 (8 images x 5 steps) images/s; threads = min(32, physical):
