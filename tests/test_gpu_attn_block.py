@@ -1,4 +1,7 @@
-"""k_attn_blk256 (csrc/attn_blk256.h): the whole 16x16 attention block of NCSN++ (AttnBlockpp, deps/score_sde_pytorch/models/layerspp.py:75-91) as ONE launch -- q stays in
+"""The one-launch forms of the 16x16 attention block (csrc/attn_blk256.h).  The DEFAULT plan since round 6 is k_attn_blk256_v2 (natinf_set_attn_block(2): q k^T and P V against the
+normalised tokens themselves through folded weight matrices -- another arithmetic, bounded below against fp32 and, per module, in tests/test_gpu_ncsnpp.py); plans 1 and 0 are
+the four-projection kernels, byte-identical to each other:
+k_attn_blk256 (plan 1): the whole 16x16 attention block of NCSN++ (AttnBlockpp, deps/score_sde_pytorch/models/layerspp.py:75-91) as ONE launch -- q stays in
 registers, k and V^T are written and re-read through L2 by the same block -- against the two launches it replaces (k_qkv256 + k_attn256<true, 8>, natinf_set_attn_block(0)).
 Every output element is the same arithmetic in the same order (the wave's queries are only taken in another order), and since round 6 the GroupNorm partial sums of the
 block's output are added up in the two launches' order too (dpp_row_sum_tau: the same addition tree over the wave's 32 queries), so EVERY module and the network's output
