@@ -614,8 +614,10 @@ __global__ __launch_bounds__(512, 1) void k_attn_blk256_v2(const bf16* __restric
     float2 part[16];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (tile 0 landed during P V; the first pass waits for tiles 1-3 as well: one L2 round trip per block)
-        __syncthreads();
+        if (t == 0) {                                              // tile 0 landed during P V; this one wait covers tiles 1-3 as well (one L2 round trip per block): every wave
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // waits for ITS pieces of all four tiles, the barrier publishes them -- the later passes need neither
+            __syncthreads();
+        }
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* sW = t == 0 ? smem + ABLK2_IMG : smem + (t - 1) * A256_STAGE;
         f32x4 a3[2][4];
